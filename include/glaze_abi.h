@@ -1,0 +1,315 @@
+/* glaze_abi.h -- C ABI of libglaze_hip.so, the MI355X-native replacement for glaze's render path.
+ *
+ * The reference (davidepi/glaze, Rust + Vulkan-RT) has no FFI seam of its own; the seam this
+ * library replaces is the public Rust API that `glaze-cli` drives (cli/src/main.rs:76-121,
+ * re-exported at lib/src/lib.rs:18-22).  Every entry point below cites the reference item it
+ * stands in for.  A Rust `glaze-hip-sys` binding maps
+ *   status < 0  ->  io::Error / panic (the reference `expect()`s on every GPU failure),
+ *   NULL handle ->  Option::None (RayTraceInstance::new, lib/src/vulkan/instance.rs:376).
+ *
+ * Conventions: plain pointers and sizes only; all handles opaque; every function returning
+ * `int` returns 0 on success or a negative GLZ_E_* code and stores a message retrievable with
+ * glz_last_error() (thread-local).  No exceptions cross the boundary.  A renderer is not
+ * thread-safe (the reference takes `&mut self` on every mutator, raytracer.rs:180-326).
+ */
+#ifndef GLAZE_ABI_H
+#define GLAZE_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GLZ_OK 0
+#define GLZ_E_IO (-1)          /* io::ErrorKind::NotFound / UnexpectedEof */
+#define GLZ_E_INVALID_INPUT (-2) /* io::ErrorKind::InvalidInput  (bad magic / version) */
+#define GLZ_E_INVALID_DATA (-3)  /* io::ErrorKind::InvalidData   (hash mismatch, corrupt xz/png) */
+#define GLZ_E_ARG (-4)         /* bad argument to the C ABI itself */
+#define GLZ_E_DEVICE (-5)      /* HIP failure (the reference panics here) */
+#define GLZ_E_UNSUPPORTED (-6)
+
+/* ------------------------------------------------------------------------------------------
+ * Scene model PODs (host side).  Field meaning follows the reference types; layouts are this
+ * ABI's own (the .glaze byte format is decoded by the library, lib/src/parser/v1.rs:631-1080).
+ * ---------------------------------------------------------------------------------------- */
+
+/* geometry/vertex.rs:6-15 -- 32 bytes, identical to the reference's #[repr(C)] Vertex. */
+typedef struct glz_vertex {
+  float vv[3]; /* position */
+  float vn[3]; /* normal   */
+  float vt[2]; /* texcoord */
+} glz_vertex;
+
+/* geometry/mesh.rs:5-16 -- indices of all meshes are concatenated in one u32 array; a mesh owns
+ * [index_offset, index_offset+index_count) of it (what load_indices_to_gpu builds,
+ * vulkan/scene.rs:834-850). */
+typedef struct glz_mesh {
+  uint16_t id;
+  uint16_t material;
+  uint32_t index_offset;
+  uint32_t index_count;
+} glz_mesh;
+
+/* geometry/mesh.rs:29-32 -- column-major 4x4, as cgmath::Matrix4<f32>. */
+typedef struct glz_transform {
+  float m[16];
+} glz_transform;
+
+/* geometry/mesh.rs:23-27 */
+typedef struct glz_mesh_instance {
+  uint16_t mesh_id;
+  uint16_t transform_id;
+} glz_mesh_instance;
+
+/* geometry/camera.rs:7-83 */
+#define GLZ_CAMERA_PERSPECTIVE 0
+#define GLZ_CAMERA_ORTHOGRAPHIC 1
+typedef struct glz_camera {
+  uint32_t type;
+  float position[3];
+  float target[3];
+  float up[3];
+  float fovx_or_scale; /* fovx (radians) for perspective, scale for orthographic */
+  float near_plane;
+  float far_plane;
+} glz_camera;
+
+/* materials/material.rs:17-42, ids :62-73 */
+#define GLZ_MAT_FLAT 0
+#define GLZ_MAT_LAMBERT 1
+#define GLZ_MAT_MIRROR 2
+#define GLZ_MAT_GLASS 3
+#define GLZ_MAT_METAL 4
+#define GLZ_MAT_FROSTED 5
+#define GLZ_MAT_UBER 6
+#define GLZ_NAME_MAX 256
+/* materials/material.rs:290-325 */
+typedef struct glz_material {
+  uint8_t mtype;  /* GLZ_MAT_* */
+  uint8_t metal;  /* index into materials/metal.rs:6-37 (0 = SILVER) */
+  uint8_t diffuse_mul[3];
+  uint8_t emissive_col[3];
+  uint8_t has_emissive; /* Option<[u8;3]>::is_some() */
+  uint8_t _pad[3];
+  float ior;
+  float roughness_mul;
+  float metalness_mul;
+  float anisotropy;
+  uint16_t diffuse;   /* texture ids; 0 = none (white 1x1 default texture) */
+  uint16_t roughness;
+  uint16_t metalness;
+  uint16_t normal;
+  uint16_t opacity;
+  uint16_t _pad2;
+  char name[GLZ_NAME_MAX];
+} glz_material;
+
+/* geometry/light.rs:12-22, :146-170 */
+#define GLZ_LIGHT_OMNI 0
+#define GLZ_LIGHT_SUN 1
+#define GLZ_LIGHT_AREA 2
+#define GLZ_LIGHT_SKY 3
+typedef struct glz_light {
+  uint32_t ltype;
+  float position[3];
+  float direction[3];
+  uint32_t resource_id; /* material id (AREA) or texture id (SKY) */
+  float intensity;
+  float yaw_deg, pitch_deg, roll_deg;
+  float color[16]; /* Spectrum: 16 bins, 400..700 nm (geometry/spectrum.rs:11-24) */
+  char name[GLZ_NAME_MAX];
+} glz_light;
+
+/* materials/texture.rs:94-130; only mip level 0 is used by the ray-tracing stages. */
+#define GLZ_TEX_GRAY 1      /* R8_UNORM  */
+#define GLZ_TEX_RGBA_SRGB 2 /* R8G8B8A8_SRGB */
+#define GLZ_TEX_RGBA_NORM 3 /* R8G8B8A8_UNORM */
+typedef struct glz_texture {
+  uint32_t format; /* GLZ_TEX_* */
+  uint32_t width, height;
+  uint32_t mip_levels;   /* as stored in the file; informational */
+  const uint8_t* pixels; /* level 0, tightly packed rows, 1 or 4 bytes per pixel */
+  char name[GLZ_NAME_MAX];
+} glz_texture;
+
+/* parser/mod.rs:274-288 */
+typedef struct glz_meta {
+  float scene_centre[3];
+  float scene_radius;
+  float exposure;
+} glz_meta;
+
+/* In-memory scene (no reference counterpart as a type: it is what `Box<dyn ParsedScene>` hands
+ * to RayTraceScene::new, vulkan/scene.rs:1414-1434).  NULL / 0 members take the reference's
+ * defaults: one identity transform, one default material, one default 1x1 white texture,
+ * default camera, Meta::default(). */
+typedef struct glz_scene_desc {
+  const glz_vertex* vertices;        uint64_t n_vertices;
+  const uint32_t* indices;           uint64_t n_indices;
+  const glz_mesh* meshes;            uint32_t n_meshes;
+  const glz_transform* transforms;   uint32_t n_transforms;
+  const glz_mesh_instance* instances;uint32_t n_instances;
+  const glz_material* materials;     uint32_t n_materials;
+  const glz_light* lights;           uint32_t n_lights;
+  const glz_texture* textures;       uint32_t n_textures;
+  const glz_camera* camera;          /* the LAST camera of the file (scene.rs:1487-1491) */
+  const glz_meta* meta;
+} glz_scene_desc;
+
+/* ------------------------------------------------------------------------------------------
+ * Errors
+ * ---------------------------------------------------------------------------------------- */
+const char* glz_last_error(void);
+const char* glz_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * parse()  --  lib/src/parser/mod.rs:93-116 + ContentV1 read side (parser/v1.rs:135-175,
+ * :298-362, :476-609).  Header and offset table are checked at open; chunks are decoded lazily
+ * by the getters (hash mismatch -> GLZ_E_INVALID_DATA, missing chunk -> count 0).
+ * Getter protocol: pass out == NULL to obtain the element count; otherwise up to `cap` elements
+ * are written and the total count is returned (negative = error).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct glz_parsed glz_parsed;
+glz_parsed* glz_parse(const char* path);            /* NULL on error, see glz_last_error() */
+int glz_last_status(void);                           /* status code of the last failing call on this thread */
+void glz_parsed_free(glz_parsed*);
+int64_t glz_parsed_vertices(glz_parsed*, glz_vertex* out, int64_t cap);           /* ParsedScene::vertices   */
+int64_t glz_parsed_meshes(glz_parsed*, glz_mesh* out, int64_t cap);               /* ParsedScene::meshes     */
+int64_t glz_parsed_indices(glz_parsed*, uint32_t* out, int64_t cap);              /*   (their index arrays)  */
+int64_t glz_parsed_transforms(glz_parsed*, glz_transform* out, int64_t cap);      /* ParsedScene::transforms */
+int64_t glz_parsed_instances(glz_parsed*, glz_mesh_instance* out, int64_t cap);   /* ParsedScene::instances  */
+int64_t glz_parsed_cameras(glz_parsed*, glz_camera* out, int64_t cap);            /* ParsedScene::cameras    */
+int64_t glz_parsed_materials(glz_parsed*, glz_material* out, int64_t cap);        /* ParsedScene::materials  */
+int64_t glz_parsed_lights(glz_parsed*, glz_light* out, int64_t cap);              /* ParsedScene::lights     */
+/* textures: `pixels` of each returned glz_texture points into memory owned by the glz_parsed. */
+int64_t glz_parsed_textures(glz_parsed*, glz_texture* out, int64_t cap);          /* ParsedScene::textures   */
+int glz_parsed_meta(glz_parsed*, glz_meta* out);  /* ParsedScene::meta; returns 1 if the chunk is absent (out = default) */
+int glz_converted_file(const char* path);         /* parser/mod.rs:259-271: 1 if the magic matches */
+
+/* ------------------------------------------------------------------------------------------
+ * RayTraceInstance::new() -> Option<Self>   (lib/src/vulkan/instance.rs:376-427)
+ * hip_device = -1 picks the first gfx950 device (LOCAL_RANK-agnostic; pass the ordinal for
+ * one-process-per-GPU jobs).  NULL <=> None: no usable device or the HIP code object is missing.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct glz_instance glz_instance;
+glz_instance* glz_instance_create(int hip_device);
+void glz_instance_destroy(glz_instance*);
+int glz_instance_device(const glz_instance*);
+/* stream all of this instance's kernels run on (a hipStream_t), for event timing by the caller */
+void* glz_instance_stream(const glz_instance*);
+
+/* ------------------------------------------------------------------------------------------
+ * RayTraceScene::new(instance, parsed)   (lib/src/vulkan/scene.rs:1414-1556)
+ * Uploads geometry, runs the derivative kernel (scene.rs:2113-2188), builds the LBVH that
+ * replaces SceneASBuilder (vulkan/acceleration.rs:89-494), builds RTInstance/RTMaterial/RTLight
+ * arrays (scene.rs:1784-1927) and the sky sampling tables (scene.rs:2191-2313).
+ * glz_scene_create consumes `parsed` (it is freed, as the Box is moved in the reference).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct glz_scene glz_scene;
+glz_scene* glz_scene_create(glz_instance*, glz_parsed* parsed);
+glz_scene* glz_scene_create_from_desc(glz_instance*, const glz_scene_desc*);
+void glz_scene_destroy(glz_scene*);
+
+typedef struct glz_scene_info {
+  uint64_t n_vertices, n_triangles;          /* object-space triangles over all meshes */
+  uint64_t n_world_triangles;                /* after instancing (BVH primitives)       */
+  uint32_t n_instances, n_materials, n_lights /* lights_no, scene.rs:1549 */, n_rt_lights, n_textures;
+  uint32_t bvh_nodes, bvh_depth;
+  float bvh_sah_cost;
+  float build_ms;                            /* LBVH build time on the device */
+  float bounds_min[3], bounds_max[3];
+} glz_scene_info;
+int glz_scene_get_info(const glz_scene*, glz_scene_info* out);
+int glz_scene_camera(const glz_scene*, glz_camera* out);
+
+/* ------------------------------------------------------------------------------------------
+ * RayTraceRenderer   (lib/src/vulkan/raytracer.rs:109-687)
+ * ---------------------------------------------------------------------------------------- */
+typedef struct glz_renderer glz_renderer;
+#define GLZ_DIRECT 0      /* Integrator::DIRECT      raytracer.rs:36-52 */
+#define GLZ_PATH_TRACE 1  /* Integrator::PATH_TRACE */
+
+/* RayTraceRenderer::new(instance, Some(scene), w, h)  raytracer.rs:164-177; the renderer owns
+ * the scene from here on (raytracer.rs:109-111): do not destroy it yourself. */
+glz_renderer* glz_renderer_create(glz_instance*, glz_scene* scene, uint32_t width, uint32_t height);
+void glz_renderer_destroy(glz_renderer*);
+int glz_renderer_set_integrator(glz_renderer*, int integrator);          /* raytracer.rs:196-231 */
+int glz_renderer_set_exposure(glz_renderer*, float exposure);            /* raytracer.rs:180-194 */
+int glz_renderer_update_camera(glz_renderer*, const glz_camera*);        /* raytracer.rs:300-309 */
+int glz_renderer_change_resolution(glz_renderer*, uint32_t w, uint32_t h);/* raytracer.rs:250-298 */
+int glz_renderer_change_scene(glz_renderer*, glz_scene* scene);          /* raytracer.rs:233-248 */
+/* raytracer.rs:311-326: rebuilds RTMaterial / RTLight / sky tables; restarts accumulation. */
+int glz_renderer_update_materials_and_lights(glz_renderer*, const glz_material* mats, uint32_t n_mats,
+                                             const glz_light* lights, uint32_t n_lights);
+int glz_renderer_wait_idle(glz_renderer*);                                /* raytracer.rs:328-340 */
+/* Integrator::steps_per_sample()  raytracer.rs:78-85 (PATH_TRACE -> the configured depth) */
+uint32_t glz_renderer_steps_per_sample(const glz_renderer*);
+
+/* draw(spp, callback) -> RgbaImage   raytracer.rs:615-687.  Resets accumulation, runs
+ * spp * steps_per_sample launches, calls `cb(user)` once per spp on the caller's thread
+ * (raytracer.rs:651-653), writes W*H RGBA8 sRGB pixels (alpha 255) to rgba8_out (may be NULL). */
+int glz_renderer_draw(glz_renderer*, size_t spp, void (*cb)(void*), void* user, uint8_t* rgba8_out);
+
+/* draw_frame(): ONE launch = one path segment per pixel  (raytracer.rs:369-613), the unit the
+ * interactive viewer drives.  `n` launches are enqueued; accumulation continues unless
+ * glz_renderer_restart() was called (request_new_frame). */
+int glz_renderer_restart(glz_renderer*);
+int glz_renderer_step(glz_renderer*, uint32_t n_launches);
+int glz_renderer_read_rgba8(glz_renderer*, uint8_t* rgba8_out); /* blit out32->out8 + export, memory.rs:269-483 */
+
+/* ---- build-defined extensions (no reference counterpart) ---------------- */
+int glz_renderer_set_seed(glz_renderer*, uint64_t seed);    /* replaces Xoshiro128PlusPlus::from_entropy, raytracer.rs:779 */
+int glz_renderer_set_depth(glz_renderer*, uint32_t pt_steps);/* replaces const PT_STEPS = 6, raytrace_structures.rs:87 */
+/* cumulative image (xyz = sum of rgb radiance, w = launch count; path_trace.rgen:119-133),
+ * W*H*4 floats, row-major, to host memory. */
+int glz_renderer_read_hdr(glz_renderer*, float* rgba32f_out);
+/* result image (`out32`: cumulative.xyz*exposure/w at the pixel's last update, path_trace.rgen:131-132) */
+int glz_renderer_read_result(glz_renderer*, float* rgba32f_out);
+/* per-launch host constants the draw loop will use for launch `i` after a restart:
+ * seed (u32) and WorkScheduler pixel offset (raytracer.rs:486-489, :1168-1206). */
+int glz_renderer_launch_constants(glz_renderer*, uint32_t launch, uint32_t* seed, float offset[2]);
+/* camera push constants: camera2world then screen2camera, column-major (raytracer.rs:1098-1120) */
+int glz_renderer_push_constants(glz_renderer*, float out32[32]);
+
+/* Multi-GPU (one process per GPU): this renderer owns the 64x64-pixel tiles t with
+ * t % world == rank; other pixels stay zero.  The reduce of the HDR accumulator itself is done
+ * by the caller (RCCL through torch.distributed or rccl directly) on the device buffer below. */
+int glz_renderer_set_partition(glz_renderer*, uint32_t rank, uint32_t world);
+/* Scatters the owned tiles into a caller-provided DEVICE buffer of W*H*4 floats (zero-filled
+ * elsewhere) on the instance stream: the operand of ncclReduce(sum). */
+int glz_renderer_export_hdr_device(glz_renderer*, void* dev_rgba32f);
+/* Tonemaps a full-frame DEVICE cumulative buffer (e.g. the reduced one on rank 0) to RGBA8 host. */
+int glz_renderer_tonemap_device(glz_renderer*, const void* dev_rgba32f_cumulative, const void* dev_rgba32f_lastw, uint8_t* rgba8_out);
+
+/* ---- measurement ------------------------------------------------------------------------ */
+typedef struct glz_render_stats {
+  uint64_t launches;        /* launches since the last restart */
+  uint64_t samples;         /* owned pixels x launches */
+  double   render_ms;       /* device time of those launches (hipEvent, instance stream) */
+  double   trace_closest_ms, shade_ms, trace_shadow_ms, other_ms; /* per-kernel-class device time */
+  uint64_t closest_rays, shadow_rays;
+  /* traversal work counters (only filled when counting is enabled, slows rendering down) */
+  uint64_t closest_nodes, closest_tris, shadow_nodes, shadow_tris, hits;
+} glz_render_stats;
+int glz_renderer_enable_counters(glz_renderer*, int on);
+int glz_renderer_get_stats(glz_renderer*, glz_render_stats* out);
+
+/* ---- debug / parity hooks (used by tests; run on the device, no CPU fallback) -------------- */
+/* closest hit of n rays: t (inf = miss), world triangle id (instance-major), barycentric u,v */
+int glz_debug_trace_closest(glz_scene*, const float* origins3, const float* dirs3, uint64_t n, float tmin,
+                            float* t_out, uint32_t* tri_out, uint32_t* inst_out, float* u_out, float* v_out);
+int glz_debug_trace_any(glz_scene*, const float* origins3, const float* dirs3, const float* tmax, uint64_t n,
+                        float tmin, uint8_t* hit_out);
+/* Derivatives buffer (normal, dpdu, dpdv as 3 x vec4 per object-space triangle), generate_derivatives.comp */
+int64_t glz_debug_read_derivatives(glz_scene*, float* out12, int64_t cap_triangles);
+/* Device-side sky tables / RT arrays as uploaded (for parity with the oracle's host prep) */
+int64_t glz_debug_read_rt_materials(glz_scene*, void* out, int64_t cap_bytes); /* 208-byte RTMaterial records */
+int64_t glz_debug_read_rt_lights(glz_scene*, void* out, int64_t cap_bytes);    /* 112-byte RTLight records */
+int64_t glz_debug_read_sky(glz_scene*, float* out, int64_t cap_floats);        /* RTSky(36 f32) | header(4) | marginal arrays */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GLAZE_ABI_H */
