@@ -1,0 +1,376 @@
+"""glaze_amd -- MI355X-native render path behind glaze's Scene / parse / Renderer interface.
+
+Python mirror of the slice of the reference's public Rust API that `glaze-cli` drives
+(lib/src/lib.rs:10-24, cli/src/main.rs:76-121), implemented over the C ABI of libglaze_hip.so
+(include/glaze_abi.h).  Names, argument meaning and error behaviour follow the reference:
+
+    parsed   = glaze_amd.parse("scene.glaze")                       # glaze::parse            parser/mod.rs:93
+    instance = glaze_amd.RayTraceInstance.new()                     # Option<RayTraceInstance> vulkan/instance.rs:376
+    scene    = glaze_amd.RayTraceScene.new(instance, parsed)        # vulkan/scene.rs:1414
+    renderer = glaze_amd.RayTraceRenderer.new(instance, scene, w, h)# vulkan/raytracer.rs:164
+    renderer.set_integrator(glaze_amd.Integrator.PATH_TRACE)
+    image    = renderer.draw(spp, callback)                         # HxWx4 uint8 sRGB, raytracer.rs:615
+
+The render path has no CPU fallback: without libglaze_hip.so / a gfx950 device, RayTraceInstance.new()
+returns None exactly like the reference does without a ray-tracing capable Vulkan device.
+"""
+import ctypes as C
+import enum
+
+import numpy as np
+
+from . import abi
+from .abi import GlazeError
+from .scene_desc import SceneDesc, make_camera, make_light, make_material, make_meta  # noqa: F401
+
+__all__ = ["parse", "converted_file", "ParsedScene", "RayTraceInstance", "RayTraceScene", "RayTraceRenderer", "Integrator",
+           "GlazeError", "SceneDesc"]
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Integrator(enum.Enum):
+    """lib/src/vulkan/raytracer.rs:30-86"""
+    DIRECT = abi.DIRECT
+    PATH_TRACE = abi.PATH_TRACE
+
+    @staticmethod
+    def values():
+        return [Integrator.DIRECT, Integrator.PATH_TRACE]
+
+    def name_str(self):
+        return "Direct light only" if self is Integrator.DIRECT else "Path tracing"
+
+    def steps_per_sample(self, pt_steps=6):
+        return 1 if self is Integrator.DIRECT else pt_steps
+
+
+class ParsedScene:
+    """`Box<dyn ParsedScene>` (lib/src/parser/mod.rs:294-323): lazy, per-chunk getters."""
+
+    def __init__(self, handle, path):
+        self._h = handle
+        self.path = path
+
+    def __del__(self):
+        self.close()
+
+    def close(self):
+        if getattr(self, "_h", None):
+            abi.lib().glz_parsed_free(self._h)
+            self._h = None
+
+    def _take(self):
+        h, self._h = self._h, None
+        if not h:
+            raise ValueError("parsed scene was already consumed by RayTraceScene.new")
+        return h
+
+    def _array(self, fn, ctype):
+        L = abi.lib()
+        n = abi.check(fn(self._h, None, 0))
+        arr = (ctype * max(1, n))()
+        abi.check(fn(self._h, C.cast(arr, C.c_void_p), n))
+        return arr, n
+
+    def vertices(self):
+        arr, n = self._array(abi.lib().glz_parsed_vertices, abi.Vertex)
+        return np.frombuffer(arr, dtype=np.float32, count=n * 8).reshape(n, 8).copy()
+
+    def meshes(self):
+        """[(id, material, indices uint32[])]"""
+        arr, n = self._array(abi.lib().glz_parsed_meshes, abi.Mesh)
+        idx_arr, ni = self._array(abi.lib().glz_parsed_indices, C.c_uint32)
+        idx = np.frombuffer(idx_arr, dtype=np.uint32, count=ni)
+        return [dict(id=arr[i].id, material=arr[i].material,
+                     indices=idx[arr[i].index_offset:arr[i].index_offset + arr[i].index_count].copy()) for i in range(n)]
+
+    def transforms(self):
+        arr, n = self._array(abi.lib().glz_parsed_transforms, abi.Transform)
+        return np.frombuffer(arr, dtype=np.float32, count=n * 16).reshape(n, 16).copy()
+
+    def instances(self):
+        arr, n = self._array(abi.lib().glz_parsed_instances, abi.MeshInstance)
+        return np.frombuffer(arr, dtype=np.uint16, count=n * 2).reshape(n, 2).copy()
+
+    def cameras(self):
+        arr, n = self._array(abi.lib().glz_parsed_cameras, abi.Camera)
+        return [arr[i] for i in range(n)]
+
+    def materials(self):
+        arr, n = self._array(abi.lib().glz_parsed_materials, abi.Material)
+        return [arr[i] for i in range(n)]
+
+    def lights(self):
+        arr, n = self._array(abi.lib().glz_parsed_lights, abi.Light)
+        return [arr[i] for i in range(n)]
+
+    def textures(self):
+        """[(format, pixels HxW or HxWx4 uint8, name, mip_levels)]"""
+        arr, n = self._array(abi.lib().glz_parsed_textures, abi.Texture)
+        out = []
+        for i in range(n):
+            t = arr[i]
+            ch = 1 if t.format == abi.TEX_GRAY else 4
+            buf = (C.c_uint8 * (t.width * t.height * ch)).from_address(t.pixels)
+            px = np.frombuffer(buf, dtype=np.uint8).copy()
+            px = px.reshape(t.height, t.width) if ch == 1 else px.reshape(t.height, t.width, 4)
+            out.append((t.format, px, t.name.decode("utf8", "replace"), t.mip_levels))
+        return out
+
+    def meta(self):
+        m = abi.Meta()
+        abi.check(abi.lib().glz_parsed_meta(self._h, C.byref(m)))
+        return m
+
+
+def parse(path):
+    """glaze::parse (lib/src/parser/mod.rs:93-116).  Raises GlazeError (io::Error) on a bad file."""
+    h = abi.lib().glz_parse(str(path).encode())
+    if not h:
+        raise abi.last_error()
+    return ParsedScene(h, str(path))
+
+
+def converted_file(path):
+    """lib/src/parser/mod.rs:259-271"""
+    return bool(abi.lib().glz_converted_file(str(path).encode()))
+
+
+class RayTraceInstance:
+    """lib/src/vulkan/instance.rs:376-427"""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @staticmethod
+    def new(hip_device=-1):
+        """Returns None when no gfx950 device (or no libglaze_hip.so code object) is usable."""
+        h = abi.lib().glz_instance_create(hip_device)
+        return RayTraceInstance(h) if h else None
+
+    @property
+    def device(self):
+        return abi.lib().glz_instance_device(self._h)
+
+    @property
+    def stream(self):
+        """hipStream_t (as int) all kernels of this instance run on."""
+        return abi.lib().glz_instance_stream(self._h)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            abi.lib().glz_instance_destroy(self._h)
+            self._h = None
+
+
+class RayTraceScene:
+    """lib/src/vulkan/scene.rs:1352-1556"""
+
+    def __init__(self, handle, instance, keep=None):
+        self._h = handle
+        self.instance = instance
+        self._keep = keep
+        self._owned = True
+
+    @staticmethod
+    def new(instance, parsed):
+        if isinstance(parsed, SceneDesc):
+            return RayTraceScene.from_desc(instance, parsed)
+        h = abi.lib().glz_scene_create(instance._h, parsed._take())
+        if not h:
+            raise abi.last_error()
+        return RayTraceScene(h, instance)
+
+    @staticmethod
+    def from_desc(instance, desc):
+        c = desc.as_c()
+        h = abi.lib().glz_scene_create_from_desc(instance._h, C.byref(c))
+        if not h:
+            raise abi.last_error()
+        return RayTraceScene(h, instance)
+
+    def info(self):
+        i = abi.SceneInfo()
+        abi.check(abi.lib().glz_scene_get_info(self._h, C.byref(i)))
+        return i
+
+    def camera(self):
+        c = abi.Camera()
+        abi.check(abi.lib().glz_scene_camera(self._h, C.byref(c)))
+        return c
+
+    # ---- parity hooks (tests) ----
+    def debug_trace_closest(self, origins, dirs, tmin=1e-4):
+        o = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)
+        n = o.shape[0]
+        t, u, v = (np.zeros(n, np.float32) for _ in range(3))
+        tri, inst = (np.zeros(n, np.uint32) for _ in range(2))
+        abi.check(abi.lib().glz_debug_trace_closest(self._h, _ptr(o), _ptr(d), n, tmin, _ptr(t), _ptr(tri), _ptr(inst), _ptr(u), _ptr(v)))
+        return t, tri, inst, u, v
+
+    def debug_trace_any(self, origins, dirs, tmax, tmin=1e-3):
+        o = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)
+        tm = np.ascontiguousarray(tmax, np.float32)
+        out = np.zeros(o.shape[0], np.uint8)
+        abi.check(abi.lib().glz_debug_trace_any(self._h, _ptr(o), _ptr(d), _ptr(tm), o.shape[0], tmin, _ptr(out)))
+        return out
+
+    def debug_derivatives(self):
+        n = abi.check(abi.lib().glz_debug_read_derivatives(self._h, None, 0))
+        out = np.zeros((n, 12), np.float32)
+        abi.check(abi.lib().glz_debug_read_derivatives(self._h, _ptr(out), n))
+        return out
+
+    def debug_rt_materials(self):
+        n = abi.check(abi.lib().glz_debug_read_rt_materials(self._h, None, 0))
+        out = np.zeros(n, np.uint8)
+        abi.check(abi.lib().glz_debug_read_rt_materials(self._h, _ptr(out), n))
+        return out
+
+    def debug_rt_lights(self):
+        n = abi.check(abi.lib().glz_debug_read_rt_lights(self._h, None, 0))
+        out = np.zeros(n, np.uint8)
+        abi.check(abi.lib().glz_debug_read_rt_lights(self._h, _ptr(out), n))
+        return out
+
+    def debug_sky(self):
+        n = abi.check(abi.lib().glz_debug_read_sky(self._h, None, 0))
+        out = np.zeros(n, np.float32)
+        abi.check(abi.lib().glz_debug_read_sky(self._h, _ptr(out), n))
+        return out
+
+    def debug_bvh(self):
+        i = self.info()
+        nodes = np.zeros((max(1, i.bvh_nodes), 16), np.float32)
+        tris = np.zeros((max(1, i.n_world_triangles), 12), np.float32)
+        abi.check(abi.lib().glz_debug_read_bvh(self._h, _ptr(nodes), i.bvh_nodes, _ptr(tris), i.n_world_triangles))
+        return nodes[:i.bvh_nodes], tris[:i.n_world_triangles]
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            abi.lib().glz_scene_destroy(self._h)
+            self._h = None
+
+
+class RayTraceRenderer:
+    """lib/src/vulkan/raytracer.rs:109-687"""
+
+    def __init__(self, handle, instance, scene, width, height):
+        self._h = handle
+        self.instance = instance
+        self.scene = scene
+        self.width, self.height = width, height
+
+    @staticmethod
+    def new(instance, scene, width, height):
+        h = abi.lib().glz_renderer_create(instance._h, scene._h if scene is not None else None, width, height)
+        if not h:
+            raise abi.last_error()
+        return RayTraceRenderer(h, instance, scene, width, height)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            abi.lib().glz_renderer_destroy(self._h)
+            self._h = None
+
+    # ---- reference API ----
+    def set_integrator(self, integrator):
+        abi.check(abi.lib().glz_renderer_set_integrator(self._h, integrator.value if isinstance(integrator, Integrator) else int(integrator)))
+
+    def set_exposure(self, exposure):
+        abi.check(abi.lib().glz_renderer_set_exposure(self._h, exposure))
+
+    def update_camera(self, camera):
+        abi.check(abi.lib().glz_renderer_update_camera(self._h, C.byref(camera)))
+
+    def change_resolution(self, width, height):
+        abi.check(abi.lib().glz_renderer_change_resolution(self._h, width, height))
+        self.width, self.height = width, height
+
+    def change_scene(self, scene):
+        abi.check(abi.lib().glz_renderer_change_scene(self._h, scene._h))
+        self.scene = scene
+
+    def update_materials_and_lights(self, materials, lights, textures=None):
+        if textures is not None:
+            raise NotImplementedError("texture replacement is not part of the hot path (SURVEY 8f rank 2)")
+        m = (abi.Material * max(1, len(materials)))(*materials)
+        l = (abi.Light * max(1, len(lights)))(*lights)
+        abi.check(abi.lib().glz_renderer_update_materials_and_lights(self._h, C.cast(m, C.c_void_p), len(materials), C.cast(l, C.c_void_p), len(lights)))
+
+    def wait_idle(self):
+        abi.check(abi.lib().glz_renderer_wait_idle(self._h))
+
+    def steps_per_sample(self):
+        return abi.lib().glz_renderer_steps_per_sample(self._h)
+
+    def draw(self, spp, callback=None, want_image=True):
+        """draw(spp, callback) -> HxWx4 uint8 sRGB image (raytracer.rs:615-687)."""
+        out = np.zeros((self.height, self.width, 4), np.uint8) if want_image else None
+        cb = abi.DRAW_CALLBACK((lambda _u: callback()) if callback else (lambda _u: None))
+        abi.check(abi.lib().glz_renderer_draw(self._h, spp, C.cast(cb, C.c_void_p) if callback else None, None, _ptr(out) if want_image else None))
+        return out
+
+    # ---- progressive API (draw_frame) ----
+    def restart(self):
+        abi.check(abi.lib().glz_renderer_restart(self._h))
+
+    def step(self, n=1):
+        abi.check(abi.lib().glz_renderer_step(self._h, n))
+
+    def read_rgba8(self):
+        out = np.zeros((self.height, self.width, 4), np.uint8)
+        abi.check(abi.lib().glz_renderer_read_rgba8(self._h, _ptr(out)))
+        return out
+
+    # ---- build-defined extensions ----
+    def set_seed(self, seed):
+        abi.check(abi.lib().glz_renderer_set_seed(self._h, seed))
+
+    def set_depth(self, pt_steps):
+        abi.check(abi.lib().glz_renderer_set_depth(self._h, pt_steps))
+
+    def read_hdr(self):
+        out = np.zeros((self.height, self.width, 4), np.float32)
+        abi.check(abi.lib().glz_renderer_read_hdr(self._h, _ptr(out)))
+        return out
+
+    def read_result(self):
+        out = np.zeros((self.height, self.width, 4), np.float32)
+        abi.check(abi.lib().glz_renderer_read_result(self._h, _ptr(out)))
+        return out
+
+    def launch_constants(self, launch):
+        s = C.c_uint32()
+        off = (C.c_float * 2)()
+        abi.check(abi.lib().glz_renderer_launch_constants(self._h, launch, C.byref(s), off))
+        return s.value, (off[0], off[1])
+
+    def push_constants(self):
+        out = np.zeros(32, np.float32)
+        abi.check(abi.lib().glz_renderer_push_constants(self._h, _ptr(out)))
+        return out
+
+    def set_partition(self, rank, world):
+        abi.check(abi.lib().glz_renderer_set_partition(self._h, rank, world))
+
+    def export_device(self, which, device_ptr):
+        abi.check(abi.lib().glz_renderer_export_device(self._h, which, C.c_void_p(device_ptr)))
+
+    def tonemap_device(self, device_ptr):
+        out = np.zeros((self.height, self.width, 4), np.uint8)
+        abi.check(abi.lib().glz_renderer_tonemap_device(self._h, C.c_void_p(device_ptr), _ptr(out)))
+        return out
+
+    def enable_counters(self, counters=False, kernel_timing=True):
+        abi.check(abi.lib().glz_renderer_enable_counters(self._h, (1 if counters else 0) | (2 if kernel_timing else 0)))
+
+    def stats(self):
+        s = abi.RenderStats()
+        abi.check(abi.lib().glz_renderer_get_stats(self._h, C.byref(s)))
+        return s

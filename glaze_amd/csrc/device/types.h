@@ -1,0 +1,152 @@
+// Host<->device PODs.  The RT* structs keep the byte layout of the reference's
+// lib/src/vulkan/raytrace_structures.rs (mirrored into GLSL by lib/build.rs:138-184) so that the
+// debug read-back hooks can be compared field by field; everything else is this build's own.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace glz {
+
+struct Spectrum16 {
+  float w[16];
+};
+
+// raytrace_structures.rs:4-15 (52 bytes in the reference; we add the integrator knobs behind it)
+struct FrameData {
+  uint32_t seed;
+  uint32_t lights_no;
+  float pixel_offset[2];
+  float scene_radius;
+  float exposure;
+  float scene_size[2];
+  float scene_centre[4];
+  uint32_t camera_persp;
+  // build-defined: PT_STEPS and the DIRECT_ONLY compile-time switch as run-time values
+  uint32_t pt_steps;
+  uint32_t direct_only;
+  uint32_t _pad;
+};
+
+// raytrace_structures.rs:36-42
+struct RTInstance {
+  uint32_t index_offset;
+  uint32_t index_count;
+  uint32_t material_id;
+  uint32_t transform_id;
+};
+static_assert(sizeof(RTInstance) == 16, "RTInstance is 16 bytes");
+
+// raytrace_structures.rs:44-64
+struct alignas(16) RTMaterial {
+  float diffuse_mul[4];
+  float emissive_col[4];
+  Spectrum16 metal_ior;
+  Spectrum16 metal_fresnel;
+  uint32_t diffuse;
+  uint32_t roughness;
+  uint32_t metalness;
+  uint32_t opacity;
+  uint32_t normal;
+  uint32_t bsdf_index;
+  float roughness_mul;
+  float metalness_mul;
+  float anisotropy;
+  float ior_dielectric;
+  uint32_t is_specular;
+  uint32_t is_emissive;
+};
+static_assert(sizeof(RTMaterial) == 208, "RTMaterial is 208 bytes");
+
+// raytrace_structures.rs:66-76
+struct alignas(16) RTLight {
+  Spectrum16 color;
+  float pos[4];
+  float dir[4];
+  uint32_t shader;
+  uint32_t instance_id;
+  float intensity;
+  uint32_t delta;
+};
+static_assert(sizeof(RTLight) == 112, "RTLight is 112 bytes");
+
+// raytrace_structures.rs:78-85
+struct alignas(16) RTSky {
+  float obj2world[16];
+  float world2obj[16];
+  uint32_t tex_id;
+  float intensity;
+  uint32_t _pad[2];
+};
+static_assert(sizeof(RTSky) == 144, "RTSky is 144 bytes");
+
+// SBT callable indices (light.rs:111-119, material.rs:244-258)
+enum : uint32_t {
+  kLightOmni = 0, kLightSun = 1, kLightArea = 2, kLightSky = 3,
+  kBsdfLambert = 4, kBsdfMirror = 6, kBsdfGlass = 8, kBsdfMetal = 10, kBsdfFrosted = 12, kBsdfUber = 14
+};
+
+// Texture descriptor: texels of all textures live in one byte pool.
+struct TexDesc {
+  uint32_t offset;    // byte offset of level 0 in the pool
+  uint32_t width, height;
+  uint32_t format;    // GLZ_TEX_GRAY / RGBA_SRGB / RGBA_NORM
+};
+
+// Object<->world matrices of one transform: column-major mat4 (as uploaded by the reference,
+// scene.rs load_transforms_to_gpu) and its inverse (what the driver exposes as gl_WorldToObjectEXT).
+struct TransformPair {
+  float o2w[16];
+  float w2o[16];
+};
+
+// BVH2 node, 64 bytes: both children's boxes + child links (>= 0 inner node, < 0 ~leaf).
+struct alignas(16) BvhNode {
+  float lo0[3]; int32_t child0;
+  float hi0[3]; int32_t child1;
+  float lo1[3]; uint32_t _p0;
+  float hi1[3]; uint32_t _p1;
+};
+static_assert(sizeof(BvhNode) == 64, "BvhNode is 64 bytes");
+
+// World-space triangle in BVH leaf order, 48 bytes (36 algorithmic + ids).
+struct alignas(16) BvhTri {
+  float v0[3]; uint32_t world_id;   // instance-major id: tie-break key for equal t
+  float e1[3]; uint32_t instance;
+  float e2[3]; uint32_t prim_flags; // bit 31: non-opaque (alpha tested), bits 0-30: primitive in instance
+};
+static_assert(sizeof(BvhTri) == 48, "BvhTri is 48 bytes");
+
+// Sky table header following RTSky in the reference SSBO (light_sky_sample_visible.rcall:19-26)
+struct SkyHeader {
+  uint32_t marginal_cdf_count;
+  uint32_t conditional_integral_offset;
+  uint32_t conditional_cdf_count;
+  float marginal_integral;
+};
+
+// Everything the kernels need about a scene (device pointers).
+struct DeviceScene {
+  const float4* vertices;          // 2 x float4 per vertex (VertexPacked, raytrace_commons.glsl:11-14)
+  const uint32_t* indices;
+  const RTInstance* instances;
+  const RTMaterial* materials;
+  const RTLight* lights;
+  const TransformPair* transforms;
+  const float4* derivatives;       // 3 x float4 per object triangle (normal, dpdu, dpdv)
+  const TexDesc* tex_desc;
+  const uint8_t* tex_pool;
+  const float* srgb_lut;           // 256 entries
+  const BvhNode* bvh_nodes;
+  const BvhTri* bvh_tris;
+  uint32_t n_world_tris;
+  uint32_t n_textures;
+  // sky
+  RTSky sky;
+  SkyHeader sky_header;
+  const float* sky_marginal;       // cdf (H+1) | values (H) | conditional integrals (H)
+  const float* sky_cond_values;    // W x H
+  const float* sky_cond_cdf;       // (W+1) x H
+  uint32_t sky_w, sky_h;
+};
+
+}  // namespace glz

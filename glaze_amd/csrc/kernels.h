@@ -1,0 +1,89 @@
+// Host-callable launchers of the HIP kernels (kernels_build.hip, kernels_render.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device/types.h"
+
+namespace glz {
+
+// ---- scene build --------------------------------------------------------------------------------
+hipError_t launch_derivatives(hipStream_t st, const float4* vertices, const uint32_t* indices, uint32_t n_tris, float4* out);
+
+struct LbvhInputs {
+  const float4* vertices;
+  const uint32_t* indices;
+  const RTInstance* instances;
+  const uint32_t* inst_base;   // exclusive prefix sum of triangles per instance (n_instances entries)
+  uint32_t n_instances;
+  const TransformPair* transforms;
+  const RTMaterial* materials;
+  uint32_t n_world;
+};
+struct LbvhOutputs {
+  BvhNode* nodes;   // max(n_world - 1, 1) entries, preallocated
+  BvhTri* tris;     // n_world entries, preallocated, leaf order
+  uint32_t depth;   // number of inner nodes above the deepest leaf
+  float sah;
+  float bounds_lo[3], bounds_hi[3];
+};
+hipError_t build_lbvh(hipStream_t st, const LbvhInputs& in, LbvhOutputs& out);
+
+// ---- rendering ------------------------------------------------------------------------------------
+// Per-pixel wavefront state, indexed by the LOCAL pixel id `lid` (tile-major, one wave = one 8x8 block):
+//   lid = ((local_tile * 64 + sub_block) * 64 + lane)
+struct PathState {
+  float4* ray_o;     // origin.xyz, bounce number        (PTLastVertex.hit, raytrace_structures.rs:89-95)
+  float4* ray_d;     // direction.xyz, last-bounce-specular flag (PTLastVertex.wi)
+  float4* imp[4];    // importance spectrum, 4 x vec4    (PTLastVertex.importance)
+  float4* hit;       // t, u, v, leaf index (bits)       closest-hit record of the current launch
+  float4* sh_o;      // shadow ray origin.xyz, tmax
+  float4* sh_d;      // shadow ray direction.xyz, -
+  float4* contrib;   // rgb radiance to add if unoccluded, flags (bits)
+  float4* cumulative;// accumulate_image (xyz = sum rgb, w = launches)
+  float4* result;    // result_image (out32)
+  uint32_t* overflow;// traversal stack spill, `overflow_depth` words per pixel
+  uint32_t overflow_depth;
+};
+
+struct TileMap {
+  uint32_t width, height;
+  uint32_t tiles_x, tiles_y;
+  uint32_t rank, world;      // this renderer owns global tiles t with t % world == rank
+  uint32_t n_local_tiles;
+  uint32_t n_local_pixels;   // n_local_tiles * 4096
+};
+
+struct CameraConsts {
+  float camera2world[16];
+  float screen2camera[16];
+};
+
+struct TraceCounters {
+  unsigned long long closest_rays, shadow_rays, closest_nodes, closest_tris, shadow_nodes, shadow_tris, hits;
+};
+
+struct LaunchArgs {
+  DeviceScene scene;
+  PathState st;
+  TileMap map;
+  FrameData frame;
+  CameraConsts cam;
+  TraceCounters* counters;   // nullptr unless counting is enabled
+};
+
+hipError_t launch_trace_closest(hipStream_t st, const LaunchArgs& a);
+hipError_t launch_shade(hipStream_t st, const LaunchArgs& a);
+hipError_t launch_shadow_accumulate(hipStream_t st, const LaunchArgs& a);
+// scatter the tile-major cumulative / result images into full-frame row-major RGBA32F buffers
+hipError_t launch_export(hipStream_t st, const TileMap& map, const float4* tiled, float4* frame, bool zero_first);
+// result (out32) -> RGBA8 sRGB, full-frame row-major (the blit of raytracer.rs:576-584)
+hipError_t launch_tonemap(hipStream_t st, uint32_t n_pixels, const float4* result_frame, uchar4* out);
+
+// debug / parity hooks
+hipError_t launch_debug_closest(hipStream_t st, const DeviceScene& scene, const float* origins, const float* dirs, uint32_t n, float tmin,
+                                float* t, uint32_t* tri, uint32_t* inst, float* u, float* v, uint32_t* overflow, uint32_t overflow_depth);
+hipError_t launch_debug_any(hipStream_t st, const DeviceScene& scene, const float* origins, const float* dirs, const float* tmax, uint32_t n,
+                            float tmin, uint8_t* hit, uint32_t* overflow, uint32_t overflow_depth);
+
+}  // namespace glz

@@ -1,0 +1,450 @@
+// Scene-build kernels for gfx950: per-triangle derivatives, instance flattening, and the LBVH
+// (Morton codes -> bitonic sort -> Karras hierarchy -> bottom-up fit) that replaces the driver's
+// BLAS/TLAS build (lib/src/vulkan/acceleration.rs:89-494).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "device/math.h"
+#include "device/types.h"
+#include "kernels.h"
+
+namespace glz {
+using namespace dev;
+
+// ---------------------------------------------------------------------------------------------
+// generate_derivatives.comp:23-64 -- one thread per object-space triangle, 48 bytes out
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_tri_derivatives(const float4* __restrict__ vertices, const uint32_t* __restrict__ indices,
+                                                         uint32_t n_tris, float4* __restrict__ out) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_tris) return;
+  const uint32_t i0 = indices[3 * t], i1 = indices[3 * t + 1], i2 = indices[3 * t + 2];
+  const float4 a0 = vertices[2 * i0], a1 = vertices[2 * i0 + 1];
+  const float4 b0 = vertices[2 * i1], b1 = vertices[2 * i1 + 1];
+  const float4 c0 = vertices[2 * i2], c1 = vertices[2 * i2 + 1];
+  const vec3 p0 = mk3(a0.x, a0.y, a0.z), p1 = mk3(b0.x, b0.y, b0.z), p2 = mk3(c0.x, c0.y, c0.z);
+  // texcoords are the last two floats of the packed vertex (raytrace_commons.glsl:28-31)
+  const float duv02x = a1.z - c1.z, duv02y = a1.w - c1.w;
+  const float duv12x = b1.z - c1.z, duv12y = b1.w - c1.w;
+  const float det = duv02x * duv12y - duv02y * duv12x;
+  const vec3 n = normalize3(cross3(p1 - p0, p2 - p0));
+  vec3 dpdu, dpdv;
+  if (det == 0.0f) {
+    if (fabsf(n.x) > fabsf(n.y)) dpdu = mk3(-n.z, 0.0f, n.x) / sqrtf(n.x * n.x + n.z * n.z);
+    else dpdu = mk3(0.0f, n.z, -n.y) / sqrtf(n.y * n.y + n.z * n.z);
+    dpdv = cross3(n, dpdu);
+  } else {
+    const vec3 dp02 = p0 - p2, dp12 = p1 - p2;
+    const float invdet = 1.0f / det;
+    dpdu = (duv12y * dp02 - duv02y * dp12) * invdet;
+    dpdv = ((-duv12x) * dp02 + duv02x * dp12) * invdet;
+  }
+  out[3 * t] = make_float4(n.x, n.y, n.z, 0.0f);
+  out[3 * t + 1] = make_float4(dpdu.x, dpdu.y, dpdu.z, 0.0f);
+  out[3 * t + 2] = make_float4(dpdv.x, dpdv.y, dpdv.z, 0.0f);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Instance flattening: world triangle w -> (instance, primitive), world-space v0/e1/e2 + AABB.
+// Scene bounds are reduced per block in LDS, then one ordered-int atomic per block and axis.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int float_to_ordered(float f) {
+  int i = __float_as_int(f);
+  return i >= 0 ? i : i ^ 0x7FFFFFFF;
+}
+__device__ __forceinline__ float ordered_to_float(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7FFFFFFF); }
+
+__global__ void __launch_bounds__(256) k_world_tris(const float4* __restrict__ vertices, const uint32_t* __restrict__ indices,
+                                                    const RTInstance* __restrict__ instances, const uint32_t* __restrict__ inst_base,
+                                                    uint32_t n_instances, const TransformPair* __restrict__ transforms,
+                                                    const RTMaterial* __restrict__ materials, uint32_t n_world,
+                                                    BvhTri* __restrict__ tris, float4* __restrict__ box_lo, float4* __restrict__ box_hi,
+                                                    int* __restrict__ scene_bounds /* 6 ordered ints: centroid lo xyz, hi xyz */) {
+  __shared__ float s_lo[3][256], s_hi[3][256];
+  const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+  float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  if (w < n_world) {
+    // binary search: last instance whose first world triangle is <= w
+    uint32_t lo = 0, hi = n_instances - 1;
+    while (lo < hi) {
+      uint32_t mid = (lo + hi + 1) >> 1;
+      if (inst_base[mid] <= w) lo = mid; else hi = mid - 1;
+    }
+    const uint32_t inst = lo, prim = w - inst_base[inst];
+    const RTInstance in = instances[inst];
+    const uint32_t* ix = indices + in.index_offset + 3 * prim;
+    const float* M = transforms[in.transform_id].o2w;
+    vec3 v[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float4 p = vertices[2 * ix[k]];
+      v[k] = xform_point(M, mk3(p.x, p.y, p.z));
+    }
+    const vec3 e1 = v[1] - v[0], e2 = v[2] - v[0];
+    BvhTri t;
+    t.v0[0] = v[0].x; t.v0[1] = v[0].y; t.v0[2] = v[0].z; t.world_id = w;
+    t.e1[0] = e1.x; t.e1[1] = e1.y; t.e1[2] = e1.z; t.instance = inst;
+    t.e2[0] = e2.x; t.e2[1] = e2.y; t.e2[2] = e2.z;
+    t.prim_flags = prim | (materials[in.material_id].opacity != 0 ? 0x80000000u : 0u);   // acceleration.rs:136-141
+    tris[w] = t;
+    const float* A = &v[0].x; const float* B = &v[1].x; const float* C = &v[2].x;
+    float l[3], h[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      l[k] = fminf(A[k], fminf(B[k], C[k]));
+      h[k] = fmaxf(A[k], fmaxf(B[k], C[k]));
+      // conservative pad: the ray/triangle test may accept points a few ulps outside the exact box
+      const float pad = 1e-5f * fmaxf(fmaxf(fabsf(l[k]), fabsf(h[k])), 1e-3f);
+      l[k] -= pad; h[k] += pad;
+      clo[k] = chi[k] = 0.5f * (l[k] + h[k]);
+    }
+    box_lo[w] = make_float4(l[0], l[1], l[2], 0.0f);
+    box_hi[w] = make_float4(h[0], h[1], h[2], 0.0f);
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { s_lo[k][threadIdx.x] = clo[k]; s_hi[k][threadIdx.x] = chi[k]; }
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        s_lo[k][threadIdx.x] = fminf(s_lo[k][threadIdx.x], s_lo[k][threadIdx.x + s]);
+        s_hi[k][threadIdx.x] = fmaxf(s_hi[k][threadIdx.x], s_hi[k][threadIdx.x + s]);
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 3) {
+    atomicMin(&scene_bounds[threadIdx.x], float_to_ordered(s_lo[threadIdx.x][0]));
+    atomicMax(&scene_bounds[3 + threadIdx.x], float_to_ordered(s_hi[threadIdx.x][0]));
+  }
+}
+
+// 21 bits per axis interleaved to a 63-bit Morton code
+__device__ __forceinline__ uint64_t spread21(uint64_t x) {
+  x &= 0x1FFFFFull;
+  x = (x | x << 32) & 0x1F00000000FFFFull;
+  x = (x | x << 16) & 0x1F0000FF0000FFull;
+  x = (x | x << 8) & 0x100F00F00F00F00Full;
+  x = (x | x << 4) & 0x10C30C30C30C30C3ull;
+  x = (x | x << 2) & 0x1249249249249249ull;
+  return x;
+}
+
+__global__ void __launch_bounds__(256) k_morton(const float4* __restrict__ box_lo, const float4* __restrict__ box_hi,
+                                                const int* __restrict__ scene_bounds, uint32_t n, uint32_t n_padded,
+                                                uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_padded) return;
+  if (i >= n) {   // padding of the power-of-two bitonic network sorts to the end
+    keys[i] = ~0ull;
+    vals[i] = 0xFFFFFFFFu;
+    return;
+  }
+  float q[3];
+  const float4 l = box_lo[i], h = box_hi[i];
+  const float c[3] = {0.5f * (l.x + h.x), 0.5f * (l.y + h.y), 0.5f * (l.z + h.z)};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float lo = ordered_to_float(scene_bounds[k]), hi = ordered_to_float(scene_bounds[3 + k]);
+    const float ext = hi - lo;
+    float t = ext > 0.0f ? (c[k] - lo) / ext : 0.0f;
+    t = fminf(fmaxf(t, 0.0f), 1.0f);
+    q[k] = fminf(t * 2097152.0f, 2097151.0f);
+  }
+  keys[i] = (spread21((uint64_t)q[0]) << 2) | (spread21((uint64_t)q[1]) << 1) | spread21((uint64_t)q[2]);
+  vals[i] = i;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Bitonic sort of (key, value) pairs, n a power of two.  Strides >= 1024 run one compare-exchange
+// per launch in global memory; all strides below are fused in LDS (2048 pairs per 1024-thread block).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool key_greater(uint64_t ka, uint32_t va, uint64_t kb, uint32_t vb) {
+  return ka > kb || (ka == kb && va > vb);
+}
+
+__global__ void __launch_bounds__(256) k_bitonic_global(uint64_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t n, uint32_t k,
+                                                        uint32_t j) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;   // one thread per pair
+  if (t >= n / 2) return;
+  const uint32_t i = 2 * t - (t & (j - 1));   // index with bit j cleared
+  const uint32_t p = i + j;
+  const bool up = (i & k) == 0;
+  const uint64_t ka = keys[i], kb = keys[p];
+  const uint32_t va = vals[i], vb = vals[p];
+  if (key_greater(ka, va, kb, vb) == up) {
+    keys[i] = kb; keys[p] = ka;
+    vals[i] = vb; vals[p] = va;
+  }
+}
+
+constexpr uint32_t kSortTile = 2048;
+__global__ void __launch_bounds__(1024) k_bitonic_lds(uint64_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t n, uint32_t k_first,
+                                                      uint32_t k_last, uint32_t j_first) {
+  // Runs, for k = k_first..k_last (doubling), the strides j = min(j_first or k/2, 1024) .. 1 inside one tile.
+  __shared__ uint64_t s_k[kSortTile];
+  __shared__ uint32_t s_v[kSortTile];
+  const uint32_t base = blockIdx.x * kSortTile;
+  for (uint32_t t = threadIdx.x; t < kSortTile; t += blockDim.x) {
+    s_k[t] = keys[base + t];
+    s_v[t] = vals[base + t];
+  }
+  __syncthreads();
+  for (uint32_t k = k_first; k <= k_last; k <<= 1) {
+    uint32_t j = (k == k_first && j_first) ? j_first : k >> 1;
+    if (j > kSortTile / 2) j = kSortTile / 2;
+    for (; j > 0; j >>= 1) {
+      const uint32_t t = threadIdx.x;
+      const uint32_t i = 2 * t - (t & (j - 1));
+      const uint32_t p = i + j;
+      const bool up = ((base + i) & k) == 0;
+      const uint64_t ka = s_k[i], kb = s_k[p];
+      const uint32_t va = s_v[i], vb = s_v[p];
+      if (key_greater(ka, va, kb, vb) == up) {
+        s_k[i] = kb; s_k[p] = ka;
+        s_v[i] = vb; s_v[p] = va;
+      }
+      __syncthreads();
+    }
+  }
+  for (uint32_t t = threadIdx.x; t < kSortTile; t += blockDim.x) {
+    keys[base + t] = s_k[t];
+    vals[base + t] = s_v[t];
+  }
+}
+
+// gathers triangles and boxes into leaf (sorted) order
+__global__ void __launch_bounds__(256) k_gather_leaves(const uint32_t* __restrict__ vals, uint32_t n, const BvhTri* __restrict__ tris_in,
+                                                       const float4* __restrict__ lo_in, const float4* __restrict__ hi_in,
+                                                       BvhTri* __restrict__ tris_out, float4* __restrict__ node_lo,
+                                                       float4* __restrict__ node_hi) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t src = vals[i];
+  tris_out[i] = tris_in[src];
+  node_lo[(n - 1) + i] = lo_in[src];   // leaf j's box lives at slot (n-1)+j, inner node i's at slot i
+  node_hi[(n - 1) + i] = hi_in[src];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Karras 2012: one thread per internal node finds its key range and split
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int common_prefix(const uint64_t* __restrict__ keys, int n, int i, int j) {
+  if (j < 0 || j >= n) return -1;
+  const uint64_t x = keys[i] ^ keys[j];
+  if (x == 0) return 64 + __clz(i ^ j);   // duplicate codes: fall back to the index bits
+  return __clzll((long long)x);
+}
+
+__global__ void __launch_bounds__(256) k_hierarchy(const uint64_t* __restrict__ keys, int n, int2* __restrict__ children,
+                                                   int* __restrict__ parent) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n - 1) return;
+  const int d = common_prefix(keys, n, i, i + 1) - common_prefix(keys, n, i, i - 1) >= 0 ? 1 : -1;
+  const int dmin = common_prefix(keys, n, i, i - d);
+  int lmax = 2;
+  while (common_prefix(keys, n, i, i + lmax * d) > dmin) lmax <<= 1;
+  int l = 0;
+  for (int t = lmax >> 1; t > 0; t >>= 1)
+    if (common_prefix(keys, n, i, i + (l + t) * d) > dmin) l += t;
+  const int j = i + l * d;
+  const int dnode = common_prefix(keys, n, i, j);
+  int s = 0;
+  for (int t = (l + 1) >> 1;; t = (t + 1) >> 1) {
+    if (common_prefix(keys, n, i, i + (s + t) * d) > dnode) s += t;
+    if (t <= 1) break;
+  }
+  const int gamma = i + s * d + min(d, 0);
+  const int lo = min(i, j), hi = max(i, j);
+  // child link: >= 0 inner node, < 0 ~leaf
+  const int left = (lo == gamma) ? ~gamma : gamma;
+  const int right = (hi == gamma + 1) ? ~(gamma + 1) : gamma + 1;
+  children[i] = make_int2(left, right);
+  parent[left >= 0 ? left : (n - 1) + ~left] = i;
+  parent[right >= 0 ? right : (n - 1) + ~right] = i;
+  if (i == 0) parent[0] = -1;
+}
+
+// Bottom-up fit: the second thread to reach a node merges its children.  Visibility between
+// workgroups goes through agent-scope fences around the arrival counter (L1 is per CU and the
+// per-XCD L2s are not coherent: cdna_hip_programming.md Guideline 16).
+__global__ void __launch_bounds__(256) k_fit(int n, const int2* __restrict__ children, const int* __restrict__ parent,
+                                             float4* node_lo, float4* node_hi, int* __restrict__ arrivals, int* __restrict__ max_depth) {
+  const int leaf = blockIdx.x * blockDim.x + threadIdx.x;
+  if (leaf >= n) return;
+  int node = parent[(n - 1) + leaf];
+  int depth = 1;
+  while (node >= 0) {
+    __threadfence();   // release: this thread's box stores (leaf or merged) before the arrival
+    const int seen = atomicAdd(&arrivals[node], 1);
+    if (seen == 0) return;   // first arrival: the sibling subtree is not finished yet
+    __threadfence();   // acquire: the sibling's box stores
+    const int2 c = children[node];
+    const int s0 = c.x >= 0 ? c.x : (n - 1) + ~c.x, s1 = c.y >= 0 ? c.y : (n - 1) + ~c.y;
+    const float4 l0 = node_lo[s0], l1 = node_lo[s1];
+    const float4 h0 = node_hi[s0], h1 = node_hi[s1];
+    node_lo[node] = make_float4(fminf(l0.x, l1.x), fminf(l0.y, l1.y), fminf(l0.z, l1.z), 0.0f);
+    node_hi[node] = make_float4(fmaxf(h0.x, h1.x), fmaxf(h0.y, h1.y), fmaxf(h0.z, h1.z), 0.0f);
+    node = parent[node];
+    ++depth;
+  }
+  atomicMax(max_depth, depth);
+}
+
+// leaf depth = number of ancestors + 1 (for sizing the traversal stack)
+__global__ void __launch_bounds__(256) k_leaf_depth(int n, const int* __restrict__ parent, int* __restrict__ max_depth) {
+  const int leaf = blockIdx.x * blockDim.x + threadIdx.x;
+  if (leaf >= n) return;
+  int depth = 0;
+  for (int node = parent[(n - 1) + leaf]; node >= 0; node = parent[node]) ++depth;
+  atomicMax(max_depth, depth);
+}
+
+__global__ void __launch_bounds__(256) k_emit_nodes(int n, const int2* __restrict__ children, const float4* __restrict__ node_lo,
+                                                    const float4* __restrict__ node_hi, BvhNode* __restrict__ nodes, float* __restrict__ sah) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n - 1) return;
+  const int2 c = children[i];
+  const int s0 = c.x >= 0 ? c.x : (n - 1) + ~c.x, s1 = c.y >= 0 ? c.y : (n - 1) + ~c.y;
+  const float4 l0 = node_lo[s0], h0 = node_hi[s0], l1 = node_lo[s1], h1 = node_hi[s1];
+  BvhNode nd;
+  nd.lo0[0] = l0.x; nd.lo0[1] = l0.y; nd.lo0[2] = l0.z; nd.child0 = c.x;
+  nd.hi0[0] = h0.x; nd.hi0[1] = h0.y; nd.hi0[2] = h0.z; nd.child1 = c.y;
+  nd.lo1[0] = l1.x; nd.lo1[1] = l1.y; nd.lo1[2] = l1.z; nd._p0 = 0;
+  nd.hi1[0] = h1.x; nd.hi1[1] = h1.y; nd.hi1[2] = h1.z; nd._p1 = 0;
+  nodes[i] = nd;
+  // SAH cost numerator: sum of surface areas of inner nodes (1.2) and leaves (1.0), normalised on the host
+  auto area = [](float4 l, float4 h) { float dx = h.x - l.x, dy = h.y - l.y, dz = h.z - l.z; return 2.0f * (dx * dy + dy * dz + dz * dx); };
+  float acc = 1.2f * area(node_lo[i], node_hi[i]);
+  if (c.x < 0) acc += area(l0, h0);
+  if (c.y < 0) acc += area(l1, h1);
+  atomicAdd(sah, acc);
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-side launcher
+// ---------------------------------------------------------------------------------------------
+#define GLZ_LAUNCH_CHECK()                         \
+  do {                                             \
+    hipError_t e_ = hipGetLastError();             \
+    if (e_ != hipSuccess) return e_;               \
+  } while (0)
+
+hipError_t launch_derivatives(hipStream_t st, const float4* vertices, const uint32_t* indices, uint32_t n_tris, float4* out) {
+  if (n_tris == 0) return hipSuccess;
+  // the reference dispatches (triangles/256)+1 groups of 256 (scene.rs:2162)
+  hipLaunchKernelGGL(k_tri_derivatives, dim3(n_tris / 256 + 1), dim3(256), 0, st, vertices, indices, n_tris, out);
+  return hipGetLastError();
+}
+
+static uint32_t next_pow2(uint32_t v) {
+  uint32_t p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+hipError_t build_lbvh(hipStream_t st, const LbvhInputs& in, LbvhOutputs& out) {
+  const uint32_t n = in.n_world;
+  out.depth = 0;
+  out.sah = 0.0f;
+  if (n == 0) return hipSuccess;
+  const uint32_t np = std::max<uint32_t>(next_pow2(n), kSortTile);
+  hipError_t e;
+  BvhTri* tris_unsorted = nullptr;
+  float4 *lo = nullptr, *hi = nullptr, *node_lo = nullptr, *node_hi = nullptr;
+  uint64_t* keys = nullptr;
+  uint32_t* vals = nullptr;
+  int2* children = nullptr;
+  int *parent = nullptr, *arrivals = nullptr, *scalars = nullptr;
+  float* sah = nullptr;
+  auto cleanup = [&]() {
+    hipFree(tris_unsorted); hipFree(lo); hipFree(hi); hipFree(node_lo); hipFree(node_hi); hipFree(keys); hipFree(vals);
+    hipFree(children); hipFree(parent); hipFree(arrivals); hipFree(scalars); hipFree(sah);
+  };
+#define GLZ_TRY(x) do { e = (x); if (e != hipSuccess) { cleanup(); return e; } } while (0)
+  GLZ_TRY(hipMalloc(&tris_unsorted, sizeof(BvhTri) * n));
+  GLZ_TRY(hipMalloc(&lo, sizeof(float4) * n));
+  GLZ_TRY(hipMalloc(&hi, sizeof(float4) * n));
+  GLZ_TRY(hipMalloc(&node_lo, sizeof(float4) * (2 * (size_t)n)));
+  GLZ_TRY(hipMalloc(&node_hi, sizeof(float4) * (2 * (size_t)n)));
+  GLZ_TRY(hipMalloc(&keys, sizeof(uint64_t) * np));
+  GLZ_TRY(hipMalloc(&vals, sizeof(uint32_t) * np));
+  GLZ_TRY(hipMalloc(&children, sizeof(int2) * n));
+  GLZ_TRY(hipMalloc(&parent, sizeof(int) * (2 * (size_t)n)));
+  GLZ_TRY(hipMalloc(&arrivals, sizeof(int) * n));
+  GLZ_TRY(hipMalloc(&scalars, sizeof(int) * 8));
+  GLZ_TRY(hipMalloc(&sah, sizeof(float)));
+  GLZ_TRY(hipMemsetAsync(arrivals, 0, sizeof(int) * n, st));
+  GLZ_TRY(hipMemsetAsync(sah, 0, sizeof(float), st));
+  {
+    // ordered-int encodings of +inf / -inf, then depth counter
+    const int init[8] = {0x7F800000, 0x7F800000, 0x7F800000, (int)0xFF800000 ^ 0x7FFFFFFF, (int)0xFF800000 ^ 0x7FFFFFFF,
+                         (int)0xFF800000 ^ 0x7FFFFFFF, 0, 0};
+    GLZ_TRY(hipMemcpyAsync(scalars, init, sizeof(init), hipMemcpyHostToDevice, st));
+  }
+  const dim3 blk(256), grd((n + 255) / 256);
+  hipLaunchKernelGGL(k_world_tris, grd, blk, 0, st, in.vertices, in.indices, in.instances, in.inst_base, in.n_instances, in.transforms,
+                     in.materials, n, tris_unsorted, lo, hi, scalars);
+  GLZ_TRY(hipGetLastError());
+  hipLaunchKernelGGL(k_morton, dim3((np + 255) / 256), blk, 0, st, lo, hi, scalars, n, np, keys, vals);
+  GLZ_TRY(hipGetLastError());
+  // bitonic network: stages k = 2..np; strides j = k/2..1
+  hipLaunchKernelGGL(k_bitonic_lds, dim3(np / kSortTile), dim3(1024), 0, st, keys, vals, np, 2u, kSortTile, 0u);
+  GLZ_TRY(hipGetLastError());
+  for (uint32_t k = kSortTile * 2; k <= np; k <<= 1) {
+    for (uint32_t j = k >> 1; j >= kSortTile; j >>= 1) {
+      hipLaunchKernelGGL(k_bitonic_global, dim3((np / 2 + 255) / 256), blk, 0, st, keys, vals, np, k, j);
+      GLZ_TRY(hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_bitonic_lds, dim3(np / kSortTile), dim3(1024), 0, st, keys, vals, np, k, k, kSortTile / 2);
+    GLZ_TRY(hipGetLastError());
+  }
+  hipLaunchKernelGGL(k_gather_leaves, grd, blk, 0, st, vals, n, tris_unsorted, lo, hi, out.tris, node_lo, node_hi);
+  GLZ_TRY(hipGetLastError());
+  if (n >= 2) {
+    hipLaunchKernelGGL(k_hierarchy, grd, blk, 0, st, keys, (int)n, children, parent);
+    GLZ_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_fit, grd, blk, 0, st, (int)n, children, parent, node_lo, node_hi, arrivals, scalars + 7);
+    GLZ_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_leaf_depth, grd, blk, 0, st, (int)n, parent, scalars + 6);
+    GLZ_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_emit_nodes, grd, blk, 0, st, (int)n, children, node_lo, node_hi, out.nodes, sah);
+    GLZ_TRY(hipGetLastError());
+  }
+  int host_scalars[8];
+  float host_sah = 0.0f;
+  float4 root_lo, root_hi;
+  GLZ_TRY(hipMemcpyAsync(host_scalars, scalars, sizeof(host_scalars), hipMemcpyDeviceToHost, st));
+  GLZ_TRY(hipMemcpyAsync(&host_sah, sah, sizeof(float), hipMemcpyDeviceToHost, st));
+  GLZ_TRY(hipMemcpyAsync(&root_lo, node_lo, sizeof(float4), hipMemcpyDeviceToHost, st));
+  GLZ_TRY(hipMemcpyAsync(&root_hi, node_hi, sizeof(float4), hipMemcpyDeviceToHost, st));
+  GLZ_TRY(hipStreamSynchronize(st));
+  if (n == 1) {
+    // single triangle: one inner node whose second child is an empty box
+    BvhNode nd{};
+    float4 l, h;
+    GLZ_TRY(hipMemcpy(&l, node_lo + 0, sizeof(float4), hipMemcpyDeviceToHost));   // slot (n-1)+0 = 0
+    GLZ_TRY(hipMemcpy(&h, node_hi + 0, sizeof(float4), hipMemcpyDeviceToHost));
+    nd.lo0[0] = l.x; nd.lo0[1] = l.y; nd.lo0[2] = l.z; nd.hi0[0] = h.x; nd.hi0[1] = h.y; nd.hi0[2] = h.z;
+    nd.child0 = ~0;
+    nd.lo1[0] = nd.lo1[1] = nd.lo1[2] = INFINITY; nd.hi1[0] = nd.hi1[1] = nd.hi1[2] = -INFINITY;
+    nd.child1 = ~0;
+    GLZ_TRY(hipMemcpy(out.nodes, &nd, sizeof(nd), hipMemcpyHostToDevice));
+    root_lo = l; root_hi = h;
+    out.depth = 1;
+  } else {
+    out.depth = (uint32_t)host_scalars[6];
+    const float dx = root_hi.x - root_lo.x, dy = root_hi.y - root_lo.y, dz = root_hi.z - root_lo.z;
+    const float ra = 2.0f * (dx * dy + dy * dz + dz * dx);
+    out.sah = ra > 0.0f ? host_sah / ra : 0.0f;
+  }
+  out.bounds_lo[0] = root_lo.x; out.bounds_lo[1] = root_lo.y; out.bounds_lo[2] = root_lo.z;
+  out.bounds_hi[0] = root_hi.x; out.bounds_hi[1] = root_hi.y; out.bounds_hi[2] = root_hi.z;
+  cleanup();
+#undef GLZ_TRY
+  return hipSuccess;
+}
+
+}  // namespace glz

@@ -1,0 +1,85 @@
+// RayTraceRenderer on HIP (lib/src/vulkan/raytracer.rs:109-687): launch loop, per-launch frame
+// constants, accumulation buffers, tile partition for one-process-per-GPU jobs.
+#pragma once
+#include <memory>
+#include <vector>
+
+#include "host_math.h"
+#include "kernels.h"
+#include "scene.h"
+
+namespace glz {
+
+class Renderer {
+ public:
+  static Renderer* create(Instance* inst, Scene* scene /* owned from here on; may be null */, uint32_t w, uint32_t h, Error& err);
+  ~Renderer();
+
+  bool set_integrator(int integrator, Error& err);
+  bool set_exposure(float e);
+  bool update_camera(const glz_camera& c, Error& err);
+  bool change_resolution(uint32_t w, uint32_t h, Error& err);
+  bool change_scene(Scene* scene, Error& err);
+  bool update_materials_and_lights(const glz_material* m, uint32_t nm, const glz_light* l, uint32_t nl, Error& err);
+  bool wait_idle(Error& err);
+  uint32_t steps_per_sample() const { return integrator_ == GLZ_DIRECT ? 1u : pt_steps_; }
+
+  bool draw(size_t spp, void (*cb)(void*), void* user, uint8_t* rgba8_out, Error& err);
+  bool restart();
+  bool step(uint32_t n, Error& err);
+  bool read_rgba8(uint8_t* out, Error& err);
+  bool read_frame(bool result, float* out, Error& err);
+
+  bool set_seed(uint64_t s);
+  bool set_depth(uint32_t d, Error& err);
+  bool set_partition(uint32_t rank, uint32_t world, Error& err);
+  bool export_device(int which, void* dev_rgba32f, Error& err);
+  bool tonemap_device(const void* dev_result, uint8_t* out, Error& err);
+  bool launch_constants(uint32_t launch, uint32_t* seed, float off[2]);
+  void push_constants(float out[32]) const;
+  void enable_counters(int flags) { counting_ = (flags & 1) != 0; profile_kernels_ = (flags & 2) != 0; }
+  bool get_stats(glz_render_stats* out, Error& err);
+
+  Instance* instance() const { return inst_; }
+  Scene* scene() const { return scene_.get(); }
+  uint32_t width() const { return w_; }
+  uint32_t height() const { return h_; }
+
+ private:
+  Renderer() = default;
+  bool allocate(Error& err);
+  bool reset_buffers(Error& err);
+  bool one_launch(Error& err);
+  void fill_args(LaunchArgs& a) const;
+
+  Instance* inst_ = nullptr;
+  std::unique_ptr<Scene> scene_;
+  uint32_t w_ = 0, h_ = 0;
+  int integrator_ = GLZ_PATH_TRACE;
+  uint32_t pt_steps_ = 6;   // PT_STEPS, raytrace_structures.rs:87
+  float exposure_ = 1.0f;
+  glz_camera camera_{};
+  CameraConsts cam_{};
+  uint64_t seed_ = 0;
+  host::SeedStream rng_;
+  host::WorkScheduler sched_;
+  bool request_new_frame_ = true;
+  TileMap map_{};
+  // state
+  DeviceBuffer<float4> ray_o_, ray_d_, imp_[4], hit_, sh_o_, sh_d_, contrib_, cumulative_, result_, frame_tmp_;
+  DeviceBuffer<uint32_t> overflow_;
+  DeviceBuffer<uchar4> rgba8_;
+  DeviceBuffer<TraceCounters> counters_;
+  // stats
+  bool counting_ = false;
+  uint64_t launches_ = 0;
+  double render_ms_ = 0, closest_ms_ = 0, shade_ms_ = 0, shadow_ms_ = 0;
+  struct EventSet {
+    hipEvent_t e[4];
+  };
+  std::vector<EventSet> pending_events_;   // per-launch kernel boundaries, resolved lazily in get_stats
+  std::vector<EventSet> free_events_;
+  bool profile_kernels_ = true;
+};
+
+}  // namespace glz

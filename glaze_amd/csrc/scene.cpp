@@ -1,0 +1,455 @@
+// RayTraceInstance::new / RayTraceScene::new on HIP (lib/src/vulkan/instance.rs:376-427,
+// lib/src/vulkan/scene.rs:1414-1556 and the helpers it calls).
+#include "scene.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "host_math.h"
+#include "kernels.h"
+
+namespace glz {
+
+bool hip_ok(hipError_t e, const char* what, Error& err) {
+  if (e == hipSuccess) return true;
+  err.code = GLZ_E_DEVICE;
+  err.msg = std::string(what) + ": " + hipGetErrorString(e);
+  return false;
+}
+
+Instance::~Instance() {
+  if (stream) (void)hipStreamDestroy(stream);
+}
+
+Instance* Instance::create(int hip_device, Error& err) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+    err.code = GLZ_E_DEVICE;
+    err.msg = "no HIP device available";
+    return nullptr;
+  }
+  int chosen = -1;
+  std::string arch;
+  auto arch_of = [](int d) {
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, d) != hipSuccess) return std::string();
+    return std::string(p.gcnArchName);
+  };
+  if (hip_device >= 0) {
+    if (hip_device >= count) {
+      err.code = GLZ_E_ARG;
+      err.msg = "HIP device ordinal out of range";
+      return nullptr;
+    }
+    chosen = hip_device;
+    arch = arch_of(chosen);
+  } else {
+    for (int d = 0; d < count; ++d) {
+      std::string a = arch_of(d);
+      if (a.rfind("gfx950", 0) == 0) {
+        chosen = d;
+        arch = a;
+        break;
+      }
+    }
+  }
+  // the code object is built for gfx950 only: any other device cannot run it (no fallback)
+  if (chosen < 0 || arch.rfind("gfx950", 0) != 0) {
+    err.code = GLZ_E_DEVICE;
+    err.msg = "no gfx950 (MI355X) device found" + (arch.empty() ? std::string() : " (device is " + arch + ")");
+    return nullptr;
+  }
+  if (!hip_ok(hipSetDevice(chosen), "hipSetDevice", err)) return nullptr;
+  Instance* inst = new Instance();
+  inst->device = chosen;
+  inst->arch = arch;
+  if (!hip_ok(hipStreamCreateWithFlags(&inst->stream, hipStreamNonBlocking), "hipStreamCreate", err)) {
+    delete inst;
+    return nullptr;
+  }
+  return inst;
+}
+
+static uint32_t sbt_callable_index(uint8_t mtype) {   // materials/material.rs:244-258
+  switch (mtype) {
+    case GLZ_MAT_FLAT:
+    case GLZ_MAT_LAMBERT: return kBsdfLambert;
+    case GLZ_MAT_MIRROR: return kBsdfMirror;
+    case GLZ_MAT_GLASS: return kBsdfGlass;
+    case GLZ_MAT_METAL: return kBsdfMetal;
+    case GLZ_MAT_FROSTED: return kBsdfFrosted;
+    default: return kBsdfUber;
+  }
+}
+
+Scene* Scene::create(Instance* inst, SceneData&& data, Error& err) {
+  std::unique_ptr<Scene> s(new Scene());
+  s->instance = inst;
+  s->data = std::move(data);
+  SceneData& d = s->data;
+  // defaults for absent pieces (scene.rs:1427-1434, :1467-1469; Texture::default is texture 0)
+  if (d.transforms.empty()) d.transforms.push_back(identity_transform());
+  if (d.materials.empty()) d.materials.push_back(default_material());
+  if (d.textures.empty()) d.textures.push_back(default_texture());
+  for (auto& t : d.textures) t.info.pixels = t.level0.data();
+  if (!hip_ok(hipSetDevice(inst->device), "hipSetDevice", err)) return nullptr;
+  // validate references so that no kernel can index out of bounds
+  for (const glz_mesh& m : d.meshes) {
+    if ((uint64_t)m.index_offset + m.index_count > d.indices.size() || m.index_count % 3 != 0) {
+      err.code = GLZ_E_INVALID_DATA;
+      err.msg = "mesh index range outside the index buffer";
+      return nullptr;
+    }
+    if (m.material >= d.materials.size()) {
+      err.code = GLZ_E_INVALID_DATA;
+      err.msg = "mesh references a missing material";
+      return nullptr;
+    }
+  }
+  for (uint32_t i : d.indices)
+    if (i >= d.vertices.size()) {
+      err.code = GLZ_E_INVALID_DATA;
+      err.msg = "vertex index out of range";
+      return nullptr;
+    }
+  for (const glz_mesh_instance& in : d.instances)
+    if (in.transform_id >= d.transforms.size()) {
+      err.code = GLZ_E_INVALID_DATA;
+      err.msg = "instance references a missing transform";
+      return nullptr;
+    }
+  auto tex_ok = [&](uint32_t id) { return id < d.textures.size(); };
+  for (const glz_material& m : d.materials)
+    if (!tex_ok(m.diffuse) || !tex_ok(m.roughness) || !tex_ok(m.metalness) || !tex_ok(m.normal) || !tex_ok(m.opacity)) {
+      err.code = GLZ_E_INVALID_DATA;
+      err.msg = "material references a missing texture";
+      return nullptr;
+    }
+  if (!s->upload_geometry(err)) return nullptr;
+  if (!s->build_materials(err)) return nullptr;
+  if (!s->build_lights_and_sky(err)) return nullptr;
+  if (!s->build_bvh(err)) return nullptr;
+  if (!hip_ok(hipStreamSynchronize(inst->stream), "scene upload", err)) return nullptr;
+  s->info.n_vertices = d.vertices.size();
+  s->info.n_triangles = d.indices.size() / 3;
+  s->info.n_instances = (uint32_t)s->h_instances.size();
+  s->info.n_materials = (uint32_t)d.materials.size();
+  s->info.n_lights = s->lights_no;
+  s->info.n_rt_lights = (uint32_t)s->h_lights.size();
+  s->info.n_textures = (uint32_t)d.textures.size();
+  return s.release();
+}
+
+bool Scene::upload_geometry(Error& err) {
+  hipStream_t st = instance->stream;
+  SceneData& d = data;
+  static_assert(sizeof(glz_vertex) == 2 * sizeof(float4), "vertex = 2 x float4");
+  if (!hip_ok(d_vertices_.upload(reinterpret_cast<const float4*>(d.vertices.data()), d.vertices.size() * 2, st), "upload vertices", err)) return false;
+  if (!hip_ok(d_indices_.upload(d.indices.data(), d.indices.size(), st), "upload indices", err)) return false;
+  // load_raytrace_instances_to_gpu (scene.rs:1784-1818): meshes indexed by id (last one wins), dangling instances dropped
+  h_instances.clear();
+  for (const glz_mesh_instance& in : d.instances) {
+    const glz_mesh* found = nullptr;
+    for (const glz_mesh& m : d.meshes)
+      if (m.id == in.mesh_id) found = &m;
+    if (!found) continue;
+    h_instances.push_back(RTInstance{found->index_offset, found->index_count, found->material, in.transform_id});
+  }
+  if (!hip_ok(d_instances_.upload(h_instances.data(), h_instances.size(), st), "upload instances", err)) return false;
+  inst_base_.assign(h_instances.size(), 0);
+  uint64_t total = 0;
+  for (size_t i = 0; i < h_instances.size(); ++i) {
+    inst_base_[i] = (uint32_t)total;
+    total += h_instances[i].index_count / 3;
+  }
+  if (total >= 0x7FFFFFFFull) {
+    err.code = GLZ_E_UNSUPPORTED;
+    err.msg = "more than 2^31 world triangles";
+    return false;
+  }
+  info.n_world_triangles = total;
+  if (!hip_ok(d_inst_base_.upload(inst_base_.data(), inst_base_.size(), st), "upload instance bases", err)) return false;
+  // transforms + inverses (gl_WorldToObjectEXT is supplied by the driver in the reference)
+  std::vector<TransformPair> xf(d.transforms.size());
+  for (size_t i = 0; i < xf.size(); ++i) {
+    memcpy(xf[i].o2w, d.transforms[i].m, 64);
+    host::Mat4d inv;
+    if (!host::invert(host::Mat4d::from_f32(d.transforms[i].m), inv)) inv = host::Mat4d::identity();
+    inv.to_f32(xf[i].w2o);
+  }
+  if (!hip_ok(d_transforms_.upload(xf.data(), xf.size(), st), "upload transforms", err)) return false;
+  // textures: one byte pool, level 0 only (16-byte aligned starts)
+  std::vector<TexDesc> desc(d.textures.size());
+  std::vector<uint8_t> pool;
+  for (size_t i = 0; i < d.textures.size(); ++i) {
+    const TextureData& t = d.textures[i];
+    const size_t bytes = (size_t)t.info.width * t.info.height * (t.info.format == GLZ_TEX_GRAY ? 1 : 4);
+    if (t.level0.size() < bytes || t.info.width == 0 || t.info.height == 0 || t.info.format < 1 || t.info.format > 3) {
+      err.code = GLZ_E_INVALID_DATA;
+      err.msg = "texture has inconsistent dimensions";
+      return false;
+    }
+    pool.resize((pool.size() + 15) & ~size_t(15));
+    if (pool.size() + bytes > 0xFFFFFFFFull) {
+      err.code = GLZ_E_UNSUPPORTED;
+      err.msg = "texture pool larger than 4 GiB";
+      return false;
+    }
+    desc[i] = TexDesc{(uint32_t)pool.size(), t.info.width, t.info.height, t.info.format};
+    pool.insert(pool.end(), t.level0.begin(), t.level0.begin() + bytes);
+  }
+  if (!hip_ok(d_tex_desc_.upload(desc.data(), desc.size(), st), "upload texture descriptors", err)) return false;
+  if (!hip_ok(d_tex_pool_.upload(pool.data(), pool.size(), st), "upload texture pool", err)) return false;
+  float lut[256];
+  for (int i = 0; i < 256; ++i) {   // sRGB EOTF of the R8G8B8A8_SRGB format (scene.rs:1028-1032) [ext]
+    const double c = i / 255.0;
+    lut[i] = (float)(c <= 0.04045 ? c / 12.92 : std::pow((c + 0.055) / 1.055, 2.4));
+  }
+  if (!hip_ok(d_srgb_lut_.upload(lut, 256, st), "upload sRGB LUT", err)) return false;
+  // calculate_geometric_derivatives (scene.rs:2113-2188)
+  uint32_t ntri = 0;
+  for (const glz_mesh& m : d.meshes) ntri = std::max<uint32_t>(ntri, (m.index_offset + m.index_count) / 3);
+  if (!hip_ok(d_derivatives_.alloc((size_t)ntri * 3), "alloc derivatives", err)) return false;
+  if (!hip_ok(launch_derivatives(st, d_vertices_.ptr, d_indices_.ptr, ntri, d_derivatives_.ptr), "derivatives kernel", err)) return false;
+  // the host staging vectors above must outlive the async copies
+  if (!hip_ok(hipStreamSynchronize(st), "geometry upload", err)) return false;
+  dev.vertices = d_vertices_.ptr;
+  dev.indices = d_indices_.ptr;
+  dev.instances = d_instances_.ptr;
+  dev.transforms = d_transforms_.ptr;
+  dev.derivatives = d_derivatives_.ptr;
+  dev.tex_desc = d_tex_desc_.ptr;
+  dev.tex_pool = d_tex_pool_.ptr;
+  dev.srgb_lut = d_srgb_lut_.ptr;
+  dev.n_textures = (uint32_t)d.textures.size();
+  return true;
+}
+
+// load_raytrace_materials_to_gpu (scene.rs:1821-1860)
+bool Scene::build_materials(Error& err) {
+  h_materials.clear();
+  for (const glz_material& m : data.materials) {
+    RTMaterial r{};
+    for (int i = 0; i < 3; ++i) {
+      r.diffuse_mul[i] = (float)m.diffuse_mul[i] / 255.0f;   // col_int_to_f32, scene.rs:1930-1937
+      r.emissive_col[i] = m.has_emissive ? (float)m.emissive_col[i] / 255.0f : 0.0f;
+    }
+    r.diffuse_mul[3] = r.emissive_col[3] = 1.0f;
+    const unsigned metal = m.metal < GLZ_METAL_COUNT ? m.metal : 0;
+    for (int i = 0; i < 16; ++i) {
+      const float n = GLZ_METAL_N[metal][i], k = GLZ_METAL_K[metal][i];
+      r.metal_ior.w[i] = n;
+      r.metal_fresnel.w[i] = (n * n) + (k * k);
+    }
+    r.diffuse = m.diffuse;
+    r.roughness = m.roughness;
+    r.metalness = m.metalness;
+    r.opacity = m.opacity;
+    r.normal = m.normal;
+    r.bsdf_index = sbt_callable_index(m.mtype);
+    r.roughness_mul = m.roughness_mul;
+    r.metalness_mul = m.metalness_mul;
+    r.anisotropy = m.anisotropy;
+    r.ior_dielectric = m.ior;
+    r.is_specular = (m.mtype == GLZ_MAT_MIRROR || m.mtype == GLZ_MAT_GLASS) ? 1u : 0u;   // material.rs:103-114
+    r.is_emissive = m.has_emissive ? 1u : 0u;
+    h_materials.push_back(r);
+  }
+  if (!hip_ok(d_materials_.upload(h_materials.data(), h_materials.size(), instance->stream), "upload materials", err)) return false;
+  if (!hip_ok(hipStreamSynchronize(instance->stream), "materials upload", err)) return false;
+  dev.materials = d_materials_.ptr;
+  return true;
+}
+
+// reorder_lights (scene.rs:628-635), load_raytrace_lights_to_gpu (:1863-1927),
+// calculate_skymap_distributions + build_sky_raytrace_buffers (:2191-2313)
+bool Scene::build_lights_and_sky(Error& err) {
+  hipStream_t st = instance->stream;
+  std::vector<glz_light> ordered;
+  const glz_light* sky = nullptr;
+  for (const glz_light& l : data.lights) {
+    if (l.ltype > GLZ_LIGHT_SKY) {
+      err.code = GLZ_E_INVALID_DATA;
+      err.msg = "Invalid enum value for LightType";
+      return false;
+    }
+    if (l.ltype == GLZ_LIGHT_SKY) { if (!sky) sky = &l; }
+    else ordered.push_back(l);
+  }
+  const bool has_sky = sky != nullptr;
+  if (sky) ordered.push_back(*sky);
+  lights_no = (uint32_t)ordered.size();   // scene.rs:1549 -- NOT the number of expanded RTLights
+  h_lights.clear();
+  for (const glz_light& l : ordered) {
+    RTLight r{};
+    memcpy(r.color.w, l.color, 64);
+    float dx = l.direction[0], dy = l.direction[1], dz = l.direction[2];
+    if (dx == 0.0f && dy == 0.0f && dz == 0.0f) dy = -1.0f;
+    // the reference calls `dir.normalize()` and drops the result: directions stay un-normalised (Q14)
+    r.pos[0] = l.position[0]; r.pos[1] = l.position[1]; r.pos[2] = l.position[2];
+    r.dir[0] = dx; r.dir[1] = dy; r.dir[2] = dz;
+    r.shader = l.ltype;   // sbt_callable_index, light.rs:111-119
+    r.instance_id = 0xFFFFFFFFu;
+    r.intensity = l.intensity;
+    r.delta = (l.ltype == GLZ_LIGHT_OMNI || l.ltype == GLZ_LIGHT_SUN) ? 1u : 0u;
+    if (l.ltype == GLZ_LIGHT_AREA) {
+      // one RTLight per instance whose mesh uses the emitting material (map_materials_to_instances, :1764-1781)
+      const uint16_t material_id = (uint16_t)l.resource_id;
+      std::vector<uint32_t> ids;
+      for (size_t i = 0; i < data.instances.size(); ++i) {
+        const glz_mesh* found = nullptr;
+        for (const glz_mesh& m : data.meshes)
+          if (m.id == data.instances[i].mesh_id) found = &m;
+        if (found && found->material == material_id) ids.push_back((uint32_t)(uint16_t)i);
+      }
+      if (ids.empty()) ids.push_back(0);
+      for (uint32_t id : ids) {
+        if (id >= h_instances.size()) {
+          err.code = GLZ_E_INVALID_DATA;
+          err.msg = "area light refers to a missing instance";
+          return false;
+        }
+        r.instance_id = id;
+        h_lights.push_back(r);
+      }
+    } else {
+      h_lights.push_back(r);
+    }
+  }
+  if (h_lights.empty()) {   // dummy light so the buffer is never empty (:1906-1918)
+    RTLight r{};
+    r.instance_id = 0xFFFFFFFFu;
+    r.intensity = 1.0f;
+    r.delta = 1u;
+    h_lights.push_back(r);
+  }
+  if (!hip_ok(d_lights_.upload(h_lights.data(), h_lights.size(), st), "upload lights", err)) return false;
+  dev.lights = d_lights_.ptr;
+
+  // sky: Light::default() when the scene has none (scene.rs:2249)
+  glz_light dflt{};
+  dflt.intensity = 1.0f;
+  const glz_light& sl = has_sky ? ordered.back() : dflt;
+  if (sl.resource_id >= data.textures.size()) {
+    err.code = GLZ_E_INVALID_DATA;
+    err.msg = "sky light references a missing texture";
+    return false;
+  }
+  float rot32[16];
+  host::sky_rotation(sl.yaw_deg, sl.pitch_deg, sl.roll_deg).to_f32(rot32);   // Matrix4<f32> in the reference
+  host::Mat4d inv;
+  if (!host::invert(host::Mat4d::from_f32(rot32), inv)) inv = host::Mat4d::identity();
+  memcpy(h_sky.obj2world, rot32, 64);
+  inv.to_f32(h_sky.world2obj);
+  h_sky.tex_id = sl.resource_id;
+  h_sky.intensity = sl.intensity;
+  if (sky_distribution_tex_ != h_sky.tex_id) {
+    // recalculated only when the sky texture changes (scene.rs:2256-2260)
+    const TextureData& map = data.textures[h_sky.tex_id];
+    const uint32_t W = map.info.width, H = map.info.height;
+    const size_t bpp = map.info.format == GLZ_TEX_GRAY ? 1 : 4;
+    std::vector<float> values((size_t)W * H);
+    const float pi = 3.14159265358979323846f;
+    for (uint32_t y = 0; y < H; ++y) {
+      const float sint = sinf(pi * ((float)y + 0.5f) / (float)H);
+      const uint8_t* row = map.level0.data() + (size_t)y * W * bpp;
+      for (uint32_t x = 0; x < W; ++x) {
+        const uint8_t* p = row + x * bpp;
+        const float r = (float)p[0] / 255.0f, g = (float)p[bpp > 1 ? 1 : 0] / 255.0f, b = (float)p[bpp > 1 ? 2 : 0] / 255.0f;
+        values[(size_t)y * W + x] = host::illuminant_luminance(r, g, b) * sint;
+      }
+    }
+    std::vector<float> cond_cdf, integrals(H), marginal_cdf;
+    cond_cdf.reserve((size_t)(W + 1) * H);
+    for (uint32_t y = 0; y < H; ++y) integrals[y] = host::distribution1d(values.data() + (size_t)y * W, W, cond_cdf);
+    h_sky_header.marginal_integral = host::distribution1d(integrals.data(), H, marginal_cdf);
+    h_sky_header.marginal_cdf_count = H + 1;
+    h_sky_header.conditional_integral_offset = H + (H + 1);
+    h_sky_header.conditional_cdf_count = W + 1;
+    h_sky_marginal = marginal_cdf;
+    h_sky_marginal.insert(h_sky_marginal.end(), integrals.begin(), integrals.end());   // marginal values
+    h_sky_marginal.insert(h_sky_marginal.end(), integrals.begin(), integrals.end());   // conditional integrals
+    if (!hip_ok(d_sky_marginal_.upload(h_sky_marginal.data(), h_sky_marginal.size(), st), "upload sky marginal", err)) return false;
+    if (!hip_ok(d_sky_cond_values_.upload(values.data(), values.size(), st), "upload sky values", err)) return false;
+    if (!hip_ok(d_sky_cond_cdf_.upload(cond_cdf.data(), cond_cdf.size(), st), "upload sky cdf", err)) return false;
+    if (!hip_ok(hipStreamSynchronize(st), "sky upload", err)) return false;
+    dev.sky_w = W;
+    dev.sky_h = H;
+    sky_distribution_tex_ = h_sky.tex_id;
+  }
+  if (!hip_ok(hipStreamSynchronize(st), "lights upload", err)) return false;
+  dev.sky = h_sky;
+  dev.sky_header = h_sky_header;
+  dev.sky_marginal = d_sky_marginal_.ptr;
+  dev.sky_cond_values = d_sky_cond_values_.ptr;
+  dev.sky_cond_cdf = d_sky_cond_cdf_.ptr;
+  return true;
+}
+
+bool Scene::build_bvh(Error& err) {
+  hipStream_t st = instance->stream;
+  const uint32_t n = (uint32_t)info.n_world_triangles;
+  if (!hip_ok(d_nodes_.alloc(n > 1 ? n - 1 : 1), "alloc BVH nodes", err)) return false;
+  if (!hip_ok(d_tris_.alloc(n), "alloc BVH triangles", err)) return false;
+  LbvhInputs in{d_vertices_.ptr, d_indices_.ptr, d_instances_.ptr, d_inst_base_.ptr, (uint32_t)h_instances.size(), d_transforms_.ptr,
+                d_materials_.ptr, n};
+  LbvhOutputs out{};
+  out.nodes = d_nodes_.ptr;
+  out.tris = d_tris_.ptr;
+  hipEvent_t e0, e1;
+  if (!hip_ok(hipEventCreate(&e0), "event", err) || !hip_ok(hipEventCreate(&e1), "event", err)) return false;
+  (void)hipEventRecord(e0, st);
+  const hipError_t be = build_lbvh(st, in, out);
+  (void)hipEventRecord(e1, st);
+  (void)hipEventSynchronize(e1);
+  float ms = 0.0f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (!hip_ok(be, "LBVH build", err)) return false;
+  info.bvh_nodes = n > 1 ? n - 1 : (n == 1 ? 1 : 0);
+  info.bvh_depth = out.depth;
+  info.bvh_sah_cost = out.sah;
+  info.build_ms = ms;
+  for (int k = 0; k < 3; ++k) {
+    info.bounds_min[k] = out.bounds_lo[k];
+    info.bounds_max[k] = out.bounds_hi[k];
+  }
+  // traversal stack: kLdsStack (24) levels live in LDS, the rest spills to a per-pixel HBM area
+  stack_overflow_depth = out.depth > 24 ? out.depth - 24 + 1 : 1;
+  dev.bvh_nodes = d_nodes_.ptr;
+  dev.bvh_tris = d_tris_.ptr;
+  dev.n_world_tris = n;
+  return true;
+}
+
+bool Scene::update_materials_and_lights(const glz_material* mats, uint32_t n_mats, const glz_light* lights, uint32_t n_lights, Error& err) {
+  if (!hip_ok(hipSetDevice(instance->device), "hipSetDevice", err)) return false;
+  if (n_mats != data.materials.size()) {
+    err.code = GLZ_E_ARG;
+    err.msg = "update_materials_and_lights: the material count must not change (meshes index materials)";
+    return false;
+  }
+  for (uint32_t i = 0; i < n_mats; ++i) {
+    const glz_material& m = mats[i];
+    const size_t nt = data.textures.size();
+    if (m.diffuse >= nt || m.roughness >= nt || m.metalness >= nt || m.normal >= nt || m.opacity >= nt) {
+      err.code = GLZ_E_INVALID_DATA;
+      err.msg = "material references a missing texture";
+      return false;
+    }
+  }
+  bool opacity_changed = false;
+  for (uint32_t i = 0; i < n_mats; ++i) opacity_changed |= (mats[i].opacity != 0) != (data.materials[i].opacity != 0);
+  data.materials.assign(mats, mats + n_mats);
+  data.lights.assign(lights, lights + n_lights);
+  if (!build_materials(err)) return false;
+  if (!build_lights_and_sky(err)) return false;
+  if (opacity_changed && !build_bvh(err)) return false;   // the non-opaque flag lives in the leaf records
+  info.n_lights = lights_no;
+  info.n_rt_lights = (uint32_t)h_lights.size();
+  return hip_ok(hipStreamSynchronize(instance->stream), "update_materials_and_lights", err);
+}
+
+}  // namespace glz

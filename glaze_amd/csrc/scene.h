@@ -1,0 +1,95 @@
+// RayTraceInstance / RayTraceScene equivalents: device selection, scene upload, LBVH build.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "device/types.h"
+#include "glaze_abi.h"
+#include "parser.h"
+
+namespace glz {
+
+// RayTraceInstance (lib/src/vulkan/instance.rs:376-427): one HIP device + the stream all work runs on.
+struct Instance {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  std::string arch;
+  ~Instance();
+  static Instance* create(int hip_device, Error& err);
+};
+
+template <class T>
+struct DeviceBuffer {
+  T* ptr = nullptr;
+  size_t count = 0;
+  DeviceBuffer() = default;
+  DeviceBuffer(const DeviceBuffer&) = delete;
+  DeviceBuffer& operator=(const DeviceBuffer&) = delete;
+  ~DeviceBuffer() { release(); }
+  void release() {
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    count = 0;
+  }
+  hipError_t alloc(size_t n) {
+    release();
+    count = n;
+    return hipMalloc(reinterpret_cast<void**>(&ptr), sizeof(T) * (n ? n : 1));
+  }
+  hipError_t upload(const T* host, size_t n, hipStream_t st) {
+    hipError_t e = alloc(n);
+    if (e != hipSuccess || n == 0) return e;
+    return hipMemcpyAsync(ptr, host, sizeof(T) * n, hipMemcpyHostToDevice, st);
+  }
+};
+
+// RayTraceScene (lib/src/vulkan/scene.rs:1352-1556)
+class Scene {
+ public:
+  static Scene* create(Instance* inst, SceneData&& data, Error& err);
+  // update_materials_and_lights (scene.rs:1587-1716): rebuilds RTMaterial / RTLight / sky tables.
+  // The BVH is rebuilt only if a material's opacity flag changed (acceleration.rs:136-141).
+  bool update_materials_and_lights(const glz_material* mats, uint32_t n_mats, const glz_light* lights, uint32_t n_lights, Error& err);
+
+  Instance* instance = nullptr;
+  SceneData data;           // host copy (materials/lights are kept for updates)
+  glz_scene_info info{};
+  DeviceScene dev{};        // what the kernels see
+  uint32_t lights_no = 0;   // lights.len() after reorder_lights (scene.rs:1549)
+  uint32_t stack_overflow_depth = 1;
+
+  // host mirrors of the uploaded RT arrays (debug read-back / parity with the oracle)
+  std::vector<RTInstance> h_instances;
+  std::vector<RTMaterial> h_materials;
+  std::vector<RTLight> h_lights;
+  std::vector<float> h_sky_marginal;
+  SkyHeader h_sky_header{};
+  RTSky h_sky{};
+
+ private:
+  bool upload_geometry(Error& err);
+  bool build_materials(Error& err);
+  bool build_lights_and_sky(Error& err);
+  bool build_bvh(Error& err);
+
+  DeviceBuffer<float4> d_vertices_, d_derivatives_;
+  DeviceBuffer<uint32_t> d_indices_, d_inst_base_;
+  DeviceBuffer<RTInstance> d_instances_;
+  DeviceBuffer<RTMaterial> d_materials_;
+  DeviceBuffer<RTLight> d_lights_;
+  DeviceBuffer<TransformPair> d_transforms_;
+  DeviceBuffer<TexDesc> d_tex_desc_;
+  DeviceBuffer<uint8_t> d_tex_pool_;
+  DeviceBuffer<float> d_srgb_lut_, d_sky_marginal_, d_sky_cond_values_, d_sky_cond_cdf_;
+  DeviceBuffer<BvhNode> d_nodes_;
+  DeviceBuffer<BvhTri> d_tris_;
+  std::vector<uint32_t> inst_base_;
+  uint32_t sky_distribution_tex_ = 0xFFFFFFFFu;
+};
+
+bool hip_ok(hipError_t e, const char* what, Error& err);
+
+}  // namespace glz

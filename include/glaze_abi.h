@@ -277,11 +277,13 @@ int glz_renderer_push_constants(glz_renderer*, float out32[32]);
  * t % world == rank; other pixels stay zero.  The reduce of the HDR accumulator itself is done
  * by the caller (RCCL through torch.distributed or rccl directly) on the device buffer below. */
 int glz_renderer_set_partition(glz_renderer*, uint32_t rank, uint32_t world);
-/* Scatters the owned tiles into a caller-provided DEVICE buffer of W*H*4 floats (zero-filled
- * elsewhere) on the instance stream: the operand of ncclReduce(sum). */
-int glz_renderer_export_hdr_device(glz_renderer*, void* dev_rgba32f);
-/* Tonemaps a full-frame DEVICE cumulative buffer (e.g. the reduced one on rank 0) to RGBA8 host. */
-int glz_renderer_tonemap_device(glz_renderer*, const void* dev_rgba32f_cumulative, const void* dev_rgba32f_lastw, uint8_t* rgba8_out);
+/* Scatters the owned tiles of the cumulative image (which = 0) or of the result image `out32`
+ * (which = 1) into a caller-provided DEVICE buffer of W*H*4 floats, zero elsewhere, on the instance
+ * stream (synchronised before returning): the operand of ncclReduce(sum).  Tiles are disjoint, so
+ * the sum over ranks is bit-identical to a single-GPU render. */
+int glz_renderer_export_device(glz_renderer*, int which, void* dev_rgba32f);
+/* Tonemaps a full-frame DEVICE result image (e.g. the reduced one on rank 0) to RGBA8 sRGB host memory. */
+int glz_renderer_tonemap_device(glz_renderer*, const void* dev_result_rgba32f, uint8_t* rgba8_out);
 
 /* ---- measurement ------------------------------------------------------------------------ */
 typedef struct glz_render_stats {
@@ -293,7 +295,8 @@ typedef struct glz_render_stats {
   /* traversal work counters (only filled when counting is enabled, slows rendering down) */
   uint64_t closest_nodes, closest_tris, shadow_nodes, shadow_tris, hits;
 } glz_render_stats;
-int glz_renderer_enable_counters(glz_renderer*, int on);
+/* bit 0: traversal work counters (slower kernels); bit 1: per-kernel hipEvent timing (on by default) */
+int glz_renderer_enable_counters(glz_renderer*, int flags);
 int glz_renderer_get_stats(glz_renderer*, glz_render_stats* out);
 
 /* ---- debug / parity hooks (used by tests; run on the device, no CPU fallback) -------------- */
@@ -308,6 +311,18 @@ int64_t glz_debug_read_derivatives(glz_scene*, float* out12, int64_t cap_triangl
 int64_t glz_debug_read_rt_materials(glz_scene*, void* out, int64_t cap_bytes); /* 208-byte RTMaterial records */
 int64_t glz_debug_read_rt_lights(glz_scene*, void* out, int64_t cap_bytes);    /* 112-byte RTLight records */
 int64_t glz_debug_read_sky(glz_scene*, float* out, int64_t cap_floats);        /* RTSky(36 f32) | header(4) | marginal arrays */
+/* LBVH as traversed by the kernels: 64-byte nodes (returns the node count) and 48-byte leaf
+ * triangles in leaf order (n_world_triangles of them); see DESIGN.md for the layouts. */
+int64_t glz_debug_read_bvh(glz_scene*, void* nodes_out, int64_t cap_nodes, void* tris_out, int64_t cap_tris);
+
+/* ---- host logic, callable without a device (used by the CPU test-suite and by bindings) ------ */
+/* seed + pixel offset of launch `launch` after a restart, for renderer seed `seed`
+ * (rng.gen::<u32>() + WorkScheduler::next(), raytracer.rs:486-489, :1168-1206) */
+int glz_host_launch_constants(uint64_t seed, uint32_t launch, uint32_t* seed_out, float offset[2]);
+/* build_push_constants (raytracer.rs:1098-1120): camera2world then screen2camera, column-major */
+int glz_host_push_constants(const glz_camera* camera, uint32_t width, uint32_t height, float out32[32]);
+/* rank owning each pixel under glz_renderer_set_partition(., world): 64x64 tiles, tile t -> t % world */
+int glz_host_tile_owner(uint32_t width, uint32_t height, uint32_t world, uint16_t* owner_out);
 
 #ifdef __cplusplus
 }

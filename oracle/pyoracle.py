@@ -1,0 +1,235 @@
+"""ctypes front-end of oracle/_build/liboracle.so (ORACLE: test infrastructure, not product code)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from glaze_amd import abi  # interface PODs only (ctypes mirrors of include/glaze_abi.h)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+_P = C.c_void_p
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "_build", "liboracle.so")
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        sig = {
+            "orc_scene_create": (_P, [_P]), "orc_scene_destroy": (None, [_P]),
+            "orc_scene_lights_no": (C.c_uint32, [_P]), "orc_scene_world_tris": (C.c_uint64, [_P]),
+            "orc_read_derivatives": (C.c_int64, [_P, _P, C.c_int64]),
+            "orc_read_rt_materials": (C.c_int64, [_P, _P, C.c_int64]),
+            "orc_read_rt_lights": (C.c_int64, [_P, _P, C.c_int64]),
+            "orc_read_sky": (C.c_int64, [_P, _P, C.c_int64]),
+            "orc_read_sky_cond": (C.c_int64, [_P, _P, _P]),
+            "orc_scene_set_ext_bvh": (None, [_P, _P, C.c_uint64, _P, C.c_uint64]),
+            "orc_trace_closest": (None, [_P, _P, _P, C.c_uint64, C.c_float, _P, _P, _P, _P, _P]),
+            "orc_trace_any": (None, [_P, _P, _P, _P, C.c_uint64, C.c_float, _P]),
+            "orc_trace_closest_brute": (None, [_P, _P, _P, C.c_uint64, C.c_float, _P, _P]),
+            "orc_renderer_create": (_P, [_P, C.c_uint32, C.c_uint32]), "orc_renderer_destroy": (None, [_P]),
+            "orc_renderer_set_integrator": (None, [_P, C.c_int]), "orc_renderer_set_depth": (None, [_P, C.c_uint32]),
+            "orc_renderer_set_seed": (None, [_P, C.c_uint64]), "orc_renderer_set_exposure": (None, [_P, C.c_float]),
+            "orc_renderer_set_threads": (None, [_P, C.c_int]), "orc_renderer_set_counting": (None, [_P, C.c_int]),
+            "orc_renderer_update_camera": (None, [_P, _P]),
+            "orc_renderer_steps_per_sample": (C.c_uint32, [_P]),
+            "orc_renderer_restart": (None, [_P]), "orc_renderer_step": (None, [_P, C.c_uint32]),
+            "orc_renderer_draw": (None, [_P, C.c_uint64]),
+            "orc_renderer_read_hdr": (None, [_P, _P]), "orc_renderer_read_result": (None, [_P, _P]),
+            "orc_renderer_read_rgba8": (None, [_P, _P]), "orc_renderer_read_state": (None, [_P, _P]),
+            "orc_renderer_push_constants": (None, [_P, _P]),
+            "orc_launch_constants": (None, [C.c_uint64, C.c_uint32, _P, _P]),
+            "orc_renderer_counters": (None, [_P, _P]),
+            "orc_spectrum_from_rgb": (None, [C.c_float, C.c_float, C.c_float, C.c_int, _P]),
+            "orc_spectrum_to_xyz": (None, [_P, _P]), "orc_spectrum_luminance": (C.c_float, [_P]),
+            "orc_spectrum_from_blackbody": (None, [C.c_float, _P]),
+            "orc_xyz_to_rgb": (None, [_P, _P]), "orc_rgb_to_xyz": (None, [_P, _P]),
+            "orc_fovy": (C.c_float, [C.c_float, C.c_float]), "orc_spectrum_white": (None, [_P]),
+            "orc_dev_from_surface_color": (None, [_P, _P]), "orc_dev_from_illuminant_color": (None, [_P, _P]),
+            "orc_dev_rgb": (None, [_P, _P]), "orc_dev_luminance": (C.c_float, [_P]),
+            "orc_detmath": (None, [C.c_int, _P, _P, _P, C.c_uint64]),
+            "orc_pcg_hash": (C.c_uint32, [C.c_uint32]),
+            "orc_rand_stream": (None, [C.c_uint32, C.c_uint32, C.c_uint32, _P, C.c_uint32]),
+        }
+        for name, (res, args) in sig.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        _LIB = L
+    return _LIB
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_P)
+
+
+class OracleScene:
+    def __init__(self, desc):
+        """desc: glaze_amd.scene_desc.SceneDesc"""
+        self.desc = desc
+        self._c = desc.as_c()
+        self.handle = lib().orc_scene_create(C.byref(self._c))
+
+    def __del__(self):
+        if getattr(self, "handle", None):
+            lib().orc_scene_destroy(self.handle)
+            self.handle = None
+
+    @property
+    def lights_no(self):
+        return lib().orc_scene_lights_no(self.handle)
+
+    @property
+    def n_world_triangles(self):
+        return lib().orc_scene_world_tris(self.handle)
+
+    def derivatives(self):
+        n = lib().orc_read_derivatives(self.handle, None, 0)
+        out = np.zeros((n, 12), np.float32)
+        lib().orc_read_derivatives(self.handle, _ptr(out), n)
+        return out
+
+    def rt_materials(self):
+        n = lib().orc_read_rt_materials(self.handle, None, 0)
+        out = np.zeros(n, np.uint8)
+        lib().orc_read_rt_materials(self.handle, _ptr(out), n)
+        return out
+
+    def rt_lights(self):
+        n = lib().orc_read_rt_lights(self.handle, None, 0)
+        out = np.zeros(n, np.uint8)
+        lib().orc_read_rt_lights(self.handle, _ptr(out), n)
+        return out
+
+    def sky(self):
+        n = lib().orc_read_sky(self.handle, None, 0)
+        out = np.zeros(n, np.float32)
+        lib().orc_read_sky(self.handle, _ptr(out), n)
+        return out
+
+    def set_ext_bvh(self, nodes, tris):
+        nodes = np.ascontiguousarray(nodes).view(np.float32).reshape(-1, 16)
+        tris = np.ascontiguousarray(tris).view(np.float32).reshape(-1, 12)
+        lib().orc_scene_set_ext_bvh(self.handle, _ptr(nodes), nodes.shape[0], _ptr(tris), tris.shape[0])
+
+    def trace_closest(self, origins, dirs, tmin=1e-4, brute=False):
+        o = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)
+        n = o.shape[0]
+        t = np.zeros(n, np.float32)
+        tri = np.zeros(n, np.uint32)
+        if brute:
+            lib().orc_trace_closest_brute(self.handle, _ptr(o), _ptr(d), n, tmin, _ptr(t), _ptr(tri))
+            return t, tri
+        inst = np.zeros(n, np.uint32)
+        u = np.zeros(n, np.float32)
+        v = np.zeros(n, np.float32)
+        lib().orc_trace_closest(self.handle, _ptr(o), _ptr(d), n, tmin, _ptr(t), _ptr(tri), _ptr(inst), _ptr(u), _ptr(v))
+        return t, tri, inst, u, v
+
+    def trace_any(self, origins, dirs, tmax, tmin=1e-3):
+        o = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)
+        tm = np.ascontiguousarray(tmax, np.float32)
+        out = np.zeros(o.shape[0], np.uint8)
+        lib().orc_trace_any(self.handle, _ptr(o), _ptr(d), _ptr(tm), o.shape[0], tmin, _ptr(out))
+        return out
+
+
+class OracleRenderer:
+    def __init__(self, scene, width, height, threads=None):
+        self.scene = scene
+        self.w, self.h = width, height
+        self.handle = lib().orc_renderer_create(scene.handle, width, height)
+        lib().orc_renderer_set_threads(self.handle, threads or (os.cpu_count() or 1))
+
+    def __del__(self):
+        if getattr(self, "handle", None):
+            lib().orc_renderer_destroy(self.handle)
+            self.handle = None
+
+    def set_threads(self, n):
+        lib().orc_renderer_set_threads(self.handle, n)
+
+    def set_integrator(self, i):
+        lib().orc_renderer_set_integrator(self.handle, i)
+
+    def set_depth(self, d):
+        lib().orc_renderer_set_depth(self.handle, d)
+
+    def set_seed(self, s):
+        lib().orc_renderer_set_seed(self.handle, s)
+
+    def set_exposure(self, e):
+        lib().orc_renderer_set_exposure(self.handle, e)
+
+    def set_counting(self, on):
+        lib().orc_renderer_set_counting(self.handle, int(on))
+
+    def update_camera(self, cam):
+        lib().orc_renderer_update_camera(self.handle, C.byref(cam))
+
+    def steps_per_sample(self):
+        return lib().orc_renderer_steps_per_sample(self.handle)
+
+    def restart(self):
+        lib().orc_renderer_restart(self.handle)
+
+    def step(self, n=1):
+        lib().orc_renderer_step(self.handle, n)
+
+    def draw(self, spp):
+        lib().orc_renderer_draw(self.handle, spp)
+
+    def read_hdr(self):
+        out = np.zeros((self.h, self.w, 4), np.float32)
+        lib().orc_renderer_read_hdr(self.handle, _ptr(out))
+        return out
+
+    def read_result(self):
+        out = np.zeros((self.h, self.w, 4), np.float32)
+        lib().orc_renderer_read_result(self.handle, _ptr(out))
+        return out
+
+    def read_rgba8(self):
+        out = np.zeros((self.h, self.w, 4), np.uint8)
+        lib().orc_renderer_read_rgba8(self.handle, _ptr(out))
+        return out
+
+    def read_state(self):
+        out = np.zeros((self.h, self.w, 24), np.float32)
+        lib().orc_renderer_read_state(self.handle, _ptr(out))
+        return out
+
+    def push_constants(self):
+        out = np.zeros(32, np.float32)
+        lib().orc_renderer_push_constants(self.handle, _ptr(out))
+        return out
+
+    def counters(self):
+        out = np.zeros(7, np.uint64)
+        lib().orc_renderer_counters(self.handle, _ptr(out))
+        return dict(zip(["closest_rays", "shadow_rays", "closest_nodes", "closest_tris", "shadow_nodes", "shadow_tris", "hits"],
+                        (int(x) for x in out)))
+
+
+def launch_constants(seed, launch):
+    s = C.c_uint32()
+    off = (C.c_float * 2)()
+    lib().orc_launch_constants(seed, launch, C.byref(s), off)
+    return s.value, (off[0], off[1])
+
+
+def detmath(fn, x, y=None):
+    x = np.ascontiguousarray(x, np.float32)
+    y = np.ascontiguousarray(y if y is not None else x, np.float32)
+    out = np.zeros_like(x)
+    lib().orc_detmath({"sin": 0, "cos": 1, "acos": 2, "atan2": 3}[fn], _ptr(x), _ptr(y), _ptr(out), x.size)
+    return out

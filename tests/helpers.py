@@ -1,0 +1,59 @@
+"""Shared helpers for the tests (scene conversion, comparison metrics)."""
+import numpy as np
+
+from glaze_amd import abi
+from glaze_amd.scene_desc import (INSTANCE_DTYPE, MESH_DTYPE, VERTEX_DTYPE, SceneDesc, make_camera, make_light, make_material,
+                                  make_meta)
+
+
+def desc_from_oracle_parse(path):
+    """SceneDesc built from the ORACLE's python reader (oracle/glaze_v1.py) -- independent of the C++ reader."""
+    from oracle.glaze_v1 import parse
+    p = parse(path)
+    v = p.vertices()
+    vertices = np.zeros(v.shape[0], VERTEX_DTYPE)
+    vertices["vv"], vertices["vn"], vertices["vt"] = v[:, 0:3], v[:, 3:6], v[:, 6:8]
+    meshes, indices, off = [], [], 0
+    for m in p.meshes():
+        meshes.append((m["id"], m["material"], off, m["indices"].size))
+        indices.append(m["indices"])
+        off += m["indices"].size
+    mats = [make_material(m["name"], m["mtype"], m["metal"], m["diffuse_mul"], m["emissive"], m["ior"], m["roughness_mul"],
+                          m["metalness_mul"], m["anisotropy"], m["diffuse"], m["roughness"], m["metalness"], m["normal"], m["opacity"])
+            for m in p.materials()]
+    lights = [make_light(l["ltype"], l["name"], l["color"], l["position"], l["direction"], l["intensity"], l["resource_id"],
+                         l["yaw"], l["pitch"], l["roll"]) for l in p.lights()]
+    textures = [(t["format"], t["levels"][0], t["name"]) for t in p.textures()]
+    cams = p.cameras()
+    cam = None
+    if cams:
+        c = cams[-1]
+        cam = make_camera(c["position"], c["target"], c["up"], c["fovx_or_scale"], c["near"], c["far"],
+                          orthographic=c["type"] == 1, scale=c["fovx_or_scale"])
+    meta = p.meta()
+    meta = make_meta(meta["scene_centre"], meta["scene_radius"], meta["exposure"]) if meta else None
+    inst = np.array([tuple(x) for x in p.instances()], INSTANCE_DTYPE)
+    return SceneDesc(vertices, np.concatenate(indices) if indices else np.zeros(0, np.uint32), np.array(meshes, MESH_DTYPE),
+                     p.transforms(), inst, mats, lights, textures, cam, meta)
+
+
+def camera_rays(push, width, height, offset=(0.5, 0.5)):
+    """Perspective camera rays as the raygen stage builds them (numpy float32, not bit-exact; for hit tests only)."""
+    c2w = push[:16].reshape(4, 4).T.astype(np.float64)
+    s2c = push[16:].reshape(4, 4).T.astype(np.float64)
+    y, x = np.mgrid[0:height, 0:width]
+    ndc = np.stack([-1 + 2 * (x + offset[0]) / width, -1 + 2 * (y + offset[1]) / height], -1)
+    tgt = np.einsum("ij,hwj->hwi", s2c, np.concatenate([ndc, np.ones_like(ndc)], -1))[..., :3]
+    tgt /= np.linalg.norm(tgt, axis=-1, keepdims=True)
+    d = np.einsum("ij,hwj->hwi", c2w[:3, :3], tgt)
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    o = np.broadcast_to(c2w[:3, 3], d.shape)
+    return o.reshape(-1, 3).astype(np.float32), d.reshape(-1, 3).astype(np.float32)
+
+
+def rel_err(a, b):
+    """|a-b| / max(|b|, floor) per element, with a floor tied to the image scale."""
+    a = a.astype(np.float64)
+    b = b.astype(np.float64)
+    floor = max(1e-12, 1e-3 * float(np.abs(b).mean()))
+    return np.abs(a - b) / np.maximum(np.abs(b), floor)

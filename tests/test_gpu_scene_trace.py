@@ -1,0 +1,162 @@
+"""GPU parity, scene build + ray tracing level: HIP path (through the C ABI) vs the CPU oracle.
+
+Bit-exact unless stated: derivatives, RT material/light/sky tables, push constants, closest-hit
+records (t, triangle, u, v) and any-hit results.
+"""
+import numpy as np
+import pytest
+
+import glaze_amd
+from glaze_amd import abi
+from glaze_amd.scenes import atrium_scene, cube_scene
+from oracle.pyoracle import OracleRenderer, OracleScene
+
+from conftest import MATTEST
+from helpers import camera_rays, desc_from_oracle_parse
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cube(instance):
+    desc = cube_scene()
+    return desc, glaze_amd.RayTraceScene.from_desc(instance, desc), OracleScene(desc)
+
+
+@pytest.fixture(scope="module")
+def mattest(instance):
+    desc = desc_from_oracle_parse(MATTEST)                       # oracle reader -> oracle scene
+    gpu = glaze_amd.RayTraceScene.new(instance, glaze_amd.parse(MATTEST))   # product reader -> product scene
+    return desc, gpu, OracleScene(desc)
+
+
+def test_scene_info(cube, mattest):
+    i = cube[1].info()
+    assert (i.n_vertices, i.n_triangles, i.n_world_triangles, i.n_instances, i.n_materials, i.n_lights) == (24, 12, 12, 1, 3, 1)
+    i = mattest[1].info()
+    # SURVEY F10 / BASELINE config 1
+    assert (i.n_vertices, i.n_triangles, i.n_world_triangles) == (70876, 138480, 138480)
+    assert (i.n_instances, i.n_materials, i.n_textures, i.n_lights, i.n_rt_lights) == (3, 5, 3, 1, 1)
+    assert i.bvh_nodes == 138479 and 17 <= i.bvh_depth <= 96
+
+
+@pytest.mark.parametrize("which", ["cube", "mattest"])
+def test_derivatives_bit_exact(which, cube, mattest):
+    _, gpu, orc = cube if which == "cube" else mattest
+    a, b = gpu.debug_derivatives(), orc.derivatives()
+    assert a.shape == b.shape
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+@pytest.mark.parametrize("which", ["cube", "mattest"])
+def test_rt_tables_bit_exact(which, cube, mattest):
+    _, gpu, orc = cube if which == "cube" else mattest
+    assert np.array_equal(gpu.debug_rt_materials(), orc.rt_materials())
+    assert np.array_equal(gpu.debug_rt_lights(), orc.rt_lights())
+    a, b = gpu.debug_sky(), orc.sky()
+    assert a.shape == b.shape
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_bvh_structure(mattest):
+    _, gpu, _ = mattest
+    nodes, tris = gpu.debug_bvh()
+    n = tris.shape[0]
+    ids = tris.view(np.uint32)[:, 3]
+    assert np.array_equal(np.sort(ids), np.arange(n, dtype=np.uint32))      # every world triangle is a leaf exactly once
+    c0 = nodes.view(np.int32)[:, 3]
+    c1 = nodes.view(np.int32)[:, 7]
+    inner = np.concatenate([c0[c0 >= 0], c1[c1 >= 0]])
+    leaves = np.concatenate([~c0[c0 < 0], ~c1[c1 < 0]])
+    assert np.array_equal(np.sort(inner), np.arange(1, n - 1))              # every inner node but the root has one parent
+    assert np.array_equal(np.sort(leaves), np.arange(n))
+    # a child box of an inner child contains that child's own child boxes
+    for ci, lo_s, hi_s in ((c0, slice(0, 3), slice(4, 7)), (c1, slice(8, 11), slice(12, 15))):
+        m = ci >= 0
+        ch = nodes[ci[m]]
+        lo = np.minimum(ch[:, 0:3], ch[:, 8:11])
+        hi = np.maximum(ch[:, 4:7], ch[:, 12:15])
+        assert np.all(nodes[m][:, lo_s] <= lo) and np.all(nodes[m][:, hi_s] >= hi)
+
+
+def _check_closest(gpu, orc, o, d, tmin=1e-4):
+    t, tri, inst, u, v = gpu.debug_trace_closest(o, d, tmin)
+    t2, tri2, inst2, u2, v2 = orc.trace_closest(o, d, tmin)
+    same = (t.view(np.uint32) == t2.view(np.uint32)) & (tri == tri2) & (inst == inst2) & \
+           (u.view(np.uint32) == u2.view(np.uint32)) & (v.view(np.uint32) == v2.view(np.uint32))
+    return same, (t, tri), (t2, tri2)
+
+
+def test_closest_hit_cube(cube):
+    _, gpu, orc = cube
+    rng = np.random.default_rng(1)
+    d = rng.normal(size=(20000, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    o = (rng.random((20000, 3)).astype(np.float32) - 0.5) * 1.5
+    same, (t, tri), _ = _check_closest(gpu, orc, o, d)
+    assert same.all()
+    assert np.isfinite(t).all()            # origin inside a closed box: every ray hits
+
+
+def test_closest_hit_mattest_camera_and_random(mattest, instance):
+    desc, gpu, orc = mattest
+    push = np.zeros(32, np.float32)
+    abi.check(abi.lib().glz_host_push_constants(__import__("ctypes").byref(desc.camera), 256, 256, push.ctypes.data))
+    o, d = camera_rays(push, 256, 256)
+    same, (t, tri), (t2, tri2) = _check_closest(gpu, orc, o, d)
+    assert same.all(), "mismatching rays: %d" % (~same).sum()
+    assert np.isfinite(t).mean() > 0.5
+    # incoherent rays from points inside the scene bounds
+    rng = np.random.default_rng(2)
+    i = gpu.info()
+    lo, hi = np.array(i.bounds_min), np.array(i.bounds_max)
+    o = (lo + rng.random((50000, 3)) * (hi - lo)).astype(np.float32)
+    d = rng.normal(size=(50000, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    same, _, _ = _check_closest(gpu, orc, o, d)
+    assert same.all(), "mismatching rays: %d" % (~same).sum()
+
+
+def test_oracle_bvh_against_brute_force(mattest):
+    """The oracle's own BVH must agree with testing every triangle (checks the checker)."""
+    _, _, orc = mattest
+    rng = np.random.default_rng(3)
+    o = (rng.random((300, 3)).astype(np.float32) - 0.5) * 2.0 + np.array([0, 1, 1], np.float32)
+    d = rng.normal(size=(300, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    t, tri, _, _, _ = orc.trace_closest(o, d)
+    tb, trib = orc.trace_closest(o, d, brute=True)
+    assert np.array_equal(t.view(np.uint32), tb.view(np.uint32)) and np.array_equal(tri, trib)
+
+
+def test_any_hit_mattest(mattest):
+    _, gpu, orc = mattest
+    rng = np.random.default_rng(4)
+    i = gpu.info()
+    lo, hi = np.array(i.bounds_min), np.array(i.bounds_max)
+    o = (lo + rng.random((50000, 3)) * (hi - lo)).astype(np.float32)
+    d = rng.normal(size=(50000, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    tmax = (rng.random(50000) * 3.0).astype(np.float32)
+    a = gpu.debug_trace_any(o, d, tmax)
+    b = orc.trace_any(o, d, tmax)
+    assert np.array_equal(a, b)
+    assert 0.05 < a.mean() < 0.95
+
+
+def test_axis_aligned_and_degenerate_rays(cube):
+    """Slab-parallel rays (0 * inf in the box test), rays along edges and zero directions must not diverge."""
+    _, gpu, orc = cube
+    o = np.array([[0, 0, 0]] * 6 + [[1, 1, 0], [0.999999, 0.999999, 0], [0, 0, 0], [0, 0, 0]], np.float32)
+    d = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1], [0, 0, 1], [0, 0, 1], [0, 0, 0],
+                  [1, 1, 1]], np.float32)
+    same, _, _ = _check_closest(gpu, orc, o, d)
+    assert same.all()
+
+
+def test_empty_scene_traces_nothing(instance):
+    desc = cube_scene()
+    desc.instances = desc.instances[:0]
+    gpu = glaze_amd.RayTraceScene.from_desc(instance, desc)
+    t, tri, _, _, _ = gpu.debug_trace_closest(np.zeros((4, 3), np.float32), np.array([[0, 0, 1]] * 4, np.float32))
+    assert np.isinf(t).all() and (tri == 0xFFFFFFFF).all()
