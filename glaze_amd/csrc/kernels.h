@@ -60,7 +60,7 @@ struct CameraConsts {
 };
 
 struct TraceCounters {
-  unsigned long long closest_rays, shadow_rays, closest_nodes, closest_tris, shadow_nodes, shadow_tris, hits;
+  unsigned long long closest_rays, shadow_rays, closest_nodes, closest_tris, shadow_nodes, shadow_tris, hits, fresh;
 };
 
 struct LaunchArgs {

@@ -360,8 +360,9 @@ hipError_t build_lbvh(hipStream_t st, const LbvhInputs& in, LbvhOutputs& out) {
   int *parent = nullptr, *arrivals = nullptr, *scalars = nullptr;
   float* sah = nullptr;
   auto cleanup = [&]() {
-    hipFree(tris_unsorted); hipFree(lo); hipFree(hi); hipFree(node_lo); hipFree(node_hi); hipFree(keys); hipFree(vals);
-    hipFree(children); hipFree(parent); hipFree(arrivals); hipFree(scalars); hipFree(sah);
+    void* bufs[] = {tris_unsorted, lo, hi, node_lo, node_hi, keys, vals, children, parent, arrivals, scalars, sah};
+    for (void* b : bufs)
+      if (b) (void)hipFree(b);
   };
 #define GLZ_TRY(x) do { e = (x); if (e != hipSuccess) { cleanup(); return e; } } while (0)
   GLZ_TRY(hipMalloc(&tris_unsorted, sizeof(BvhTri) * n));

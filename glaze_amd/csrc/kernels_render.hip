@@ -175,13 +175,14 @@ __device__ __forceinline__ HitRecord traverse(const DeviceScene& S, vec3 o, vec3
 }
 
 __device__ __forceinline__ void flush_counters(TraceCounters* c, bool shadow, unsigned long long rays, unsigned long long nodes,
-                                               unsigned long long tris, unsigned long long hits) {
+                                               unsigned long long tris, unsigned long long hits, unsigned long long fresh = 0) {
   // wave-level reduction first, one atomic per wave and counter (Guideline 12)
   for (int off = 32; off > 0; off >>= 1) {
     rays += __shfl_down(rays, off);
     nodes += __shfl_down(nodes, off);
     tris += __shfl_down(tris, off);
     hits += __shfl_down(hits, off);
+    fresh += __shfl_down(fresh, off);
   }
   if ((threadIdx.x & 63) == 0) {
     if (shadow) {
@@ -189,6 +190,7 @@ __device__ __forceinline__ void flush_counters(TraceCounters* c, bool shadow, un
     } else {
       atomicAdd(&c->closest_rays, rays); atomicAdd(&c->closest_nodes, nodes); atomicAdd(&c->closest_tris, tris);
       atomicAdd(&c->hits, hits);
+      atomicAdd(&c->fresh, fresh);
     }
   }
 }
@@ -201,11 +203,12 @@ __global__ void __launch_bounds__(kBlock) k_trace_closest(const LaunchArgs A) {
   __shared__ int s_stack[kLdsStack * kBlock];
   const uint32_t lid = blockIdx.x * kBlock + threadIdx.x;
   const PixelId px = pixel_of(A.map, lid);
-  unsigned long long n_nodes = 0, n_tris = 0, n_rays = 0, n_hits = 0;
+  unsigned long long n_nodes = 0, n_tris = 0, n_rays = 0, n_hits = 0, n_fresh = 0;
   if (px.active) {
     float4 ro = A.st.ray_o[lid], rd = A.st.ray_d[lid];
     vec3 origin, direction;
     if (A.frame.direct_only || ro.w == 0.0f) {
+      n_fresh = 1;
       // new path: camera ray through the jittered pixel (ray_origin / ray_dir, path_trace.rgen:47-73)
       const float pxf = (float)px.x + A.frame.pixel_offset[0], pyf = (float)px.y + A.frame.pixel_offset[1];
       const float ndcx = -1.0f + 2.0f * (pxf / A.frame.scene_size[0]), ndcy = -1.0f + 2.0f * (pyf / A.frame.scene_size[1]);
@@ -234,7 +237,7 @@ __global__ void __launch_bounds__(kBlock) k_trace_closest(const LaunchArgs A) {
     n_rays = 1;
     n_hits = h.leaf != 0xFFFFFFFFu;
   }
-  if (COUNT) flush_counters(A.counters, false, n_rays, n_nodes, n_tris, n_hits);
+  if (COUNT) flush_counters(A.counters, false, n_rays, n_nodes, n_tris, n_hits, n_fresh);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -199,6 +199,7 @@ bool Renderer::get_stats(glz_render_stats* out, Error& err) {
   out->shadow_nodes = c.shadow_nodes;
   out->shadow_tris = c.shadow_tris;
   out->hits = c.hits;
+  out->fresh_paths = c.fresh;
   return true;
 }
 

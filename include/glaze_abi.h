@@ -294,6 +294,7 @@ typedef struct glz_render_stats {
   uint64_t closest_rays, shadow_rays;
   /* traversal work counters (only filled when counting is enabled, slows rendering down) */
   uint64_t closest_nodes, closest_tris, shadow_nodes, shadow_tris, hits;
+  uint64_t fresh_paths;     /* closest rays that were new camera rays (bounce 0) */
 } glz_render_stats;
 /* bit 0: traversal work counters (slower kernels); bit 1: per-kernel hipEvent timing (on by default) */
 int glz_renderer_enable_counters(glz_renderer*, int flags);
