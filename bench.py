@@ -174,7 +174,8 @@ def main():
             # CPU baseline: the oracle (scalar C++ restatement; the reference has no CPU tracer) on a
             # bounded sample of the SAME workload: same scene/frame/depth/seed, fewer launches.
             from oracle.pyoracle import OracleRenderer, OracleScene
-            cores = os.cpu_count() or 1
+            # a 1-GPU box grants 16 host cores of the machine's CPUs; never size the pool beyond that share
+            cores = max(1, min(len(os.sched_getaffinity(0)), 16))
             o = OracleRenderer(OracleScene(desc), W, H, threads=cores)
             o.set_depth(args.depth)
             o.set_seed(args.seed)

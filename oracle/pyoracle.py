@@ -148,7 +148,7 @@ class OracleRenderer:
         self.scene = scene
         self.w, self.h = width, height
         self.handle = lib().orc_renderer_create(scene.handle, width, height)
-        lib().orc_renderer_set_threads(self.handle, threads or (os.cpu_count() or 1))
+        lib().orc_renderer_set_threads(self.handle, threads or max(1, min(len(os.sched_getaffinity(0)), 16)))
 
     def __del__(self):
         if getattr(self, "handle", None):
