@@ -29,6 +29,10 @@ struct LbvhOutputs {
 };
 hipError_t build_lbvh(hipStream_t st, const LbvhInputs& in, LbvhOutputs& out);
 
+// Traversal stack entries each lane keeps in LDS (the deepest simultaneous stack of a near-first BVH2
+// traversal is bounded by the tree depth; what does not fit spills to a per-pixel HBM area).
+constexpr int kTraversalLdsStack = 18;
+
 // ---- rendering ------------------------------------------------------------------------------------
 // Per-pixel wavefront state, indexed by the LOCAL pixel id `lid` (tile-major, one wave = one 8x8 block):
 //   lid = ((local_tile * 64 + sub_block) * 64 + lane)

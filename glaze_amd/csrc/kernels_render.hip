@@ -20,7 +20,7 @@ namespace glz {
 using namespace dev;
 
 constexpr int kBlock = 256;       // 4 waves
-constexpr int kLdsStack = 24;     // traversal stack entries kept in LDS per lane; deeper levels spill to HBM
+constexpr int kLdsStack = kTraversalLdsStack;   // stack entries kept in LDS per lane (18 KB per block -> 8 blocks per CU); deeper levels spill to HBM
 constexpr uint32_t kFlagUpdate = 1u;    // update_result() is called for this pixel in this launch
 constexpr uint32_t kFlagShadow = 2u;    // the contribution is gated by a shadow ray
 constexpr uint32_t kFlagPoison = 4u;    // 0 * (|cos|/pdf) * radiance is NaN: an occluded sample still poisons the pixel
@@ -86,7 +86,7 @@ __device__ __forceinline__ bool ray_triangle(const BvhTri& tr, vec3 o, vec3 d, f
 }
 
 // raytrace_hit.rahit:24-39 -- candidates on non-opaque geometry are dropped when opacity.r < 0.5
-__device__ __noinline__ bool alpha_test(const DeviceScene& S, const BvhTri& tr, float u, float v) {
+__device__ __forceinline__ bool alpha_test(const DeviceScene& S, const BvhTri& tr, float u, float v) {
   const RTInstance in = S.instances[tr.instance];
   const uint32_t prim = tr.prim_flags & 0x7FFFFFFFu;
   const uint32_t* ix = S.indices + (in.index_offset / 3u + prim) * 3u;

@@ -416,8 +416,8 @@ bool Scene::build_bvh(Error& err) {
     info.bounds_min[k] = out.bounds_lo[k];
     info.bounds_max[k] = out.bounds_hi[k];
   }
-  // traversal stack: kLdsStack (24) levels live in LDS, the rest spills to a per-pixel HBM area
-  stack_overflow_depth = out.depth > 24 ? out.depth - 24 + 1 : 1;
+  // traversal stack: kTraversalLdsStack levels live in LDS, the rest spills to a per-pixel HBM area
+  stack_overflow_depth = out.depth > (uint32_t)kTraversalLdsStack ? out.depth - kTraversalLdsStack + 1 : 1;
   dev.bvh_nodes = d_nodes_.ptr;
   dev.bvh_tris = d_tris_.ptr;
   dev.n_world_tris = n;

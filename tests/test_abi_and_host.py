@@ -1,0 +1,116 @@
+"""C-ABI surface and device-independent host logic (CPU only; no compute calls)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import glaze_amd
+from glaze_amd import abi
+from glaze_amd.scene_desc import make_camera
+from oracle import pyoracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "glaze_abi.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(glz_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    lib = abi.lib()
+    names = declared_symbols()
+    assert len(names) >= 55
+    for n in names:
+        assert hasattr(lib, n), "libglaze_hip.so does not export " + n
+    assert sorted(abi.PROTOTYPES) == names, "glaze_amd/abi.py and include/glaze_abi.h disagree: %s" % (
+        set(abi.PROTOTYPES) ^ set(names))
+    assert lib.glz_version().startswith(b"glaze-hip")
+
+
+def test_struct_sizes_match_the_header():
+    assert C.sizeof(abi.Vertex) == 32 and C.sizeof(abi.Mesh) == 12 and C.sizeof(abi.Transform) == 64 and C.sizeof(abi.MeshInstance) == 4
+    assert C.sizeof(abi.Camera) == 52 and C.sizeof(abi.Meta) == 20
+    assert C.sizeof(abi.Material) == 12 + 16 + 12 + 256 and C.sizeof(abi.Light) == 4 + 24 + 4 + 16 + 64 + 256
+
+
+def test_no_device_means_none_not_a_fallback():
+    """RayTraceInstance::new() -> None without a usable device (instance.rs:376-427); nothing renders on the CPU."""
+    import torch
+    inst = glaze_amd.RayTraceInstance.new()
+    if not torch.cuda.is_available():
+        assert inst is None
+        assert abi.lib().glz_last_status() == abi.E_DEVICE
+    with pytest.raises(glaze_amd.GlazeError):
+        abi.check(abi.lib().glz_renderer_step(None, 1))
+    assert abi.lib().glz_renderer_create(None, None, 4, 4) is None
+
+
+def test_launch_constants_match_the_oracle():
+    for seed in (0, 1, 0xDEADBEEFCAFE):
+        for launch in (0, 1, 5, 21, 100, 341):
+            s = C.c_uint32()
+            off = (C.c_float * 2)()
+            abi.check(abi.lib().glz_host_launch_constants(seed, launch, C.byref(s), off))
+            so, oo = pyoracle.launch_constants(seed, launch)
+            assert s.value == so and (off[0], off[1]) == oo
+    seeds = set()
+    for launch in range(64):
+        s = C.c_uint32()
+        off = (C.c_float * 2)()
+        abi.lib().glz_host_launch_constants(7, launch, C.byref(s), off)
+        seeds.add(s.value)
+    assert len(seeds) == 64
+
+
+@pytest.mark.parametrize("cam", [
+    make_camera(),                                                                  # PerspectiveCam::default()
+    make_camera(position=(-0.1331, 0.2942, -0.3347), target=(32.937, -47.133, 81.256), fovx=np.float32(0.87266), near=1e-3, far=100.0),
+    make_camera(position=(1, 2, 3), target=(0, 0, 0), up=(0, 0, 1), orthographic=True, scale=2.5, near=0.1, far=40.0),
+])
+@pytest.mark.parametrize("res", [(1920, 1080), (512, 512), (33, 77)])
+def test_push_constants_match_the_oracle_and_invert_the_view(cam, res):
+    from glaze_amd.scene_desc import SceneDesc
+    out = np.zeros(32, np.float32)
+    abi.check(abi.lib().glz_host_push_constants(C.byref(cam), res[0], res[1], out.ctypes.data))
+    # oracle: needs a renderer object; a scene with no geometry is enough
+    from glaze_amd.scenes import cube_scene
+    desc = cube_scene()
+    desc.camera = cam
+    o = pyoracle.OracleRenderer(pyoracle.OracleScene(desc), res[0], res[1], threads=1).push_constants()
+    assert np.array_equal(out.view(np.uint32), o.view(np.uint32))
+    c2w = out[:16].reshape(4, 4).T.astype(np.float64)
+    assert np.allclose(c2w[3], (0, 0, 0, 1), atol=1e-6)
+    assert np.allclose(c2w[:3, 3], tuple(cam.position), atol=1e-5)                # camera2world maps the origin to the eye
+    fwd = np.array(tuple(cam.target)) - np.array(tuple(cam.position))
+    fwd /= np.linalg.norm(fwd)
+    assert np.allclose(c2w[:3, :3] @ np.array([0, 0, -1.0]), fwd, atol=1e-5)      # right-handed: the camera looks down -z
+    assert abs(np.linalg.det(c2w[:3, :3]) - 1.0) < 1e-5
+
+
+def test_tile_owner_partition():
+    from glaze_amd.distributed import tile_owner
+    for (w, h, world) in ((1920, 1080, 8), (200, 136, 3), (64, 64, 2), (1, 1, 1), (130, 70, 5)):
+        own = tile_owner(w, h, world)
+        assert own.shape == (h, w) and own.max() < world
+        tiles_x = (w + 63) // 64
+        y, x = np.mgrid[0:h, 0:w]
+        assert np.array_equal(own, (((y // 64) * tiles_x + x // 64) % world).astype(np.uint16))
+        counts = np.bincount(own.ravel(), minlength=world)
+        if w * h >= 64 * 64 * world * 4:
+            assert counts.min() > 0.5 * counts.max()                                  # interleaved tiles balance the load
+
+
+def test_scene_desc_round_trips_through_ctypes():
+    from glaze_amd.scenes import cube_scene
+    d = cube_scene()
+    c = d.as_c()
+    assert c.n_vertices == 24 and c.n_indices == 36 and c.n_meshes == 1 and c.n_materials == 3 and c.n_textures == 2 and c.n_lights == 1
+    mats = C.cast(c.materials, C.POINTER(abi.Material))
+    assert mats[2].name == b"Material" and tuple(mats[2].diffuse_mul) == (204, 204, 204) and mats[2].diffuse == 1
+    d2 = d.copy()
+    d2.materials[2].mtype = abi.MAT_GLASS
+    assert d.materials[2].mtype == abi.MAT_LAMBERT
