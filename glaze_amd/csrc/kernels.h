@@ -41,9 +41,11 @@ struct PathState {
   float4* ray_d;     // direction.xyz, last-bounce-specular flag (PTLastVertex.wi)
   float4* imp[4];    // importance spectrum, 4 x vec4    (PTLastVertex.importance)
   float4* hit;       // t, u, v, leaf index (bits)       closest-hit record of the current launch
-  float4* sh_o;      // shadow ray origin.xyz, tmax
-  float4* sh_d;      // shadow ray direction.xyz, -
-  float4* contrib;   // rgb radiance to add if unoccluded, flags (bits)
+  // shadow-ray queue, compacted by k_shade (entry q, not pixel lid):
+  float4* sh_o;      //   origin.xyz, tmax
+  float4* sh_d;      //   direction.xyz, owning pixel lid (bits)
+  float4* contrib;   //   rgb radiance to add if unoccluded, flags (bits)
+  uint32_t* queue_count;
   float4* cumulative;// accumulate_image (xyz = sum rgb, w = launches)
   float4* result;    // result_image (out32)
   uint32_t* overflow;// traversal stack spill, `overflow_depth` words per pixel

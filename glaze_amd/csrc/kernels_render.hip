@@ -5,11 +5,13 @@
 //   k_trace_closest   ray generation / resume + closest-hit LBVH traversal      -> hit record
 //   k_shade           hit attributes, light sample, BSDF eval, Russian roulette,
 //                     BSDF sample, state update                                 -> shadow ray + contribution
-//   k_shadow_accum    any-hit traversal of the shadow ray, update_count/update_result
+//   k_shadow_queue    any-hit traversal of the compacted shadow-ray queue (persistent grid), update_count/update_result
 //
 // A wave owns one 8x8 pixel block of a 64x64 tile, so primary rays of a wave are coherent and all
 // per-pixel arrays are read and written as one contiguous 1 KiB (float4) line per wave.
 #include <hip/hip_runtime.h>
+
+#include <algorithm>
 
 #include "device/math.h"
 #include "device/shading.h"
@@ -21,6 +23,8 @@ using namespace dev;
 
 constexpr int kBlock = 256;       // 4 waves
 constexpr int kLdsStack = kTraversalLdsStack;   // stack entries kept in LDS per lane (18 KB per block -> 8 blocks per CU); deeper levels spill to HBM
+constexpr uint32_t kQueueShards = 8;     // shadow-ray sub-queues (see queue_slot)
+constexpr uint32_t kCounterStride = 32;  // uint32 words between shard counters (128 bytes)
 constexpr uint32_t kFlagUpdate = 1u;    // update_result() is called for this pixel in this launch
 constexpr uint32_t kFlagShadow = 2u;    // the contribution is gated by a shadow ray
 constexpr uint32_t kFlagPoison = 4u;    // 0 * (|cos|/pdf) * radiance is NaN: an occluded sample still poisons the pixel
@@ -204,6 +208,7 @@ __global__ void __launch_bounds__(kBlock) k_trace_closest(const LaunchArgs A) {
   const uint32_t lid = blockIdx.x * kBlock + threadIdx.x;
   const PixelId px = pixel_of(A.map, lid);
   unsigned long long n_nodes = 0, n_tris = 0, n_rays = 0, n_hits = 0, n_fresh = 0;
+  if (lid < kQueueShards) A.st.queue_count[lid * kCounterStride] = 0;   // the previous launch's k_shadow_queue has drained the queue; k_shade refills it
   if (px.active) {
     float4 ro = A.st.ray_o[lid], rd = A.st.ray_d[lid];
     vec3 origin, direction;
@@ -238,6 +243,42 @@ __global__ void __launch_bounds__(kBlock) k_trace_closest(const LaunchArgs A) {
     n_hits = h.leaf != 0xFFFFFFFFu;
   }
   if (COUNT) flush_counters(A.counters, false, n_rays, n_nodes, n_tris, n_hits, n_fresh);
+}
+
+// update_count() + update_result() of path_trace.rgen:119-133 for one pixel
+__device__ __forceinline__ void accumulate_pixel(const LaunchArgs& A, uint32_t lid, vec3 c, bool add, bool update) {
+  float4 cum = A.st.cumulative[lid];
+  cum.w += 1.0f;
+  if (update) {
+    if (add) { cum.x += c.x; cum.y += c.y; cum.z += c.z; }
+    A.st.result[lid] = make_float4(cum.x * A.frame.exposure / cum.w, cum.y * A.frame.exposure / cum.w, cum.z * A.frame.exposure / cum.w, 1.0f);
+  }
+  A.st.cumulative[lid] = cum;
+}
+
+// Shadow-ray queue: 8 sub-queues ("shards"), shard = blockIdx % 8.  Blocks b and b+8 are observed to land on
+// the same XCD, so a shard's counter line tends to stay in one XCD's L2; more importantly eight counters on
+// separate 128-byte lines take eight times the append rate of one word (MI355X_MICROARCH.md, row `dequeue`).
+// A shard only receives entries from its own blocks, so its capacity ceil(blocks/8) * kBlock can never overflow.
+__device__ __forceinline__ uint32_t queue_capacity(uint32_t n_local_pixels) {
+  const uint32_t blocks = (n_local_pixels + kBlock - 1) / kBlock;
+  return ((blocks + kQueueShards - 1) / kQueueShards) * kBlock;
+}
+// Appends the lanes with `push` set: one atomic per wave (ballot + popcount); the wave's entries are contiguous so
+// the three float4 stores stay coalesced.  Returns the entry index in the queue arrays.
+__device__ __forceinline__ uint32_t queue_slot(uint32_t* counters, uint32_t n_local_pixels, bool push) {
+  const unsigned long long m = __ballot(push);
+  uint32_t slot = 0;
+  if (push) {
+    const uint32_t shard = blockIdx.x % kQueueShards;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)m) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(counters + shard * kCounterStride, (uint32_t)__popcll(m));
+    base = __shfl(base, leader);
+    slot = shard * queue_capacity(n_local_pixels) + base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+  }
+  return slot;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -275,7 +316,7 @@ __global__ void __launch_bounds__(kBlock) k_shade(const LaunchArgs A) {
       c = spec_to_rgb(spec_mul(importance, from_illuminant_color(texel)));
       flags = kFlagUpdate;
     }
-    A.st.contrib[lid] = make_float4(c.x, c.y, c.z, __uint_as_float(flags));
+    accumulate_pixel(A, lid, c, true, flags != 0);
     if (!F.direct_only) A.st.ray_o[lid] = make_float4(ro.x, ro.y, ro.z, 0.0f);   // RESET_PATH
     return;
   }
@@ -329,6 +370,8 @@ __global__ void __launch_bounds__(kBlock) k_shade(const LaunchArgs A) {
     sample_light(S, li, point, xi, F.scene_radius, ls);
     vec3 c = mk3(0.0f, 0.0f, 0.0f);
     uint32_t flags = kFlagUpdate;
+    vec3 sh_dir = mk3(0.0f, 0.0f, 0.0f);
+    float sh_tmax = 0.0f;
     if (ls.pdf > 0.0f) {
       const float xi_b = rand01(rng);
       Spec value = spec_set(0.0f);
@@ -347,14 +390,29 @@ __global__ void __launch_bounds__(kBlock) k_shade(const LaunchArgs A) {
         }
         c = spec_to_rgb(rad);
         flags |= kFlagShadow | (poison == poison ? 0u : kFlagPoison);
-        A.st.sh_o[lid] = make_float4(point.x, point.y, point.z, ls.distance - 1e-3f);
-        A.st.sh_d[lid] = make_float4(ls.wiW.x, ls.wiW.y, ls.wiW.z, 0.0f);
+        sh_dir = ls.wiW;
+        sh_tmax = ls.distance - 1e-3f;
       }
     }
-    A.st.contrib[lid] = make_float4(c.x, c.y, c.z, __uint_as_float(flags));
+    if (!(flags & kFlagShadow)) {
+      // no light sample: the reference still adds rgb(0 * lights_no * importance), which is NaN for a non-finite importance
+      float probe = 0.0f;
+      GLZ_BINS probe += 0.0f * importance.w[i];
+      if (probe != probe) c = spec_to_rgb(spec_scale(importance, 0.0f * (float)F.lights_no));
+    }
+    // shadow-ray queue (consumed by k_shadow_queue); pixels without a shadow ray are accumulated right here
+    const bool push = (flags & kFlagShadow) != 0;
+    const uint32_t slot = queue_slot(A.st.queue_count, A.map.n_local_pixels, push);
+    if (push) {
+      A.st.sh_o[slot] = make_float4(point.x, point.y, point.z, sh_tmax);
+      A.st.sh_d[slot] = make_float4(sh_dir.x, sh_dir.y, sh_dir.z, __uint_as_float(lid));
+      A.st.contrib[slot] = make_float4(c.x, c.y, c.z, __uint_as_float(flags));
+    } else {
+      accumulate_pixel(A, lid, c, true, true);
+    }
     spec_flag = 0.0f;
   } else {
-    A.st.contrib[lid] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0u));
+    accumulate_pixel(A, lid, mk3(0.0f, 0.0f, 0.0f), false, false);
     spec_flag = 1.0f;
   }
   if (F.direct_only) return;
@@ -390,38 +448,39 @@ __global__ void __launch_bounds__(kBlock) k_shade(const LaunchArgs A) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_shadow_accum: the shadow traceRayEXT (path_trace.rgen:106-110) + update_count / update_result
-// (:119-133)
+// k_shadow_queue: the shadow traceRayEXT (path_trace.rgen:106-110) for the compacted queue written by
+// k_shade, followed by update_count / update_result (:119-133) of the owning pixel.  Persistent grid: each
+// thread strides over the queue, so every wave traverses with (almost) all lanes active.
 // ---------------------------------------------------------------------------------------------
 template <bool COUNT>
-__global__ void __launch_bounds__(kBlock) k_shadow_accum(const LaunchArgs A) {
+__global__ void __launch_bounds__(kBlock) k_shadow_queue(const LaunchArgs A) {
   __shared__ int s_stack[kLdsStack * kBlock];
-  const uint32_t lid = blockIdx.x * kBlock + threadIdx.x;
-  const PixelId px = pixel_of(A.map, lid);
+  // prefix sums of the eight shard counts (final: k_shade has completed)
+  uint32_t start[kQueueShards + 1];
+  start[0] = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < kQueueShards; ++k) start[k + 1] = start[k] + A.st.queue_count[k * kCounterStride];
+  const uint32_t count = start[kQueueShards], cap = queue_capacity(A.map.n_local_pixels);
   unsigned long long n_nodes = 0, n_tris = 0, n_rays = 0;
-  if (px.active) {
-    const float4 cb = A.st.contrib[lid];
-    const uint32_t flags = __float_as_uint(cb.w);
-    bool occluded = false;
-    if (flags & kFlagShadow) {
-      const float4 so = A.st.sh_o[lid], sd = A.st.sh_d[lid];
-      Stack st{&s_stack[threadIdx.x], A.st.overflow + (size_t)lid * A.st.overflow_depth, 0};
-      const HitRecord h = traverse<true, COUNT>(A.scene, mk3(so.x, so.y, so.z), mk3(sd.x, sd.y, sd.z), 0.001f, so.w, st, n_nodes, n_tris);
-      occluded = h.leaf != 0xFFFFFFFFu;
-      n_rays = 1;
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < count; i += gridDim.x * kBlock) {
+    uint32_t shard = 0;
+#pragma unroll
+    for (uint32_t k = 1; k < kQueueShards; ++k) shard += i >= start[k] ? 1u : 0u;
+    const uint32_t q = shard * cap + (i - start[shard]);
+    const float4 so = A.st.sh_o[q], sd = A.st.sh_d[q], cb = A.st.contrib[q];
+    const uint32_t lid = __float_as_uint(sd.w), flags = __float_as_uint(cb.w);
+    Stack st{&s_stack[threadIdx.x], A.st.overflow + (size_t)lid * A.st.overflow_depth, 0};
+    const HitRecord h = traverse<true, COUNT>(A.scene, mk3(so.x, so.y, so.z), mk3(sd.x, sd.y, sd.z), 0.001f, so.w, st, n_nodes, n_tris);
+    const bool occluded = h.leaf != 0xFFFFFFFFu;
+    n_rays += 1;
+    vec3 c = mk3(cb.x, cb.y, cb.z);
+    bool add = !occluded;
+    if (occluded && (flags & kFlagPoison)) {
+      const float nan = __uint_as_float(0x7FC00000u);
+      c = mk3(nan, nan, nan);
+      add = true;
     }
-    float4 cum = A.st.cumulative[lid];
-    cum.w += 1.0f;   // update_count
-    if (flags & kFlagUpdate) {
-      if (!occluded) {
-        cum.x += cb.x; cum.y += cb.y; cum.z += cb.z;
-      } else if (flags & kFlagPoison) {
-        const float nan = __uint_as_float(0x7FC00000u);
-        cum.x += nan; cum.y += nan; cum.z += nan;
-      }
-      A.st.result[lid] = make_float4(cum.x * A.frame.exposure / cum.w, cum.y * A.frame.exposure / cum.w, cum.z * A.frame.exposure / cum.w, 1.0f);
-    }
-    A.st.cumulative[lid] = cum;
+    accumulate_pixel(A, lid, c, add, true);
   }
   if (COUNT) flush_counters(A.counters, true, n_rays, n_nodes, n_tris, 0);
 }
@@ -498,8 +557,10 @@ hipError_t launch_shade(hipStream_t st, const LaunchArgs& a) {
 }
 hipError_t launch_shadow_accumulate(hipStream_t st, const LaunchArgs& a) {
   if (a.map.n_local_pixels == 0) return hipSuccess;
-  if (a.counters) hipLaunchKernelGGL(k_shadow_accum<true>, grid_for(a.map.n_local_pixels), dim3(kBlock), 0, st, a);
-  else hipLaunchKernelGGL(k_shadow_accum<false>, grid_for(a.map.n_local_pixels), dim3(kBlock), 0, st, a);
+  // persistent grid: 256 CUs x 8 resident blocks at most, never more blocks than queue capacity
+  const uint32_t blocks = std::min<uint32_t>((a.map.n_local_pixels + kBlock - 1) / kBlock, 256u * 8u);
+  if (a.counters) hipLaunchKernelGGL(k_shadow_queue<true>, dim3(blocks), dim3(kBlock), 0, st, a);
+  else hipLaunchKernelGGL(k_shadow_queue<false>, dim3(blocks), dim3(kBlock), 0, st, a);
   return hipGetLastError();
 }
 hipError_t launch_export(hipStream_t st, const TileMap& map, const float4* tiled, float4* frame, bool zero_first) {

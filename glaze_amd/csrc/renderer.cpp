@@ -60,14 +60,17 @@ bool Renderer::allocate(Error& err) {
   map_.n_local_tiles = tiles > map_.rank ? (tiles - map_.rank + map_.world - 1) / map_.world : 0;
   map_.n_local_pixels = map_.n_local_tiles * kTile * kTile;
   const size_t n = map_.n_local_pixels;
+  // shadow-ray queue: 8 shards of ceil(blocks/8)*256 entries (kernels_render.hip, queue_capacity)
+  const size_t n_queue = (((n + 255) / 256 + 7) / 8) * 256 * 8;
   DeviceBuffer<float4>* bufs[] = {&ray_o_, &ray_d_, &imp_[0], &imp_[1], &imp_[2], &imp_[3], &hit_, &sh_o_, &sh_d_, &contrib_, &cumulative_, &result_};
   for (auto* b : bufs)
-    if (!hip_ok(b->alloc(n), "alloc path state", err)) return false;
+    if (!hip_ok(b->alloc((b == &sh_o_ || b == &sh_d_ || b == &contrib_) ? n_queue : n), "alloc path state", err)) return false;
   const uint32_t od = scene_->stack_overflow_depth;
   if (!hip_ok(overflow_.alloc(n * od), "alloc traversal spill", err)) return false;
   if (!hip_ok(frame_tmp_.alloc((size_t)w_ * h_), "alloc frame", err)) return false;
   if (!hip_ok(rgba8_.alloc((size_t)w_ * h_), "alloc rgba8", err)) return false;
   if (!hip_ok(counters_.alloc(1), "alloc counters", err)) return false;
+  if (!hip_ok(queue_count_.alloc(8 * 32), "alloc queue counters", err)) return false;
   request_new_frame_ = true;
   return true;
 }
@@ -80,6 +83,7 @@ bool Renderer::reset_buffers(Error& err) {
   for (auto* b : zero)
     if (bytes && !hip_ok(hipMemsetAsync(b->ptr, 0, bytes, st), "clear path state", err)) return false;
   if (!hip_ok(hipMemsetAsync(counters_.ptr, 0, sizeof(TraceCounters), st), "clear counters", err)) return false;
+  if (!hip_ok(hipMemsetAsync(queue_count_.ptr, 0, sizeof(uint32_t) * 8 * 32, st), "clear queue counters", err)) return false;
   sched_.rewind();
   rng_.reseed(seed_);   // build-defined: a restart replays the same seed stream (the reference keeps drawing from entropy)
   launches_ = 0;
@@ -99,6 +103,7 @@ void Renderer::fill_args(LaunchArgs& a) const {
   a.st.sh_o = sh_o_.ptr;
   a.st.sh_d = sh_d_.ptr;
   a.st.contrib = contrib_.ptr;
+  a.st.queue_count = queue_count_.ptr;
   a.st.cumulative = cumulative_.ptr;
   a.st.result = result_.ptr;
   a.st.overflow = overflow_.ptr;

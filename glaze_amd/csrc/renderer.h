@@ -67,7 +67,7 @@ class Renderer {
   TileMap map_{};
   // state
   DeviceBuffer<float4> ray_o_, ray_d_, imp_[4], hit_, sh_o_, sh_d_, contrib_, cumulative_, result_, frame_tmp_;
-  DeviceBuffer<uint32_t> overflow_;
+  DeviceBuffer<uint32_t> overflow_, queue_count_;
   DeviceBuffer<uchar4> rgba8_;
   DeviceBuffer<TraceCounters> counters_;
   // stats
