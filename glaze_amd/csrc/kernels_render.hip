@@ -53,24 +53,18 @@ __device__ __forceinline__ PixelId pixel_of(const TileMap& m, uint32_t lid) {
 // intersector ([ext]).  Ties on t are broken by the smaller world triangle id so that the result
 // does not depend on traversal order.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float box_entry(const float* __restrict__ lo, const float* __restrict__ hi, vec3 o, vec3 inv, float tmin, float tmax) {
-  float t0 = tmin, t1 = tmax;
-  {
-    float a = (lo[0] - o.x) * inv.x, b = (hi[0] - o.x) * inv.x;
-    t0 = fmaxf(t0, fminf(a, b));
-    t1 = fminf(t1, fmaxf(a, b) * 1.0000005f);
-  }
-  {
-    float a = (lo[1] - o.y) * inv.y, b = (hi[1] - o.y) * inv.y;
-    t0 = fmaxf(t0, fminf(a, b));
-    t1 = fminf(t1, fmaxf(a, b) * 1.0000005f);
-  }
-  {
-    float a = (lo[2] - o.z) * inv.z, b = (hi[2] - o.z) * inv.z;
-    t0 = fmaxf(t0, fminf(a, b));
-    t1 = fminf(t1, fmaxf(a, b) * 1.0000005f);
-  }
-  return t0 <= t1 ? t0 : INFINITY;
+// Slab test.  It only prunes: the leaf boxes are padded and the exit distance is scaled by 1 + 4 ulp, so it never rejects
+// a box whose triangle the exact Moeller-Trumbore test below accepts.  (lo - o) * inv keeps slab-parallel rays robust
+// (inf * finite, or 0 * inf = NaN which fminf/fmaxf drop); the fused form fma(lo, inv, -o*inv) measured no faster and
+// turns inf - inf into NaN on those rays.
+__device__ __forceinline__ float box_entry(float lox, float loy, float loz, float hix, float hiy, float hiz, vec3 o, vec3 inv, float tmin,
+                                           float tmax) {
+  const float ax = (lox - o.x) * inv.x, bx = (hix - o.x) * inv.x;
+  const float ay = (loy - o.y) * inv.y, by = (hiy - o.y) * inv.y;
+  const float az = (loz - o.z) * inv.z, bz = (hiz - o.z) * inv.z;
+  const float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin));
+  const float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)) * 1.0000005f;
+  return t0 <= fminf(t1, tmax) ? t0 : INFINITY;
 }
 
 __device__ __forceinline__ bool ray_triangle(const BvhTri& tr, vec3 o, vec3 d, float tmin, float& t, float& u, float& v) {
@@ -122,98 +116,174 @@ struct Stack {
   }
 };
 
-// ANY = false: closest hit in (tmin, tmax).  ANY = true: first accepted hit terminates.
-// Visit order: near child first (entry distance; ties -> child0), far child pushed.
-template <bool ANY, bool COUNT>
-__device__ __forceinline__ HitRecord traverse(const DeviceScene& S, vec3 o, vec3 d, float tmin, float tmax, Stack st,
-                                              unsigned long long& n_nodes, unsigned long long& n_tris) {
-  HitRecord best{tmax, 0.0f, 0.0f, 0xFFFFFFFFu};
-  if (S.n_world_tris == 0) return best;
-  uint32_t best_id = 0xFFFFFFFFu;
-  const vec3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+struct TraceTally {
+  unsigned long long rays = 0, nodes = 0, tris = 0, hits = 0, fresh = 0;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Wave-persistent traversal.  A wave owns a strided sequence of 64-ray groups (group g of wave w is rays
+// [64 * (g * n_waves + w), +64)) and keeps its 64 lanes busy: a lane whose ray has finished takes the next
+// ray of the wave's sequence as soon as kRefill lanes are idle (no atomics: the sequence pointer is wave
+// uniform).  Each round is  [refill] -> [inner-node phase] -> [leaf phase] -> [retire]:
+//   * inner-node phase: lanes sitting on an inner node test its two child boxes, descend into the nearer
+//     hit child and push the farther one; lanes that reached a leaf wait.  The phase ends when no lane is on an
+//     inner node, or when at least kLeafQuorum lanes are waiting on a leaf.
+//   * leaf phase: every lane on a leaf runs the exact ray/triangle test once, then pops its stack.
+// This replaces the one-ray-per-thread loop whose VALU lane utilisation was 24 % on the atrium
+// (SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU), profiles/r01b_sq_counters.txt).
+//
+// ANY = false: closest hit in (tmin, tmax); ties on t go to the smaller world triangle id, so the result
+// does not depend on visit order.  ANY = true: the first accepted hit ends the ray.
+// Source: bool load(uint32_t ray, vec3& o, vec3& d, float& tmin, float& tmax)   (false = nothing to trace or report)
+// Sink:   void store(uint32_t ray, const HitRecord&)
+// ---------------------------------------------------------------------------------------------
+constexpr int kRayDone = 0x7FFFFFFF;   // `cur` of a lane without a node to visit (inner nodes are >= 0, leaves < 0)
+constexpr int kRefill = 16;
+constexpr int kLeafQuorum = 24;
+
+template <bool ANY, bool COUNT, class Source, class Sink>
+__device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Sink& sink, int* __restrict__ lds_col, uint32_t* __restrict__ spill,
+                                           uint32_t spill_depth, uint32_t total, uint32_t wave, uint32_t n_waves, TraceTally& tally) {
   const BvhNode* __restrict__ nodes = S.bvh_nodes;
   const BvhTri* __restrict__ tris = S.bvh_tris;
-  st.sp = 0;
-  int cur = 0;
+  const int lane = threadIdx.x & 63;
+  const unsigned long long lanes_below = (1ull << lane) - 1ull;
+  uint32_t seq = 0;                                         // wave-uniform: rays of this wave's sequence handed out so far
+  bool exhausted = wave * 64u >= total;                     // wave-uniform
+  // per-lane ray state
+  bool open = false;                                        // a ray is in flight and its result has not been stored
+  int cur = kRayDone;
+  uint32_t ray = 0;
+  vec3 o = mk3(0.0f, 0.0f, 0.0f), d = mk3(0.0f, 0.0f, 1.0f), inv = mk3(0.0f, 0.0f, 0.0f);
+  float tmin = 0.0f, tmax = 0.0f;
+  HitRecord best{0.0f, 0.0f, 0.0f, 0xFFFFFFFFu};
+  uint32_t best_id = 0xFFFFFFFFu;
+  Stack st{lds_col, spill, 0};
   for (;;) {
-    if (cur >= 0) {
-      // inner node: 64 bytes = 4 x dwordx4
-      const float4* np = reinterpret_cast<const float4*>(nodes + cur);
-      const float4 a = np[0], b = np[1], c = np[2], e = np[3];
-      if (COUNT) ++n_nodes;
-      const float lo0[3] = {a.x, a.y, a.z}, hi0[3] = {b.x, b.y, b.z}, lo1[3] = {c.x, c.y, c.z}, hi1[3] = {e.x, e.y, e.z};
-      const float e0 = box_entry(lo0, hi0, o, inv, tmin, best.t), e1 = box_entry(lo1, hi1, o, inv, tmin, best.t);
-      const int c0 = __float_as_int(a.w), c1 = __float_as_int(b.w);
-      const bool h0 = e0 < INFINITY, h1 = e1 < INFINITY;
-      if (h0 && h1) {
-        const bool swap = e1 < e0;
-        st.push(swap ? c0 : c1);
-        cur = swap ? c1 : c0;
-        continue;
+    // ---- refill ----
+    const unsigned long long idle = __ballot(!open);
+    const int n_idle = __popcll(idle);
+    if (!exhausted && n_idle >= kRefill) {
+      const uint32_t mine = seq + (uint32_t)__popcll(idle & lanes_below);
+      const uint32_t next_ray = ((mine >> 6) * n_waves + wave) * 64u + (mine & 63u);
+      if (!open && next_ray < total) {
+        if (src.load(next_ray, o, d, tmin, tmax)) {
+          ray = next_ray;
+          best = HitRecord{tmax, 0.0f, 0.0f, 0xFFFFFFFFu};
+          best_id = 0xFFFFFFFFu;
+          if (COUNT) tally.rays += 1;
+          if (S.n_world_tris == 0) {
+            sink.store(ray, best);                          // nothing to intersect: a miss
+          } else {
+            inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+            st.spill = spill + (size_t)ray * spill_depth;
+            st.sp = 0;
+            cur = 0;
+            open = true;
+          }
+        }
       }
-      if (h0) { cur = c0; continue; }
-      if (h1) { cur = c1; continue; }
-    } else {
+      seq += (uint32_t)n_idle;
+      exhausted = ((seq >> 6) * n_waves + wave) * 64u >= total;
+    }
+    if (__ballot(open) == 0ull) {
+      if (exhausted) break;
+      continue;
+    }
+    // ---- inner-node phase ----
+    for (;;) {
+      const bool at_node = cur >= 0 && cur != kRayDone;
+      if (__ballot(at_node) == 0ull) break;
+      if (at_node) {
+        const float4* np = reinterpret_cast<const float4*>(nodes + cur);
+        const float4 a = np[0], b = np[1], c = np[2], e = np[3];
+        if (COUNT) tally.nodes += 1;
+        const float e0 = box_entry(a.x, a.y, a.z, b.x, b.y, b.z, o, inv, tmin, best.t);
+        const float e1 = box_entry(c.x, c.y, c.z, e.x, e.y, e.z, o, inv, tmin, best.t);
+        const int c0 = __float_as_int(a.w), c1 = __float_as_int(b.w);
+        const bool h0 = e0 < INFINITY, h1 = e1 < INFINITY;
+        if (h0 && h1) {
+          const bool swap = e1 < e0;   // near child first; ties -> child0
+          st.push(swap ? c0 : c1);
+          cur = swap ? c1 : c0;
+        } else if (h0) {
+          cur = c0;
+        } else if (h1) {
+          cur = c1;
+        } else {
+          cur = st.sp ? st.pop() : kRayDone;
+        }
+      }
+      if (__popcll(__ballot(cur < 0)) >= kLeafQuorum) break;
+    }
+    // ---- leaf phase ----
+    if (cur < 0) {
       const uint32_t leaf = (uint32_t)~cur;
       const float4* tp = reinterpret_cast<const float4*>(tris + leaf);
       const float4 a = tp[0], b = tp[1], c = tp[2];
-      if (COUNT) ++n_tris;
+      if (COUNT) tally.tris += 1;
       BvhTri tr;
       tr.v0[0] = a.x; tr.v0[1] = a.y; tr.v0[2] = a.z; tr.world_id = __float_as_uint(a.w);
       tr.e1[0] = b.x; tr.e1[1] = b.y; tr.e1[2] = b.z; tr.instance = __float_as_uint(b.w);
       tr.e2[0] = c.x; tr.e2[1] = c.y; tr.e2[2] = c.z; tr.prim_flags = __float_as_uint(c.w);
       float t, u, v;
+      bool finished = false;
       if (ray_triangle(tr, o, d, tmin, t, u, v) && t < tmax) {
         const bool better = best.leaf == 0xFFFFFFFFu ? true : (t < best.t || (t == best.t && tr.world_id < best_id));
         if (better && (!(tr.prim_flags >> 31) || alpha_test(S, tr, u, v))) {
           best = HitRecord{t, u, v, leaf};
           best_id = tr.world_id;
-          if (ANY) return best;
+          finished = ANY;
         }
       }
+      cur = (finished || st.sp == 0) ? kRayDone : st.pop();
     }
-    if (st.sp == 0) break;
-    cur = st.pop();
+    // ---- retire ----
+    if (open && cur == kRayDone) {
+      if (COUNT) tally.hits += best.leaf != 0xFFFFFFFFu;
+      sink.store(ray, best);
+      open = false;
+    }
   }
-  return best;
 }
 
-__device__ __forceinline__ void flush_counters(TraceCounters* c, bool shadow, unsigned long long rays, unsigned long long nodes,
-                                               unsigned long long tris, unsigned long long hits, unsigned long long fresh = 0) {
+__device__ __forceinline__ void flush_counters(TraceCounters* c, bool shadow, TraceTally t) {
   // wave-level reduction first, one atomic per wave and counter (Guideline 12)
   for (int off = 32; off > 0; off >>= 1) {
-    rays += __shfl_down(rays, off);
-    nodes += __shfl_down(nodes, off);
-    tris += __shfl_down(tris, off);
-    hits += __shfl_down(hits, off);
-    fresh += __shfl_down(fresh, off);
+    t.rays += __shfl_down(t.rays, off);
+    t.nodes += __shfl_down(t.nodes, off);
+    t.tris += __shfl_down(t.tris, off);
+    t.hits += __shfl_down(t.hits, off);
+    t.fresh += __shfl_down(t.fresh, off);
   }
   if ((threadIdx.x & 63) == 0) {
     if (shadow) {
-      atomicAdd(&c->shadow_rays, rays); atomicAdd(&c->shadow_nodes, nodes); atomicAdd(&c->shadow_tris, tris);
+      atomicAdd(&c->shadow_rays, t.rays); atomicAdd(&c->shadow_nodes, t.nodes); atomicAdd(&c->shadow_tris, t.tris);
     } else {
-      atomicAdd(&c->closest_rays, rays); atomicAdd(&c->closest_nodes, nodes); atomicAdd(&c->closest_tris, tris);
-      atomicAdd(&c->hits, hits);
-      atomicAdd(&c->fresh, fresh);
+      atomicAdd(&c->closest_rays, t.rays); atomicAdd(&c->closest_nodes, t.nodes); atomicAdd(&c->closest_tris, t.tris);
+      atomicAdd(&c->hits, t.hits);
+      atomicAdd(&c->fresh, t.fresh);
     }
   }
 }
+
+// persistent launch geometry: every wave of the grid is one independent tracer
+__device__ __forceinline__ uint32_t wave_index() { return blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); }
+__device__ __forceinline__ uint32_t wave_count() { return gridDim.x * (kBlock / 64); }
 
 // ---------------------------------------------------------------------------------------------
 // k_trace_closest: path_trace.rgen:143-169
 // ---------------------------------------------------------------------------------------------
-template <bool COUNT>
-__global__ void __launch_bounds__(kBlock) k_trace_closest(const LaunchArgs A) {
-  __shared__ int s_stack[kLdsStack * kBlock];
-  const uint32_t lid = blockIdx.x * kBlock + threadIdx.x;
-  const PixelId px = pixel_of(A.map, lid);
-  unsigned long long n_nodes = 0, n_tris = 0, n_rays = 0, n_hits = 0, n_fresh = 0;
-  if (lid < kQueueShards) A.st.queue_count[lid * kCounterStride] = 0;   // the previous launch's k_shadow_queue has drained the queue; k_shade refills it
-  if (px.active) {
-    float4 ro = A.st.ray_o[lid], rd = A.st.ray_d[lid];
-    vec3 origin, direction;
+struct ClosestSource {
+  const LaunchArgs& A;
+  TraceTally& tally;
+  // ray generation / resume for local pixel `lid`
+  __device__ __forceinline__ bool load(uint32_t lid, vec3& origin, vec3& direction, float& tmin, float& tmax) {
+    const PixelId px = pixel_of(A.map, lid);
+    if (!px.active) return false;
+    const float4 ro = A.st.ray_o[lid], rd = A.st.ray_d[lid];
     if (A.frame.direct_only || ro.w == 0.0f) {
-      n_fresh = 1;
+      tally.fresh += 1;
       // new path: camera ray through the jittered pixel (ray_origin / ray_dir, path_trace.rgen:47-73)
       const float pxf = (float)px.x + A.frame.pixel_offset[0], pyf = (float)px.y + A.frame.pixel_offset[1];
       const float ndcx = -1.0f + 2.0f * (pxf / A.frame.scene_size[0]), ndcy = -1.0f + 2.0f * (pyf / A.frame.scene_size[1]);
@@ -236,13 +306,28 @@ __global__ void __launch_bounds__(kBlock) k_trace_closest(const LaunchArgs A) {
       origin = mk3(ro.x, ro.y, ro.z);
       direction = mk3(rd.x, rd.y, rd.z);
     }
-    Stack st{&s_stack[threadIdx.x], A.st.overflow + (size_t)lid * A.st.overflow_depth, 0};
-    const HitRecord h = traverse<false, COUNT>(A.scene, origin, direction, 0.0001f, INFINITY, st, n_nodes, n_tris);
-    A.st.hit[lid] = make_float4(h.leaf == 0xFFFFFFFFu ? INFINITY : h.t, h.u, h.v, __uint_as_float(h.leaf));
-    n_rays = 1;
-    n_hits = h.leaf != 0xFFFFFFFFu;
+    tmin = 0.0001f;
+    tmax = INFINITY;
+    return true;
   }
-  if (COUNT) flush_counters(A.counters, false, n_rays, n_nodes, n_tris, n_hits, n_fresh);
+};
+struct ClosestSink {
+  const LaunchArgs& A;
+  __device__ __forceinline__ void store(uint32_t lid, const HitRecord& h) {
+    A.st.hit[lid] = make_float4(h.leaf == 0xFFFFFFFFu ? INFINITY : h.t, h.u, h.v, __uint_as_float(h.leaf));
+  }
+};
+
+template <bool COUNT>
+__global__ void __launch_bounds__(kBlock) k_trace_closest(const LaunchArgs A) {
+  __shared__ int s_stack[kLdsStack * kBlock];
+  if (blockIdx.x == 0 && threadIdx.x < kQueueShards) A.st.queue_count[threadIdx.x * kCounterStride] = 0;   // drained by the previous launch's k_shadow_queue; k_shade refills it
+  TraceTally tally;
+  ClosestSource src{A, tally};
+  ClosestSink sink{A};
+  trace_wave<false, COUNT>(A.scene, src, sink, &s_stack[threadIdx.x], A.st.overflow, A.st.overflow_depth, A.map.n_local_pixels, wave_index(), wave_count(),
+                           tally);
+  if (COUNT) flush_counters(A.counters, false, tally);
 }
 
 // update_count() + update_result() of path_trace.rgen:119-133 for one pixel
@@ -284,7 +369,7 @@ __device__ __forceinline__ uint32_t queue_slot(uint32_t* counters, uint32_t n_lo
 // ---------------------------------------------------------------------------------------------
 // k_shade: path_trace.rgen:170-237 minus the two traceRayEXT calls, raytrace_hit.rchit:30-71
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock) k_shade(const LaunchArgs A) {
+__global__ void __launch_bounds__(kBlock, 4) k_shade(const LaunchArgs A) {
   const uint32_t lid = blockIdx.x * kBlock + threadIdx.x;
   const PixelId px = pixel_of(A.map, lid);
   if (!px.active) return;
@@ -452,6 +537,44 @@ __global__ void __launch_bounds__(kBlock) k_shade(const LaunchArgs A) {
 // k_shade, followed by update_count / update_result (:119-133) of the owning pixel.  Persistent grid: each
 // thread strides over the queue, so every wave traverses with (almost) all lanes active.
 // ---------------------------------------------------------------------------------------------
+struct ShadowSource {
+  const LaunchArgs& A;
+  const uint32_t* start;   // prefix sums of the shard counts (kQueueShards + 1 entries)
+  uint32_t cap;
+  uint32_t lid;            // per-lane: owning pixel and contribution of the ray in flight
+  float4 contrib;
+  __device__ __forceinline__ bool load(uint32_t i, vec3& o, vec3& d, float& tmin, float& tmax) {
+    uint32_t shard = 0;
+#pragma unroll
+    for (uint32_t k = 1; k < kQueueShards; ++k) shard += i >= start[k] ? 1u : 0u;
+    const uint32_t q = shard * cap + (i - start[shard]);
+    const float4 so = A.st.sh_o[q], sd = A.st.sh_d[q];
+    contrib = A.st.contrib[q];
+    lid = __float_as_uint(sd.w);
+    o = mk3(so.x, so.y, so.z);
+    d = mk3(sd.x, sd.y, sd.z);
+    tmin = 0.001f;
+    tmax = so.w;
+    return true;
+  }
+};
+struct ShadowSink {
+  const LaunchArgs& A;
+  ShadowSource& src;
+  __device__ __forceinline__ void store(uint32_t, const HitRecord& h) {
+    const bool occluded = h.leaf != 0xFFFFFFFFu;
+    const uint32_t flags = __float_as_uint(src.contrib.w);
+    vec3 c = mk3(src.contrib.x, src.contrib.y, src.contrib.z);
+    bool add = !occluded;
+    if (occluded && (flags & kFlagPoison)) {
+      const float nan = __uint_as_float(0x7FC00000u);
+      c = mk3(nan, nan, nan);
+      add = true;
+    }
+    accumulate_pixel(A, src.lid, c, add, true);
+  }
+};
+
 template <bool COUNT>
 __global__ void __launch_bounds__(kBlock) k_shadow_queue(const LaunchArgs A) {
   __shared__ int s_stack[kLdsStack * kBlock];
@@ -460,29 +583,12 @@ __global__ void __launch_bounds__(kBlock) k_shadow_queue(const LaunchArgs A) {
   start[0] = 0;
 #pragma unroll
   for (uint32_t k = 0; k < kQueueShards; ++k) start[k + 1] = start[k] + A.st.queue_count[k * kCounterStride];
-  const uint32_t count = start[kQueueShards], cap = queue_capacity(A.map.n_local_pixels);
-  unsigned long long n_nodes = 0, n_tris = 0, n_rays = 0;
-  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < count; i += gridDim.x * kBlock) {
-    uint32_t shard = 0;
-#pragma unroll
-    for (uint32_t k = 1; k < kQueueShards; ++k) shard += i >= start[k] ? 1u : 0u;
-    const uint32_t q = shard * cap + (i - start[shard]);
-    const float4 so = A.st.sh_o[q], sd = A.st.sh_d[q], cb = A.st.contrib[q];
-    const uint32_t lid = __float_as_uint(sd.w), flags = __float_as_uint(cb.w);
-    Stack st{&s_stack[threadIdx.x], A.st.overflow + (size_t)lid * A.st.overflow_depth, 0};
-    const HitRecord h = traverse<true, COUNT>(A.scene, mk3(so.x, so.y, so.z), mk3(sd.x, sd.y, sd.z), 0.001f, so.w, st, n_nodes, n_tris);
-    const bool occluded = h.leaf != 0xFFFFFFFFu;
-    n_rays += 1;
-    vec3 c = mk3(cb.x, cb.y, cb.z);
-    bool add = !occluded;
-    if (occluded && (flags & kFlagPoison)) {
-      const float nan = __uint_as_float(0x7FC00000u);
-      c = mk3(nan, nan, nan);
-      add = true;
-    }
-    accumulate_pixel(A, lid, c, add, true);
-  }
-  if (COUNT) flush_counters(A.counters, true, n_rays, n_nodes, n_tris, 0);
+  TraceTally tally;
+  ShadowSource src{A, start, queue_capacity(A.map.n_local_pixels), 0u, make_float4(0.0f, 0.0f, 0.0f, 0.0f)};
+  ShadowSink sink{A, src};
+  // the spill area is indexed by queue position here (each position is in flight at most once)
+  trace_wave<true, COUNT>(A.scene, src, sink, &s_stack[threadIdx.x], A.st.overflow, A.st.overflow_depth, start[kQueueShards], wave_index(), wave_count(), tally);
+  if (COUNT) flush_counters(A.counters, true, tally);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -511,43 +617,66 @@ __global__ void __launch_bounds__(kBlock) k_tonemap(uint32_t n, const float4* __
 // ---------------------------------------------------------------------------------------------
 // debug / parity kernels: arbitrary rays through the same traversal code
 // ---------------------------------------------------------------------------------------------
+struct DebugSource {
+  const float* __restrict__ o3;
+  const float* __restrict__ d3;
+  const float* __restrict__ tmax_arr;   // nullptr = infinity
+  float tmin_all;
+  __device__ __forceinline__ bool load(uint32_t i, vec3& o, vec3& d, float& tmin, float& tmax) {
+    o = mk3(o3[3 * i], o3[3 * i + 1], o3[3 * i + 2]);
+    d = mk3(d3[3 * i], d3[3 * i + 1], d3[3 * i + 2]);
+    tmin = tmin_all;
+    tmax = tmax_arr ? tmax_arr[i] : INFINITY;
+    return true;
+  }
+};
+struct DebugClosestSink {
+  const DeviceScene& S;
+  float* t; uint32_t* tri; uint32_t* inst; float* u; float* v;
+  __device__ __forceinline__ void store(uint32_t i, const HitRecord& h) {
+    const bool hit = h.leaf != 0xFFFFFFFFu;
+    t[i] = hit ? h.t : INFINITY;
+    tri[i] = hit ? S.bvh_tris[h.leaf].world_id : 0xFFFFFFFFu;
+    inst[i] = hit ? S.bvh_tris[h.leaf].instance : 0xFFFFFFFFu;
+    u[i] = hit ? h.u : 0.0f;
+    v[i] = hit ? h.v : 0.0f;
+  }
+};
+struct DebugAnySink {
+  uint8_t* out;
+  __device__ __forceinline__ void store(uint32_t i, const HitRecord& h) { out[i] = h.leaf != 0xFFFFFFFFu; }
+};
+
 __global__ void __launch_bounds__(kBlock) k_debug_closest(const DeviceScene S, const float* __restrict__ o, const float* __restrict__ d, uint32_t n,
                                                           float tmin, float* t, uint32_t* tri, uint32_t* inst, float* u, float* v,
                                                           uint32_t* overflow, uint32_t overflow_depth) {
   __shared__ int s_stack[kLdsStack * kBlock];
-  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n) return;
-  unsigned long long a = 0, b = 0;
-  Stack st{&s_stack[threadIdx.x], overflow + (size_t)i * overflow_depth, 0};
-  const HitRecord h = traverse<false, false>(S, mk3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), mk3(d[3 * i], d[3 * i + 1], d[3 * i + 2]), tmin, INFINITY, st, a, b);
-  const bool hit = h.leaf != 0xFFFFFFFFu;
-  t[i] = hit ? h.t : INFINITY;
-  tri[i] = hit ? S.bvh_tris[h.leaf].world_id : 0xFFFFFFFFu;
-  inst[i] = hit ? S.bvh_tris[h.leaf].instance : 0xFFFFFFFFu;
-  u[i] = hit ? h.u : 0.0f;
-  v[i] = hit ? h.v : 0.0f;
+  TraceTally tally;
+  DebugSource src{o, d, nullptr, tmin};
+  DebugClosestSink sink{S, t, tri, inst, u, v};
+  trace_wave<false, false>(S, src, sink, &s_stack[threadIdx.x], overflow, overflow_depth, n, wave_index(), wave_count(), tally);
 }
 __global__ void __launch_bounds__(kBlock) k_debug_any(const DeviceScene S, const float* __restrict__ o, const float* __restrict__ d,
                                                       const float* __restrict__ tmax, uint32_t n, float tmin, uint8_t* out, uint32_t* overflow,
                                                       uint32_t overflow_depth) {
   __shared__ int s_stack[kLdsStack * kBlock];
-  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n) return;
-  unsigned long long a = 0, b = 0;
-  Stack st{&s_stack[threadIdx.x], overflow + (size_t)i * overflow_depth, 0};
-  const HitRecord h = traverse<true, false>(S, mk3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), mk3(d[3 * i], d[3 * i + 1], d[3 * i + 2]), tmin, tmax[i], st, a, b);
-  out[i] = h.leaf != 0xFFFFFFFFu;
+  TraceTally tally;
+  DebugSource src{o, d, tmax, tmin};
+  DebugAnySink sink{out};
+  trace_wave<true, false>(S, src, sink, &s_stack[threadIdx.x], overflow, overflow_depth, n, wave_index(), wave_count(), tally);
 }
 
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
 static inline dim3 grid_for(uint32_t n) { return dim3((n + kBlock - 1) / kBlock); }
+// persistent tracers: 256 CUs x 8 resident 256-thread blocks at most, never more waves than 64-ray groups
+static inline dim3 persistent_grid(uint32_t n_rays) { return dim3(std::max<uint32_t>(1u, std::min<uint32_t>((n_rays + kBlock - 1) / kBlock, 256u * 8u))); }
 
 hipError_t launch_trace_closest(hipStream_t st, const LaunchArgs& a) {
   if (a.map.n_local_pixels == 0) return hipSuccess;
-  if (a.counters) hipLaunchKernelGGL(k_trace_closest<true>, grid_for(a.map.n_local_pixels), dim3(kBlock), 0, st, a);
-  else hipLaunchKernelGGL(k_trace_closest<false>, grid_for(a.map.n_local_pixels), dim3(kBlock), 0, st, a);
+  if (a.counters) hipLaunchKernelGGL(k_trace_closest<true>, persistent_grid(a.map.n_local_pixels), dim3(kBlock), 0, st, a);
+  else hipLaunchKernelGGL(k_trace_closest<false>, persistent_grid(a.map.n_local_pixels), dim3(kBlock), 0, st, a);
   return hipGetLastError();
 }
 hipError_t launch_shade(hipStream_t st, const LaunchArgs& a) {
@@ -557,10 +686,8 @@ hipError_t launch_shade(hipStream_t st, const LaunchArgs& a) {
 }
 hipError_t launch_shadow_accumulate(hipStream_t st, const LaunchArgs& a) {
   if (a.map.n_local_pixels == 0) return hipSuccess;
-  // persistent grid: 256 CUs x 8 resident blocks at most, never more blocks than queue capacity
-  const uint32_t blocks = std::min<uint32_t>((a.map.n_local_pixels + kBlock - 1) / kBlock, 256u * 8u);
-  if (a.counters) hipLaunchKernelGGL(k_shadow_queue<true>, dim3(blocks), dim3(kBlock), 0, st, a);
-  else hipLaunchKernelGGL(k_shadow_queue<false>, dim3(blocks), dim3(kBlock), 0, st, a);
+  if (a.counters) hipLaunchKernelGGL(k_shadow_queue<true>, persistent_grid(a.map.n_local_pixels), dim3(kBlock), 0, st, a);
+  else hipLaunchKernelGGL(k_shadow_queue<false>, persistent_grid(a.map.n_local_pixels), dim3(kBlock), 0, st, a);
   return hipGetLastError();
 }
 hipError_t launch_export(hipStream_t st, const TileMap& map, const float4* tiled, float4* frame, bool zero_first) {
@@ -579,13 +706,13 @@ hipError_t launch_tonemap(hipStream_t st, uint32_t n, const float4* result_frame
 hipError_t launch_debug_closest(hipStream_t st, const DeviceScene& scene, const float* o, const float* d, uint32_t n, float tmin, float* t,
                                 uint32_t* tri, uint32_t* inst, float* u, float* v, uint32_t* overflow, uint32_t overflow_depth) {
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_debug_closest, grid_for(n), dim3(kBlock), 0, st, scene, o, d, n, tmin, t, tri, inst, u, v, overflow, overflow_depth);
+  hipLaunchKernelGGL(k_debug_closest, persistent_grid(n), dim3(kBlock), 0, st, scene, o, d, n, tmin, t, tri, inst, u, v, overflow, overflow_depth);
   return hipGetLastError();
 }
 hipError_t launch_debug_any(hipStream_t st, const DeviceScene& scene, const float* o, const float* d, const float* tmax, uint32_t n, float tmin,
                             uint8_t* hit, uint32_t* overflow, uint32_t overflow_depth) {
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_debug_any, grid_for(n), dim3(kBlock), 0, st, scene, o, d, tmax, n, tmin, hit, overflow, overflow_depth);
+  hipLaunchKernelGGL(k_debug_any, persistent_grid(n), dim3(kBlock), 0, st, scene, o, d, tmax, n, tmin, hit, overflow, overflow_depth);
   return hipGetLastError();
 }
 
