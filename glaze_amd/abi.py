@@ -161,7 +161,8 @@ _LIB = None
 
 
 def library_path():
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libglaze_hip.so")
+    # GLAZE_HIP_LIB selects another build of the same library (kernel tuning experiments); never a different backend
+    return os.environ.get("GLAZE_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libglaze_hip.so")
 
 
 class GlazeLibraryMissing(ImportError):

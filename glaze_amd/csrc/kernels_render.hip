@@ -138,8 +138,17 @@ struct TraceTally {
 // Sink:   void store(uint32_t ray, const HitRecord&)
 // ---------------------------------------------------------------------------------------------
 constexpr int kRayDone = 0x7FFFFFFF;   // `cur` of a lane without a node to visit (inner nodes are >= 0, leaves < 0)
-constexpr int kRefill = 16;
-constexpr int kLeafQuorum = 24;
+#ifndef GLZ_TRACE_WAVES
+#define GLZ_TRACE_WAVES 7   // waves per SIMD the tracers are compiled for (__launch_bounds__): 72 VGPRs, no spills
+#endif
+#ifndef GLZ_REFILL
+#define GLZ_REFILL 16
+#endif
+#ifndef GLZ_LEAF_QUORUM
+#define GLZ_LEAF_QUORUM 8
+#endif
+constexpr int kRefill = GLZ_REFILL;
+constexpr int kLeafQuorum = GLZ_LEAF_QUORUM;
 
 template <bool ANY, bool COUNT, class Source, class Sink>
 __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Sink& sink, int* __restrict__ lds_col, uint32_t* __restrict__ spill,
@@ -319,7 +328,7 @@ struct ClosestSink {
 };
 
 template <bool COUNT>
-__global__ void __launch_bounds__(kBlock) k_trace_closest(const LaunchArgs A) {
+__global__ void __launch_bounds__(kBlock, GLZ_TRACE_WAVES) k_trace_closest(const LaunchArgs A) {
   __shared__ int s_stack[kLdsStack * kBlock];
   if (blockIdx.x == 0 && threadIdx.x < kQueueShards) A.st.queue_count[threadIdx.x * kCounterStride] = 0;   // drained by the previous launch's k_shadow_queue; k_shade refills it
   TraceTally tally;
@@ -576,7 +585,7 @@ struct ShadowSink {
 };
 
 template <bool COUNT>
-__global__ void __launch_bounds__(kBlock) k_shadow_queue(const LaunchArgs A) {
+__global__ void __launch_bounds__(kBlock, GLZ_TRACE_WAVES) k_shadow_queue(const LaunchArgs A) {
   __shared__ int s_stack[kLdsStack * kBlock];
   // prefix sums of the eight shard counts (final: k_shade has completed)
   uint32_t start[kQueueShards + 1];
@@ -670,13 +679,36 @@ __global__ void __launch_bounds__(kBlock) k_debug_any(const DeviceScene S, const
 // launchers
 // ---------------------------------------------------------------------------------------------
 static inline dim3 grid_for(uint32_t n) { return dim3((n + kBlock - 1) / kBlock); }
-// persistent tracers: 256 CUs x 8 resident 256-thread blocks at most, never more waves than 64-ray groups
-static inline dim3 persistent_grid(uint32_t n_rays) { return dim3(std::max<uint32_t>(1u, std::min<uint32_t>((n_rays + kBlock - 1) / kBlock, 256u * 8u))); }
+// Persistent tracers: the grid is exactly what is resident at once (CUs x blocks per CU from the occupancy query, at
+// most 8), and never more waves than there are 64-ray groups.  A block that had to wait for a slot would serialise
+// behind a whole persistent block (cdna_hip_programming.md section 1: size persistent grids by residency).
+template <class Kernel>
+static dim3 persistent_grid(Kernel kernel, uint32_t n_rays) {
+  int dev = 0, cus = 256, per_cu = 8;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+  }
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+  per_cu = std::min(per_cu, 8);
+  const uint32_t resident = (uint32_t)cus * (uint32_t)per_cu;
+  return dim3(std::max<uint32_t>(1u, std::min<uint32_t>((n_rays + kBlock - 1) / kBlock, resident)));
+}
+template <class Kernel>
+static dim3 cached_grid(Kernel kernel, uint32_t n_rays, uint32_t& cache_n, dim3& cache_grid) {
+  if (cache_n != n_rays || cache_grid.x == 0) {
+    cache_grid = persistent_grid(kernel, n_rays);
+    cache_n = n_rays;
+  }
+  return cache_grid;
+}
 
 hipError_t launch_trace_closest(hipStream_t st, const LaunchArgs& a) {
   if (a.map.n_local_pixels == 0) return hipSuccess;
-  if (a.counters) hipLaunchKernelGGL(k_trace_closest<true>, persistent_grid(a.map.n_local_pixels), dim3(kBlock), 0, st, a);
-  else hipLaunchKernelGGL(k_trace_closest<false>, persistent_grid(a.map.n_local_pixels), dim3(kBlock), 0, st, a);
+  static thread_local uint32_t n0 = 0, n1 = 0;
+  static thread_local dim3 g0(0), g1(0);
+  if (a.counters) hipLaunchKernelGGL(k_trace_closest<true>, cached_grid(k_trace_closest<true>, a.map.n_local_pixels, n1, g1), dim3(kBlock), 0, st, a);
+  else hipLaunchKernelGGL(k_trace_closest<false>, cached_grid(k_trace_closest<false>, a.map.n_local_pixels, n0, g0), dim3(kBlock), 0, st, a);
   return hipGetLastError();
 }
 hipError_t launch_shade(hipStream_t st, const LaunchArgs& a) {
@@ -686,8 +718,10 @@ hipError_t launch_shade(hipStream_t st, const LaunchArgs& a) {
 }
 hipError_t launch_shadow_accumulate(hipStream_t st, const LaunchArgs& a) {
   if (a.map.n_local_pixels == 0) return hipSuccess;
-  if (a.counters) hipLaunchKernelGGL(k_shadow_queue<true>, persistent_grid(a.map.n_local_pixels), dim3(kBlock), 0, st, a);
-  else hipLaunchKernelGGL(k_shadow_queue<false>, persistent_grid(a.map.n_local_pixels), dim3(kBlock), 0, st, a);
+  static thread_local uint32_t n0 = 0, n1 = 0;
+  static thread_local dim3 g0(0), g1(0);
+  if (a.counters) hipLaunchKernelGGL(k_shadow_queue<true>, cached_grid(k_shadow_queue<true>, a.map.n_local_pixels, n1, g1), dim3(kBlock), 0, st, a);
+  else hipLaunchKernelGGL(k_shadow_queue<false>, cached_grid(k_shadow_queue<false>, a.map.n_local_pixels, n0, g0), dim3(kBlock), 0, st, a);
   return hipGetLastError();
 }
 hipError_t launch_export(hipStream_t st, const TileMap& map, const float4* tiled, float4* frame, bool zero_first) {
@@ -706,13 +740,13 @@ hipError_t launch_tonemap(hipStream_t st, uint32_t n, const float4* result_frame
 hipError_t launch_debug_closest(hipStream_t st, const DeviceScene& scene, const float* o, const float* d, uint32_t n, float tmin, float* t,
                                 uint32_t* tri, uint32_t* inst, float* u, float* v, uint32_t* overflow, uint32_t overflow_depth) {
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_debug_closest, persistent_grid(n), dim3(kBlock), 0, st, scene, o, d, n, tmin, t, tri, inst, u, v, overflow, overflow_depth);
+  hipLaunchKernelGGL(k_debug_closest, persistent_grid(k_debug_closest, n), dim3(kBlock), 0, st, scene, o, d, n, tmin, t, tri, inst, u, v, overflow, overflow_depth);
   return hipGetLastError();
 }
 hipError_t launch_debug_any(hipStream_t st, const DeviceScene& scene, const float* o, const float* d, const float* tmax, uint32_t n, float tmin,
                             uint8_t* hit, uint32_t* overflow, uint32_t overflow_depth) {
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_debug_any, persistent_grid(n), dim3(kBlock), 0, st, scene, o, d, tmax, n, tmin, hit, overflow, overflow_depth);
+  hipLaunchKernelGGL(k_debug_any, persistent_grid(k_debug_any, n), dim3(kBlock), 0, st, scene, o, d, tmax, n, tmin, hit, overflow, overflow_depth);
   return hipGetLastError();
 }
 
