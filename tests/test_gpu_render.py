@@ -248,3 +248,30 @@ def test_full_size_properties_atrium(instance):
     o.set_depth(8)
     o.step(8)
     assert_parity(small, o, "atrium 96x54")
+
+
+def test_traversal_work_counters_match_the_oracle(instance, mattest_desc):
+    """node visits / triangle tests per sample are COUNTED, not estimated.  The instrumented kernels'
+    counters must equal what the oracle counts when it walks the very same LBVH (downloaded from the device) with the
+    documented visit rule (near child first, ties -> child0, prune with the current best t)."""
+    for desc, w, h, depth, launches in ((cube_scene(), 64, 64, 2, 4), (mattest_desc, 48, 48, 6, 6)):
+        scene = glaze_amd.RayTraceScene.from_desc(instance, desc)
+        nodes, tris = scene.debug_bvh()
+        r = glaze_amd.RayTraceRenderer.new(instance, scene, w, h)
+        r.set_depth(depth)
+        r.enable_counters(True, True)
+        r.step(launches)
+        r.wait_idle()
+        s = r.stats()
+        osc = OracleScene(desc)
+        osc.set_ext_bvh(nodes, tris)
+        o = OracleRenderer(osc, w, h)
+        o.set_depth(depth)
+        o.set_counting(True)
+        o.step(launches)
+        c = o.counters()
+        assert s.closest_rays == c["closest_rays"] == w * h * launches
+        assert s.shadow_rays == c["shadow_rays"] and s.hits == c["hits"]
+        assert (s.closest_nodes, s.closest_tris) == (c["closest_nodes"], c["closest_tris"])
+        assert (s.shadow_nodes, s.shadow_tris) == (c["shadow_nodes"], c["shadow_tris"])
+        assert_parity(r, o, "counting build")
