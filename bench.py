@@ -52,7 +52,7 @@ def algorithmic_bytes(c):
     closest = 32 + 16 + 32 * c["f_fresh"] + 64 * c["nodes_closest"] + 36 * c["tris_closest"]
     shade = 16 + 32 + 64 * (1 - c["f_fresh"]) + 380 * c["f_hit"] + 16 + 32 * c["f_shadow"] + 96 * c["f_hit"]
     shadow = 16 + 32 * c["f_shadow"] + 32 + 16 * c["f_hit"] + 64 * c["nodes_shadow"] + 36 * c["tris_shadow"]
-    return {"k_trace_closest": closest, "k_shade": shade, "k_shadow_accum": shadow}
+    return {"k_trace_closest": closest, "k_shade": shade, "k_shadow_queue": shadow}
 
 
 def main():
@@ -132,7 +132,7 @@ def main():
 
     # per-kernel device time inside the timed region (hipEvents on the instance stream)
     kern_ms = {"k_trace_closest": s1.trace_closest_ms - s0.trace_closest_ms, "k_shade": s1.shade_ms - s0.shade_ms,
-               "k_shadow_accum": s1.trace_shadow_ms - s0.trace_shadow_ms}
+               "k_shadow_queue": s1.trace_shadow_ms - s0.trace_shadow_ms}
 
     out = None
     if rank == 0:

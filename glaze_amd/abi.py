@@ -87,7 +87,7 @@ class RenderStats(C.Structure):
                 ("trace_closest_ms", C.c_double), ("shade_ms", C.c_double), ("trace_shadow_ms", C.c_double), ("other_ms", C.c_double),
                 ("closest_rays", C.c_uint64), ("shadow_rays", C.c_uint64),
                 ("closest_nodes", C.c_uint64), ("closest_tris", C.c_uint64), ("shadow_nodes", C.c_uint64), ("shadow_tris", C.c_uint64),
-                ("hits", C.c_uint64), ("fresh_paths", C.c_uint64)]
+                ("hits", C.c_uint64), ("fresh_paths", C.c_uint64), ("phase", C.c_uint64 * 12)]
 
 
 DRAW_CALLBACK = C.CFUNCTYPE(None, C.c_void_p)

@@ -67,6 +67,7 @@ struct CameraConsts {
 
 struct TraceCounters {
   unsigned long long closest_rays, shadow_rays, closest_nodes, closest_tris, shadow_nodes, shadow_tris, hits, fresh;
+  unsigned long long phase[12];   // {node_iters, node_lanes, leaf_iters, leaf_lanes, refill_iters, refill_lanes} x {closest, shadow}
 };
 
 struct LaunchArgs {
@@ -76,6 +77,7 @@ struct LaunchArgs {
   FrameData frame;
   CameraConsts cam;
   TraceCounters* counters;   // nullptr unless counting is enabled
+  uint32_t count_schedule;   // with counters: instrument the production (speculative) schedule instead of the algorithmic one
 };
 
 hipError_t launch_trace_closest(hipStream_t st, const LaunchArgs& a);

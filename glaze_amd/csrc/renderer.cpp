@@ -111,6 +111,7 @@ void Renderer::fill_args(LaunchArgs& a) const {
   a.map = map_;
   a.cam = cam_;
   a.counters = counting_ ? counters_.ptr : nullptr;
+  a.count_schedule = count_schedule_ ? 1u : 0u;
 }
 
 // draw_frame (raytracer.rs:369-613): one path segment per pixel
@@ -205,6 +206,7 @@ bool Renderer::get_stats(glz_render_stats* out, Error& err) {
   out->shadow_tris = c.shadow_tris;
   out->hits = c.hits;
   out->fresh_paths = c.fresh;
+  for (int i = 0; i < 12; ++i) out->phase[i] = c.phase[i];
   return true;
 }
 
