@@ -367,8 +367,8 @@ class RayTraceRenderer:
         abi.check(abi.lib().glz_renderer_tonemap_device(self._h, C.c_void_p(device_ptr), _ptr(out)))
         return out
 
-    def enable_counters(self, counters=False, kernel_timing=True, production_schedule=False):
-        abi.check(abi.lib().glz_renderer_enable_counters(self._h, (1 if counters else 0) | (2 if kernel_timing else 0) | (4 if production_schedule else 0)))
+    def enable_counters(self, counters=False, kernel_timing=True):
+        abi.check(abi.lib().glz_renderer_enable_counters(self._h, (1 if counters else 0) | (2 if kernel_timing else 0)))
 
     def stats(self):
         s = abi.RenderStats()

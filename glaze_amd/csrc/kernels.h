@@ -77,7 +77,6 @@ struct LaunchArgs {
   FrameData frame;
   CameraConsts cam;
   TraceCounters* counters;   // nullptr unless counting is enabled
-  uint32_t count_schedule;   // with counters: instrument the production (speculative) schedule instead of the algorithmic one
 };
 
 hipError_t launch_trace_closest(hipStream_t st, const LaunchArgs& a);

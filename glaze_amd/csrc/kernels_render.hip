@@ -149,14 +149,10 @@ constexpr int kRayDone = 0x7FFFFFFF;   // `cur` of a lane without a node to visi
 #ifndef GLZ_LEAF_QUORUM
 #define GLZ_LEAF_QUORUM 8
 #endif
-#ifndef GLZ_PEND_QUORUM
-#define GLZ_PEND_QUORUM 40
-#endif
 constexpr int kRefill = GLZ_REFILL;
 constexpr int kLeafQuorum = GLZ_LEAF_QUORUM;
-constexpr int kPendQuorum = GLZ_PEND_QUORUM;   // SPEC: lanes with a postponed leaf that trigger a leaf round
 
-template <bool ANY, bool COUNT, bool SPEC, class Source, class Sink>
+template <bool ANY, bool COUNT, class Source, class Sink>
 __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Sink& sink, int* __restrict__ lds_col, uint32_t* __restrict__ spill,
                                            uint32_t spill_depth, uint32_t total, uint32_t wave, uint32_t n_waves, TraceTally& tally) {
   const BvhNode* __restrict__ nodes = S.bvh_nodes;
@@ -167,8 +163,7 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
   bool exhausted = wave * 64u >= total;                     // wave-uniform
   // per-lane ray state
   bool open = false;                                        // a ray is in flight and its result has not been stored
-  int cur = kRayDone;                                       // node to visit next: >= 0 inner, < 0 ~leaf, kRayDone none
-  int pend = 0;                                             // SPEC: a postponed leaf (< 0), 0 = none
+  int cur = kRayDone;
   uint32_t ray = 0;
   vec3 o = mk3(0.0f, 0.0f, 0.0f), d = mk3(0.0f, 0.0f, 1.0f), inv = mk3(0.0f, 0.0f, 0.0f);
   float tmin = 0.0f, tmax = 0.0f;
@@ -196,7 +191,6 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
             st.spill = spill + (size_t)ray * spill_depth;
             st.sp = 0;
             cur = 0;
-            pend = 0;
             open = true;
           }
         }
@@ -233,29 +227,16 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
         } else {
           cur = st.sp ? st.pop() : kRayDone;
         }
-        if (SPEC && cur < 0 && pend == 0) {
-          // postpone this leaf and keep descending with the current best t (only pruning is affected, never the result)
-          pend = cur;
-          cur = st.sp ? st.pop() : kRayDone;
-        }
       }
-      if (SPEC) {
-        // leave when enough lanes hold a triangle to test, or when lanes are stuck holding two
-        const int n_pend = __popcll(__ballot(pend != 0));
-        const int n_stuck = __popcll(__ballot(cur < 0));
-        if (n_pend >= kPendQuorum || n_stuck >= kLeafQuorum) break;
-      } else {
-        if (__popcll(__ballot(cur < 0)) >= kLeafQuorum) break;
-      }
+      if (__popcll(__ballot(cur < 0)) >= kLeafQuorum) break;
     }
     // ---- leaf phase ----
-    const int leaf_ref = SPEC ? pend : (cur < 0 ? cur : 0);
     if (COUNT) {
-      const unsigned long long m_leaf = __ballot(leaf_ref != 0);
+      const unsigned long long m_leaf = __ballot(cur < 0);
       if (lane == 0 && m_leaf) { tally.leaf_iters += 1; tally.leaf_lanes += (unsigned)__popcll(m_leaf); }
     }
-    if (leaf_ref != 0) {
-      const uint32_t leaf = (uint32_t)~leaf_ref;
+    if (cur < 0) {
+      const uint32_t leaf = (uint32_t)~cur;
       const float4* tp = reinterpret_cast<const float4*>(tris + leaf);
       const float4 a = tp[0], b = tp[1], c = tp[2];
       if (COUNT) tally.tris += 1;
@@ -273,22 +254,10 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
           finished = ANY;
         }
       }
-      if (SPEC) {
-        if (finished) {
-          cur = kRayDone;
-          pend = 0;
-        } else if (cur < 0) {   // the second leaf this lane was holding becomes the postponed one
-          pend = cur;
-          cur = st.sp ? st.pop() : kRayDone;
-        } else {
-          pend = 0;
-        }
-      } else {
-        cur = (finished || st.sp == 0) ? kRayDone : st.pop();
-      }
+      cur = (finished || st.sp == 0) ? kRayDone : st.pop();
     }
     // ---- retire ----
-    if (open && cur == kRayDone && pend == 0) {
+    if (open && cur == kRayDone) {
       if (COUNT) tally.hits += best.leaf != 0xFFFFFFFFu;
       sink.store(ray, best);
       open = false;
@@ -372,14 +341,14 @@ struct ClosestSink {
   }
 };
 
-template <bool COUNT, bool SPEC>
+template <bool COUNT>
 __global__ void __launch_bounds__(kBlock, GLZ_TRACE_WAVES) k_trace_closest(const LaunchArgs A) {
   __shared__ int s_stack[kLdsStack * kBlock];
   if (blockIdx.x == 0 && threadIdx.x < kQueueShards) A.st.queue_count[threadIdx.x * kCounterStride] = 0;   // drained by the previous launch's k_shadow_queue; k_shade refills it
   TraceTally tally;
   ClosestSource src{A, tally};
   ClosestSink sink{A};
-  trace_wave<false, COUNT, SPEC>(A.scene, src, sink, &s_stack[threadIdx.x], A.st.overflow, A.st.overflow_depth, A.map.n_local_pixels, wave_index(), wave_count(),
+  trace_wave<false, COUNT>(A.scene, src, sink, &s_stack[threadIdx.x], A.st.overflow, A.st.overflow_depth, A.map.n_local_pixels, wave_index(), wave_count(),
                            tally);
   if (COUNT) flush_counters(A.counters, false, tally);
 }
@@ -629,7 +598,7 @@ struct ShadowSink {
   }
 };
 
-template <bool COUNT, bool SPEC>
+template <bool COUNT>
 __global__ void __launch_bounds__(kBlock, GLZ_TRACE_WAVES) k_shadow_queue(const LaunchArgs A) {
   __shared__ int s_stack[kLdsStack * kBlock];
   // prefix sums of the eight shard counts (final: k_shade has completed)
@@ -641,7 +610,7 @@ __global__ void __launch_bounds__(kBlock, GLZ_TRACE_WAVES) k_shadow_queue(const 
   ShadowSource src{A, start, queue_capacity(A.map.n_local_pixels), 0u, make_float4(0.0f, 0.0f, 0.0f, 0.0f)};
   ShadowSink sink{A, src};
   // the spill area is indexed by queue position here (each position is in flight at most once)
-  trace_wave<true, COUNT, SPEC>(A.scene, src, sink, &s_stack[threadIdx.x], A.st.overflow, A.st.overflow_depth, start[kQueueShards], wave_index(), wave_count(), tally);
+  trace_wave<true, COUNT>(A.scene, src, sink, &s_stack[threadIdx.x], A.st.overflow, A.st.overflow_depth, start[kQueueShards], wave_index(), wave_count(), tally);
   if (COUNT) flush_counters(A.counters, true, tally);
 }
 
@@ -708,7 +677,7 @@ __global__ void __launch_bounds__(kBlock) k_debug_closest(const DeviceScene S, c
   TraceTally tally;
   DebugSource src{o, d, nullptr, tmin};
   DebugClosestSink sink{S, t, tri, inst, u, v};
-  trace_wave<false, false, true>(S, src, sink, &s_stack[threadIdx.x], overflow, overflow_depth, n, wave_index(), wave_count(), tally);
+  trace_wave<false, false>(S, src, sink, &s_stack[threadIdx.x], overflow, overflow_depth, n, wave_index(), wave_count(), tally);
 }
 __global__ void __launch_bounds__(kBlock) k_debug_any(const DeviceScene S, const float* __restrict__ o, const float* __restrict__ d,
                                                       const float* __restrict__ tmax, uint32_t n, float tmin, uint8_t* out, uint32_t* overflow,
@@ -717,7 +686,7 @@ __global__ void __launch_bounds__(kBlock) k_debug_any(const DeviceScene S, const
   TraceTally tally;
   DebugSource src{o, d, tmax, tmin};
   DebugAnySink sink{out};
-  trace_wave<true, false, true>(S, src, sink, &s_stack[threadIdx.x], overflow, overflow_depth, n, wave_index(), wave_count(), tally);
+  trace_wave<true, false>(S, src, sink, &s_stack[threadIdx.x], overflow, overflow_depth, n, wave_index(), wave_count(), tally);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -750,13 +719,10 @@ static dim3 cached_grid(Kernel kernel, uint32_t n_rays, uint32_t& cache_n, dim3&
 
 hipError_t launch_trace_closest(hipStream_t st, const LaunchArgs& a) {
   if (a.map.n_local_pixels == 0) return hipSuccess;
-  // production: speculative schedule; counters: the non-speculative schedule whose per-ray visit sequence the oracle can
-  // reproduce (algorithmic counts); counters + GLZ_COUNT_SCHEDULE: the production schedule, instrumented
-  static thread_local uint32_t n0 = 0, n1 = 0, n2 = 0;
-  static thread_local dim3 g0(0), g1(0), g2(0);
-  if (a.counters && a.count_schedule) hipLaunchKernelGGL((k_trace_closest<true, true>), cached_grid(k_trace_closest<true, true>, a.map.n_local_pixels, n2, g2), dim3(kBlock), 0, st, a);
-  else if (a.counters) hipLaunchKernelGGL((k_trace_closest<true, false>), cached_grid(k_trace_closest<true, false>, a.map.n_local_pixels, n1, g1), dim3(kBlock), 0, st, a);
-  else hipLaunchKernelGGL((k_trace_closest<false, true>), cached_grid(k_trace_closest<false, true>, a.map.n_local_pixels, n0, g0), dim3(kBlock), 0, st, a);
+  static thread_local uint32_t n0 = 0, n1 = 0;
+  static thread_local dim3 g0(0), g1(0);
+  if (a.counters) hipLaunchKernelGGL(k_trace_closest<true>, cached_grid(k_trace_closest<true>, a.map.n_local_pixels, n1, g1), dim3(kBlock), 0, st, a);
+  else hipLaunchKernelGGL(k_trace_closest<false>, cached_grid(k_trace_closest<false>, a.map.n_local_pixels, n0, g0), dim3(kBlock), 0, st, a);
   return hipGetLastError();
 }
 hipError_t launch_shade(hipStream_t st, const LaunchArgs& a) {
@@ -766,11 +732,10 @@ hipError_t launch_shade(hipStream_t st, const LaunchArgs& a) {
 }
 hipError_t launch_shadow_accumulate(hipStream_t st, const LaunchArgs& a) {
   if (a.map.n_local_pixels == 0) return hipSuccess;
-  static thread_local uint32_t n0 = 0, n1 = 0, n2 = 0;
-  static thread_local dim3 g0(0), g1(0), g2(0);
-  if (a.counters && a.count_schedule) hipLaunchKernelGGL((k_shadow_queue<true, true>), cached_grid(k_shadow_queue<true, true>, a.map.n_local_pixels, n2, g2), dim3(kBlock), 0, st, a);
-  else if (a.counters) hipLaunchKernelGGL((k_shadow_queue<true, false>), cached_grid(k_shadow_queue<true, false>, a.map.n_local_pixels, n1, g1), dim3(kBlock), 0, st, a);
-  else hipLaunchKernelGGL((k_shadow_queue<false, true>), cached_grid(k_shadow_queue<false, true>, a.map.n_local_pixels, n0, g0), dim3(kBlock), 0, st, a);
+  static thread_local uint32_t n0 = 0, n1 = 0;
+  static thread_local dim3 g0(0), g1(0);
+  if (a.counters) hipLaunchKernelGGL(k_shadow_queue<true>, cached_grid(k_shadow_queue<true>, a.map.n_local_pixels, n1, g1), dim3(kBlock), 0, st, a);
+  else hipLaunchKernelGGL(k_shadow_queue<false>, cached_grid(k_shadow_queue<false>, a.map.n_local_pixels, n0, g0), dim3(kBlock), 0, st, a);
   return hipGetLastError();
 }
 hipError_t launch_export(hipStream_t st, const TileMap& map, const float4* tiled, float4* frame, bool zero_first) {

@@ -111,7 +111,6 @@ void Renderer::fill_args(LaunchArgs& a) const {
   a.map = map_;
   a.cam = cam_;
   a.counters = counting_ ? counters_.ptr : nullptr;
-  a.count_schedule = count_schedule_ ? 1u : 0u;
 }
 
 // draw_frame (raytracer.rs:369-613): one path segment per pixel

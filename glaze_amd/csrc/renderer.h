@@ -37,7 +37,7 @@ class Renderer {
   bool tonemap_device(const void* dev_result, uint8_t* out, Error& err);
   bool launch_constants(uint32_t launch, uint32_t* seed, float off[2]);
   void push_constants(float out[32]) const;
-  void enable_counters(int flags) { counting_ = (flags & 1) != 0; profile_kernels_ = (flags & 2) != 0; count_schedule_ = (flags & 4) != 0; }
+  void enable_counters(int flags) { counting_ = (flags & 1) != 0; profile_kernels_ = (flags & 2) != 0; }
   bool get_stats(glz_render_stats* out, Error& err);
 
   Instance* instance() const { return inst_; }
@@ -71,7 +71,7 @@ class Renderer {
   DeviceBuffer<uchar4> rgba8_;
   DeviceBuffer<TraceCounters> counters_;
   // stats
-  bool counting_ = false, count_schedule_ = false;
+  bool counting_ = false;
   uint64_t launches_ = 0;
   double render_ms_ = 0, closest_ms_ = 0, shade_ms_ = 0, shadow_ms_ = 0;
   struct EventSet {

@@ -298,9 +298,7 @@ typedef struct glz_render_stats {
   /* tracer phase occupancy, counting build only: {node rounds, node lanes, leaf rounds, leaf lanes, refills, refilled lanes} x {closest, shadow} */
   uint64_t phase[12];
 } glz_render_stats;
-/* bit 0: traversal work counters (slower kernels; the counting kernels use the non-speculative visit order, whose
- * per-ray counts the oracle reproduces); bit 1: per-kernel hipEvent timing (on by default); bit 2 (with bit 0):
- * instrument the production (speculative) schedule instead */
+/* bit 0: traversal work counters (slower kernels); bit 1: per-kernel hipEvent timing (on by default) */
 int glz_renderer_enable_counters(glz_renderer*, int flags);
 int glz_renderer_get_stats(glz_renderer*, glz_render_stats* out);
 

@@ -44,7 +44,7 @@ for (name, d, w, h, depth) in (("atrium1080p", None, 1920, 1080, 8), ("cube512",
     s = rr.stats()
     print("%s: %d launches %.3fs wall -> %.1f Msamples/s | kernels ms: closest %.2f shade %.2f shadow %.2f (per launch %.3f/%.3f/%.3f)" % (
         name, n, dt, w * h * n / dt / 1e6, s.trace_closest_ms, s.shade_ms, s.trace_shadow_ms, s.trace_closest_ms / n, s.shade_ms / n, s.trace_shadow_ms / n))
-    rr.enable_counters(True, True, '--sched' in sys.argv); rr.restart(); rr.step(n); rr.wait_idle(); s = rr.stats()
+    rr.enable_counters(True, True); rr.restart(); rr.step(n); rr.wait_idle(); s = rr.stats()
     smp = w * h * n
     print("   per sample: closest rays %.3f shadow rays %.3f hits %.3f | nodes c %.1f s %.1f | tris c %.2f s %.2f" % (
         s.closest_rays / smp, s.shadow_rays / smp, s.hits / smp, s.closest_nodes / smp, s.shadow_nodes / smp, s.closest_tris / smp, s.shadow_tris / smp))
