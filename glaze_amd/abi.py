@@ -79,7 +79,8 @@ class SceneInfo(C.Structure):
     _fields_ = [("n_vertices", C.c_uint64), ("n_triangles", C.c_uint64), ("n_world_triangles", C.c_uint64),
                 ("n_instances", C.c_uint32), ("n_materials", C.c_uint32), ("n_lights", C.c_uint32), ("n_rt_lights", C.c_uint32),
                 ("n_textures", C.c_uint32), ("bvh_nodes", C.c_uint32), ("bvh_depth", C.c_uint32),
-                ("bvh_sah_cost", C.c_float), ("build_ms", C.c_float), ("bounds_min", C.c_float * 3), ("bounds_max", C.c_float * 3)]
+                ("bvh_sah_cost", C.c_float), ("build_ms", C.c_float), ("bounds_min", C.c_float * 3), ("bounds_max", C.c_float * 3),
+                ("bvh_grid_lo", C.c_float * 3), ("bvh_grid_cell", C.c_float * 3)]
 
 
 class RenderStats(C.Structure):

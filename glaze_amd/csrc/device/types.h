@@ -99,14 +99,24 @@ struct TransformPair {
   float w2o[16];
 };
 
-// BVH2 node, 64 bytes: both children's boxes + child links (>= 0 inner node, < 0 ~leaf).
-struct alignas(16) BvhNode {
-  float lo0[3]; int32_t child0;
-  float hi0[3]; int32_t child1;
-  float lo1[3]; uint32_t _p0;
-  float hi1[3]; uint32_t _p1;
+// BVH2 node, 32 bytes = two dwordx4 fetches per visit (the tracers are bound by vector-memory transactions, not by
+// VALU: DESIGN.md section 4).  Both child boxes are quantised to 16 bits per coordinate on a global grid spanning
+// the scene bounds (lo rounded down, hi rounded up, so the boxes only grow); the ray is mapped into grid units once.
+//   w[0] = lo0.x | lo0.y << 16   w[1] = lo0.z | hi0.x << 16   w[2] = hi0.y | hi0.z << 16   w[3] = lo1.x | lo1.y << 16
+//   w[4] = lo1.z | hi1.x << 16   w[5] = hi1.y | hi1.z << 16   w[6] = link                  w[7] = 0
+// link: bits 0..29 = g, bit 30 = child0 is leaf g, bit 31 = child1 is leaf g+1; inner children are nodes g / g+1
+// (Karras numbering: the children of a node are always the entries g and g+1 of the leaf or the node array).
+struct alignas(16) BvhQNode {
+  uint32_t w[8];
 };
-static_assert(sizeof(BvhNode) == 64, "BvhNode is 64 bytes");
+static_assert(sizeof(BvhQNode) == 32, "BvhQNode is 32 bytes");
+
+// Quantisation grid of the BVH: world = lo + q * cell.
+struct BvhGrid {
+  float lo[3];
+  float cell[3];
+  float inv_cell[3];
+};
 
 // World-space triangle in BVH leaf order, 48 bytes (36 algorithmic + ids).
 struct alignas(16) BvhTri {
@@ -136,7 +146,8 @@ struct DeviceScene {
   const TexDesc* tex_desc;
   const uint8_t* tex_pool;
   const float* srgb_lut;           // 256 entries
-  const BvhNode* bvh_nodes;
+  const BvhQNode* bvh_nodes;
+  BvhGrid bvh_grid;
   const BvhTri* bvh_tris;
   uint32_t n_world_tris;
   uint32_t n_textures;

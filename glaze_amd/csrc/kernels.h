@@ -21,7 +21,8 @@ struct LbvhInputs {
   uint32_t n_world;
 };
 struct LbvhOutputs {
-  BvhNode* nodes;   // max(n_world - 1, 1) entries, preallocated
+  BvhQNode* nodes;  // max(n_world - 1, 1) entries, preallocated
+  BvhGrid grid;     // quantisation grid of the node boxes
   BvhTri* tris;     // n_world entries, preallocated, leaf order
   uint32_t depth;   // number of inner nodes above the deepest leaf
   float sah;

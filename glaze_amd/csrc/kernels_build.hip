@@ -302,18 +302,55 @@ __global__ void __launch_bounds__(256) k_leaf_depth(int n, const int* __restrict
   atomicMax(max_depth, depth);
 }
 
+// Quantisation grid from the root box: 65535 cells per axis, stretched by 2^-16 so the top plane stays below 65535.
+__global__ void k_grid_params(const float4* __restrict__ node_lo, const float4* __restrict__ node_hi, BvhGrid* __restrict__ grid) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  const float lo[3] = {node_lo[0].x, node_lo[0].y, node_lo[0].z}, hi[3] = {node_hi[0].x, node_hi[0].y, node_hi[0].z};
+  for (int k = 0; k < 3; ++k) {
+    float ext = hi[k] - lo[k];
+    if (!(ext > 0.0f)) ext = 1.0f;
+    const float cell = ext * 1.00002f / 65535.0f;
+    grid->lo[k] = lo[k] - 0.5f * cell;
+    grid->cell[k] = cell;
+    grid->inv_cell[k] = 1.0f / cell;
+  }
+}
+
+// grid coordinate of a world coordinate; the SAME expression maps the ray origin in the tracer
+__device__ __forceinline__ float to_grid(float x, float lo, float inv_cell) { return (x - lo) * inv_cell; }
+__device__ __forceinline__ uint32_t quant_lo(float x, float lo, float inv_cell) {
+  // 1/16 cell of slack covers the rounding of to_grid() at grid coordinates up to 65535 (ulp 2^-8)
+  const float g = floorf(to_grid(x, lo, inv_cell) - 0.0625f);
+  return (uint32_t)fminf(fmaxf(g, 0.0f), 65535.0f);
+}
+__device__ __forceinline__ uint32_t quant_hi(float x, float lo, float inv_cell) {
+  const float g = ceilf(to_grid(x, lo, inv_cell) + 0.0625f);
+  return (uint32_t)fminf(fmaxf(g, 0.0f), 65535.0f);
+}
+
 __global__ void __launch_bounds__(256) k_emit_nodes(int n, const int2* __restrict__ children, const float4* __restrict__ node_lo,
-                                                    const float4* __restrict__ node_hi, BvhNode* __restrict__ nodes, float* __restrict__ sah) {
+                                                    const float4* __restrict__ node_hi, const BvhGrid* __restrict__ grid,
+                                                    BvhQNode* __restrict__ nodes, float* __restrict__ sah) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n - 1) return;
   const int2 c = children[i];
   const int s0 = c.x >= 0 ? c.x : (n - 1) + ~c.x, s1 = c.y >= 0 ? c.y : (n - 1) + ~c.y;
   const float4 l0 = node_lo[s0], h0 = node_hi[s0], l1 = node_lo[s1], h1 = node_hi[s1];
-  BvhNode nd;
-  nd.lo0[0] = l0.x; nd.lo0[1] = l0.y; nd.lo0[2] = l0.z; nd.child0 = c.x;
-  nd.hi0[0] = h0.x; nd.hi0[1] = h0.y; nd.hi0[2] = h0.z; nd.child1 = c.y;
-  nd.lo1[0] = l1.x; nd.lo1[1] = l1.y; nd.lo1[2] = l1.z; nd._p0 = 0;
-  nd.hi1[0] = h1.x; nd.hi1[1] = h1.y; nd.hi1[2] = h1.z; nd._p1 = 0;
+  const BvhGrid g = *grid;
+  const uint32_t q0[6] = {quant_lo(l0.x, g.lo[0], g.inv_cell[0]), quant_lo(l0.y, g.lo[1], g.inv_cell[1]), quant_lo(l0.z, g.lo[2], g.inv_cell[2]),
+                          quant_hi(h0.x, g.lo[0], g.inv_cell[0]), quant_hi(h0.y, g.lo[1], g.inv_cell[1]), quant_hi(h0.z, g.lo[2], g.inv_cell[2])};
+  const uint32_t q1[6] = {quant_lo(l1.x, g.lo[0], g.inv_cell[0]), quant_lo(l1.y, g.lo[1], g.inv_cell[1]), quant_lo(l1.z, g.lo[2], g.inv_cell[2]),
+                          quant_hi(h1.x, g.lo[0], g.inv_cell[0]), quant_hi(h1.y, g.lo[1], g.inv_cell[1]), quant_hi(h1.z, g.lo[2], g.inv_cell[2])};
+  const uint32_t gamma = (uint32_t)(c.x >= 0 ? c.x : ~c.x);   // the right child is always entry gamma + 1
+  BvhQNode nd;
+  nd.w[0] = q0[0] | (q0[1] << 16);
+  nd.w[1] = q0[2] | (q0[3] << 16);
+  nd.w[2] = q0[4] | (q0[5] << 16);
+  nd.w[3] = q1[0] | (q1[1] << 16);
+  nd.w[4] = q1[2] | (q1[3] << 16);
+  nd.w[5] = q1[4] | (q1[5] << 16);
+  nd.w[6] = gamma | (c.x < 0 ? 0x40000000u : 0u) | (c.y < 0 ? 0x80000000u : 0u);
+  nd.w[7] = 0;
   nodes[i] = nd;
   // SAH cost numerator: sum of surface areas of inner nodes (1.2) and leaves (1.0), normalised on the host
   auto area = [](float4 l, float4 h) { float dx = h.x - l.x, dy = h.y - l.y, dz = h.z - l.z; return 2.0f * (dx * dy + dy * dz + dz * dx); };
@@ -359,8 +396,9 @@ hipError_t build_lbvh(hipStream_t st, const LbvhInputs& in, LbvhOutputs& out) {
   int2* children = nullptr;
   int *parent = nullptr, *arrivals = nullptr, *scalars = nullptr;
   float* sah = nullptr;
+  BvhGrid* grid = nullptr;
   auto cleanup = [&]() {
-    void* bufs[] = {tris_unsorted, lo, hi, node_lo, node_hi, keys, vals, children, parent, arrivals, scalars, sah};
+    void* bufs[] = {tris_unsorted, lo, hi, node_lo, node_hi, keys, vals, children, parent, arrivals, scalars, sah, grid};
     for (void* b : bufs)
       if (b) (void)hipFree(b);
   };
@@ -377,6 +415,7 @@ hipError_t build_lbvh(hipStream_t st, const LbvhInputs& in, LbvhOutputs& out) {
   GLZ_TRY(hipMalloc(&arrivals, sizeof(int) * n));
   GLZ_TRY(hipMalloc(&scalars, sizeof(int) * 8));
   GLZ_TRY(hipMalloc(&sah, sizeof(float)));
+  GLZ_TRY(hipMalloc(&grid, sizeof(BvhGrid)));
   GLZ_TRY(hipMemsetAsync(arrivals, 0, sizeof(int) * n, st));
   GLZ_TRY(hipMemsetAsync(sah, 0, sizeof(float), st));
   {
@@ -411,7 +450,9 @@ hipError_t build_lbvh(hipStream_t st, const LbvhInputs& in, LbvhOutputs& out) {
     GLZ_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_leaf_depth, grd, blk, 0, st, (int)n, parent, scalars + 6);
     GLZ_TRY(hipGetLastError());
-    hipLaunchKernelGGL(k_emit_nodes, grd, blk, 0, st, (int)n, children, node_lo, node_hi, out.nodes, sah);
+    hipLaunchKernelGGL(k_grid_params, dim3(1), dim3(64), 0, st, node_lo, node_hi, grid);
+    GLZ_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_emit_nodes, grd, blk, 0, st, (int)n, children, node_lo, node_hi, grid, out.nodes, sah);
     GLZ_TRY(hipGetLastError());
   }
   int host_scalars[8];
@@ -423,17 +464,22 @@ hipError_t build_lbvh(hipStream_t st, const LbvhInputs& in, LbvhOutputs& out) {
   GLZ_TRY(hipMemcpyAsync(&root_hi, node_hi, sizeof(float4), hipMemcpyDeviceToHost, st));
   GLZ_TRY(hipStreamSynchronize(st));
   if (n == 1) {
-    // single triangle: one inner node whose second child is an empty box
-    BvhNode nd{};
-    float4 l, h;
-    GLZ_TRY(hipMemcpy(&l, node_lo + 0, sizeof(float4), hipMemcpyDeviceToHost));   // slot (n-1)+0 = 0
-    GLZ_TRY(hipMemcpy(&h, node_hi + 0, sizeof(float4), hipMemcpyDeviceToHost));
-    nd.lo0[0] = l.x; nd.lo0[1] = l.y; nd.lo0[2] = l.z; nd.hi0[0] = h.x; nd.hi0[1] = h.y; nd.hi0[2] = h.z;
-    nd.child0 = ~0;
-    nd.lo1[0] = nd.lo1[1] = nd.lo1[2] = INFINITY; nd.hi1[0] = nd.hi1[1] = nd.hi1[2] = -INFINITY;
-    nd.child1 = ~0;
-    GLZ_TRY(hipMemcpy(out.nodes, &nd, sizeof(nd), hipMemcpyHostToDevice));
-    root_lo = l; root_hi = h;
+    // single triangle: the leaf array (allocated with two entries) gets a second copy of the triangle, and the one inner
+    // node holds leaf 0 and leaf 1, each with a box spanning the whole grid (testing the same triangle twice is harmless:
+    // same world id, same result)
+    hipLaunchKernelGGL(k_grid_params, dim3(1), dim3(64), 0, st, node_lo, node_hi, grid);   // slot (n-1)+0 = 0 is the leaf box
+    GLZ_TRY(hipGetLastError());
+    GLZ_TRY(hipMemcpyAsync(out.tris + 1, out.tris, sizeof(BvhTri), hipMemcpyDeviceToDevice, st));
+    BvhQNode nd{};
+    nd.w[0] = 0u;
+    nd.w[1] = 0u | (65535u << 16);
+    nd.w[2] = 65535u | (65535u << 16);
+    nd.w[3] = 0u;
+    nd.w[4] = 0u | (65535u << 16);
+    nd.w[5] = 65535u | (65535u << 16);
+    nd.w[6] = 0u | 0x40000000u | 0x80000000u;
+    GLZ_TRY(hipMemcpyAsync(out.nodes, &nd, sizeof(nd), hipMemcpyHostToDevice, st));
+    GLZ_TRY(hipStreamSynchronize(st));
     out.depth = 1;
   } else {
     out.depth = (uint32_t)host_scalars[6];
@@ -441,6 +487,7 @@ hipError_t build_lbvh(hipStream_t st, const LbvhInputs& in, LbvhOutputs& out) {
     const float ra = 2.0f * (dx * dy + dy * dz + dz * dx);
     out.sah = ra > 0.0f ? host_sah / ra : 0.0f;
   }
+  GLZ_TRY(hipMemcpy(&out.grid, grid, sizeof(BvhGrid), hipMemcpyDeviceToHost));
   out.bounds_lo[0] = root_lo.x; out.bounds_lo[1] = root_lo.y; out.bounds_lo[2] = root_lo.z;
   out.bounds_hi[0] = root_hi.x; out.bounds_hi[1] = root_hi.y; out.bounds_hi[2] = root_hi.z;
   cleanup();

@@ -155,7 +155,8 @@ constexpr int kLeafQuorum = GLZ_LEAF_QUORUM;
 template <bool ANY, bool COUNT, class Source, class Sink>
 __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Sink& sink, int* __restrict__ lds_col, uint32_t* __restrict__ spill,
                                            uint32_t spill_depth, uint32_t total, uint32_t wave, uint32_t n_waves, TraceTally& tally) {
-  const BvhNode* __restrict__ nodes = S.bvh_nodes;
+  const BvhQNode* __restrict__ nodes = S.bvh_nodes;
+  const BvhGrid grid = S.bvh_grid;
   const BvhTri* __restrict__ tris = S.bvh_tris;
   const int lane = threadIdx.x & 63;
   const unsigned long long lanes_below = (1ull << lane) - 1ull;
@@ -165,7 +166,8 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
   bool open = false;                                        // a ray is in flight and its result has not been stored
   int cur = kRayDone;
   uint32_t ray = 0;
-  vec3 o = mk3(0.0f, 0.0f, 0.0f), d = mk3(0.0f, 0.0f, 1.0f), inv = mk3(0.0f, 0.0f, 0.0f);
+  vec3 o = mk3(0.0f, 0.0f, 0.0f), d = mk3(0.0f, 0.0f, 1.0f);
+  vec3 og = mk3(0.0f, 0.0f, 0.0f), ig = mk3(0.0f, 0.0f, 0.0f);   // origin and 1/direction in grid units (same t parameter)
   float tmin = 0.0f, tmax = 0.0f;
   HitRecord best{0.0f, 0.0f, 0.0f, 0xFFFFFFFFu};
   uint32_t best_id = 0xFFFFFFFFu;
@@ -187,7 +189,8 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
           if (S.n_world_tris == 0) {
             sink.store(ray, best);                          // nothing to intersect: a miss
           } else {
-            inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+            og = mk3((o.x - grid.lo[0]) * grid.inv_cell[0], (o.y - grid.lo[1]) * grid.inv_cell[1], (o.z - grid.lo[2]) * grid.inv_cell[2]);
+            ig = mk3((1.0f / d.x) * grid.cell[0], (1.0f / d.y) * grid.cell[1], (1.0f / d.z) * grid.cell[2]);
             st.spill = spill + (size_t)ray * spill_depth;
             st.sp = 0;
             cur = 0;
@@ -209,12 +212,16 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
       if (m_node == 0ull) break;
       if (COUNT && lane == 0) { tally.node_iters += 1; tally.node_lanes += (unsigned)__popcll(m_node); }
       if (at_node) {
-        const float4* np = reinterpret_cast<const float4*>(nodes + cur);
-        const float4 a = np[0], b = np[1], c = np[2], e = np[3];
+        // 32-byte node = 2 x dwordx4; boxes are 16-bit grid coordinates, the ray was mapped into grid units at refill
+        const uint4* np = reinterpret_cast<const uint4*>(nodes + cur);
+        const uint4 w0 = np[0], w1 = np[1];
         if (COUNT) tally.nodes += 1;
-        const float e0 = box_entry(a.x, a.y, a.z, b.x, b.y, b.z, o, inv, tmin, best.t);
-        const float e1 = box_entry(c.x, c.y, c.z, e.x, e.y, e.z, o, inv, tmin, best.t);
-        const int c0 = __float_as_int(a.w), c1 = __float_as_int(b.w);
+        const float e0 = box_entry((float)(w0.x & 0xFFFFu), (float)(w0.x >> 16), (float)(w0.y & 0xFFFFu), (float)(w0.y >> 16), (float)(w0.z & 0xFFFFu),
+                                   (float)(w0.z >> 16), og, ig, tmin, best.t);
+        const float e1 = box_entry((float)(w0.w & 0xFFFFu), (float)(w0.w >> 16), (float)(w1.x & 0xFFFFu), (float)(w1.x >> 16), (float)(w1.y & 0xFFFFu),
+                                   (float)(w1.y >> 16), og, ig, tmin, best.t);
+        const int gamma = (int)(w1.z & 0x3FFFFFFFu);
+        const int c0 = (w1.z & 0x40000000u) ? ~gamma : gamma, c1 = (w1.z & 0x80000000u) ? ~(gamma + 1) : gamma + 1;
         const bool h0 = e0 < INFINITY, h1 = e1 < INFINITY;
         if (h0 && h1) {
           const bool swap = e1 < e0;   // near child first; ties -> child0

@@ -391,7 +391,7 @@ bool Scene::build_bvh(Error& err) {
   hipStream_t st = instance->stream;
   const uint32_t n = (uint32_t)info.n_world_triangles;
   if (!hip_ok(d_nodes_.alloc(n > 1 ? n - 1 : 1), "alloc BVH nodes", err)) return false;
-  if (!hip_ok(d_tris_.alloc(n), "alloc BVH triangles", err)) return false;
+  if (!hip_ok(d_tris_.alloc(n == 1 ? 2 : n), "alloc BVH triangles", err)) return false;   // n == 1: see build_lbvh
   LbvhInputs in{d_vertices_.ptr, d_indices_.ptr, d_instances_.ptr, d_inst_base_.ptr, (uint32_t)h_instances.size(), d_transforms_.ptr,
                 d_materials_.ptr, n};
   LbvhOutputs out{};
@@ -419,6 +419,11 @@ bool Scene::build_bvh(Error& err) {
   // traversal stack: kTraversalLdsStack levels live in LDS, the rest spills to a per-pixel HBM area
   stack_overflow_depth = out.depth > (uint32_t)kTraversalLdsStack ? out.depth - kTraversalLdsStack + 1 : 1;
   dev.bvh_nodes = d_nodes_.ptr;
+  dev.bvh_grid = out.grid;
+  for (int k = 0; k < 3; ++k) {
+    info.bvh_grid_lo[k] = out.grid.lo[k];
+    info.bvh_grid_cell[k] = out.grid.cell[k];
+  }
   dev.bvh_tris = d_tris_.ptr;
   dev.n_world_tris = n;
   return true;

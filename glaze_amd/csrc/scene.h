@@ -84,7 +84,7 @@ class Scene {
   DeviceBuffer<TexDesc> d_tex_desc_;
   DeviceBuffer<uint8_t> d_tex_pool_;
   DeviceBuffer<float> d_srgb_lut_, d_sky_marginal_, d_sky_cond_values_, d_sky_cond_cdf_;
-  DeviceBuffer<BvhNode> d_nodes_;
+  DeviceBuffer<BvhQNode> d_nodes_;
   DeviceBuffer<BvhTri> d_tris_;
   std::vector<uint32_t> inst_base_;
   uint32_t sky_distribution_tex_ = 0xFFFFFFFFu;

@@ -220,6 +220,7 @@ typedef struct glz_scene_info {
   float bvh_sah_cost;
   float build_ms;                            /* LBVH build time on the device */
   float bounds_min[3], bounds_max[3];
+  float bvh_grid_lo[3], bvh_grid_cell[3];    /* quantisation grid of the BVH node boxes: world = lo + q * cell */
 } glz_scene_info;
 int glz_scene_get_info(const glz_scene*, glz_scene_info* out);
 int glz_scene_camera(const glz_scene*, glz_camera* out);
@@ -314,7 +315,7 @@ int64_t glz_debug_read_derivatives(glz_scene*, float* out12, int64_t cap_triangl
 int64_t glz_debug_read_rt_materials(glz_scene*, void* out, int64_t cap_bytes); /* 208-byte RTMaterial records */
 int64_t glz_debug_read_rt_lights(glz_scene*, void* out, int64_t cap_bytes);    /* 112-byte RTLight records */
 int64_t glz_debug_read_sky(glz_scene*, float* out, int64_t cap_floats);        /* RTSky(36 f32) | header(4) | marginal arrays */
-/* LBVH as traversed by the kernels: 64-byte nodes (returns the node count) and 48-byte leaf
+/* LBVH as traversed by the kernels: 32-byte quantised nodes (returns the node count) and 48-byte leaf
  * triangles in leaf order (n_world_triangles of them); see DESIGN.md for the layouts. */
 int64_t glz_debug_read_bvh(glz_scene*, void* nodes_out, int64_t cap_nodes, void* tris_out, int64_t cap_tris);
 

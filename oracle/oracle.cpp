@@ -451,8 +451,9 @@ struct Scene {
   std::vector<Tri> tris;                 // in BVH order
   std::vector<BNode> nodes;
   // optional externally supplied BVH2 (the product's LBVH) for work counting
-  std::vector<float> ext_nodes;          // 16 floats per node (BvhNode layout)
+  std::vector<uint32_t> ext_nodes;       // 8 words per node (BvhQNode layout)
   std::vector<float> ext_tris;           // 12 floats per tri (BvhTri layout)
+  float ext_grid[9] = {0};               // BvhGrid: lo[3], cell[3], inv_cell[3]
 };
 
 // ------------------------------------------------------------------------------------------
@@ -865,41 +866,48 @@ bool trace_any(const Scene& sc, V3 o, V3 d, float tmin, float tmax) {
   return false;
 }
 
-// Traversal of an externally supplied BVH2 in the product's node/leaf layout, counting node and
-// triangle visits: the "counted on the shared LBVH" figures of SURVEY 8(d).  Ordered (near child
-// first) closest-hit traversal, exactly the visit rule the HIP kernel documents in DESIGN.md.
-struct ExtNode { float lo0[3]; int32_t c0; float hi0[3]; int32_t c1; float lo1[3]; uint32_t p0; float hi1[3]; uint32_t p1; };
+// Traversal of an externally supplied BVH2 in the product's node/leaf layout (32-byte nodes with 16-bit grid boxes,
+// DESIGN.md section 2), counting node and triangle visits: the "counted on the shared LBVH" figures of SURVEY 8(d).
+// Ordered (near child first, ties -> child0) traversal with pruning against the current best t -- exactly the visit
+// rule of the HIP tracer, so the instrumented kernels' counters must equal these counts.
+struct ExtNode { uint32_t w[8]; };
 struct ExtTri { float v0[3]; uint32_t world_id; float e1[3]; uint32_t instance; float e2[3]; uint32_t prim_flags; };
-inline float box_entry(const float* lo, const float* hi, V3 o, V3 inv, float tmin, float tmax) {
-  float t0 = tmin, t1 = tmax;
-  const float* O = &o.x; const float* I = &inv.x;
-  for (int k = 0; k < 3; ++k) {
-    float a = (lo[k] - O[k]) * I[k], b = (hi[k] - O[k]) * I[k];
-    t0 = fmaxf(t0, fminf(a, b));
-    t1 = fminf(t1, fmaxf(a, b) * 1.0000005f);
-  }
-  return t0 <= t1 ? t0 : INF;
+inline float box_entry(float lox, float loy, float loz, float hix, float hiy, float hiz, V3 o, V3 inv, float tmin, float tmax) {
+  const float ax = (lox - o.x) * inv.x, bx = (hix - o.x) * inv.x;
+  const float ay = (loy - o.y) * inv.y, by = (hiy - o.y) * inv.y;
+  const float az = (loz - o.z) * inv.z, bz = (hiz - o.z) * inv.z;
+  const float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin));
+  const float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)) * 1.0000005f;
+  return t0 <= fminf(t1, tmax) ? t0 : INF;
 }
 void ext_trace(const Scene& sc, V3 o, V3 d, float tmin, float tmax, bool any, Counters& c, float& t_out, uint32_t& id_out) {
   const ExtNode* nodes = (const ExtNode*)sc.ext_nodes.data();
   const ExtTri* tris = (const ExtTri*)sc.ext_tris.data();
   t_out = INF; id_out = 0xFFFFFFFFu;
   if (sc.ext_nodes.empty()) return;
-  V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  const float* G = sc.ext_grid;   // lo[3], cell[3], inv_cell[3]
+  const V3 og = v3((o.x - G[0]) * G[6], (o.y - G[1]) * G[7], (o.z - G[2]) * G[8]);
+  const V3 ig = v3((1.0f / d.x) * G[3], (1.0f / d.y) * G[4], (1.0f / d.z) * G[5]);
   float best = tmax; uint32_t best_id = 0xFFFFFFFFu; bool found = false;
   int stack[128]; int sp = 0; int cur = 0;
   for (;;) {
     if (cur >= 0) {
-      const ExtNode& n = nodes[cur];
+      const uint32_t* w = nodes[cur].w;
       c.nodes++;
-      float e0 = box_entry(n.lo0, n.hi0, o, inv, tmin, best), e1 = box_entry(n.lo1, n.hi1, o, inv, tmin, best);
-      bool h0 = e0 < INF, h1 = e1 < INF;
+      const float e0 = box_entry((float)(w[0] & 0xFFFFu), (float)(w[0] >> 16), (float)(w[1] & 0xFFFFu), (float)(w[1] >> 16), (float)(w[2] & 0xFFFFu),
+                                 (float)(w[2] >> 16), og, ig, tmin, best);
+      const float e1 = box_entry((float)(w[3] & 0xFFFFu), (float)(w[3] >> 16), (float)(w[4] & 0xFFFFu), (float)(w[4] >> 16), (float)(w[5] & 0xFFFFu),
+                                 (float)(w[5] >> 16), og, ig, tmin, best);
+      const int gamma = (int)(w[6] & 0x3FFFFFFFu);
+      const int c0 = (w[6] & 0x40000000u) ? ~gamma : gamma, c1 = (w[6] & 0x80000000u) ? ~(gamma + 1) : gamma + 1;
+      const bool h0 = e0 < INF, h1 = e1 < INF;
       if (h0 && h1) {
-        int nearc = n.c0, farc = n.c1;
-        if (e1 < e0) { nearc = n.c1; farc = n.c0; }
-        stack[sp++] = farc; cur = nearc; continue;
-      } else if (h0) { cur = n.c0; continue; }
-      else if (h1) { cur = n.c1; continue; }
+        const bool swap = e1 < e0;
+        stack[sp++] = swap ? c0 : c1;
+        cur = swap ? c1 : c0;
+        continue;
+      } else if (h0) { cur = c0; continue; }
+      else if (h1) { cur = c1; continue; }
     } else {
       const ExtTri& et = tris[~cur];
       c.tris++;
@@ -1837,11 +1845,16 @@ int64_t orc_read_sky_cond(void* s, float* values, float* cdf) {
   return (int64_t)sc->cond_values.size();
 }
 
-// product LBVH import for work counting (nodes: 16 floats each, tris: 12 floats each)
-void orc_scene_set_ext_bvh(void* s, const float* nodes, uint64_t n_nodes, const float* tris, uint64_t n_tris) {
+// product LBVH import for work counting (nodes: 8 words each, tris: 12 floats each, grid: lo[3], cell[3])
+void orc_scene_set_ext_bvh(void* s, const uint32_t* nodes, uint64_t n_nodes, const float* tris, uint64_t n_tris, const float* grid_lo, const float* grid_cell) {
   Scene* sc = (Scene*)s;
-  sc->ext_nodes.assign(nodes, nodes + n_nodes * 16);
+  sc->ext_nodes.assign(nodes, nodes + n_nodes * 8);
   sc->ext_tris.assign(tris, tris + n_tris * 12);
+  for (int k = 0; k < 3; ++k) {
+    sc->ext_grid[k] = grid_lo[k];
+    sc->ext_grid[3 + k] = grid_cell[k];
+    sc->ext_grid[6 + k] = 1.0f / grid_cell[k];   // k_grid_params computes inv_cell the same way
+  }
 }
 
 void orc_trace_closest(void* s, const float* o, const float* d, uint64_t n, float tmin, float* t_out, uint32_t* tri_out,

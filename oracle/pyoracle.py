@@ -31,7 +31,7 @@ def lib():
             "orc_read_rt_lights": (C.c_int64, [_P, _P, C.c_int64]),
             "orc_read_sky": (C.c_int64, [_P, _P, C.c_int64]),
             "orc_read_sky_cond": (C.c_int64, [_P, _P, _P]),
-            "orc_scene_set_ext_bvh": (None, [_P, _P, C.c_uint64, _P, C.c_uint64]),
+            "orc_scene_set_ext_bvh": (None, [_P, _P, C.c_uint64, _P, C.c_uint64, _P, _P]),
             "orc_trace_closest": (None, [_P, _P, _P, C.c_uint64, C.c_float, _P, _P, _P, _P, _P]),
             "orc_trace_any": (None, [_P, _P, _P, _P, C.c_uint64, C.c_float, _P]),
             "orc_trace_closest_brute": (None, [_P, _P, _P, C.c_uint64, C.c_float, _P, _P]),
@@ -114,10 +114,12 @@ class OracleScene:
         lib().orc_read_sky(self.handle, _ptr(out), n)
         return out
 
-    def set_ext_bvh(self, nodes, tris):
-        nodes = np.ascontiguousarray(nodes).view(np.float32).reshape(-1, 16)
+    def set_ext_bvh(self, nodes, tris, grid_lo, grid_cell):
+        nodes = np.ascontiguousarray(nodes).view(np.uint32).reshape(-1, 8)
         tris = np.ascontiguousarray(tris).view(np.float32).reshape(-1, 12)
-        lib().orc_scene_set_ext_bvh(self.handle, _ptr(nodes), nodes.shape[0], _ptr(tris), tris.shape[0])
+        glo = np.ascontiguousarray(grid_lo, np.float32)
+        gcell = np.ascontiguousarray(grid_cell, np.float32)
+        lib().orc_scene_set_ext_bvh(self.handle, _ptr(nodes), nodes.shape[0], _ptr(tris), tris.shape[0], _ptr(glo), _ptr(gcell))
 
     def trace_closest(self, origins, dirs, tmin=1e-4, brute=False):
         o = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)

@@ -264,7 +264,8 @@ def test_traversal_work_counters_match_the_oracle(instance, mattest_desc):
         r.wait_idle()
         s = r.stats()
         osc = OracleScene(desc)
-        osc.set_ext_bvh(nodes, tris)
+        info = scene.info()
+        osc.set_ext_bvh(nodes, tris, list(info.bvh_grid_lo), list(info.bvh_grid_cell))
         o = OracleRenderer(osc, w, h)
         o.set_depth(depth)
         o.set_counting(True)

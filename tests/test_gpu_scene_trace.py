@@ -61,22 +61,46 @@ def test_rt_tables_bit_exact(which, cube, mattest):
 def test_bvh_structure(mattest):
     _, gpu, _ = mattest
     nodes, tris = gpu.debug_bvh()
+    info = gpu.info()
     n = tris.shape[0]
+    assert nodes.shape == (n - 1, 8) and nodes.dtype == np.uint32              # 32-byte quantised nodes
     ids = tris.view(np.uint32)[:, 3]
-    assert np.array_equal(np.sort(ids), np.arange(n, dtype=np.uint32))      # every world triangle is a leaf exactly once
-    c0 = nodes.view(np.int32)[:, 3]
-    c1 = nodes.view(np.int32)[:, 7]
-    inner = np.concatenate([c0[c0 >= 0], c1[c1 >= 0]])
-    leaves = np.concatenate([~c0[c0 < 0], ~c1[c1 < 0]])
-    assert np.array_equal(np.sort(inner), np.arange(1, n - 1))              # every inner node but the root has one parent
+    assert np.array_equal(np.sort(ids), np.arange(n, dtype=np.uint32))         # every world triangle is a leaf exactly once
+    link = nodes[:, 6]
+    gamma = (link & 0x3FFFFFFF).astype(np.int64)
+    leaf0, leaf1 = (link & 0x40000000) != 0, (link & 0x80000000) != 0
+    inner = np.concatenate([gamma[~leaf0], gamma[~leaf1] + 1])
+    leaves = np.concatenate([gamma[leaf0], gamma[leaf1] + 1])
+    assert np.array_equal(np.sort(inner), np.arange(1, n - 1))                 # every inner node but the root has one parent
     assert np.array_equal(np.sort(leaves), np.arange(n))
-    # a child box of an inner child contains that child's own child boxes
-    for ci, lo_s, hi_s in ((c0, slice(0, 3), slice(4, 7)), (c1, slice(8, 11), slice(12, 15))):
-        m = ci >= 0
-        ch = nodes[ci[m]]
-        lo = np.minimum(ch[:, 0:3], ch[:, 8:11])
-        hi = np.maximum(ch[:, 4:7], ch[:, 12:15])
-        assert np.all(nodes[m][:, lo_s] <= lo) and np.all(nodes[m][:, hi_s] >= hi)
+
+    def boxes(w):   # (lo0, hi0, lo1, hi1) in grid units
+        u = lambda x, hi: ((x >> 16) if hi else (x & 0xFFFF)).astype(np.int64)
+        lo0 = np.stack([u(w[:, 0], 0), u(w[:, 0], 1), u(w[:, 1], 0)], -1)
+        hi0 = np.stack([u(w[:, 1], 1), u(w[:, 2], 0), u(w[:, 2], 1)], -1)
+        lo1 = np.stack([u(w[:, 3], 0), u(w[:, 3], 1), u(w[:, 4], 0)], -1)
+        hi1 = np.stack([u(w[:, 4], 1), u(w[:, 5], 0), u(w[:, 5], 1)], -1)
+        return lo0, hi0, lo1, hi1
+    lo0, hi0, lo1, hi1 = boxes(nodes)
+    assert (lo0 <= hi0).all() and (lo1 <= hi1).all()
+    # the box stored for an inner child contains both boxes stored in that child (quantisation only grows boxes, and
+    # the same world box is quantised to the same grid cell everywhere)
+    for is_leaf, g, lo, hi in ((leaf0, gamma, lo0, hi0), (leaf1, gamma + 1, lo1, hi1)):
+        m = ~is_leaf
+        ch = g[m]
+        clo = np.minimum(lo0[ch], lo1[ch])
+        chi = np.maximum(hi0[ch], hi1[ch])
+        assert (lo[m] <= clo).all() and (hi[m] >= chi).all()
+    # a leaf's quantised box contains the triangle's vertices
+    glo, cell = np.array(info.bvh_grid_lo, np.float64), np.array(info.bvh_grid_cell, np.float64)
+    v0 = tris[:, 0:3].astype(np.float64)
+    v1 = v0 + tris[:, 4:7]
+    v2 = v0 + tris[:, 8:11]
+    for is_leaf, g, lo, hi in ((leaf0, gamma, lo0, hi0), (leaf1, gamma + 1, lo1, hi1)):
+        t = g[is_leaf]
+        for v in (v0, v1, v2):
+            q = (v[t] - glo) / cell
+            assert (lo[is_leaf] <= q + 1e-6).all() and (hi[is_leaf] >= q - 1e-6).all()
 
 
 def _check_closest(gpu, orc, o, d, tmin=1e-4):
