@@ -99,7 +99,9 @@ GLZ_D int wrap_coord(int i, int n) {
 }
 GLZ_D float lerp_ab(float a, float b, float t) { return a + (b - a) * t; }
 GLZ_D vec4 texture2d(const DeviceScene& S, uint32_t id, float u, float v) {
-  const TexDesc t = S.tex_desc[id];
+  // one dwordx4 for the whole descriptor (the shade kernel is bound by vector-memory transactions)
+  const uint4 td = reinterpret_cast<const uint4*>(S.tex_desc)[id];
+  const TexDesc t{td.x, td.y, td.z, td.w};
   float fu = u * (float)t.width - 0.5f, fv = v * (float)t.height - 0.5f;
   float iu = glz_floorf(fu), iv = glz_floorf(fv);
   float ax = fu - iu, ay = fv - iv;
@@ -242,17 +244,38 @@ GLZ_D vec2 anisotropic_alpha(float a, float anis) { return vec2{a * (1.0f + anis
 // BSDFs.  One switch on RTMaterial::bsdf_index replaces the SBT callable dispatch
 // (executeCallableEXT(material.bsdf_index [+1]), path_trace.rgen:103, :218).
 // ---------------------------------------------------------------------------------------------
+// The scalar part of an RTMaterial, fetched with four dwordx4 loads (bytes 0..15 and 160..207 of the 208-byte record)
+// instead of one load per field; the two 64-byte metal spectra stay in memory and are read only by conductor lobes.
+struct MatScalars {
+  float diffuse_mul[3];
+  uint32_t diffuse, roughness, metalness, opacity, normal, bsdf_index;
+  float roughness_mul, metalness_mul, anisotropy, ior_dielectric;
+  uint32_t is_specular;
+  const RTMaterial* spectra;   // metal_ior / metal_fresnel
+};
+GLZ_D MatScalars load_material(const RTMaterial* m) {
+  const float4* q = reinterpret_cast<const float4*>(m);
+  const float4 a = q[0], b = q[10], c = q[11], d = q[12];
+  MatScalars r;
+  r.diffuse_mul[0] = a.x; r.diffuse_mul[1] = a.y; r.diffuse_mul[2] = a.z;
+  r.diffuse = __float_as_uint(b.x); r.roughness = __float_as_uint(b.y); r.metalness = __float_as_uint(b.z); r.opacity = __float_as_uint(b.w);
+  r.normal = __float_as_uint(c.x); r.bsdf_index = __float_as_uint(c.y); r.roughness_mul = c.z; r.metalness_mul = c.w;
+  r.anisotropy = d.x; r.ior_dielectric = d.y; r.is_specular = __float_as_uint(d.z);
+  r.spectra = m;
+  return r;
+}
+
 struct SurfacePoint {
   vec3 woW;
   vec2 uv;
   Frame frame;
-  const RTMaterial* mat;
+  MatScalars mat;
 };
 
-GLZ_D void dielectric_etas(const RTMaterial* m, float woz, float& etai, float& etat) {
+GLZ_D void dielectric_etas(const MatScalars& m, float woz, float& etai, float& etat) {
   float outside = gl_step(0.0f, woz);
-  etai = gl_mix(m->ior_dielectric, kDefaultIor, outside);
-  etat = gl_mix(kDefaultIor, m->ior_dielectric, outside);
+  etai = gl_mix(m.ior_dielectric, kDefaultIor, outside);
+  etat = gl_mix(kDefaultIor, m.ior_dielectric, outside);
 }
 
 // reflective microfacet terms shared by Frosted and Uber (mat_frosted_value.rcall:35-47, mat_uber_value.rcall:39-52)
@@ -289,14 +312,14 @@ GLZ_D float oren_nayar(float roughness, vec3 wo, vec3 wi) {
 }
 
 GLZ_D vec3 diffuse_tint(const DeviceScene& S, const SurfacePoint& P) {
-  vec3 tx = texture_rgb(S, P.mat->diffuse, P.uv);
-  return tx * mk3(P.mat->diffuse_mul[0], P.mat->diffuse_mul[1], P.mat->diffuse_mul[2]);
+  vec3 tx = texture_rgb(S, P.mat.diffuse, P.uv);
+  return tx * mk3(P.mat.diffuse_mul[0], P.mat.diffuse_mul[1], P.mat.diffuse_mul[2]);
 }
 
 // BSDF evaluation for next-event estimation; returns the pdf (0 = no contribution).
 GLZ_D float bsdf_eval(const DeviceScene& S, const SurfacePoint& P, vec3 wiW, float xi, Spec& value) {
-  const RTMaterial* m = P.mat;
-  const uint32_t kind = m->bsdf_index;
+  const MatScalars& m = P.mat;
+  const uint32_t kind = m.bsdf_index;
   if (kind == kBsdfMirror || kind == kBsdfGlass) return 0.0f;   // mat_mirror_value.rcall:8-11, mat_glass_value.rcall:8-11
   const vec3 wo = to_local(P.woW, P.frame), wi = to_local(wiW, P.frame);
   if (kind == kBsdfLambert) {   // mat_lambert_value.rcall:23-34
@@ -307,8 +330,8 @@ GLZ_D float bsdf_eval(const DeviceScene& S, const SurfacePoint& P, vec3 wiW, flo
   if (kind == kBsdfMetal) {   // mat_metal_value.rcall:19-44
     vec3 wh = normalize3(wo + wi);
     if (!(wo.z * wi.z > 0.0f)) return 0.0f;
-    Spec F = fresnel_conductor(dot3(wi, wh), m->metal_ior, m->metal_fresnel);
-    vec2 a = anisotropic_alpha(texture_r(S, m->roughness, P.uv) * m->roughness_mul, m->anisotropy);
+    Spec F = fresnel_conductor(dot3(wi, wh), m.spectra->metal_ior, m.spectra->metal_fresnel);
+    vec2 a = anisotropic_alpha(texture_r(S, m.roughness, P.uv) * m.roughness_mul, m.anisotropy);
     float d = ggx_d(wh, a);
     float g = ggx_g(wo, wi, a);
     float term = d * g / (4.0f * fabsf(wo.z) * fabsf(wi.z));
@@ -317,7 +340,7 @@ GLZ_D float bsdf_eval(const DeviceScene& S, const SurfacePoint& P, vec3 wiW, flo
     return check_nan(pdf);
   }
   if (kind == kBsdfFrosted) {   // mat_frosted_value.rcall:19-66
-    vec2 a = anisotropic_alpha(texture_r(S, m->roughness, P.uv) * m->roughness_mul, m->anisotropy);
+    vec2 a = anisotropic_alpha(texture_r(S, m.roughness, P.uv) * m.roughness_mul, m.anisotropy);
     float etai, etat;
     dielectric_etas(m, wo.z, etai, etat);
     float eta = etai / etat;
@@ -341,17 +364,17 @@ GLZ_D float bsdf_eval(const DeviceScene& S, const SurfacePoint& P, vec3 wiW, flo
     return check_nan(pdf);
   }
   // Uber: mat_uber_value.rcall:20-77
-  float roughness = texture_r(S, m->roughness, P.uv) * m->roughness_mul;
+  float roughness = texture_r(S, m.roughness, P.uv) * m.roughness_mul;
   float same = gl_step(0.0f, wo.z * wi.z);
   if (xi < 0.5f) {
-    vec2 a = anisotropic_alpha(roughness * m->roughness_mul, m->anisotropy);   // roughness_mul applied twice (Q5)
+    vec2 a = anisotropic_alpha(roughness * m.roughness_mul, m.anisotropy);   // roughness_mul applied twice (Q5)
     vec3 wh = normalize3(wo + wi);
-    float metalness = texture_r(S, m->metalness, P.uv) * m->metalness_mul;
+    float metalness = texture_r(S, m.metalness, P.uv) * m.metalness_mul;
     float etai, etat;
     dielectric_etas(m, wo.z, etai, etat);
     Lobe L = reflect_lobe(wo, wi, wh, a);
     float fd = fresnel_dielectric(L.costi, etai, etat);
-    Spec fc = fresnel_conductor(L.costi, m->metal_ior, m->metal_fresnel);
+    Spec fc = fresnel_conductor(L.costi, m.spectra->metal_ior, m.spectra->metal_fresnel);
     float term = L.d * L.g / (4.0f * L.cwo * L.cwi);
     GLZ_BINS value.w[i] = gl_mix(fd, fc.w[i], metalness) * term;
     return check_nan(same * 0.5f * L.pdf);
@@ -373,8 +396,8 @@ GLZ_D vec3 cosine_hemisphere(float rx, float ry, float woz) {   // mat_lambert_s
 
 // BSDF sampling for the path continuation; returns the pdf (0 = terminate the path).
 GLZ_D float bsdf_sample(const DeviceScene& S, const SurfacePoint& P, vec3 xi, Spec& value, vec3& wiW) {
-  const RTMaterial* m = P.mat;
-  const uint32_t kind = m->bsdf_index;
+  const MatScalars& m = P.mat;
+  const uint32_t kind = m.bsdf_index;
   const vec3 wo = to_local(P.woW, P.frame);
   if (kind == kBsdfLambert) {   // mat_lambert_sample_value.rcall:31-41
     vec3 wi = cosine_hemisphere(xi.x, xi.y, wo.z);
@@ -383,15 +406,15 @@ GLZ_D float bsdf_sample(const DeviceScene& S, const SurfacePoint& P, vec3 xi, Sp
     return fabsf(wi.z) * kInvPi;
   }
   if (kind == kBsdfMirror) {   // mat_mirror_sample_value.rcall:16-34
-    Spec F = fresnel_conductor(wo.z, m->metal_ior, m->metal_fresnel);
+    Spec F = fresnel_conductor(wo.z, m.spectra->metal_ior, m.spectra->metal_fresnel);
     wiW = normalize3(to_world(mk3(-wo.x, -wo.y, wo.z), P.frame));
     value = spec_div(F, fabsf(wo.z));
     return 1.0f;
   }
   if (kind == kBsdfGlass) {   // mat_glass_sample_value.rcall:34-56
     float outside = gl_step(0.0f, wo.z);
-    float etai = gl_mix(m->ior_dielectric, kDefaultIor, outside);
-    float etat = gl_mix(kDefaultIor, m->ior_dielectric, outside);
+    float etai = gl_mix(m.ior_dielectric, kDefaultIor, outside);
+    float etat = gl_mix(kDefaultIor, m.ior_dielectric, outside);
     float costi = gl_mix(fabsf(wo.z), wo.z, outside);
     float F = fresnel_dielectric(costi, etai, etat);
     vec3 wi;
@@ -410,14 +433,14 @@ GLZ_D float bsdf_sample(const DeviceScene& S, const SurfacePoint& P, vec3 xi, Sp
     return pdf;
   }
   if (kind == kBsdfMetal) {   // mat_metal_sample_value.rcall:21-49
-    vec2 a = anisotropic_alpha(texture_r(S, m->roughness, P.uv) * m->roughness_mul, m->anisotropy);
+    vec2 a = anisotropic_alpha(texture_r(S, m.roughness, P.uv) * m.roughness_mul, m.anisotropy);
     vec3 wh = normalize3(ggx_sample_wh(wo, vec2{xi.x, xi.y}, a));
     vec3 wi = -normalize3(gl_reflect(wo, wh));
     if (!(wo.z * wi.z > 0.0f)) return 0.0f;
     float d = ggx_d(wh, a);
     float g = ggx_g(wo, wi, a);
     float gp = ggx_pdf(d, a, wo, wh);
-    Spec F = fresnel_conductor(dot3(wi, wh), m->metal_ior, m->metal_fresnel);
+    Spec F = fresnel_conductor(dot3(wi, wh), m.spectra->metal_ior, m.spectra->metal_fresnel);
     float term = d * g / (4.0f * fabsf(wo.z) * fabsf(wi.z));
     float pdf = gp / (4.0f * dot3(wo, wh));
     value = spec_scale(F, term);
@@ -425,7 +448,7 @@ GLZ_D float bsdf_sample(const DeviceScene& S, const SurfacePoint& P, vec3 xi, Sp
     return check_nan(pdf);
   }
   if (kind == kBsdfFrosted) {   // mat_frosted_sample_value.rcall:21-71
-    vec2 a = anisotropic_alpha(texture_r(S, m->roughness, P.uv) * m->roughness_mul, m->anisotropy);
+    vec2 a = anisotropic_alpha(texture_r(S, m.roughness, P.uv) * m.roughness_mul, m.anisotropy);
     vec3 wh = normalize3(ggx_sample_wh(wo, vec2{xi.x, xi.y}, a));
     float etai, etat;
     dielectric_etas(m, wo.z, etai, etat);
@@ -454,19 +477,19 @@ GLZ_D float bsdf_sample(const DeviceScene& S, const SurfacePoint& P, vec3 xi, Sp
     return pdf;
   }
   // Uber: mat_uber_sample_value.rcall:21-86
-  float roughness = texture_r(S, m->roughness, P.uv) * m->roughness_mul;
+  float roughness = texture_r(S, m.roughness, P.uv) * m.roughness_mul;
   vec3 wi;
   float pdf;
   if (xi.z < 0.5f) {
-    vec2 a = anisotropic_alpha(roughness * m->roughness_mul, m->anisotropy);
+    vec2 a = anisotropic_alpha(roughness * m.roughness_mul, m.anisotropy);
     vec3 wh = normalize3(ggx_sample_wh(wo, vec2{xi.x, xi.y}, a));
-    float metalness = texture_r(S, m->metalness, P.uv) * m->metalness_mul;
+    float metalness = texture_r(S, m.metalness, P.uv) * m.metalness_mul;
     float etai, etat;
     dielectric_etas(m, wo.z, etai, etat);
     wi = -normalize3(gl_reflect(wo, wh));
     Lobe L = reflect_lobe(wo, wi, wh, a);
     float fd = fresnel_dielectric(L.costi, etai, etat);
-    Spec fc = fresnel_conductor(L.costi, m->metal_ior, m->metal_fresnel);
+    Spec fc = fresnel_conductor(L.costi, m.spectra->metal_ior, m.spectra->metal_fresnel);
     float term = L.d * L.g / (4.0f * L.cwo * L.cwi);
     GLZ_BINS value.w[i] = gl_mix(fd, fc.w[i], metalness) * term;
     pdf = check_nan(0.5f * L.pdf);

@@ -149,6 +149,9 @@ struct DeviceScene {
   const BvhQNode* bvh_nodes;
   BvhGrid bvh_grid;
   const BvhTri* bvh_tris;
+  // per-leaf shading record, 8 x float4 = 128 bytes, in leaf order: VertexPacked x 3 (object space), then
+  // (geometric normal.xyz, material id), (dpdu.xyz, transform id | identity flag in bit 31)
+  const float4* shade_tris;
   uint32_t n_world_tris;
   uint32_t n_textures;
   // sky

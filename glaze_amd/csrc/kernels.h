@@ -29,6 +29,9 @@ struct LbvhOutputs {
   float bounds_lo[3], bounds_hi[3];
 };
 hipError_t build_lbvh(hipStream_t st, const LbvhInputs& in, LbvhOutputs& out);
+// 128-byte per-leaf shading records (see k_shade_records); xf_identity[t] != 0 marks an exact identity transform
+hipError_t launch_shade_records(hipStream_t st, uint32_t n, const BvhTri* tris, const RTInstance* instances, const uint32_t* indices,
+                                const float4* vertices, const float4* derivatives, const uint32_t* xf_identity, float4* out);
 
 // Traversal stack entries each lane keeps in LDS (the deepest simultaneous stack of a near-first BVH2
 // traversal is bounded by the tree depth; what does not fit spills to a per-pixel HBM area).

@@ -399,11 +399,29 @@ __device__ __forceinline__ uint32_t queue_slot(uint32_t* counters, uint32_t n_lo
 // ---------------------------------------------------------------------------------------------
 // k_shade: path_trace.rgen:170-237 minus the two traceRayEXT calls, raytrace_hit.rchit:30-71
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock, 4) k_shade(const LaunchArgs A) {
+constexpr uint32_t kSkyLdsFloats = 4096;   // sky marginal tables (3H+1 floats) are staged in LDS when they fit: H <= 1365 rows
+
+#ifndef GLZ_SHADE_WAVES
+#define GLZ_SHADE_WAVES 3   // 168 VGPRs: no scratch spills (spill traffic is vector-memory traffic too)
+#endif
+__global__ void __launch_bounds__(kBlock, GLZ_SHADE_WAVES) k_shade(const LaunchArgs A) {
+  // The kernel is bound by vector-memory transactions (16 extra scattered loads per pixel cost +27 %, 200 extra VALU
+  // instructions nothing), so the two small tables every texture fetch / sky sample walks are staged in LDS once per
+  // block: the sRGB decode LUT (12 lookups per bilinear fetch) and the sky marginal CDF (an 11-step dependent search).
+  __shared__ float s_lut[256];
+  __shared__ float s_sky[kSkyLdsFloats];
+  const uint32_t n_sky = 3u * (A.scene.sky_header.marginal_cdf_count - 1u) + 1u;
+  const bool sky_in_lds = A.scene.sky_header.marginal_cdf_count > 1u && n_sky <= kSkyLdsFloats;
+  s_lut[threadIdx.x] = A.scene.srgb_lut[threadIdx.x];
+  if (sky_in_lds)
+    for (uint32_t i = threadIdx.x; i < n_sky; i += kBlock) s_sky[i] = A.scene.sky_marginal[i];
+  __syncthreads();
+  DeviceScene S = A.scene;
+  S.srgb_lut = s_lut;
+  if (sky_in_lds) S.sky_marginal = s_sky;
   const uint32_t lid = blockIdx.x * kBlock + threadIdx.x;
   const PixelId px = pixel_of(A.map, lid);
   if (!px.active) return;
-  const DeviceScene& S = A.scene;
   const FrameData& F = A.frame;
   const float4 ro = A.st.ray_o[lid], rd = A.st.ray_d[lid], hr = A.st.hit[lid];
   const bool fresh = F.direct_only || ro.w == 0.0f;
@@ -419,6 +437,22 @@ __global__ void __launch_bounds__(kBlock, 4) k_shade(const LaunchArgs A) {
       importance.w[4 * q] = v.x; importance.w[4 * q + 1] = v.y; importance.w[4 * q + 2] = v.z; importance.w[4 * q + 3] = v.w;
     }
   }
+#ifdef GLZ_EXPERIMENT_SHADE_LOADS   // timing experiment only: 16 extra scattered 16-byte loads per pixel
+  {
+    float acc = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc += S.vertices[((lid * 2654435761u) >> 8) % 200000u + q * 7u].x;
+    if (acc == 1.2345e-30f) bounce += 1.0f;
+  }
+#endif
+#ifdef GLZ_EXPERIMENT_SHADE_VALU    // timing experiment only: ~200 extra dependent VALU instructions per pixel
+  {
+    float z = hr.x;
+#pragma unroll
+    for (int q = 0; q < 100; ++q) z = z * 1.0000001f + hr.y;
+    if (z == 1.2345e-30f) bounce += 1.0f;
+  }
+#endif
   const uint32_t leaf = __float_as_uint(hr.w);
   if (leaf == 0xFFFFFFFFu) {
     // miss: optional sky radiance, path reset (path_trace.rgen:170-179)
@@ -435,25 +469,18 @@ __global__ void __launch_bounds__(kBlock, 4) k_shade(const LaunchArgs A) {
     if (!F.direct_only) A.st.ray_o[lid] = make_float4(ro.x, ro.y, ro.z, 0.0f);   // RESET_PATH
     return;
   }
-  // ---- closest-hit shader (raytrace_hit.rchit:30-71) ----
-  const float4* tp = reinterpret_cast<const float4*>(S.bvh_tris + leaf);
-  const uint32_t inst_id = __float_as_uint(tp[1].w), prim = __float_as_uint(tp[2].w) & 0x7FFFFFFFu;
-  const RTInstance inst = S.instances[inst_id];
-  const uint32_t tri_id = inst.index_offset / 3u + prim;
+  // ---- closest-hit shader (raytrace_hit.rchit:30-71), inputs from the 128-byte per-leaf shading record ----
+  const float4* rec = S.shade_tris + 8u * (size_t)leaf;
+  const float4 va0 = rec[0], va1 = rec[1], vb0 = rec[2], vb1 = rec[3], vc0 = rec[4], vc1 = rec[5], dn = rec[6], du = rec[7];
+  const uint32_t material_id = __float_as_uint(dn.w), xf_bits = __float_as_uint(du.w);
   const float b0 = 1.0f - hr.y - hr.z, b1 = hr.y, b2 = hr.z;
-  const uint32_t i0 = S.indices[3u * tri_id], i1 = S.indices[3u * tri_id + 1u], i2 = S.indices[3u * tri_id + 2u];
-  const float4 va0 = S.vertices[2u * i0], va1 = S.vertices[2u * i0 + 1u];
-  const float4 vb0 = S.vertices[2u * i1], vb1 = S.vertices[2u * i1 + 1u];
-  const float4 vc0 = S.vertices[2u * i2], vc1 = S.vertices[2u * i2 + 1u];
   vec3 point = (mk3(va0.x, va0.y, va0.z) * b0 + mk3(vb0.x, vb0.y, vb0.z) * b1) + mk3(vc0.x, vc0.y, vc0.z) * b2;
   const vec2 uv = vec2{(va1.z * b0 + vb1.z * b1) + vc1.z * b2, (va1.w * b0 + vb1.w * b1) + vc1.w * b2};
-  const float4 dn = S.derivatives[3u * tri_id], du = S.derivatives[3u * tri_id + 1u], dv = S.derivatives[3u * tri_id + 2u];
-  vec3 ng = mk3(dn.x, dn.y, dn.z), dpdu = mk3(du.x, du.y, du.z);
-  (void)dv;   // dpdv is transformed by the reference but never read afterwards
+  vec3 ng = mk3(dn.x, dn.y, dn.z), dpdu = mk3(du.x, du.y, du.z);   // dpdv is transformed by the reference but never read afterwards
   vec3 ns = (mk3(va0.w, va1.x, va1.y) * b0 + mk3(vb0.w, vb1.x, vb1.y) * b1) + mk3(vc0.w, vc1.x, vc1.y) * b2;
-  const RTMaterial* mat = &S.materials[inst.material_id];
-  if (mat->normal != 0) {
-    const vec4 tx = texture2d(S, mat->normal, uv.x, uv.y);
+  const MatScalars mat = load_material(&S.materials[material_id]);
+  if (mat.normal != 0) {
+    const vec4 tx = texture2d(S, mat.normal, uv.x, uv.y);
     Frame old;
     old.s = normalize3(dpdu);
     old.n = ns;
@@ -461,11 +488,18 @@ __global__ void __launch_bounds__(kBlock, 4) k_shade(const LaunchArgs A) {
     ns = normalize3(to_world(mk3(tx.x * 2.0f - 1.0f, tx.y * 2.0f - 1.0f, tx.z * 2.0f - 1.0f), old));
     ns = ns * gl_sign(dot3(ng, ns));
   }
-  const TransformPair* xf = &S.transforms[inst.transform_id];
-  point = xform_point(xf->o2w, point);
-  dpdu = xform_point(xf->o2w, dpdu);   // transformed as a point, w = 1 (Q8)
-  ng = xform_tdir(xf->w2o, ng);
-  ns = xform_tdir(xf->w2o, ns);
+  if (!(xf_bits >> 31)) {
+    // object -> world.  Skipped for an exact identity transform: m*x with m = I reproduces x bit for bit
+    // (x*1 + y*0 + z*0 + 0 for finite coordinates), so the result is unchanged and ~25 scalar loads are saved.
+    const float4* xq = reinterpret_cast<const float4*>(&S.transforms[xf_bits & 0x7FFFFFFFu]);
+    const float4 m0 = xq[0], m1 = xq[1], m2 = xq[2], m3 = xq[3], w0 = xq[4], w1 = xq[5], w2 = xq[6];
+    const float o2w[16] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w, m2.x, m2.y, m2.z, m2.w, m3.x, m3.y, m3.z, m3.w};
+    const float w2o[12] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
+    point = xform_point(o2w, point);
+    dpdu = xform_point(o2w, dpdu);   // transformed as a point, w = 1 (Q8)
+    ng = xform_tdir(w2o, ng);
+    ns = xform_tdir(w2o, ns);
+  }
   (void)ng;
   // ---- raygen continues (path_trace.rgen:180-237) ----
   uint32_t rng = pcg(__float_as_uint((float)F.seed) ^ pcg(__float_as_uint((float)px.x) ^ pcg(__float_as_uint((float)px.y))));   // :143, Q11
@@ -475,7 +509,7 @@ __global__ void __launch_bounds__(kBlock, 4) k_shade(const LaunchArgs A) {
   P.frame = make_frame(dpdu, ns);
   P.mat = mat;
   float spec_flag;
-  if (mat->is_specular == 0) {
+  if (mat.is_specular == 0) {
     // direct_light(), :84-117
     const uint32_t li = (uint32_t)gl_min(rand01(rng) * (float)F.lights_no, (float)(F.lights_no - 1u));
     vec3 xi;

@@ -425,6 +425,19 @@ bool Scene::build_bvh(Error& err) {
     info.bvh_grid_cell[k] = out.grid.cell[k];
   }
   dev.bvh_tris = d_tris_.ptr;
+  // per-leaf shading records (the identity flags let k_shade skip the object->world transform exactly)
+  std::vector<uint32_t> ident(data.transforms.size(), 0u);
+  for (size_t i = 0; i < ident.size(); ++i) {
+    static const float id[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    ident[i] = memcmp(data.transforms[i].m, id, 64) == 0 ? 1u : 0u;   // bitwise: -0.0 does not count
+  }
+  if (!hip_ok(d_xf_identity_.upload(ident.data(), ident.size(), st), "upload transform flags", err)) return false;
+  if (!hip_ok(d_shade_tris_.alloc((size_t)(n == 1 ? 2 : n) * 8), "alloc shading records", err)) return false;
+  if (!hip_ok(launch_shade_records(st, n == 1 ? 2 : n, d_tris_.ptr, d_instances_.ptr, d_indices_.ptr, d_vertices_.ptr, d_derivatives_.ptr, d_xf_identity_.ptr,
+                                   d_shade_tris_.ptr), "k_shade_records", err))
+    return false;
+  if (!hip_ok(hipStreamSynchronize(st), "shading records", err)) return false;
+  dev.shade_tris = d_shade_tris_.ptr;
   dev.n_world_tris = n;
   return true;
 }

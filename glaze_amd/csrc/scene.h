@@ -86,6 +86,8 @@ class Scene {
   DeviceBuffer<float> d_srgb_lut_, d_sky_marginal_, d_sky_cond_values_, d_sky_cond_cdf_;
   DeviceBuffer<BvhQNode> d_nodes_;
   DeviceBuffer<BvhTri> d_tris_;
+  DeviceBuffer<float4> d_shade_tris_;
+  DeviceBuffer<uint32_t> d_xf_identity_;
   std::vector<uint32_t> inst_base_;
   uint32_t sky_distribution_tex_ = 0xFFFFFFFFu;
 };
