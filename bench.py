@@ -45,13 +45,15 @@ def parse_args():
 def algorithmic_bytes(c):
     """Algorithmic bytes per SAMPLE of each kernel, from counted per-sample work.
 
-    node visit = 64 B (one BVH2 node: two child boxes + links), triangle test = 36 B (v0, e1, e2),
-    hit-attribute fetch = 380 B (RTInstance 16 + indices 12 + 3 vertices 96 + derivatives 48 + RTMaterial 208),
-    path state = 96 B (ray 32 + importance 64), accumulator = 32 B r/w + 16 B result.
+    node visit = 32 B (one quantised BVH2 node: two child boxes + two links), triangle test = 48 B (BvhTri: v0, e1, e2 and
+    the ids the tie-break / alpha test need), hit-attribute fetch = 192 B (128-B shading record + the 64 B of RTMaterial
+    scalars k_shade loads; texels are not counted), path state = 96 B (ray 32 + importance 64), hit record 16 B,
+    accumulator = 32 B r/w + 16 B result, shadow-queue entry = 48 B.
     """
-    closest = 32 + 16 + 32 * c["f_fresh"] + 64 * c["nodes_closest"] + 36 * c["tris_closest"]
-    shade = 16 + 32 + 64 * (1 - c["f_fresh"]) + 380 * c["f_hit"] + 16 + 32 * c["f_shadow"] + 96 * c["f_hit"]
-    shadow = 16 + 32 * c["f_shadow"] + 32 + 16 * c["f_hit"] + 64 * c["nodes_shadow"] + 36 * c["tris_shadow"]
+    closest = 32 + 16 + 32 * c["f_fresh"] + 32 * c["nodes_closest"] + 48 * c["tris_closest"]
+    shade = (16 + 32 + 64 * (1 - c["f_fresh"]) + 192 * c["f_hit"] + 48 * c["f_shadow"] + 48 * (1 - c["f_shadow"])
+             + 96 * c["f_hit"])
+    shadow = 48 * c["f_shadow"] + 48 * c["f_shadow"] + 32 * c["nodes_shadow"] + 48 * c["tris_shadow"]
     return {"k_trace_closest": closest, "k_shade": shade, "k_shadow_queue": shadow}
 
 

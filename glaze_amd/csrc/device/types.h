@@ -103,8 +103,8 @@ struct TransformPair {
 // VALU: DESIGN.md section 4).  Both child boxes are quantised to 16 bits per coordinate on a global grid spanning
 // the scene bounds (lo rounded down, hi rounded up, so the boxes only grow); the ray is mapped into grid units once.
 //   w[0] = lo0.x | lo0.y << 16   w[1] = lo0.z | hi0.x << 16   w[2] = hi0.y | hi0.z << 16   w[3] = lo1.x | lo1.y << 16
-//   w[4] = lo1.z | hi1.x << 16   w[5] = hi1.y | hi1.z << 16   w[6] = link                  w[7] = 0
-// link: bits 0..29 = g, bit 30 = child0 is leaf g, bit 31 = child1 is leaf g+1; inner children are nodes g / g+1
+//   w[4] = lo1.z | hi1.x << 16   w[5] = hi1.y | hi1.z << 16   w[6] = child0                w[7] = child1
+// child: index of an inner node (>= 0), or ~index of a leaf in bvh_tris (< 0), as a two's complement int32
 // (Karras numbering: the children of a node are always the entries g and g+1 of the leaf or the node array).
 struct alignas(16) BvhQNode {
   uint32_t w[8];

@@ -341,7 +341,6 @@ __global__ void __launch_bounds__(256) k_emit_nodes(int n, const int2* __restric
                           quant_hi(h0.x, g.lo[0], g.inv_cell[0]), quant_hi(h0.y, g.lo[1], g.inv_cell[1]), quant_hi(h0.z, g.lo[2], g.inv_cell[2])};
   const uint32_t q1[6] = {quant_lo(l1.x, g.lo[0], g.inv_cell[0]), quant_lo(l1.y, g.lo[1], g.inv_cell[1]), quant_lo(l1.z, g.lo[2], g.inv_cell[2]),
                           quant_hi(h1.x, g.lo[0], g.inv_cell[0]), quant_hi(h1.y, g.lo[1], g.inv_cell[1]), quant_hi(h1.z, g.lo[2], g.inv_cell[2])};
-  const uint32_t gamma = (uint32_t)(c.x >= 0 ? c.x : ~c.x);   // the right child is always entry gamma + 1
   BvhQNode nd;
   nd.w[0] = q0[0] | (q0[1] << 16);
   nd.w[1] = q0[2] | (q0[3] << 16);
@@ -349,8 +348,8 @@ __global__ void __launch_bounds__(256) k_emit_nodes(int n, const int2* __restric
   nd.w[3] = q1[0] | (q1[1] << 16);
   nd.w[4] = q1[2] | (q1[3] << 16);
   nd.w[5] = q1[4] | (q1[5] << 16);
-  nd.w[6] = gamma | (c.x < 0 ? 0x40000000u : 0u) | (c.y < 0 ? 0x80000000u : 0u);
-  nd.w[7] = 0;
+  nd.w[6] = (uint32_t)c.x;   // child links as the hierarchy holds them: inner node index >= 0, or ~leaf
+  nd.w[7] = (uint32_t)c.y;
   nodes[i] = nd;
   // SAH cost numerator: sum of surface areas of inner nodes (1.2) and leaves (1.0), normalised on the host
   auto area = [](float4 l, float4 h) { float dx = h.x - l.x, dy = h.y - l.y, dz = h.z - l.z; return 2.0f * (dx * dy + dy * dz + dz * dx); };
@@ -509,7 +508,8 @@ hipError_t build_lbvh(hipStream_t st, const LbvhInputs& in, LbvhOutputs& out) {
     nd.w[3] = 0u;
     nd.w[4] = 0u | (65535u << 16);
     nd.w[5] = 65535u | (65535u << 16);
-    nd.w[6] = 0u | 0x40000000u | 0x80000000u;
+    nd.w[6] = ~0u;   // leaf 0
+    nd.w[7] = ~1u;   // leaf 1 (the copy)
     GLZ_TRY(hipMemcpyAsync(out.nodes, &nd, sizeof(nd), hipMemcpyHostToDevice, st));
     GLZ_TRY(hipStreamSynchronize(st));
     out.depth = 1;

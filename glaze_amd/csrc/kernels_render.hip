@@ -53,34 +53,52 @@ __device__ __forceinline__ PixelId pixel_of(const TileMap& m, uint32_t lid) {
 // intersector ([ext]).  Ties on t are broken by the smaller world triangle id so that the result
 // does not depend on traversal order.
 // ---------------------------------------------------------------------------------------------
-// Slab test.  It only prunes: the leaf boxes are padded and the exit distance is scaled by 1 + 4 ulp, so it never rejects
-// a box whose triangle the exact Moeller-Trumbore test below accepts.  (lo - o) * inv keeps slab-parallel rays robust
-// (inf * finite, or 0 * inf = NaN which fminf/fmaxf drop); the fused form fma(lo, inv, -o*inv) measured no faster and
-// turns inf - inf into NaN on those rays.
-__device__ __forceinline__ float box_entry(float lox, float loy, float loz, float hix, float hiy, float hiz, vec3 o, vec3 inv, float tmin,
+// Slab test on a quantised box.  It only prunes: boxes are padded by 1/16 cell when they are quantised and the exit distance
+// is scaled by 1 + 4 ulp, so it never rejects a box whose triangle the exact Moeller-Trumbore test below accepts.
+// The ray is mapped into grid units once (ig = cell / d, cg = -(origin_grid * ig)), each plane distance is then one
+// fma(q, ig, cg); the (lo, hi) planes of an axis go through one packed v_pk_fma_f32.  The tracers are VALU-issue bound
+// (profiles/r01_pmc.json: SQ_INSTS_VALU * 4 cycles / 1024 SIMDs is 80 % of the kernel time), so instructions per node
+// visit are what counts.  ig is kept finite (grid_inv_dir), so no plane distance is ever NaN: a ray parallel to a slab
+// gets +-1e30-scale distances whose signs still say on which side of each plane the origin lies.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float box_entry(float lox, float loy, float loz, float hix, float hiy, float hiz, vec3 ig, vec3 cg, float tmin,
                                            float tmax) {
-  const float ax = (lox - o.x) * inv.x, bx = (hix - o.x) * inv.x;
-  const float ay = (loy - o.y) * inv.y, by = (hiy - o.y) * inv.y;
-  const float az = (loz - o.z) * inv.z, bz = (hiz - o.z) * inv.z;
-  const float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin));
-  const float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)) * 1.0000005f;
+  const f32x2 tx = __builtin_elementwise_fma(f32x2{lox, hix}, f32x2{ig.x, ig.x}, f32x2{cg.x, cg.x});
+  const f32x2 ty = __builtin_elementwise_fma(f32x2{loy, hiy}, f32x2{ig.y, ig.y}, f32x2{cg.y, cg.y});
+  const f32x2 tz = __builtin_elementwise_fma(f32x2{loz, hiz}, f32x2{ig.z, ig.z}, f32x2{cg.z, cg.z});
+  const float t0 = fmaxf(fmaxf(fminf(tx.x, tx.y), fminf(ty.x, ty.y)), fmaxf(fminf(tz.x, tz.y), tmin));
+  const float t1 = fminf(fminf(fmaxf(tx.x, tx.y), fmaxf(ty.x, ty.y)), fmaxf(tz.x, tz.y)) * 1.0000005f;
   return t0 <= fminf(t1, tmax) ? t0 : INFINITY;
 }
 
+// 1 / d clamped to +-1e30: zero (or denormal) direction components must not produce inf - inf in the fma above --
+// a ray with a NaN plane distance on every axis would pass every box test and walk the whole tree.
+__device__ __forceinline__ float grid_inv_dir(float d) {
+  const float i = 1.0f / d;
+  return fabsf(i) <= 1e30f ? i : copysignf(1e30f, i);
+}
+// rays with a NaN / infinite origin or direction cannot be accepted by ray_triangle (every comparison fails): they
+// are reported as misses without traversal
+__device__ __forceinline__ bool ray_is_finite(vec3 o, vec3 d) {
+  const float s = ((o.x + o.y) + o.z) + ((d.x + d.y) + d.z);
+  return s - s == 0.0f;
+}
+
+// Straight-line on purpose: with ~10 of 64 lanes in a leaf round an early exit is almost never taken by all of them,
+// and without branches the three 16-byte loads of the triangle are issued together (the compiler otherwise sinks the
+// v0 load behind the det test: a second memory round trip).  A zero determinant gives inf / NaN barycentrics that fail
+// the comparisons; the explicit det test keeps the rule the oracle states.
 __device__ __forceinline__ bool ray_triangle(const BvhTri& tr, vec3 o, vec3 d, float tmin, float& t, float& u, float& v) {
   const vec3 e1 = mk3(tr.e1[0], tr.e1[1], tr.e1[2]), e2 = mk3(tr.e2[0], tr.e2[1], tr.e2[2]);
   const vec3 pvec = cross3(d, e2);
   const float det = dot3(e1, pvec);
-  if (det == 0.0f) return false;
   const float inv = 1.0f / det;
   const vec3 tvec = o - mk3(tr.v0[0], tr.v0[1], tr.v0[2]);
   u = dot3(tvec, pvec) * inv;
-  if (!(u >= 0.0f && u <= 1.0f)) return false;
   const vec3 qvec = cross3(tvec, e1);
   v = dot3(d, qvec) * inv;
-  if (!(v >= 0.0f && u + v <= 1.0f)) return false;
   t = dot3(e2, qvec) * inv;
-  return t > tmin;
+  return (det != 0.0f) & (u >= 0.0f) & (u <= 1.0f) & (v >= 0.0f) & (u + v <= 1.0f) & (t > tmin);
 }
 
 // raytrace_hit.rahit:24-39 -- candidates on non-opaque geometry are dropped when opacity.r < 0.5
@@ -167,7 +185,7 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
   int cur = kRayDone;
   uint32_t ray = 0;
   vec3 o = mk3(0.0f, 0.0f, 0.0f), d = mk3(0.0f, 0.0f, 1.0f);
-  vec3 og = mk3(0.0f, 0.0f, 0.0f), ig = mk3(0.0f, 0.0f, 0.0f);   // origin and 1/direction in grid units (same t parameter)
+  vec3 ig = mk3(0.0f, 0.0f, 0.0f), cg = mk3(0.0f, 0.0f, 0.0f);   // grid-space ray: plane q is crossed at t = q * ig + cg
   float tmin = 0.0f, tmax = 0.0f;
   HitRecord best{0.0f, 0.0f, 0.0f, 0xFFFFFFFFu};
   uint32_t best_id = 0xFFFFFFFFu;
@@ -186,11 +204,12 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
           best = HitRecord{tmax, 0.0f, 0.0f, 0xFFFFFFFFu};
           best_id = 0xFFFFFFFFu;
           if (COUNT) tally.rays += 1;
-          if (S.n_world_tris == 0) {
-            sink.store(ray, best);                          // nothing to intersect: a miss
+          if (S.n_world_tris == 0 || !ray_is_finite(o, d)) {
+            sink.store(ray, best);                          // nothing to intersect / nothing can be hit: a miss
           } else {
-            og = mk3((o.x - grid.lo[0]) * grid.inv_cell[0], (o.y - grid.lo[1]) * grid.inv_cell[1], (o.z - grid.lo[2]) * grid.inv_cell[2]);
-            ig = mk3((1.0f / d.x) * grid.cell[0], (1.0f / d.y) * grid.cell[1], (1.0f / d.z) * grid.cell[2]);
+            const vec3 og = mk3((o.x - grid.lo[0]) * grid.inv_cell[0], (o.y - grid.lo[1]) * grid.inv_cell[1], (o.z - grid.lo[2]) * grid.inv_cell[2]);
+            ig = mk3(grid_inv_dir(d.x) * grid.cell[0], grid_inv_dir(d.y) * grid.cell[1], grid_inv_dir(d.z) * grid.cell[2]);
+            cg = mk3(-(og.x * ig.x), -(og.y * ig.y), -(og.z * ig.z));
             st.spill = spill + (size_t)ray * spill_depth;
             st.sp = 0;
             cur = 0;
@@ -217,11 +236,10 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
         const uint4 w0 = np[0], w1 = np[1];
         if (COUNT) tally.nodes += 1;
         const float e0 = box_entry((float)(w0.x & 0xFFFFu), (float)(w0.x >> 16), (float)(w0.y & 0xFFFFu), (float)(w0.y >> 16), (float)(w0.z & 0xFFFFu),
-                                   (float)(w0.z >> 16), og, ig, tmin, best.t);
+                                   (float)(w0.z >> 16), ig, cg, tmin, best.t);
         const float e1 = box_entry((float)(w0.w & 0xFFFFu), (float)(w0.w >> 16), (float)(w1.x & 0xFFFFu), (float)(w1.x >> 16), (float)(w1.y & 0xFFFFu),
-                                   (float)(w1.y >> 16), og, ig, tmin, best.t);
-        const int gamma = (int)(w1.z & 0x3FFFFFFFu);
-        const int c0 = (w1.z & 0x40000000u) ? ~gamma : gamma, c1 = (w1.z & 0x80000000u) ? ~(gamma + 1) : gamma + 1;
+                                   (float)(w1.y >> 16), ig, cg, tmin, best.t);
+        const int c0 = (int)w1.z, c1 = (int)w1.w;   // child links: inner node index, or ~leaf
         const bool h0 = e0 < INFINITY, h1 = e1 < INFINITY;
         if (h0 && h1) {
           const bool swap = e1 < e0;   // near child first; ties -> child0
@@ -410,19 +428,65 @@ __global__ void __launch_bounds__(kBlock, GLZ_SHADE_WAVES) k_shade(const LaunchA
   // block: the sRGB decode LUT (12 lookups per bilinear fetch) and the sky marginal CDF (an 11-step dependent search).
   __shared__ float s_lut[256];
   __shared__ float s_sky[kSkyLdsFloats];
+  __shared__ uint32_t s_bin[64];
+  __shared__ uint16_t s_perm[kBlock];
   const uint32_t n_sky = 3u * (A.scene.sky_header.marginal_cdf_count - 1u) + 1u;
   const bool sky_in_lds = A.scene.sky_header.marginal_cdf_count > 1u && n_sky <= kSkyLdsFloats;
   s_lut[threadIdx.x] = A.scene.srgb_lut[threadIdx.x];
   if (sky_in_lds)
     for (uint32_t i = threadIdx.x; i < n_sky; i += kBlock) s_sky[i] = A.scene.sky_marginal[i];
+  if (threadIdx.x < 64) s_bin[threadIdx.x] = 0;
   __syncthreads();
   DeviceScene S = A.scene;
   S.srgb_lut = s_lut;
   if (sky_in_lds) S.sky_marginal = s_sky;
+  const FrameData& F = A.frame;
+#ifndef GLZ_SHADE_NO_REGROUP
+  // Block-local regrouping: the 256 pixels of the block are bucketed by the code path they are going to take -- miss,
+  // or (BSDF kind, light kind of the NEE sample) -- and every thread then shades the pixel at its sorted position, so
+  // a wave mostly runs one material and one light routine instead of all of them one after the other (lane utilisation
+  // was 32 %, SQ_THREAD_CYCLES_VALU / 64 / SQ_ACTIVE_INST_VALU, profiles/r01_pmc.json).  Pixels are independent and
+  // all state is addressed by pixel, so the permutation changes no result; only the order of the shadow queue differs.
+  uint32_t key = 63u;   // pixels outside the image sort last
+  {
+    const uint32_t lid0 = blockIdx.x * kBlock + threadIdx.x;
+    const PixelId px0 = pixel_of(A.map, lid0);
+    if (px0.active) {
+      const uint32_t leaf0 = __float_as_uint(A.st.hit[lid0].w);
+      key = 0u;
+      if (leaf0 != 0xFFFFFFFFu) {
+        const RTMaterial* m0 = &S.materials[__float_as_uint(S.shade_tris[8u * (size_t)leaf0 + 6u].w)];
+        uint32_t light = 4u;
+        if (m0->is_specular == 0 && F.lights_no != 0u) {
+          uint32_t rng0 = pcg(__float_as_uint((float)F.seed) ^ pcg(__float_as_uint((float)px0.x) ^ pcg(__float_as_uint((float)px0.y))));
+          const uint32_t li0 = (uint32_t)gl_min(rand01(rng0) * (float)F.lights_no, (float)(F.lights_no - 1u));
+          light = S.lights[li0].shader;
+        }
+        key = 1u + (m0->bsdf_index < 6u ? m0->bsdf_index : 5u) * 5u + (light < 4u ? light : 4u);
+      }
+    }
+  }
+  const uint32_t rank = atomicAdd(&s_bin[key], 1u);
+  __syncthreads();
+  if (threadIdx.x < 64) {   // exclusive prefix sum of the 64 bucket sizes
+    const uint32_t cnt = s_bin[threadIdx.x];
+    uint32_t incl = cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t up = __shfl_up(incl, off);
+      if ((int)threadIdx.x >= off) incl += up;
+    }
+    s_bin[threadIdx.x] = incl - cnt;
+  }
+  __syncthreads();
+  s_perm[s_bin[key] + rank] = (uint16_t)threadIdx.x;
+  __syncthreads();
+  const uint32_t lid = blockIdx.x * kBlock + s_perm[threadIdx.x];
+#else
   const uint32_t lid = blockIdx.x * kBlock + threadIdx.x;
+#endif
   const PixelId px = pixel_of(A.map, lid);
   if (!px.active) return;
-  const FrameData& F = A.frame;
   const float4 ro = A.st.ray_o[lid], rd = A.st.ray_d[lid], hr = A.st.hit[lid];
   const bool fresh = F.direct_only || ro.w == 0.0f;
   float bounce = F.direct_only ? 0.0f : ro.w;
@@ -437,22 +501,6 @@ __global__ void __launch_bounds__(kBlock, GLZ_SHADE_WAVES) k_shade(const LaunchA
       importance.w[4 * q] = v.x; importance.w[4 * q + 1] = v.y; importance.w[4 * q + 2] = v.z; importance.w[4 * q + 3] = v.w;
     }
   }
-#ifdef GLZ_EXPERIMENT_SHADE_LOADS   // timing experiment only: 16 extra scattered 16-byte loads per pixel
-  {
-    float acc = 0.0f;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) acc += S.vertices[((lid * 2654435761u) >> 8) % 200000u + q * 7u].x;
-    if (acc == 1.2345e-30f) bounce += 1.0f;
-  }
-#endif
-#ifdef GLZ_EXPERIMENT_SHADE_VALU    // timing experiment only: ~200 extra dependent VALU instructions per pixel
-  {
-    float z = hr.x;
-#pragma unroll
-    for (int q = 0; q < 100; ++q) z = z * 1.0000001f + hr.y;
-    if (z == 1.2345e-30f) bounce += 1.0f;
-  }
-#endif
   const uint32_t leaf = __float_as_uint(hr.w);
   if (leaf == 0xFFFFFFFFu) {
     // miss: optional sky radiance, path reset (path_trace.rgen:170-179)

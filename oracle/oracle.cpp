@@ -872,10 +872,11 @@ bool trace_any(const Scene& sc, V3 o, V3 d, float tmin, float tmax) {
 // rule of the HIP tracer, so the instrumented kernels' counters must equal these counts.
 struct ExtNode { uint32_t w[8]; };
 struct ExtTri { float v0[3]; uint32_t world_id; float e1[3]; uint32_t instance; float e2[3]; uint32_t prim_flags; };
-inline float box_entry(float lox, float loy, float loz, float hix, float hiy, float hiz, V3 o, V3 inv, float tmin, float tmax) {
-  const float ax = (lox - o.x) * inv.x, bx = (hix - o.x) * inv.x;
-  const float ay = (loy - o.y) * inv.y, by = (hiy - o.y) * inv.y;
-  const float az = (loz - o.z) * inv.z, bz = (hiz - o.z) * inv.z;
+inline float box_entry_q(float lox, float loy, float loz, float hix, float hiy, float hiz, V3 ig, V3 cg, float tmin, float tmax) {
+  // plane distances as one correctly rounded fma each (kernels_render.hip box_entry: v_pk_fma_f32)
+  const float ax = fmaf(lox, ig.x, cg.x), bx = fmaf(hix, ig.x, cg.x);
+  const float ay = fmaf(loy, ig.y, cg.y), by = fmaf(hiy, ig.y, cg.y);
+  const float az = fmaf(loz, ig.z, cg.z), bz = fmaf(hiz, ig.z, cg.z);
   const float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin));
   const float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)) * 1.0000005f;
   return t0 <= fminf(t1, tmax) ? t0 : INF;
@@ -887,19 +888,24 @@ void ext_trace(const Scene& sc, V3 o, V3 d, float tmin, float tmax, bool any, Co
   if (sc.ext_nodes.empty()) return;
   const float* G = sc.ext_grid;   // lo[3], cell[3], inv_cell[3]
   const V3 og = v3((o.x - G[0]) * G[6], (o.y - G[1]) * G[7], (o.z - G[2]) * G[8]);
-  const V3 ig = v3((1.0f / d.x) * G[3], (1.0f / d.y) * G[4], (1.0f / d.z) * G[5]);
+  {   // kernels_render.hip ray_is_finite: such a ray is a miss without traversal
+    const float s = ((o.x + o.y) + o.z) + ((d.x + d.y) + d.z);
+    if (!(s - s == 0.0f)) return;
+  }
+  auto inv_dir = [](float x) { const float i = 1.0f / x; return fabsf(i) <= 1e30f ? i : copysignf(1e30f, i); };   // grid_inv_dir
+  const V3 ig = v3(inv_dir(d.x) * G[3], inv_dir(d.y) * G[4], inv_dir(d.z) * G[5]);
+  const V3 cg = v3(-(og.x * ig.x), -(og.y * ig.y), -(og.z * ig.z));
   float best = tmax; uint32_t best_id = 0xFFFFFFFFu; bool found = false;
   int stack[128]; int sp = 0; int cur = 0;
   for (;;) {
     if (cur >= 0) {
       const uint32_t* w = nodes[cur].w;
       c.nodes++;
-      const float e0 = box_entry((float)(w[0] & 0xFFFFu), (float)(w[0] >> 16), (float)(w[1] & 0xFFFFu), (float)(w[1] >> 16), (float)(w[2] & 0xFFFFu),
-                                 (float)(w[2] >> 16), og, ig, tmin, best);
-      const float e1 = box_entry((float)(w[3] & 0xFFFFu), (float)(w[3] >> 16), (float)(w[4] & 0xFFFFu), (float)(w[4] >> 16), (float)(w[5] & 0xFFFFu),
-                                 (float)(w[5] >> 16), og, ig, tmin, best);
-      const int gamma = (int)(w[6] & 0x3FFFFFFFu);
-      const int c0 = (w[6] & 0x40000000u) ? ~gamma : gamma, c1 = (w[6] & 0x80000000u) ? ~(gamma + 1) : gamma + 1;
+      const float e0 = box_entry_q((float)(w[0] & 0xFFFFu), (float)(w[0] >> 16), (float)(w[1] & 0xFFFFu), (float)(w[1] >> 16), (float)(w[2] & 0xFFFFu),
+                                   (float)(w[2] >> 16), ig, cg, tmin, best);
+      const float e1 = box_entry_q((float)(w[3] & 0xFFFFu), (float)(w[3] >> 16), (float)(w[4] & 0xFFFFu), (float)(w[4] >> 16), (float)(w[5] & 0xFFFFu),
+                                   (float)(w[5] >> 16), ig, cg, tmin, best);
+      const int c0 = (int)w[6], c1 = (int)w[7];
       const bool h0 = e0 < INF, h1 = e1 < INF;
       if (h0 && h1) {
         const bool swap = e1 < e0;

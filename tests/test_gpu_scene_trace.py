@@ -66,11 +66,11 @@ def test_bvh_structure(mattest):
     assert nodes.shape == (n - 1, 8) and nodes.dtype == np.uint32              # 32-byte quantised nodes
     ids = tris.view(np.uint32)[:, 3]
     assert np.array_equal(np.sort(ids), np.arange(n, dtype=np.uint32))         # every world triangle is a leaf exactly once
-    link = nodes[:, 6]
-    gamma = (link & 0x3FFFFFFF).astype(np.int64)
-    leaf0, leaf1 = (link & 0x40000000) != 0, (link & 0x80000000) != 0
-    inner = np.concatenate([gamma[~leaf0], gamma[~leaf1] + 1])
-    leaves = np.concatenate([gamma[leaf0], gamma[leaf1] + 1])
+    c0, c1 = nodes[:, 6].view(np.int32).astype(np.int64), nodes[:, 7].view(np.int32).astype(np.int64)
+    leaf0, leaf1 = c0 < 0, c1 < 0
+    id0, id1 = np.where(leaf0, ~c0, c0), np.where(leaf1, ~c1, c1)     # inner node index or leaf index
+    inner = np.concatenate([id0[~leaf0], id1[~leaf1]])
+    leaves = np.concatenate([id0[leaf0], id1[leaf1]])
     assert np.array_equal(np.sort(inner), np.arange(1, n - 1))                 # every inner node but the root has one parent
     assert np.array_equal(np.sort(leaves), np.arange(n))
 
@@ -85,7 +85,7 @@ def test_bvh_structure(mattest):
     assert (lo0 <= hi0).all() and (lo1 <= hi1).all()
     # the box stored for an inner child contains both boxes stored in that child (quantisation only grows boxes, and
     # the same world box is quantised to the same grid cell everywhere)
-    for is_leaf, g, lo, hi in ((leaf0, gamma, lo0, hi0), (leaf1, gamma + 1, lo1, hi1)):
+    for is_leaf, g, lo, hi in ((leaf0, id0, lo0, hi0), (leaf1, id1, lo1, hi1)):
         m = ~is_leaf
         ch = g[m]
         clo = np.minimum(lo0[ch], lo1[ch])
@@ -96,7 +96,7 @@ def test_bvh_structure(mattest):
     v0 = tris[:, 0:3].astype(np.float64)
     v1 = v0 + tris[:, 4:7]
     v2 = v0 + tris[:, 8:11]
-    for is_leaf, g, lo, hi in ((leaf0, gamma, lo0, hi0), (leaf1, gamma + 1, lo1, hi1)):
+    for is_leaf, g, lo, hi in ((leaf0, id0, lo0, hi0), (leaf1, id1, lo1, hi1)):
         t = g[is_leaf]
         for v in (v0, v1, v2):
             q = (v[t] - glo) / cell
