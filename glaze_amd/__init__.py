@@ -160,6 +160,10 @@ class RayTraceInstance:
         """hipStream_t (as int) all kernels of this instance run on."""
         return abi.lib().glz_instance_stream(self._h)
 
+    def set_bvh_builder(self, name):
+        """'lbvh' (default) or 'ploc' for scenes created afterwards."""
+        abi.check(abi.lib().glz_instance_set_bvh_builder(self._h, {"lbvh": 0, "ploc": 1}[name]))
+
     def __del__(self):
         if getattr(self, "_h", None):
             abi.lib().glz_instance_destroy(self._h)

@@ -116,6 +116,7 @@ PROTOTYPES = {
     "glz_instance_destroy": (None, [_P]),
     "glz_instance_device": (C.c_int, [_P]),
     "glz_instance_stream": (_P, [_P]),
+    "glz_instance_set_bvh_builder": (C.c_int, [_P, C.c_int]),
     "glz_scene_create": (_P, [_P, _P]),
     "glz_scene_create_from_desc": (_P, [_P, _P]),
     "glz_scene_destroy": (None, [_P]),

@@ -165,6 +165,11 @@ glz_instance* glz_instance_create(int hip_device) {
 void glz_instance_destroy(glz_instance* h) { delete h; }
 int glz_instance_device(const glz_instance* h) { return h ? h->i->device : -1; }
 void* glz_instance_stream(const glz_instance* h) { return h ? (void*)h->i->stream : nullptr; }
+int glz_instance_set_bvh_builder(glz_instance* h, int builder) {
+  if (!h || (builder != GLZ_BVH_PLOC && builder != GLZ_BVH_LBVH)) return fail(GLZ_E_INVALID_INPUT, "glz_instance_set_bvh_builder: bad argument");
+  h->i->bvh_builder = builder;
+  return GLZ_OK;
+}
 
 // ---- scene -----------------------------------------------------------------------------------
 glz_scene* glz_scene_create(glz_instance* inst, glz_parsed* parsed) {

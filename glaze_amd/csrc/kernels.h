@@ -19,13 +19,16 @@ struct LbvhInputs {
   const TransformPair* transforms;
   const RTMaterial* materials;
   uint32_t n_world;
+  int builder;                 // kBvhBuilderLbvh (default) or kBvhBuilderPloc
 };
+constexpr int kBvhBuilderLbvh = 0, kBvhBuilderPloc = 1;   // = GLZ_BVH_LBVH / GLZ_BVH_PLOC
 struct LbvhOutputs {
   BvhQNode* nodes;  // max(n_world - 1, 1) entries, preallocated
   BvhGrid grid;     // quantisation grid of the node boxes
   BvhTri* tris;     // n_world entries, preallocated, leaf order
   uint32_t depth;   // number of inner nodes above the deepest leaf
   float sah;
+  uint32_t rounds;  // PLOC merge rounds (0 for the LBVH)
   float bounds_lo[3], bounds_hi[3];
 };
 hipError_t build_lbvh(hipStream_t st, const LbvhInputs& in, LbvhOutputs& out);

@@ -293,6 +293,172 @@ __global__ void __launch_bounds__(256) k_fit(int n, const int2* __restrict__ chi
   atomicMax(max_depth, depth);
 }
 
+// ---------------------------------------------------------------------------------------------
+// PLOC (parallel locally-ordered clustering, Meister & Bittner 2018): bottom-up agglomerative build over the
+// Morton-ordered leaves.  Every round each cluster looks kPlocRadius positions to both sides for the neighbour
+// whose merged box has the smallest surface area; mutually nearest pairs merge into a new inner node and the
+// cluster array is compacted IN ORDER (prefix sum), so it stays spatially sorted.  Optional builder
+// (glz_instance_set_bvh_builder): on the atrium its trees cost the same as the Karras LBVH's overall.
+// Inner-node ids are handed out downwards from n-2, so the last merge creates the root as node 0.
+// ---------------------------------------------------------------------------------------------
+constexpr int kPlocRadius = 16;
+constexpr int kScanTile = 1024;   // elements per block of the scan kernels (256 threads x 4)
+
+__device__ __forceinline__ int box_slot(int ref, int n) { return ref >= 0 ? ref : (n - 1) + ~ref; }
+
+__global__ void __launch_bounds__(256) k_ploc_nearest(int m, int n, const int* __restrict__ refs, const float4* __restrict__ node_lo,
+                                                      const float4* __restrict__ node_hi, int* __restrict__ nearest) {
+  __shared__ float4 s_lo[256 + 2 * kPlocRadius], s_hi[256 + 2 * kPlocRadius];
+  const int base = (int)(blockIdx.x * 256) - kPlocRadius;
+  for (int k = threadIdx.x; k < 256 + 2 * kPlocRadius; k += 256) {
+    const int idx = base + k;
+    if (idx >= 0 && idx < m) {
+      const int slot = box_slot(refs[idx], n);
+      s_lo[k] = node_lo[slot];
+      s_hi[k] = node_hi[slot];
+    }
+  }
+  __syncthreads();
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= m) return;
+  const float4 lo = s_lo[threadIdx.x + kPlocRadius], hi = s_hi[threadIdx.x + kPlocRadius];
+  float best = INFINITY;
+  int best_j = -1;
+  for (int d = -kPlocRadius; d <= kPlocRadius; ++d) {
+    const int j = i + d;
+    if (d == 0 || j < 0 || j >= m) continue;
+    const float4 l = s_lo[threadIdx.x + kPlocRadius + d], h = s_hi[threadIdx.x + kPlocRadius + d];
+    const float dx = fmaxf(hi.x, h.x) - fminf(lo.x, l.x), dy = fmaxf(hi.y, h.y) - fminf(lo.y, l.y), dz = fmaxf(hi.z, h.z) - fminf(lo.z, l.z);
+    const float area = dx * dy + dy * dz + dz * dx;
+    if (area < best) {   // d ascends, so ties keep the smaller index: the globally closest pair is then always mutual
+      best = area;
+      best_j = j;
+    }
+  }
+  nearest[i] = best_j;
+}
+
+// flags: low word = the cluster survives this round (merged pairs survive as their left member), high word = it is the
+// left member of a merging pair (it allocates the new node)
+__global__ void __launch_bounds__(256) k_ploc_flags(int m, const int* __restrict__ nearest, unsigned long long* __restrict__ flags) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= m) return;
+  const int j = nearest[i];
+  const bool mutual = j >= 0 && nearest[j] == i;
+  const bool leader = mutual && i < j, absorbed = mutual && i > j;
+  flags[i] = (absorbed ? 0ull : 1ull) | (leader ? (1ull << 32) : 0ull);
+}
+
+// exclusive prefix sum of packed counters, three phases: per-tile scan + tile totals, scan of the totals (recursive), add
+__global__ void __launch_bounds__(256) k_scan_tiles(int m, const unsigned long long* __restrict__ in, unsigned long long* __restrict__ out,
+                                                    unsigned long long* __restrict__ tile_sums) {
+  __shared__ unsigned long long s_wave[4];
+  const int base = blockIdx.x * kScanTile + threadIdx.x * 4;
+  unsigned long long v[4], run = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    v[k] = base + k < m ? in[base + k] : 0ull;
+    run += v[k];
+  }
+  unsigned long long incl = run;   // inclusive scan of the per-thread sums: wave shuffle, then the 4 wave totals
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned long long up = __shfl_up(incl, off);
+    if (lane >= off) incl += up;
+  }
+  if (lane == 63) s_wave[wave] = incl;
+  __syncthreads();
+  unsigned long long before = 0;
+  for (int w = 0; w < wave; ++w) before += s_wave[w];
+  unsigned long long excl = before + incl - run;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (base + k < m) out[base + k] = excl;
+    excl += v[k];
+  }
+  if (threadIdx.x == 255) tile_sums[blockIdx.x] = before + incl;
+}
+__global__ void __launch_bounds__(256) k_scan_add(int m, unsigned long long* __restrict__ out, const unsigned long long* __restrict__ tile_offsets) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < m) out[i] += tile_offsets[i / kScanTile];
+}
+// total = exclusive[m-1] + in[m-1]
+__global__ void k_scan_total(int m, const unsigned long long* __restrict__ in, const unsigned long long* __restrict__ out,
+                             unsigned long long* __restrict__ total) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) *total = out[m - 1] + in[m - 1];
+}
+// in/out: m elements; tmp: scratch for the tile sums of every level (>= m / 1023 + 8 elements)
+static hipError_t scan_exclusive(hipStream_t st, int m, const unsigned long long* in, unsigned long long* out, unsigned long long* tmp) {
+  const int tiles = (m + kScanTile - 1) / kScanTile;
+  hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(256), 0, st, m, in, out, tmp);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess || tiles == 1) return e;
+  unsigned long long* sums_scanned = tmp + tiles;
+  e = scan_exclusive(st, tiles, tmp, sums_scanned, sums_scanned + tiles);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_scan_add, dim3((m + 255) / 256), dim3(256), 0, st, m, out, sums_scanned);
+  return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256) k_ploc_merge(int m, int n, int next_free, const int* __restrict__ refs, const int* __restrict__ nearest,
+                                                    const unsigned long long* __restrict__ flags, const unsigned long long* __restrict__ pos,
+                                                    int* __restrict__ refs_out, int2* __restrict__ children, int* __restrict__ parent,
+                                                    float4* node_lo, float4* node_hi) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= m) return;
+  const unsigned long long f = flags[i], p = pos[i];
+  if (!(f & 1ull)) return;   // absorbed by its left partner
+  int ref = refs[i];
+  if (f >> 32) {
+    const int id = next_free - (int)(p >> 32);
+    const int a = ref, b = refs[nearest[i]];
+    const int sa = box_slot(a, n), sb = box_slot(b, n);
+    const float4 l0 = node_lo[sa], l1 = node_lo[sb], h0 = node_hi[sa], h1 = node_hi[sb];
+    children[id] = make_int2(a, b);
+    node_lo[id] = make_float4(fminf(l0.x, l1.x), fminf(l0.y, l1.y), fminf(l0.z, l1.z), 0.0f);
+    node_hi[id] = make_float4(fmaxf(h0.x, h1.x), fmaxf(h0.y, h1.y), fmaxf(h0.z, h1.z), 0.0f);
+    parent[sa] = id;
+    parent[sb] = id;
+    ref = id;
+  }
+  refs_out[(uint32_t)p] = ref;
+}
+__global__ void __launch_bounds__(256) k_ploc_init(int n, int* __restrict__ refs, int* __restrict__ parent) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) refs[i] = ~i;
+  if (i == 0) parent[0] = -1;
+}
+
+// ---- layout: depth-first (pre-order) numbering, so every subtree is one contiguous run of nodes and a node's left
+// child is its neighbour.  counts[t] = inner nodes in the subtree of t (bottom-up, same arrival scheme as k_fit).
+__global__ void __launch_bounds__(256) k_subtree_counts(int n, const int2* __restrict__ children, const int* __restrict__ parent,
+                                                        int* counts, int* __restrict__ arrivals) {
+  const int leaf = blockIdx.x * blockDim.x + threadIdx.x;
+  if (leaf >= n) return;
+  int node = parent[(n - 1) + leaf];
+  while (node >= 0) {
+    __threadfence();
+    const int seen = atomicAdd(&arrivals[node], 1);
+    if (seen == 0) return;
+    __threadfence();
+    const int2 c = children[node];
+    counts[node] = 1 + (c.x >= 0 ? counts[c.x] : 0) + (c.y >= 0 ? counts[c.y] : 0);
+    node = parent[node];
+  }
+}
+__global__ void __launch_bounds__(256) k_dfs_ids(int n, const int2* __restrict__ children, const int* __restrict__ parent,
+                                                 const int* __restrict__ counts, int* __restrict__ new_id) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n - 1) return;
+  int id = 0;
+  for (int cur = t, p = parent[t]; p >= 0; cur = p, p = parent[p]) {
+    const int2 c = children[p];
+    id += 1 + ((c.y == cur && c.x >= 0) ? counts[c.x] : 0);
+  }
+  new_id[t] = id;
+}
+
 // leaf depth = number of ancestors + 1 (for sizing the traversal stack)
 __global__ void __launch_bounds__(256) k_leaf_depth(int n, const int* __restrict__ parent, int* __restrict__ max_depth) {
   const int leaf = blockIdx.x * blockDim.x + threadIdx.x;
@@ -330,7 +496,7 @@ __device__ __forceinline__ uint32_t quant_hi(float x, float lo, float inv_cell) 
 
 __global__ void __launch_bounds__(256) k_emit_nodes(int n, const int2* __restrict__ children, const float4* __restrict__ node_lo,
                                                     const float4* __restrict__ node_hi, const BvhGrid* __restrict__ grid,
-                                                    BvhQNode* __restrict__ nodes, float* __restrict__ sah) {
+                                                    const int* __restrict__ new_id, BvhQNode* __restrict__ nodes, float* __restrict__ sah) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n - 1) return;
   const int2 c = children[i];
@@ -348,9 +514,9 @@ __global__ void __launch_bounds__(256) k_emit_nodes(int n, const int2* __restric
   nd.w[3] = q1[0] | (q1[1] << 16);
   nd.w[4] = q1[2] | (q1[3] << 16);
   nd.w[5] = q1[4] | (q1[5] << 16);
-  nd.w[6] = (uint32_t)c.x;   // child links as the hierarchy holds them: inner node index >= 0, or ~leaf
-  nd.w[7] = (uint32_t)c.y;
-  nodes[i] = nd;
+  nd.w[6] = (uint32_t)(c.x >= 0 ? new_id[c.x] : c.x);   // child links: inner node index (in the final layout) >= 0, or ~leaf
+  nd.w[7] = (uint32_t)(c.y >= 0 ? new_id[c.y] : c.y);
+  nodes[new_id[i]] = nd;
   // SAH cost numerator: sum of surface areas of inner nodes (1.2) and leaves (1.0), normalised on the host
   auto area = [](float4 l, float4 h) { float dx = h.x - l.x, dy = h.y - l.y, dz = h.z - l.z; return 2.0f * (dx * dy + dy * dz + dz * dx); };
   float acc = 1.2f * area(node_lo[i], node_hi[i]);
@@ -417,6 +583,7 @@ hipError_t build_lbvh(hipStream_t st, const LbvhInputs& in, LbvhOutputs& out) {
   const uint32_t n = in.n_world;
   out.depth = 0;
   out.sah = 0.0f;
+  out.rounds = 0;
   if (n == 0) return hipSuccess;
   const uint32_t np = std::max<uint32_t>(next_pow2(n), kSortTile);
   hipError_t e;
@@ -425,11 +592,14 @@ hipError_t build_lbvh(hipStream_t st, const LbvhInputs& in, LbvhOutputs& out) {
   uint64_t* keys = nullptr;
   uint32_t* vals = nullptr;
   int2* children = nullptr;
-  int *parent = nullptr, *arrivals = nullptr, *scalars = nullptr;
+  int *parent = nullptr, *arrivals = nullptr, *scalars = nullptr, *counts = nullptr, *new_id = nullptr;
+  int *refs_a = nullptr, *refs_b = nullptr, *nearest = nullptr;
+  unsigned long long *flags = nullptr, *pos = nullptr, *scan_tmp = nullptr, *scan_total = nullptr;
   float* sah = nullptr;
   BvhGrid* grid = nullptr;
   auto cleanup = [&]() {
-    void* bufs[] = {tris_unsorted, lo, hi, node_lo, node_hi, keys, vals, children, parent, arrivals, scalars, sah, grid};
+    void* bufs[] = {tris_unsorted, lo, hi, node_lo, node_hi, keys, vals, children, parent, arrivals, scalars, sah, grid, counts, new_id,
+                    refs_a, refs_b, nearest, flags, pos, scan_tmp, scan_total};
     for (void* b : bufs)
       if (b) (void)hipFree(b);
   };
@@ -447,6 +617,8 @@ hipError_t build_lbvh(hipStream_t st, const LbvhInputs& in, LbvhOutputs& out) {
   GLZ_TRY(hipMalloc(&scalars, sizeof(int) * 8));
   GLZ_TRY(hipMalloc(&sah, sizeof(float)));
   GLZ_TRY(hipMalloc(&grid, sizeof(BvhGrid)));
+  GLZ_TRY(hipMalloc(&counts, sizeof(int) * n));
+  GLZ_TRY(hipMalloc(&new_id, sizeof(int) * n));
   GLZ_TRY(hipMemsetAsync(arrivals, 0, sizeof(int) * n, st));
   GLZ_TRY(hipMemsetAsync(sah, 0, sizeof(float), st));
   {
@@ -475,15 +647,58 @@ hipError_t build_lbvh(hipStream_t st, const LbvhInputs& in, LbvhOutputs& out) {
   hipLaunchKernelGGL(k_gather_leaves, grd, blk, 0, st, vals, n, tris_unsorted, lo, hi, out.tris, node_lo, node_hi);
   GLZ_TRY(hipGetLastError());
   if (n >= 2) {
-    hipLaunchKernelGGL(k_hierarchy, grd, blk, 0, st, keys, (int)n, children, parent);
+    if (in.builder == kBvhBuilderLbvh) {
+      hipLaunchKernelGGL(k_hierarchy, grd, blk, 0, st, keys, (int)n, children, parent);
+      GLZ_TRY(hipGetLastError());
+      hipLaunchKernelGGL(k_fit, grd, blk, 0, st, (int)n, children, parent, node_lo, node_hi, arrivals, scalars + 7);
+      GLZ_TRY(hipGetLastError());
+      GLZ_TRY(hipMemsetAsync(arrivals, 0, sizeof(int) * n, st));
+    } else {
+      const size_t tiles = ((size_t)n + kScanTile - 1) / kScanTile;
+      GLZ_TRY(hipMalloc(&refs_a, sizeof(int) * n));
+      GLZ_TRY(hipMalloc(&refs_b, sizeof(int) * n));
+      GLZ_TRY(hipMalloc(&nearest, sizeof(int) * n));
+      GLZ_TRY(hipMalloc(&flags, sizeof(unsigned long long) * n));
+      GLZ_TRY(hipMalloc(&pos, sizeof(unsigned long long) * n));
+      GLZ_TRY(hipMalloc(&scan_tmp, sizeof(unsigned long long) * (2 * tiles + 4096)));
+      GLZ_TRY(hipMalloc(&scan_total, sizeof(unsigned long long)));
+      hipLaunchKernelGGL(k_ploc_init, grd, blk, 0, st, (int)n, refs_a, parent);
+      GLZ_TRY(hipGetLastError());
+      int m = (int)n, next_free = (int)n - 2;
+      out.rounds = 0;
+      while (m > 1) {
+        const dim3 gm((m + 255) / 256);
+        hipLaunchKernelGGL(k_ploc_nearest, gm, blk, 0, st, m, (int)n, refs_a, node_lo, node_hi, nearest);
+        GLZ_TRY(hipGetLastError());
+        hipLaunchKernelGGL(k_ploc_flags, gm, blk, 0, st, m, nearest, flags);
+        GLZ_TRY(hipGetLastError());
+        GLZ_TRY(scan_exclusive(st, m, flags, pos, scan_tmp));
+        hipLaunchKernelGGL(k_scan_total, dim3(1), dim3(64), 0, st, m, flags, pos, scan_total);
+        GLZ_TRY(hipGetLastError());
+        hipLaunchKernelGGL(k_ploc_merge, gm, blk, 0, st, m, (int)n, next_free, refs_a, nearest, flags, pos, refs_b, children, parent, node_lo,
+                           node_hi);
+        GLZ_TRY(hipGetLastError());
+        unsigned long long total = 0;
+        GLZ_TRY(hipMemcpyAsync(&total, scan_total, sizeof(total), hipMemcpyDeviceToHost, st));
+        GLZ_TRY(hipStreamSynchronize(st));
+        const int survivors = (int)(total & 0xFFFFFFFFull), merges = (int)(total >> 32);
+        if (merges <= 0 || survivors != m - merges) { cleanup(); return hipErrorUnknown; }   // cannot happen: the closest pair is always mutual
+        next_free -= merges;
+        m = survivors;
+        std::swap(refs_a, refs_b);
+        ++out.rounds;
+      }
+    }
+    // depth-first layout of the finished hierarchy
+    hipLaunchKernelGGL(k_subtree_counts, grd, blk, 0, st, (int)n, children, parent, counts, arrivals);
     GLZ_TRY(hipGetLastError());
-    hipLaunchKernelGGL(k_fit, grd, blk, 0, st, (int)n, children, parent, node_lo, node_hi, arrivals, scalars + 7);
+    hipLaunchKernelGGL(k_dfs_ids, grd, blk, 0, st, (int)n, children, parent, counts, new_id);
     GLZ_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_leaf_depth, grd, blk, 0, st, (int)n, parent, scalars + 6);
     GLZ_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_grid_params, dim3(1), dim3(64), 0, st, node_lo, node_hi, grid);
     GLZ_TRY(hipGetLastError());
-    hipLaunchKernelGGL(k_emit_nodes, grd, blk, 0, st, (int)n, children, node_lo, node_hi, grid, out.nodes, sah);
+    hipLaunchKernelGGL(k_emit_nodes, grd, blk, 0, st, (int)n, children, node_lo, node_hi, grid, new_id, out.nodes, sah);
     GLZ_TRY(hipGetLastError());
   }
   int host_scalars[8];

@@ -393,7 +393,7 @@ bool Scene::build_bvh(Error& err) {
   if (!hip_ok(d_nodes_.alloc(n > 1 ? n - 1 : 1), "alloc BVH nodes", err)) return false;
   if (!hip_ok(d_tris_.alloc(n == 1 ? 2 : n), "alloc BVH triangles", err)) return false;   // n == 1: see build_lbvh
   LbvhInputs in{d_vertices_.ptr, d_indices_.ptr, d_instances_.ptr, d_inst_base_.ptr, (uint32_t)h_instances.size(), d_transforms_.ptr,
-                d_materials_.ptr, n};
+                d_materials_.ptr, n, instance->bvh_builder};
   LbvhOutputs out{};
   out.nodes = d_nodes_.ptr;
   out.tris = d_tris_.ptr;

@@ -199,6 +199,13 @@ void glz_instance_destroy(glz_instance*);
 int glz_instance_device(const glz_instance*);
 /* stream all of this instance's kernels run on (a hipStream_t), for event timing by the caller */
 void* glz_instance_stream(const glz_instance*);
+/* [extension] acceleration-structure builder for scenes created afterwards (the reference leaves the choice to the
+ * Vulkan driver, acceleration.rs:253-257 asks for PREFER_FAST_TRACE): GLZ_BVH_LBVH (default; Karras 2012, fastest
+ * build) or GLZ_BVH_PLOC (parallel locally-ordered clustering, Meister & Bittner 2018: a few more milliseconds of
+ * build; on the atrium it trades closest-hit visits +10 % for shadow-ray visits -15 %).  Hits do not depend on it. */
+#define GLZ_BVH_LBVH 0
+#define GLZ_BVH_PLOC 1
+int glz_instance_set_bvh_builder(glz_instance*, int builder);
 
 /* ------------------------------------------------------------------------------------------
  * RayTraceScene::new(instance, parsed)   (lib/src/vulkan/scene.rs:1414-1556)

@@ -58,8 +58,17 @@ def test_rt_tables_bit_exact(which, cube, mattest):
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
 
 
-def test_bvh_structure(mattest):
-    _, gpu, _ = mattest
+@pytest.fixture(scope="module")
+def mattest_ploc(mattest):
+    """Same scene built with the optional PLOC builder (glz_instance_set_bvh_builder) on its own instance."""
+    inst = glaze_amd.RayTraceInstance.new()
+    inst.set_bvh_builder("ploc")
+    return glaze_amd.RayTraceScene.new(inst, glaze_amd.parse(MATTEST))
+
+
+@pytest.mark.parametrize("builder", ["lbvh", "ploc"])
+def test_bvh_structure(builder, mattest, mattest_ploc):
+    gpu = mattest[1] if builder == "lbvh" else mattest_ploc
     nodes, tris = gpu.debug_bvh()
     info = gpu.info()
     n = tris.shape[0]
@@ -139,6 +148,39 @@ def test_closest_hit_mattest_camera_and_random(mattest, instance):
     d /= np.linalg.norm(d, axis=1, keepdims=True)
     same, _, _ = _check_closest(gpu, orc, o, d)
     assert same.all(), "mismatching rays: %d" % (~same).sum()
+
+
+def test_ploc_builder_same_hits(mattest, mattest_ploc):
+    """Hits must not depend on the acceleration structure: PLOC-built scene vs the oracle."""
+    _, _, orc = mattest
+    rng = np.random.default_rng(7)
+    i = mattest_ploc.info()
+    assert i.bvh_nodes == 138479 and 17 <= i.bvh_depth <= 96
+    lo, hi = np.array(i.bounds_min), np.array(i.bounds_max)
+    o = (lo + rng.random((50000, 3)) * (hi - lo)).astype(np.float32)
+    d = rng.normal(size=(50000, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    same, _, _ = _check_closest(mattest_ploc, orc, o, d)
+    assert same.all(), "mismatching rays: %d" % (~same).sum()
+    tmax = (rng.random(50000) * 3.0).astype(np.float32)
+    assert np.array_equal(mattest_ploc.debug_trace_any(o, d, tmax), orc.trace_any(o, d, tmax))
+
+
+def test_ploc_tiny_scenes():
+    """1, 2 and 3 triangles: the merge loop's smallest cases."""
+    inst = glaze_amd.RayTraceInstance.new()
+    inst.set_bvh_builder("ploc")
+    for ntri in (1, 2, 3):
+        desc = cube_scene()
+        desc.indices = desc.indices[: 3 * ntri].copy()
+        desc.meshes["index_count"][0] = 3 * ntri
+        gpu, orc = glaze_amd.RayTraceScene.from_desc(inst, desc), OracleScene(desc)
+        rng = np.random.default_rng(ntri)
+        d = rng.normal(size=(4000, 3)).astype(np.float32)
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        o = (rng.random((4000, 3)).astype(np.float32) - 0.5) * 1.5
+        same, (t, _), _ = _check_closest(gpu, orc, o, d)
+        assert same.all() and np.isfinite(t).any()
 
 
 def test_oracle_bvh_against_brute_force(mattest):

@@ -6,7 +6,10 @@ import glaze_amd
 from glaze_amd.scenes import atrium_scene, cube_scene
 from oracle.pyoracle import OracleScene, OracleRenderer
 
+import os
 inst = glaze_amd.RayTraceInstance.new()
+if os.environ.get("GLZ_DIAG_BUILDER"):
+    inst.set_bvh_builder(os.environ["GLZ_DIAG_BUILDER"])
 desc = atrium_scene()
 t = time.time(); scene = glaze_amd.RayTraceScene.from_desc(inst, desc); print("scene create %.3fs" % (time.time() - t))
 i = scene.info(); print("tris", i.n_world_triangles, "bvh depth", i.bvh_depth, "sah", i.bvh_sah_cost, "build ms", i.build_ms)
