@@ -125,6 +125,117 @@ class ParsedScene:
         abi.check(abi.lib().glz_parsed_meta(self._h, C.byref(m)))
         return m
 
+    def update(self, cameras=None, materials=None, lights=None, textures=None, meta=None):
+        """ParsedScene::update (lib/src/parser/v1.rs:364-422): None keeps the chunk as stored; the file is rewritten.
+
+        cameras / materials / lights: lists of abi.Camera / abi.Material / abi.Light;
+        textures: [(format, pixels, name)] or [(format, pixels, name, mip_levels)]; meta: abi.Meta."""
+        keep = []
+
+        def arr(items, ctype):
+            if items is None:
+                return None, -1
+            a = (ctype * max(1, len(items)))(*items)
+            keep.append(a)
+            return C.cast(a, C.c_void_p), len(items)
+
+        cam, ncam = arr(cameras, abi.Camera)
+        mat, nmat = arr(materials, abi.Material)
+        lig, nlig = arr(lights, abi.Light)
+        tex, ntex = (None, -1) if textures is None else _texture_array(textures, keep)
+        abi.check(abi.lib().glz_parsed_update(self._h, cam, ncam, mat, nmat, lig, nlig, tex, ntex,
+                                              C.cast(C.pointer(meta), C.c_void_p) if meta is not None else None))
+
+
+def _texture_array(textures, keep):
+    texs = (abi.Texture * max(1, len(textures)))()
+    for i, t in enumerate(textures):
+        fmt, px, name = t[0], np.ascontiguousarray(t[1], np.uint8), t[2]
+        keep.append(px)
+        texs[i].format, texs[i].height, texs[i].width = fmt, px.shape[0], px.shape[1]
+        texs[i].mip_levels = t[3] if len(t) > 3 else 1
+        texs[i].pixels = px.ctypes.data
+        texs[i].name = name.encode("utf8")[:abi.NAME_MAX - 1]
+    keep.append(texs)
+    return C.cast(texs, C.c_void_p), len(textures)
+
+
+class Serializer:
+    """glaze::Serializer (lib/src/parser/mod.rs:130-233): `Serializer(path).with_vertices(v)....serialize()`."""
+
+    def __init__(self, path):
+        self.path = str(path)
+        self._v = np.zeros((0, 8), np.float32)
+        self._meshes, self._transforms, self._instances = [], np.zeros((0, 16), np.float32), np.zeros((0, 2), np.uint16)
+        self._cameras, self._textures, self._materials, self._lights, self._meta = [], [], [], [], None
+
+    def with_vertices(self, v):
+        v = np.ascontiguousarray(v)
+        self._v = (v.view(np.float32) if v.dtype.names else v.astype(np.float32, copy=False)).reshape(-1, 8)
+        return self
+
+    def with_meshes(self, meshes):
+        """[dict(id, material, indices)]"""
+        self._meshes = list(meshes)
+        return self
+
+    def with_transforms(self, t):
+        t = np.ascontiguousarray(t)
+        self._transforms = (t.view(np.float32) if t.dtype.names else t.astype(np.float32, copy=False)).reshape(-1, 16)
+        return self
+
+    def with_instances(self, i):
+        i = np.ascontiguousarray(i)
+        self._instances = (i.view(np.uint16) if i.dtype.names else i.astype(np.uint16, copy=False)).reshape(-1, 2)
+        return self
+
+    def with_cameras(self, c):
+        self._cameras = list(c)
+        return self
+
+    def with_textures(self, t):
+        self._textures = list(t)
+        return self
+
+    def with_materials(self, m):
+        self._materials = list(m)
+        return self
+
+    def with_lights(self, l):
+        self._lights = list(l)
+        return self
+
+    def with_metadata(self, m):
+        self._meta = m
+        return self
+
+    def serialize(self):
+        keep = []
+        d = abi.SerializeDescC()
+        idx = np.concatenate([np.asarray(m["indices"], np.uint32).ravel() for m in self._meshes]) if self._meshes else np.zeros(0, np.uint32)
+        meshes = (abi.Mesh * max(1, len(self._meshes)))()
+        off = 0
+        for i, m in enumerate(self._meshes):
+            n = int(np.asarray(m["indices"]).size)
+            meshes[i].id, meshes[i].material, meshes[i].index_offset, meshes[i].index_count = m["id"], m["material"], off, n
+            off += n
+        d.vertices, d.n_vertices = (self._v.ctypes.data if self._v.size else None), self._v.shape[0]
+        d.indices, d.n_indices = (idx.ctypes.data if idx.size else None), idx.size
+        d.meshes, d.n_meshes = C.cast(meshes, C.c_void_p), len(self._meshes)
+        d.transforms, d.n_transforms = (self._transforms.ctypes.data if self._transforms.size else None), self._transforms.shape[0]
+        d.instances, d.n_instances = (self._instances.ctypes.data if self._instances.size else None), self._instances.shape[0]
+        for name, items, ctype in (("cameras", self._cameras, abi.Camera), ("materials", self._materials, abi.Material),
+                                   ("lights", self._lights, abi.Light)):
+            a = (ctype * max(1, len(items)))(*items)
+            keep.append(a)
+            setattr(d, name, C.cast(a, C.c_void_p))
+            setattr(d, "n_" + name, len(items))
+        d.textures, d.n_textures = _texture_array(self._textures, keep)
+        if self._meta is not None:
+            d.meta = C.cast(C.pointer(self._meta), C.c_void_p)
+        keep += [idx, meshes]
+        abi.check(abi.lib().glz_serialize(self.path.encode(), C.byref(d)))
+
 
 def parse(path):
     """glaze::parse (lib/src/parser/mod.rs:93-116).  Raises GlazeError (io::Error) on a bad file."""
@@ -132,6 +243,19 @@ def parse(path):
     if not h:
         raise abi.last_error()
     return ParsedScene(h, str(path))
+
+
+def save_image(path, rgba8):
+    """image.save() of the CLI (cli/src/main.rs:121): HxWx4 uint8 -> .png or .jpg by extension."""
+    a = np.ascontiguousarray(rgba8, np.uint8)
+    abi.check(abi.lib().glz_save_image(str(path).encode(), a.ctypes.data, a.shape[1], a.shape[0]))
+
+
+def convert_obj(obj_path, out_path, gen_mipmaps=False):
+    """glaze-converter for OBJ input (converter/src/main.rs:116-637, assimp-free subset).  Returns the element counts."""
+    counts = (C.c_uint64 * 6)()
+    abi.check(abi.lib().glz_convert_obj(str(obj_path).encode(), str(out_path).encode(), int(gen_mipmaps), counts))
+    return dict(zip(("vertices", "triangles", "meshes", "materials", "textures", "lights"), (int(c) for c in counts)))
 
 
 def converted_file(path):

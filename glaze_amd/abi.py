@@ -75,6 +75,14 @@ class SceneDescC(C.Structure):
                 ("camera", C.c_void_p), ("meta", C.c_void_p)]
 
 
+class SerializeDescC(C.Structure):
+    _fields_ = [("vertices", C.c_void_p), ("n_vertices", C.c_uint64), ("indices", C.c_void_p), ("n_indices", C.c_uint64),
+                ("meshes", C.c_void_p), ("n_meshes", C.c_uint64), ("transforms", C.c_void_p), ("n_transforms", C.c_uint64),
+                ("instances", C.c_void_p), ("n_instances", C.c_uint64), ("cameras", C.c_void_p), ("n_cameras", C.c_uint64),
+                ("textures", C.c_void_p), ("n_textures", C.c_uint64), ("materials", C.c_void_p), ("n_materials", C.c_uint64),
+                ("lights", C.c_void_p), ("n_lights", C.c_uint64), ("meta", C.c_void_p)]
+
+
 class SceneInfo(C.Structure):
     _fields_ = [("n_vertices", C.c_uint64), ("n_triangles", C.c_uint64), ("n_world_triangles", C.c_uint64),
                 ("n_instances", C.c_uint32), ("n_materials", C.c_uint32), ("n_lights", C.c_uint32), ("n_rt_lights", C.c_uint32),
@@ -110,6 +118,10 @@ PROTOTYPES = {
     "glz_parsed_materials": (C.c_int64, [_P, _P, C.c_int64]),
     "glz_parsed_lights": (C.c_int64, [_P, _P, C.c_int64]),
     "glz_parsed_textures": (C.c_int64, [_P, _P, C.c_int64]),
+    "glz_serialize": (C.c_int, [C.c_char_p, _P]),
+    "glz_convert_obj": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, _P]),
+    "glz_save_image": (C.c_int, [C.c_char_p, _P, C.c_uint32, C.c_uint32]),
+    "glz_parsed_update": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64, _P, C.c_int64, _P, C.c_int64, _P]),
     "glz_parsed_meta": (C.c_int, [_P, _P]),
     "glz_converted_file": (C.c_int, [C.c_char_p]),
     "glz_instance_create": (_P, [C.c_int]),

@@ -8,6 +8,11 @@
 
 #include "glaze_abi.h"
 #include "parser.h"
+#include "serializer.h"
+#include "converter.h"
+#include "codec/jpeg.h"
+#include "codec/png_enc.h"
+#include <strings.h>
 #include "renderer.h"
 #include "scene.h"
 
@@ -139,6 +144,72 @@ int glz_parsed_meta(glz_parsed* h, glz_meta* out) {
   bool present = false;
   if (!h->p->meta(*out, present, e)) return fail(e);
   return present ? 0 : 1;
+  GLZ_GUARD_END(GLZ_E_IO)
+}
+int glz_serialize(const char* path, const glz_serialize_desc* d) {
+  GLZ_GUARD_BEGIN
+  if (!path || !d) return fail(GLZ_E_ARG, "null argument");
+  SerializeInput in;
+  in.vertices = d->vertices; in.n_vertices = d->n_vertices;
+  in.indices = d->indices; in.n_indices = d->n_indices;
+  in.meshes = d->meshes; in.n_meshes = d->n_meshes;
+  in.transforms = d->transforms; in.n_transforms = d->n_transforms;
+  in.instances = d->instances; in.n_instances = d->n_instances;
+  in.cameras = d->cameras; in.n_cameras = d->n_cameras;
+  in.textures = d->textures; in.n_textures = d->n_textures;
+  in.materials = d->materials; in.n_materials = d->n_materials;
+  in.lights = d->lights; in.n_lights = d->n_lights;
+  in.meta = d->meta;
+  Error e;
+  if (!serialize_scene(path, in, e)) return fail(e);
+  return GLZ_OK;
+  GLZ_GUARD_END(GLZ_E_IO)
+}
+int glz_parsed_update(glz_parsed* h, const glz_camera* cameras, int64_t n_cameras, const glz_material* materials, int64_t n_materials,
+                      const glz_light* lights, int64_t n_lights, const glz_texture* textures, int64_t n_textures, const glz_meta* meta) {
+  GLZ_GUARD_BEGIN
+  if (!h) return fail(GLZ_E_ARG, "parsed handle is null");
+  Parsed::Update u;
+  u.cameras = cameras; u.n_cameras = n_cameras;
+  u.materials = materials; u.n_materials = n_materials;
+  u.lights = lights; u.n_lights = n_lights;
+  u.textures = textures; u.n_textures = n_textures;
+  u.meta = meta;
+  Error e;
+  if (!h->p->update(u, e)) return fail(e);
+  h->tex_view.clear();
+  return GLZ_OK;
+  GLZ_GUARD_END(GLZ_E_IO)
+}
+int glz_save_image(const char* path, const uint8_t* rgba8, uint32_t width, uint32_t height) {
+  GLZ_GUARD_BEGIN
+  if (!path || !rgba8 || !width || !height) return fail(GLZ_E_ARG, "null argument or empty image");
+  const std::string p(path);
+  auto ends = [&](const char* suf) { const size_t n = strlen(suf); return p.size() >= n && strcasecmp(p.c_str() + p.size() - n, suf) == 0; };
+  std::vector<uint8_t> bytes;
+  bool ok;
+  if (ends(".png")) ok = png_encode(rgba8, width, height, 4, bytes);
+  else if (ends(".jpg") || ends(".jpeg")) ok = jpeg_encode(rgba8, width, height, 4, 75, bytes);
+  else return fail(GLZ_E_INVALID_INPUT, "The output image must end with .jpg or .png");
+  if (!ok) return fail(GLZ_E_INVALID_INPUT, "image cannot be encoded (JPEG is limited to 65535 x 65535)");
+  FILE* f = fopen(path, "wb");
+  if (!f) return fail(GLZ_E_IO, "The output file can not be written");
+  ok = fwrite(bytes.data(), 1, bytes.size(), f) == bytes.size();
+  ok = (fclose(f) == 0) && ok;
+  return ok ? GLZ_OK : fail(GLZ_E_IO, "short write");
+  GLZ_GUARD_END(GLZ_E_IO)
+}
+int glz_convert_obj(const char* input_obj, const char* output_glaze, int gen_mipmaps, uint64_t counts[6]) {
+  GLZ_GUARD_BEGIN
+  if (!input_obj || !output_glaze) return fail(GLZ_E_ARG, "null argument");
+  Error e;
+  ConvertReport rep;
+  if (!convert_obj(input_obj, output_glaze, gen_mipmaps != 0, &rep, e)) return fail(e);
+  if (counts) {
+    counts[0] = rep.vertices; counts[1] = rep.triangles; counts[2] = rep.meshes;
+    counts[3] = rep.materials; counts[4] = rep.textures; counts[5] = rep.lights;
+  }
+  return GLZ_OK;
   GLZ_GUARD_END(GLZ_E_IO)
 }
 int glz_converted_file(const char* path) {

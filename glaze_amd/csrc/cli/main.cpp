@@ -2,8 +2,6 @@
 // (cli/src/main.rs:24-39: `input output -r/--res WxH -s/--spp N -i/--integrator {direct,pt}`),
 // same messages and exit codes (cli/src/main.rs:41-135), driving the C ABI of libglaze_hip.so.
 // Build-defined extras: --seed, --depth, --device, --hdr-out file.pfm, --report (JSON on stdout).
-#include <zlib.h>
-
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -20,40 +18,6 @@ bool ends_with(const std::string& s, const char* suffix) {
   return s.size() >= n && s.compare(s.size() - n, n, suffix) == 0;
 }
 
-void be32(std::vector<uint8_t>& v, uint32_t x) {
-  v.push_back(x >> 24); v.push_back(x >> 16); v.push_back(x >> 8); v.push_back(x);
-}
-void png_chunk(std::vector<uint8_t>& out, const char* type, const std::vector<uint8_t>& body) {
-  be32(out, (uint32_t)body.size());
-  const size_t start = out.size();
-  out.insert(out.end(), type, type + 4);
-  out.insert(out.end(), body.begin(), body.end());
-  be32(out, (uint32_t)crc32(crc32(0, Z_NULL, 0), out.data() + start, (uInt)(4 + body.size())));
-}
-// RGBA8 PNG, filter 0 on every row, zlib default compression (image.save(), cli/src/main.rs:121)
-bool write_png(const std::string& path, const uint8_t* rgba, uint32_t w, uint32_t h) {
-  std::vector<uint8_t> raw((size_t)(w * 4 + 1) * h);
-  for (uint32_t y = 0; y < h; ++y) {
-    raw[(size_t)y * (w * 4 + 1)] = 0;
-    memcpy(&raw[(size_t)y * (w * 4 + 1) + 1], rgba + (size_t)y * w * 4, (size_t)w * 4);
-  }
-  uLongf clen = compressBound((uLong)raw.size());
-  std::vector<uint8_t> comp(clen);
-  if (compress2(comp.data(), &clen, raw.data(), (uLong)raw.size(), 6) != Z_OK) return false;
-  comp.resize(clen);
-  std::vector<uint8_t> out = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
-  std::vector<uint8_t> ihdr;
-  be32(ihdr, w); be32(ihdr, h);
-  ihdr.push_back(8); ihdr.push_back(6); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);
-  png_chunk(out, "IHDR", ihdr);
-  png_chunk(out, "IDAT", comp);
-  png_chunk(out, "IEND", {});
-  FILE* f = fopen(path.c_str(), "wb");
-  if (!f) return false;
-  const bool ok = fwrite(out.data(), 1, out.size(), f) == out.size();
-  fclose(f);
-  return ok;
-}
 // little-endian PFM (RGB float), bottom-up rows, of the cumulative image normalised by the launch count
 bool write_pfm(const std::string& path, const float* rgba, uint32_t w, uint32_t h) {
   FILE* f = fopen(path.c_str(), "wb");
@@ -148,10 +112,6 @@ int main(int argc, char** argv) {
     fprintf(stderr, "[ERROR] The output image must end with .jpg or .png\n");
     return 1;
   }
-  if (ends_with(output, "jpg")) {
-    fprintf(stderr, "[ERROR] The output file can not be written (this build has no JPEG encoder; use .png)\n");
-    return 1;
-  }
   {
     FILE* f = fopen(output.c_str(), "wb");
     if (!f) { fprintf(stderr, "[ERROR] The output file can not be written\n"); return 1; }
@@ -207,7 +167,7 @@ int main(int argc, char** argv) {
   const double render_ms = std::chrono::duration<double, std::milli>(r1 - r0).count();
   fprintf(stderr, "\r%sDone (%.0f ms)%60s\n", pb.msg.c_str(), render_ms, "");
   int rc = 0;
-  if (!write_png(output, image.data(), (uint32_t)width, (uint32_t)height)) {
+  if (glz_save_image(output.c_str(), image.data(), (uint32_t)width, (uint32_t)height) != GLZ_OK) {
     fprintf(stderr, "[ERROR] Failed to save image: %s\n", output.c_str());
     rc = 1;
   } else {

@@ -1,5 +1,6 @@
 // .glaze V1 reader.  See parser.h for the reference items this mirrors.
 #include "parser.h"
+#include "serializer.h"
 
 #include <cmath>
 #include <cstdio>
@@ -103,55 +104,84 @@ TextureData default_texture() {
 }
 
 std::unique_ptr<Parsed> Parsed::open(const std::string& path, Error& err) {
-  FILE* f = fopen(path.c_str(), "rb");
-  if (!f) {
-    fail(err, GLZ_E_IO, "cannot open " + path);
-    return nullptr;
-  }
   std::unique_ptr<Parsed> p(new Parsed());
+  if (!p->load(path, err)) return nullptr;
+  return p;
+}
+
+bool Parsed::load(const std::string& path, Error& err) {
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) return fail(err, GLZ_E_IO, "cannot open " + path);
   fseek(f, 0, SEEK_END);
   long sz = ftell(f);
   fseek(f, 0, SEEK_SET);
-  p->file_.resize(sz > 0 ? (size_t)sz : 0);
-  size_t got = p->file_.empty() ? 0 : fread(p->file_.data(), 1, p->file_.size(), f);
+  std::vector<uint8_t> d(sz > 0 ? (size_t)sz : 0);
+  size_t got = d.empty() ? 0 : fread(d.data(), 1, d.size(), f);
   fclose(f);
-  if (got != p->file_.size()) {
-    fail(err, GLZ_E_IO, "short read on " + path);
-    return nullptr;
-  }
-  const auto& d = p->file_;
+  if (got != d.size()) return fail(err, GLZ_E_IO, "short read on " + path);
   // parse(): header (mod.rs:93-116)
-  if (d.size() < kHeaderLen || memcmp(d.data(), kMagic, 5) != 0) {
-    fail(err, GLZ_E_INVALID_INPUT, "Wrong or empty input file");
-    return nullptr;
-  }
-  if (d[5] != 1) {
-    fail(err, GLZ_E_INVALID_INPUT, "Unsupported file version");
-    return nullptr;
-  }
+  if (d.size() < kHeaderLen || memcmp(d.data(), kMagic, 5) != 0) return fail(err, GLZ_E_INVALID_INPUT, "Wrong or empty input file");
+  if (d[5] != 1) return fail(err, GLZ_E_INVALID_INPUT, "Unsupported file version");
   // OffsetsTable::seek_and_parse (v1.rs:135-175)
-  if (d.size() < kHeaderLen + kHashSize + 1) {
-    fail(err, GLZ_E_IO, "failed to fill whole buffer");
-    return nullptr;
-  }
+  if (d.size() < kHeaderLen + kHashSize + 1) return fail(err, GLZ_E_IO, "failed to fill whole buffer");
   const uint64_t expected = rd64(&d[kHeaderLen]);
   const size_t n = d[kHeaderLen + kHashSize];
   size_t table_len = 1 + n * 17;
   const uint8_t* table = &d[kHeaderLen + kHashSize];
   if (kHeaderLen + kHashSize + table_len > d.size()) table_len = d.size() - kHeaderLen - kHashSize;  // take().read_to_end()
-  if (xxh64(table, table_len, kHasherSeed) != expected) {
-    fail(err, GLZ_E_INVALID_DATA, "Corrupted file structure");
-    return nullptr;
-  }
-  for (size_t i = 0; i < n; ++i) {
+  if (xxh64(table, table_len, kHasherSeed) != expected) return fail(err, GLZ_E_INVALID_DATA, "Corrupted file structure");
+  Slot slots[256];
+  for (size_t i = 0; i < n && 1 + 17 * (i + 1) <= table_len; ++i) {
     const uint8_t* e = table + 1 + 17 * i;
     unsigned id = e[0];
     if (!known_chunk(id)) continue;  // unknown chunks are ignored (v1.rs:160-162)
-    p->slots_[id].off = rd64(e + 1);
-    p->slots_[id].len = rd64(e + 9);
-    p->slots_[id].present = true;
+    slots[id].off = rd64(e + 1);
+    slots[id].len = rd64(e + 9);
+    slots[id].present = true;
   }
-  return p;
+  // commit: file image, offsets, and every cached getter result is dropped
+  path_ = path;
+  file_.swap(d);
+  for (int i = 0; i < 256; ++i) slots_[i] = slots[i];
+  vertices_ = {}; meshes_ = {}; indices_.clear(); transforms_ = {}; instances_ = {}; cameras_ = {}; materials_ = {}; lights_ = {};
+  textures_ = {};
+  return true;
+}
+
+bool Parsed::update(const Update& u, Error& err) {
+  auto raw = [&](int id, ChunkBytes& out) {   // read_chunk: the stored bytes (hash + body), empty when absent
+    const Slot& s = slots_[id];
+    out.clear();
+    if (!s.present || s.len == 0) return true;
+    if (s.off > file_.size() || s.len > file_.size() - s.off) return fail(err, GLZ_E_IO, "failed to fill whole buffer");
+    out.assign(file_.begin() + s.off, file_.begin() + s.off + s.len);
+    return true;
+  };
+  ChunkBytes vertices, meshes, transforms, instances, meta, cameras, materials, lights, textures;
+  if (!raw(kVertex, vertices) || !raw(kMesh, meshes) || !raw(kTransform, transforms) || !raw(kInstance, instances)) return false;
+  if (u.meta) meta = encode_meta(*u.meta); else if (!raw(kMeta, meta)) return false;
+  if (u.n_cameras >= 0) cameras = encode_cameras(u.cameras, (uint64_t)u.n_cameras); else if (!raw(kCamera, cameras)) return false;
+  if (u.n_materials >= 0) materials = encode_materials(u.materials, (uint64_t)u.n_materials); else if (!raw(kMaterial, materials)) return false;
+  if (u.n_lights >= 0) lights = encode_lights(u.lights, (uint64_t)u.n_lights); else if (!raw(kLight, lights)) return false;
+  if (u.n_textures >= 0) {
+    textures = encode_textures(u.textures, (uint64_t)u.n_textures, err);
+    if (err.code != GLZ_OK) return false;
+  } else if (!raw(kTexture, textures)) {
+    return false;
+  }
+  std::vector<std::pair<int, ChunkBytes>> chunks;   // order of v1.rs:403-413
+  chunks.emplace_back(kVertex, std::move(vertices));
+  chunks.emplace_back(kMesh, std::move(meshes));
+  chunks.emplace_back(kCamera, std::move(cameras));
+  chunks.emplace_back(kTexture, std::move(textures));
+  chunks.emplace_back(kMaterial, std::move(materials));
+  chunks.emplace_back(kTransform, std::move(transforms));
+  chunks.emplace_back(kInstance, std::move(instances));
+  chunks.emplace_back(kLight, std::move(lights));
+  chunks.emplace_back(kMeta, std::move(meta));
+  const std::string path = path_;
+  if (!write_glaze_file(path, chunks, err)) return false;
+  return load(path, err);   // reopen + OffsetsTable::seek_and_parse (v1.rs:415-419)
 }
 
 // read_chunk + verify_hash (+ decompress), v1.rs:298-313, :437-449, :59-67

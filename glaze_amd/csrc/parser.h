@@ -62,9 +62,23 @@ class Parsed {
   // (vulkan/scene.rs:1427-1434, :1467-1469, :1487-1491, :1532).
   bool to_scene_data(SceneData& out, Error& err);
 
+  // ParsedScene::update (v1.rs:364-422): rewrites the file with the given chunks replaced (a null pointer keeps the chunk
+  // as stored, byte for byte; geometry chunks are always kept), then re-reads it.  Unknown chunks are dropped, like the
+  // reference does.
+  struct Update {
+    const glz_camera* cameras = nullptr;      int64_t n_cameras = -1;     // -1 = None
+    const glz_material* materials = nullptr;  int64_t n_materials = -1;
+    const glz_light* lights = nullptr;        int64_t n_lights = -1;
+    const glz_texture* textures = nullptr;    int64_t n_textures = -1;
+    const glz_meta* meta = nullptr;
+  };
+  bool update(const Update& u, Error& err);
+
  private:
   struct Slot { uint64_t off = 0, len = 0; bool present = false; };
   bool chunk_payload(int id, const char* what, bool xz, std::vector<uint8_t>& payload, bool& present, Error& err);
+  bool load(const std::string& path, Error& err);
+  std::string path_;
   std::vector<uint8_t> file_;
   Slot slots_[256];
   template <class T> struct Cache { bool done = false; std::vector<T> v; };

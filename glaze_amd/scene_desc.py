@@ -131,6 +131,16 @@ class SceneDesc:
         return d
 
 
+def save_scene(desc, path, cameras=None):
+    """Writes a SceneDesc as a `.glaze` file through glaze_amd.Serializer (lets the synthetic benchmark scenes be real files)."""
+    import glaze_amd
+    meshes = [dict(id=int(m["id"]), material=int(m["material"]),
+                   indices=desc.indices[int(m["index_offset"]):int(m["index_offset"]) + int(m["index_count"])]) for m in desc.meshes]
+    (glaze_amd.Serializer(path).with_vertices(desc.vertices).with_meshes(meshes).with_transforms(desc.transforms)
+     .with_instances(desc.instances).with_cameras(cameras if cameras is not None else [desc.camera])
+     .with_textures(desc.textures).with_materials(desc.materials).with_lights(desc.lights).with_metadata(desc.meta).serialize())
+
+
 def _clone(s):
     c = type(s)()
     C.memmove(C.byref(c), C.byref(s), C.sizeof(s))

@@ -189,6 +189,42 @@ int glz_parsed_meta(glz_parsed*, glz_meta* out);  /* ParsedScene::meta; returns 
 int glz_converted_file(const char* path);         /* parser/mod.rs:259-271: 1 if the magic matches */
 
 /* ------------------------------------------------------------------------------------------
+ * Write side.  Serializer::new(file, ParserVersion::V1).with_*(..).serialize()
+ * (lib/src/parser/mod.rs:130-233; ContentV1::serialize / write_chunks, parser/v1.rs:230-295; record encoders :613-1061).
+ * Every array may be empty (no chunk is written for it); `meta` NULL = Serializer without with_metadata().
+ * Chunks are xz streams (LZMA2, CRC64) with an XXH64 prefix, textures are PNGs: the output is read back by glz_parse and
+ * by the reference's parser alike.  glz_texture.mip_levels > 1 asks for that many box-filtered levels below level 0.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct glz_serialize_desc {
+  const glz_vertex* vertices;         uint64_t n_vertices;
+  const uint32_t* indices;            uint64_t n_indices;    /* index arrays of all meshes (glz_mesh.index_offset/count) */
+  const glz_mesh* meshes;             uint64_t n_meshes;
+  const glz_transform* transforms;    uint64_t n_transforms;
+  const glz_mesh_instance* instances; uint64_t n_instances;
+  const glz_camera* cameras;          uint64_t n_cameras;
+  const glz_texture* textures;        uint64_t n_textures;
+  const glz_material* materials;      uint64_t n_materials;
+  const glz_light* lights;            uint64_t n_lights;
+  const glz_meta* meta;
+} glz_serialize_desc;
+int glz_serialize(const char* path, const glz_serialize_desc* desc);
+/* ParsedScene::update (parser/v1.rs:364-422): rewrites the parsed file in place with the given chunks replaced and
+ * re-reads it.  A count of -1 (or meta == NULL) keeps that chunk exactly as stored; geometry is always kept.  Pointers
+ * obtained earlier from this handle's getters are invalidated. */
+int glz_parsed_update(glz_parsed*, const glz_camera* cameras, int64_t n_cameras, const glz_material* materials, int64_t n_materials,
+                      const glz_light* lights, int64_t n_lights, const glz_texture* textures, int64_t n_textures, const glz_meta* meta);
+
+/* image.save(path) of the CLI (cli/src/main.rs:121): RGBA8 rows top-down -> PNG (RGBA) or baseline JPEG (alpha dropped,
+ * quality 75) chosen by the extension (.png / .jpg / .jpeg). */
+int glz_save_image(const char* path, const uint8_t* rgba8, uint32_t width, uint32_t height);
+/* glaze-converter for Wavefront OBJ input (converter/src/main.rs:116-637 without assimp): OBJ + MTL + PNG / baseline-JPEG
+ * textures -> .glaze V1 with the reference converter's layout (default material/texture first, "DefaultMaterial" second,
+ * de-duplicated flipped-v vertices, one identity transform, AREA lights for emissive materials, default camera, Meta
+ * from the bounds).  gen_mipmaps != 0 stores the full mip chain (--gen-mipmaps).  counts (may be NULL) receives
+ * {vertices, triangles, meshes, materials, textures, lights}. */
+int glz_convert_obj(const char* input_obj, const char* output_glaze, int gen_mipmaps, uint64_t counts[6]);
+
+/* ------------------------------------------------------------------------------------------
  * RayTraceInstance::new() -> Option<Self>   (lib/src/vulkan/instance.rs:376-427)
  * hip_device = -1 picks the first gfx950 device (LOCAL_RANK-agnostic; pass the ordinal for
  * one-process-per-GPU jobs).  NULL <=> None: no usable device or the HIP code object is missing.
