@@ -425,11 +425,19 @@ class RayTraceRenderer:
         self.scene = scene
 
     def update_materials_and_lights(self, materials, lights, textures=None):
-        if textures is not None:
-            raise NotImplementedError("texture replacement is not part of the hot path (SURVEY 8f rank 2)")
+        """raytracer.rs:311-326.  textures: None (keep) or [(format, pixels, name)] replacing the scene's texture array."""
         m = (abi.Material * max(1, len(materials)))(*materials)
         l = (abi.Light * max(1, len(lights)))(*lights)
-        abi.check(abi.lib().glz_renderer_update_materials_and_lights(self._h, C.cast(m, C.c_void_p), len(materials), C.cast(l, C.c_void_p), len(lights)))
+        keep = []
+        t, nt = (None, 0) if textures is None else _texture_array(textures, keep)
+        abi.check(abi.lib().glz_renderer_update_materials_and_lights(self._h, C.cast(m, C.c_void_p), len(materials), C.cast(l, C.c_void_p),
+                                                                     len(lights), t, nt))
+
+    def refresh_binded_textures(self, textures):
+        """raytracer.rs:328-356: new texture array under the same materials and lights; accumulation continues."""
+        keep = []
+        t, nt = _texture_array(textures, keep)
+        abi.check(abi.lib().glz_renderer_refresh_binded_textures(self._h, t, nt))
 
     def wait_idle(self):
         abi.check(abi.lib().glz_renderer_wait_idle(self._h))

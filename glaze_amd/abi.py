@@ -141,7 +141,8 @@ PROTOTYPES = {
     "glz_renderer_update_camera": (C.c_int, [_P, _P]),
     "glz_renderer_change_resolution": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
     "glz_renderer_change_scene": (C.c_int, [_P, _P]),
-    "glz_renderer_update_materials_and_lights": (C.c_int, [_P, _P, C.c_uint32, _P, C.c_uint32]),
+    "glz_renderer_update_materials_and_lights": (C.c_int, [_P, _P, C.c_uint32, _P, C.c_uint32, _P, C.c_uint32]),
+    "glz_renderer_refresh_binded_textures": (C.c_int, [_P, _P, C.c_uint32]),
     "glz_renderer_wait_idle": (C.c_int, [_P]),
     "glz_renderer_steps_per_sample": (C.c_uint32, [_P]),
     "glz_renderer_draw": (C.c_int, [_P, C.c_size_t, _P, _P, _P]),

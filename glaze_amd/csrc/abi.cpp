@@ -349,10 +349,17 @@ int glz_renderer_change_scene(glz_renderer* h, glz_scene* s) {
   GLZ_RET(h->r->change_scene(s->s, e));
   GLZ_GUARD_END(GLZ_E_IO)
 }
-int glz_renderer_update_materials_and_lights(glz_renderer* h, const glz_material* m, uint32_t nm, const glz_light* l, uint32_t nl) {
+int glz_renderer_update_materials_and_lights(glz_renderer* h, const glz_material* m, uint32_t nm, const glz_light* l, uint32_t nl,
+                                             const glz_texture* t, uint32_t nt) {
   GLZ_GUARD_BEGIN GLZ_R(h);
-  if ((!m && nm) || (!l && nl)) return fail(GLZ_E_ARG, "null array");
-  GLZ_RET(h->r->update_materials_and_lights(m, nm, l, nl, e));
+  if ((!m && nm) || (!l && nl) || (t && !nt)) return fail(GLZ_E_ARG, "null array");
+  GLZ_RET(h->r->update_materials_and_lights(m, nm, l, nl, t, nt, e));
+  GLZ_GUARD_END(GLZ_E_IO)
+}
+int glz_renderer_refresh_binded_textures(glz_renderer* h, const glz_texture* t, uint32_t nt) {
+  GLZ_GUARD_BEGIN GLZ_R(h);
+  if (!t || !nt) return fail(GLZ_E_ARG, "null array");
+  GLZ_RET(h->r->refresh_binded_textures(t, nt, e));
   GLZ_GUARD_END(GLZ_E_IO)
 }
 int glz_renderer_wait_idle(glz_renderer* h) { GLZ_GUARD_BEGIN GLZ_R(h); GLZ_RET(h->r->wait_idle(e)); GLZ_GUARD_END(GLZ_E_IO) }

@@ -265,13 +265,21 @@ bool Renderer::change_scene(Scene* scene, Error& err) {
   return update_camera(scene->data.camera, err);   // raytracer.rs:246-247
 }
 
-bool Renderer::update_materials_and_lights(const glz_material* m, uint32_t nm, const glz_light* l, uint32_t nl, Error& err) {
+bool Renderer::update_materials_and_lights(const glz_material* m, uint32_t nm, const glz_light* l, uint32_t nl, const glz_texture* t, uint32_t nt,
+                                           Error& err) {
   if (!wait_idle(err)) return false;
   const uint32_t od = scene_->stack_overflow_depth;
-  if (!scene_->update_materials_and_lights(m, nm, l, nl, err)) return false;
+  if (!scene_->update_materials_and_lights(m, nm, l, nl, t, nt, err)) return false;
   if (scene_->stack_overflow_depth != od && !allocate(err)) return false;
   request_new_frame_ = true;   // raytracer.rs:325
   return true;
+}
+
+// raytracer.rs:328-356.  The reference rebuilds descriptors, pipeline and SBT and leaves the accumulation alone; here the
+// kernels read the texture array through the scene struct of every launch, so re-uploading it is all there is to do.
+bool Renderer::refresh_binded_textures(const glz_texture* t, uint32_t nt, Error& err) {
+  if (!wait_idle(err)) return false;
+  return scene_->refresh_textures(t, nt, err);
 }
 
 bool Renderer::wait_idle(Error& err) {

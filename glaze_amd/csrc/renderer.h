@@ -20,7 +20,8 @@ class Renderer {
   bool update_camera(const glz_camera& c, Error& err);
   bool change_resolution(uint32_t w, uint32_t h, Error& err);
   bool change_scene(Scene* scene, Error& err);
-  bool update_materials_and_lights(const glz_material* m, uint32_t nm, const glz_light* l, uint32_t nl, Error& err);
+  bool update_materials_and_lights(const glz_material* m, uint32_t nm, const glz_light* l, uint32_t nl, const glz_texture* t, uint32_t nt, Error& err);
+  bool refresh_binded_textures(const glz_texture* t, uint32_t nt, Error& err);
   bool wait_idle(Error& err);
   uint32_t steps_per_sample() const { return integrator_ == GLZ_DIRECT ? 1u : pt_steps_; }
 

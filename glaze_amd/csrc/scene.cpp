@@ -179,7 +179,34 @@ bool Scene::upload_geometry(Error& err) {
     inv.to_f32(xf[i].w2o);
   }
   if (!hip_ok(d_transforms_.upload(xf.data(), xf.size(), st), "upload transforms", err)) return false;
-  // textures: one byte pool, level 0 only (16-byte aligned starts)
+  if (!upload_textures(err)) return false;
+  float lut[256];
+  for (int i = 0; i < 256; ++i) {   // sRGB EOTF of the R8G8B8A8_SRGB format (scene.rs:1028-1032) [ext]
+    const double c = i / 255.0;
+    lut[i] = (float)(c <= 0.04045 ? c / 12.92 : std::pow((c + 0.055) / 1.055, 2.4));
+  }
+  if (!hip_ok(d_srgb_lut_.upload(lut, 256, st), "upload sRGB LUT", err)) return false;
+  // calculate_geometric_derivatives (scene.rs:2113-2188)
+  uint32_t ntri = 0;
+  for (const glz_mesh& m : d.meshes) ntri = std::max<uint32_t>(ntri, (m.index_offset + m.index_count) / 3);
+  if (!hip_ok(d_derivatives_.alloc((size_t)ntri * 3), "alloc derivatives", err)) return false;
+  if (!hip_ok(launch_derivatives(st, d_vertices_.ptr, d_indices_.ptr, ntri, d_derivatives_.ptr), "derivatives kernel", err)) return false;
+  // the host staging vectors above must outlive the async copies
+  if (!hip_ok(hipStreamSynchronize(st), "geometry upload", err)) return false;
+  dev.vertices = d_vertices_.ptr;
+  dev.indices = d_indices_.ptr;
+  dev.instances = d_instances_.ptr;
+  dev.transforms = d_transforms_.ptr;
+  dev.derivatives = d_derivatives_.ptr;
+  dev.srgb_lut = d_srgb_lut_.ptr;
+  return true;
+}
+
+// Level 0 of every texture in one byte pool (16-byte aligned starts) + a descriptor per texture; what the reference
+// keeps as one VkImage per texture behind a descriptor array (scene.rs:1264-1350).
+bool Scene::upload_textures(Error& err) {
+  hipStream_t st = instance->stream;
+  SceneData& d = data;
   std::vector<TexDesc> desc(d.textures.size());
   std::vector<uint8_t> pool;
   for (size_t i = 0; i < d.textures.size(); ++i) {
@@ -201,27 +228,9 @@ bool Scene::upload_geometry(Error& err) {
   }
   if (!hip_ok(d_tex_desc_.upload(desc.data(), desc.size(), st), "upload texture descriptors", err)) return false;
   if (!hip_ok(d_tex_pool_.upload(pool.data(), pool.size(), st), "upload texture pool", err)) return false;
-  float lut[256];
-  for (int i = 0; i < 256; ++i) {   // sRGB EOTF of the R8G8B8A8_SRGB format (scene.rs:1028-1032) [ext]
-    const double c = i / 255.0;
-    lut[i] = (float)(c <= 0.04045 ? c / 12.92 : std::pow((c + 0.055) / 1.055, 2.4));
-  }
-  if (!hip_ok(d_srgb_lut_.upload(lut, 256, st), "upload sRGB LUT", err)) return false;
-  // calculate_geometric_derivatives (scene.rs:2113-2188)
-  uint32_t ntri = 0;
-  for (const glz_mesh& m : d.meshes) ntri = std::max<uint32_t>(ntri, (m.index_offset + m.index_count) / 3);
-  if (!hip_ok(d_derivatives_.alloc((size_t)ntri * 3), "alloc derivatives", err)) return false;
-  if (!hip_ok(launch_derivatives(st, d_vertices_.ptr, d_indices_.ptr, ntri, d_derivatives_.ptr), "derivatives kernel", err)) return false;
-  // the host staging vectors above must outlive the async copies
-  if (!hip_ok(hipStreamSynchronize(st), "geometry upload", err)) return false;
-  dev.vertices = d_vertices_.ptr;
-  dev.indices = d_indices_.ptr;
-  dev.instances = d_instances_.ptr;
-  dev.transforms = d_transforms_.ptr;
-  dev.derivatives = d_derivatives_.ptr;
+  if (!hip_ok(hipStreamSynchronize(st), "texture upload", err)) return false;   // the staging vectors above must outlive the copies
   dev.tex_desc = d_tex_desc_.ptr;
   dev.tex_pool = d_tex_pool_.ptr;
-  dev.srgb_lut = d_srgb_lut_.ptr;
   dev.n_textures = (uint32_t)d.textures.size();
   return true;
 }
@@ -442,22 +451,58 @@ bool Scene::build_bvh(Error& err) {
   return true;
 }
 
-bool Scene::update_materials_and_lights(const glz_material* mats, uint32_t n_mats, const glz_light* lights, uint32_t n_lights, Error& err) {
+bool Scene::update_textures(const glz_texture* textures, uint32_t n, Error& err) {
+  if (!hip_ok(hipSetDevice(instance->device), "hipSetDevice", err)) return false;
+  if (n == 0 || !textures) {
+    err.code = GLZ_E_ARG;
+    err.msg = "the texture list must keep at least the default texture";
+    return false;
+  }
+  std::vector<TextureData> fresh(n);
+  for (uint32_t i = 0; i < n; ++i) {
+    const glz_texture& t = textures[i];
+    const size_t bytes = (size_t)t.width * t.height * (t.format == GLZ_TEX_GRAY ? 1 : 4);
+    if (!t.pixels || !bytes || t.format < 1 || t.format > 3) {
+      err.code = GLZ_E_INVALID_DATA;
+      err.msg = "texture has inconsistent dimensions";
+      return false;
+    }
+    fresh[i].info = t;
+    fresh[i].level0.assign(t.pixels, t.pixels + bytes);
+    fresh[i].info.pixels = fresh[i].level0.data();
+  }
+  data.textures.swap(fresh);
+  for (auto& t : data.textures) t.info.pixels = t.level0.data();
+  if (!upload_textures(err)) return false;
+  info.n_textures = n;
+  sky_distribution_tex_ = 0xFFFFFFFFu;   // the sky map's texels may have changed: its distributions are rebuilt
+  return true;
+}
+
+bool Scene::update_materials_and_lights(const glz_material* mats, uint32_t n_mats, const glz_light* lights, uint32_t n_lights,
+                                        const glz_texture* textures, uint32_t n_textures, Error& err) {
   if (!hip_ok(hipSetDevice(instance->device), "hipSetDevice", err)) return false;
   if (n_mats != data.materials.size()) {
     err.code = GLZ_E_ARG;
     err.msg = "update_materials_and_lights: the material count must not change (meshes index materials)";
     return false;
   }
+  const size_t nt = textures ? n_textures : data.textures.size();
   for (uint32_t i = 0; i < n_mats; ++i) {
     const glz_material& m = mats[i];
-    const size_t nt = data.textures.size();
     if (m.diffuse >= nt || m.roughness >= nt || m.metalness >= nt || m.normal >= nt || m.opacity >= nt) {
       err.code = GLZ_E_INVALID_DATA;
       err.msg = "material references a missing texture";
       return false;
     }
   }
+  for (uint32_t i = 0; i < n_lights; ++i)
+    if (lights[i].ltype == GLZ_LIGHT_SKY && lights[i].resource_id >= nt) {
+      err.code = GLZ_E_INVALID_DATA;
+      err.msg = "sky light references a missing texture";
+      return false;
+    }
+  if (textures && !update_textures(textures, n_textures, err)) return false;
   bool opacity_changed = false;
   for (uint32_t i = 0; i < n_mats; ++i) opacity_changed |= (mats[i].opacity != 0) != (data.materials[i].opacity != 0);
   data.materials.assign(mats, mats + n_mats);
@@ -468,6 +513,14 @@ bool Scene::update_materials_and_lights(const glz_material* mats, uint32_t n_mat
   info.n_lights = lights_no;
   info.n_rt_lights = (uint32_t)h_lights.size();
   return hip_ok(hipStreamSynchronize(instance->stream), "update_materials_and_lights", err);
+}
+
+// refresh_binded_textures (raytracer.rs:328-356): the texture array changed under the same materials and lights
+bool Scene::refresh_textures(const glz_texture* textures, uint32_t n, Error& err) {
+  const size_t nm = data.materials.size();
+  std::vector<glz_material> mats = data.materials;
+  std::vector<glz_light> lights = data.lights;
+  return update_materials_and_lights(mats.data(), (uint32_t)nm, lights.data(), (uint32_t)lights.size(), textures, n, err);
 }
 
 }  // namespace glz

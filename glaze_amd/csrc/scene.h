@@ -53,7 +53,11 @@ class Scene {
   static Scene* create(Instance* inst, SceneData&& data, Error& err);
   // update_materials_and_lights (scene.rs:1587-1716): rebuilds RTMaterial / RTLight / sky tables.
   // The BVH is rebuilt only if a material's opacity flag changed (acceleration.rs:136-141).
-  bool update_materials_and_lights(const glz_material* mats, uint32_t n_mats, const glz_light* lights, uint32_t n_lights, Error& err);
+  // `textures` (may be null = keep) replaces the texture array: the reference passes the raw textures for the sky
+  // distributions (scene.rs:1598-1615) and re-binds the shared GPU textures separately (refresh_descriptors).
+  bool update_materials_and_lights(const glz_material* mats, uint32_t n_mats, const glz_light* lights, uint32_t n_lights,
+                                   const glz_texture* textures, uint32_t n_textures, Error& err);
+  bool refresh_textures(const glz_texture* textures, uint32_t n, Error& err);   // refresh_binded_textures, raytracer.rs:328-356
 
   Instance* instance = nullptr;
   SceneData data;           // host copy (materials/lights are kept for updates)
@@ -72,6 +76,8 @@ class Scene {
 
  private:
   bool upload_geometry(Error& err);
+  bool upload_textures(Error& err);
+  bool update_textures(const glz_texture* textures, uint32_t n, Error& err);
   bool build_materials(Error& err);
   bool build_lights_and_sky(Error& err);
   bool build_bvh(Error& err);

@@ -284,9 +284,15 @@ int glz_renderer_set_exposure(glz_renderer*, float exposure);            /* rayt
 int glz_renderer_update_camera(glz_renderer*, const glz_camera*);        /* raytracer.rs:300-309 */
 int glz_renderer_change_resolution(glz_renderer*, uint32_t w, uint32_t h);/* raytracer.rs:250-298 */
 int glz_renderer_change_scene(glz_renderer*, glz_scene* scene);          /* raytracer.rs:233-248 */
-/* raytracer.rs:311-326: rebuilds RTMaterial / RTLight / sky tables; restarts accumulation. */
+/* raytracer.rs:311-326 (&[Material], &[Light], &[Texture]): rebuilds RTMaterial / RTLight / sky tables; restarts
+ * accumulation.  The material count must not change.  `textures` NULL keeps the scene's texture array; otherwise it
+ * replaces it (level 0 is uploaded; the reference needs the raw textures for the sky distributions, scene.rs:1598-1615). */
 int glz_renderer_update_materials_and_lights(glz_renderer*, const glz_material* mats, uint32_t n_mats,
-                                             const glz_light* lights, uint32_t n_lights);
+                                             const glz_light* lights, uint32_t n_lights,
+                                             const glz_texture* textures, uint32_t n_textures);
+/* raytracer.rs:328-356: the texture array changed under the same materials and lights (the reference re-binds the
+ * textures it shares with the realtime viewer); accumulation is NOT restarted, like the reference. */
+int glz_renderer_refresh_binded_textures(glz_renderer*, const glz_texture* textures, uint32_t n_textures);
 int glz_renderer_wait_idle(glz_renderer*);                                /* raytracer.rs:328-340 */
 /* Integrator::steps_per_sample()  raytracer.rs:78-85 (PATH_TRACE -> the configured depth) */
 uint32_t glz_renderer_steps_per_sample(const glz_renderer*);

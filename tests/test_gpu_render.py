@@ -166,6 +166,85 @@ def test_update_materials_and_lights_restarts(instance, mattest_desc):
     assert_parity(r, o, "after material update")
 
 
+def _sky_cube(textures=None):
+    desc = cube_scene()
+    desc.lights = [make_light(abi.LIGHT_OMNI, "omni", position=(0.0, 0.5, 0.0), intensity=1.0),
+                   make_light(abi.LIGHT_SKY, "sky", resource_id=1, intensity=0.3, yaw=20, pitch=75, roll=10)]
+    if textures is not None:
+        desc.textures = textures
+    return desc
+
+
+def _stripes(seed, size=64):
+    rng = np.random.default_rng(seed)
+    px = np.zeros((size, size, 4), np.uint8)
+    px[..., :3] = rng.integers(0, 256, (size, 1, 3))          # horizontal bands: a different sky distribution per seed
+    px[::7, :, :3] = 255
+    px[..., 3] = 255
+    return px
+
+
+def test_update_textures_through_update_materials_and_lights(instance):
+    """raytracer.rs:311-326 with Some textures: new texels for the materials AND a rebuilt sky distribution (the sky light samples texture 1)."""
+    desc = _sky_cube()
+    scene = glaze_amd.RayTraceScene.from_desc(instance, desc)
+    r = glaze_amd.RayTraceRenderer.new(instance, scene, 64, 64)
+    r.set_depth(3)
+    r.draw(2, want_image=False)
+    new_textures = [desc.textures[0], (abi.TEX_RGBA_SRGB, _stripes(1), "stripes")]
+    r.update_materials_and_lights(desc.materials, desc.lights, new_textures)
+    assert scene.info().n_textures == 2
+    want = _sky_cube(new_textures)
+    orc = OracleScene(want)
+    assert np.array_equal(scene.debug_sky().view(np.uint32), orc.sky().view(np.uint32))          # marginal / conditional tables follow the new texels
+    r.step(9)                                                                                     # request_new_frame: restarted
+    assert r.read_hdr()[..., 3].max() == 9.0
+    o = OracleRenderer(orc, 64, 64)
+    o.set_depth(3)
+    o.step(9)
+    assert_parity(r, o, "after texture replacement")
+    # a longer texture list, the cube's material switched to the new entry
+    more = new_textures + [(abi.TEX_RGBA_SRGB, _stripes(2, 32), "more")]
+    mats = [m for m in desc.materials]
+    mats[2] = make_material("Material", mtype=abi.MAT_LAMBERT, diffuse=2, diffuse_mul=(204, 204, 204), ior=1.45)   # the cube's material
+    r.update_materials_and_lights(mats, desc.lights, more)
+    want = _sky_cube(more)
+    want.materials = mats
+    r.step(6)
+    o = OracleRenderer(OracleScene(want), 64, 64)
+    o.set_depth(3)
+    o.step(6)
+    assert_parity(r, o, "after texture list growth")
+    # errors: a material or the sky pointing past the new list, an empty list
+    with pytest.raises(abi.GlazeError):
+        r.update_materials_and_lights(mats, desc.lights, more[:2])
+    with pytest.raises(abi.GlazeError):
+        r.update_materials_and_lights(desc.materials, desc.lights, more[:1])
+    r.step(1)                                                                                     # failed updates left the scene usable
+
+
+def test_refresh_binded_textures_keeps_accumulating(instance):
+    """raytracer.rs:328-356: texture array swapped under the same materials; no request_new_frame."""
+    desc = _sky_cube()
+    scene = glaze_amd.RayTraceScene.from_desc(instance, desc)
+    r = glaze_amd.RayTraceRenderer.new(instance, scene, 48, 48)
+    r.set_depth(2)
+    r.step(4)
+    before = r.read_hdr()
+    new_textures = [desc.textures[0], (abi.TEX_RGBA_SRGB, _stripes(5), "stripes")]
+    r.refresh_binded_textures(new_textures)
+    r.step(4)
+    after = r.read_hdr()
+    assert after[..., 3].min() == 8.0 and before[..., 3].max() == 4.0                            # same accumulation, continued
+    assert not np.array_equal(after[..., :3], before[..., :3])
+    r.restart()
+    r.step(8)
+    o = OracleRenderer(OracleScene(_sky_cube(new_textures)), 48, 48)
+    o.set_depth(2)
+    o.step(8)
+    assert_parity(r, o, "fresh frame on the refreshed textures")
+
+
 def test_progressive_step_equals_draw(instance):
     desc = cube_scene()
     scene = glaze_amd.RayTraceScene.from_desc(instance, desc)
