@@ -441,7 +441,7 @@ int glz_debug_trace_closest(glz_scene* h, const float* o, const float* d, uint64
   DeviceBuffer<uint32_t> d_tri, d_inst, d_ovf;
   if (!to_device(d_o, o, n * 3, st, e) || !to_device(d_d, d, n * 3, st, e)) return fail(e);
   if (!hip_ok(d_t.alloc(n), "alloc", e) || !hip_ok(d_u.alloc(n), "alloc", e) || !hip_ok(d_v.alloc(n), "alloc", e) ||
-      !hip_ok(d_tri.alloc(n), "alloc", e) || !hip_ok(d_inst.alloc(n), "alloc", e) || !hip_ok(d_ovf.alloc(n * s->stack_overflow_depth), "alloc", e))
+      !hip_ok(d_tri.alloc(n), "alloc", e) || !hip_ok(d_inst.alloc(n), "alloc", e) || !hip_ok(d_ovf.alloc((n + 512) * s->stack_overflow_depth), "alloc", e))
     return fail(e);
   if (!hip_ok(launch_debug_closest(st, s->dev, d_o.ptr, d_d.ptr, (uint32_t)n, tmin, d_t.ptr, d_tri.ptr, d_inst.ptr, d_u.ptr, d_v.ptr, d_ovf.ptr,
                                    s->stack_overflow_depth), "k_debug_closest", e))
@@ -469,7 +469,7 @@ int glz_debug_trace_any(glz_scene* h, const float* o, const float* d, const floa
   DeviceBuffer<uint8_t> d_out;
   DeviceBuffer<uint32_t> d_ovf;
   if (!to_device(d_o, o, n * 3, st, e) || !to_device(d_d, d, n * 3, st, e) || !to_device(d_tm, tmax, n, st, e)) return fail(e);
-  if (!hip_ok(d_out.alloc(n), "alloc", e) || !hip_ok(d_ovf.alloc(n * s->stack_overflow_depth), "alloc", e)) return fail(e);
+  if (!hip_ok(d_out.alloc(n), "alloc", e) || !hip_ok(d_ovf.alloc((n + 512) * s->stack_overflow_depth), "alloc", e)) return fail(e);
   if (!hip_ok(launch_debug_any(st, s->dev, d_o.ptr, d_d.ptr, d_tm.ptr, (uint32_t)n, tmin, d_out.ptr, d_ovf.ptr, s->stack_overflow_depth), "k_debug_any", e))
     return fail(e);
   (void)hipMemcpyAsync(out, d_out.ptr, n, hipMemcpyDeviceToHost, st);

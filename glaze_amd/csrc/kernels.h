@@ -84,11 +84,16 @@ struct LaunchArgs {
   FrameData frame;
   CameraConsts cam;
   TraceCounters* counters;   // nullptr unless counting is enabled
+  // k_trace phases of this call: closest-hit rays of the current launch and / or the shadow rays the PREVIOUS launch's
+  // k_shade queued (they only gate an accumulation, so nothing of the current launch depends on them)
+  uint32_t do_closest, do_shadow;
+  uint32_t shade_set;        // which of the two shadow-queue counter sets this launch's k_shade fills (the other one is drained)
+  float shadow_exposure;     // exposure of the launch that queued the shadow rays (update_result uses it)
 };
+constexpr uint32_t kQueueSetWords = 8 * 32;   // 8 shard counters, 128 bytes apart
 
-hipError_t launch_trace_closest(hipStream_t st, const LaunchArgs& a);
+hipError_t launch_trace(hipStream_t st, const LaunchArgs& a);
 hipError_t launch_shade(hipStream_t st, const LaunchArgs& a);
-hipError_t launch_shadow_accumulate(hipStream_t st, const LaunchArgs& a);
 // scatter the tile-major cumulative / result images into full-frame row-major RGBA32F buffers
 hipError_t launch_export(hipStream_t st, const TileMap& map, const float4* tiled, float4* frame, bool zero_first);
 // result (out32) -> RGBA8 sRGB, full-frame row-major (the blit of raytracer.rs:576-584)

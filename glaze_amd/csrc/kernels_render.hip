@@ -119,7 +119,10 @@ struct HitRecord {
 
 // Per-lane traversal stack: the first kLdsStack levels in LDS (column `tid` of a [level][kBlock]
 // array: every lane always hits bank tid % 32, conflict-free whatever the per-lane depth), deeper
-// levels in a per-pixel HBM spill area.
+// levels in a per-lane HBM spill area.  kStolen marks an LDS entry that was handed to an idle lane (work sharing
+// at the tail of trace_wave); pop_live() skips such entries.
+constexpr int kRayDone = 0x7FFFFFFF;   // `cur` of a lane without a node to visit (inner nodes are >= 0, leaves < 0)
+constexpr int kStolen = 0x7FFFFFFE;
 struct Stack {
   int* lds;             // &s_stack[threadIdx.x]
   uint32_t* spill;      // overflow words of this lane
@@ -131,6 +134,13 @@ struct Stack {
   __device__ __forceinline__ int pop() {
     --sp;
     return sp < kLdsStack ? lds[sp * kBlock] : (int)spill[sp - kLdsStack];
+  }
+  __device__ __forceinline__ int pop_live() {
+    while (sp > 0) {
+      const int v = pop();
+      if (v != kStolen) return v;
+    }
+    return kRayDone;
   }
 };
 
@@ -144,11 +154,19 @@ struct TraceTally {
 // Wave-persistent traversal.  A wave owns a strided sequence of 64-ray groups (group g of wave w is rays
 // [64 * (g * n_waves + w), +64)) and keeps its 64 lanes busy: a lane whose ray has finished takes the next
 // ray of the wave's sequence as soon as kRefill lanes are idle (no atomics: the sequence pointer is wave
-// uniform).  Each round is  [refill] -> [inner-node phase] -> [leaf phase] -> [retire]:
+// uniform).  Each round is  [refill] -> [share] -> [inner-node phase] -> [leaf phase] -> [merge] -> [retire]:
 //   * inner-node phase: lanes sitting on an inner node test its two child boxes, descend into the nearer
 //     hit child and push the farther one; lanes that reached a leaf wait.  The phase ends when no lane is on an
 //     inner node, or when at least kLeafQuorum lanes are waiting on a leaf.
 //   * leaf phase: every lane on a leaf runs the exact ray/triangle test once, then pops its stack.
+//   * share / merge (only once the wave's sequence is exhausted, i.e. in the tail): an idle lane takes the OLDEST
+//     pending subtree off the LDS stack of a busy lane (the stacks are LDS columns, so any lane can reach them),
+//     copies that lane's ray through shuffles and traverses the subtree as a helper; its result is merged back into
+//     the owner (smaller t, then smaller world id; any hit for shadow rays), which retires when no helper is left.
+//     The longest rays then finish in a fraction of their serial time: they set the duration of a launch once a GPU
+//     holds few rays per wave (tile sharding over 8 GPUs: k_trace's floor was 0.17 ms whatever the share of the frame).
+//     Closest-hit and any-hit results do not depend on the visit order, so sharing changes no result; it is compiled
+//     out of the instrumented kernels, whose node / triangle counts are defined by the serial walk.
 // This replaces the one-ray-per-thread loop whose VALU lane utilisation was 24 % on the atrium
 // (SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU), profiles/r01b_sq_counters.txt).
 //
@@ -156,8 +174,8 @@ struct TraceTally {
 // does not depend on visit order.  ANY = true: the first accepted hit ends the ray.
 // Source: bool load(uint32_t ray, vec3& o, vec3& d, float& tmin, float& tmax)   (false = nothing to trace or report)
 // Sink:   void store(uint32_t ray, const HitRecord&)
+// lds_col: this lane's stack column; aux: this WAVE's 3 x 64 ints of LDS scratch (helpers per owner, donor list, stack bottoms)
 // ---------------------------------------------------------------------------------------------
-constexpr int kRayDone = 0x7FFFFFFF;   // `cur` of a lane without a node to visit (inner nodes are >= 0, leaves < 0)
 #ifndef GLZ_TRACE_WAVES
 #define GLZ_TRACE_WAVES 7   // waves per SIMD the tracers are compiled for (__launch_bounds__): 72 VGPRs, no spills
 #endif
@@ -169,30 +187,42 @@ constexpr int kRayDone = 0x7FFFFFFF;   // `cur` of a lane without a node to visi
 #endif
 constexpr int kRefill = GLZ_REFILL;
 constexpr int kLeafQuorum = GLZ_LEAF_QUORUM;
+constexpr int kAuxPerWave = 3 * 64;
 
 template <bool ANY, bool COUNT, class Source, class Sink>
-__device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Sink& sink, int* __restrict__ lds_col, uint32_t* __restrict__ spill,
+__device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Sink& sink, int* __restrict__ lds_col, int* aux, uint32_t* __restrict__ spill,
                                            uint32_t spill_depth, uint32_t total, uint32_t wave, uint32_t n_waves, TraceTally& tally) {
+  constexpr bool SHARE = !COUNT;
+  constexpr uint32_t kNone = 0xFFFFFFFFu;
   const BvhQNode* __restrict__ nodes = S.bvh_nodes;
   const BvhGrid grid = S.bvh_grid;
   const BvhTri* __restrict__ tris = S.bvh_tris;
   const int lane = threadIdx.x & 63;
   const unsigned long long lanes_below = (1ull << lane) - 1ull;
+  int* aux_out = aux;          // [owner lane] helpers currently working for that lane's ray
+  int* aux_pair = aux + 64;    // [k] lane of the k-th donor of this round
+  int* aux_sb = aux + 128;     // [lane] lowest LDS stack level that may still hold a live entry
+  if (SHARE) {
+    aux_out[lane] = 0;
+    aux_sb[lane] = 0;
+  }
   uint32_t seq = 0;                                         // wave-uniform: rays of this wave's sequence handed out so far
   bool exhausted = wave * 64u >= total;                     // wave-uniform
   // per-lane ray state
-  bool open = false;                                        // a ray is in flight and its result has not been stored
+  bool open = false;                                        // a ray of this lane's own is in flight and its result has not been stored
+  bool helper = false;                                      // this lane traverses a subtree of lane `ray`'s ray (work sharing)
   int cur = kRayDone;
-  uint32_t ray = 0;
+  uint32_t ray = 0;                                         // ray index (open) or owner lane (helper)
   vec3 o = mk3(0.0f, 0.0f, 0.0f), d = mk3(0.0f, 0.0f, 1.0f);
   vec3 ig = mk3(0.0f, 0.0f, 0.0f), cg = mk3(0.0f, 0.0f, 0.0f);   // grid-space ray: plane q is crossed at t = q * ig + cg
   float tmin = 0.0f, tmax = 0.0f;
-  HitRecord best{0.0f, 0.0f, 0.0f, 0xFFFFFFFFu};
-  uint32_t best_id = 0xFFFFFFFFu;
-  Stack st{lds_col, spill, 0};
+  HitRecord best{0.0f, 0.0f, 0.0f, kNone};
+  uint32_t best_id = kNone;
+  // the spill area is indexed by the physical lane slot of the grid (a lane traverses one ray or subtree at a time)
+  Stack st{lds_col, spill + ((size_t)(blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 64u + (uint32_t)lane) * spill_depth, 0};
   for (;;) {
     // ---- refill ----
-    const unsigned long long idle = __ballot(!open);
+    const unsigned long long idle = __ballot(!(open || helper));
     const int n_idle = __popcll(idle);
     if (!exhausted && n_idle >= kRefill) {
       if (COUNT && lane == 0) { tally.refill_iters += 1; tally.refill_lanes += (unsigned)n_idle; }
@@ -201,8 +231,8 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
       if (!open && next_ray < total) {
         if (src.load(next_ray, o, d, tmin, tmax)) {
           ray = next_ray;
-          best = HitRecord{tmax, 0.0f, 0.0f, 0xFFFFFFFFu};
-          best_id = 0xFFFFFFFFu;
+          best = HitRecord{tmax, 0.0f, 0.0f, kNone};
+          best_id = kNone;
           if (COUNT) tally.rays += 1;
           if (S.n_world_tris == 0 || !ray_is_finite(o, d)) {
             sink.store(ray, best);                          // nothing to intersect / nothing can be hit: a miss
@@ -210,8 +240,8 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
             const vec3 og = mk3((o.x - grid.lo[0]) * grid.inv_cell[0], (o.y - grid.lo[1]) * grid.inv_cell[1], (o.z - grid.lo[2]) * grid.inv_cell[2]);
             ig = mk3(grid_inv_dir(d.x) * grid.cell[0], grid_inv_dir(d.y) * grid.cell[1], grid_inv_dir(d.z) * grid.cell[2]);
             cg = mk3(-(og.x * ig.x), -(og.y * ig.y), -(og.z * ig.z));
-            st.spill = spill + (size_t)ray * spill_depth;
             st.sp = 0;
+            if (SHARE) aux_sb[lane] = 0;
             cur = 0;
             open = true;
           }
@@ -220,13 +250,68 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
       seq += (uint32_t)n_idle;
       exhausted = ((seq >> 6) * n_waves + wave) * 64u >= total;
     }
-    if (__ballot(open) == 0ull) {
+    if (__ballot(open || helper) == 0ull) {
       if (exhausted) break;
       continue;
     }
+    // ---- share: idle lanes adopt the oldest pending subtree of a busy lane ----
+    if (SHARE && exhausted) {
+      const bool busy = open || helper;
+      const unsigned long long idle_m = __ballot(!busy);
+      if (idle_m != 0ull) {
+        if (ANY) {   // helpers of a ray whose hit has been found have nothing left to decide
+          const int owner_found = __shfl((int)(best.leaf != kNone), helper ? (int)ray : lane);
+          if (helper && owner_found) cur = kRayDone;
+        }
+        int sb = 0, lim = 0;
+        if (busy && cur != kRayDone) {
+          sb = aux_sb[lane];
+          if (sb > st.sp) sb = st.sp;
+          lim = st.sp < kLdsStack ? st.sp : kLdsStack;
+          while (sb < lim && st.lds[sb * kBlock] == kStolen) ++sb;
+          aux_sb[lane] = sb;
+        }
+        const bool can_give = busy && cur != kRayDone && sb < lim;
+        const unsigned long long give_m = __ballot(can_give);
+        const int n_give = __popcll(give_m), n_take = __popcll(idle_m);
+        const int n_pairs = n_give < n_take ? n_give : n_take;
+        if (n_pairs > 0) {
+          int give = 0;
+          if (can_give && __popcll(give_m & lanes_below) < n_pairs) {
+            give = st.lds[sb * kBlock];
+            st.lds[sb * kBlock] = kStolen;
+            aux_sb[lane] = sb + 1;
+            aux_pair[__popcll(give_m & lanes_below)] = lane;
+          }
+          const int take_rank = __popcll(idle_m & lanes_below);
+          const bool take = !busy && take_rank < n_pairs;
+          const int donor = take ? aux_pair[take_rank] : lane;   // same-wave LDS: the stores above are complete (in-order)
+          // Every lane runs the shuffles.  Lanes that take nothing read their own lane (donor == lane), so the ray registers
+          // can be assigned unconditionally: no temporaries stay live across the block (register pressure: 72 VGPRs).
+          const int t_node = __shfl(give, donor);
+          const int t_owner = __shfl(helper ? (int)ray : lane, donor);
+          o.x = __shfl(o.x, donor); o.y = __shfl(o.y, donor); o.z = __shfl(o.z, donor);
+          d.x = __shfl(d.x, donor); d.y = __shfl(d.y, donor); d.z = __shfl(d.z, donor);
+          ig.x = __shfl(ig.x, donor); ig.y = __shfl(ig.y, donor); ig.z = __shfl(ig.z, donor);
+          cg.x = __shfl(cg.x, donor); cg.y = __shfl(cg.y, donor); cg.z = __shfl(cg.z, donor);
+          tmin = __shfl(tmin, donor); tmax = __shfl(tmax, donor);
+          best.t = __shfl(best.t, donor); best.u = __shfl(best.u, donor); best.v = __shfl(best.v, donor);
+          best.leaf = (uint32_t)__shfl((int)best.leaf, donor);
+          best_id = (uint32_t)__shfl((int)best_id, donor);
+          if (take) {
+            ray = (uint32_t)t_owner;
+            cur = t_node;
+            st.sp = 0;
+            aux_sb[lane] = 0;
+            helper = true;
+            atomicAdd(&aux_out[t_owner], 1);
+          }
+        }
+      }
+    }
     // ---- inner-node phase ----
     for (;;) {
-      const bool at_node = cur >= 0 && cur != kRayDone;
+      const bool at_node = cur >= 0 && cur < kStolen;
       const unsigned long long m_node = __ballot(at_node);
       if (m_node == 0ull) break;
       if (COUNT && lane == 0) { tally.node_iters += 1; tally.node_lanes += (unsigned)__popcll(m_node); }
@@ -250,7 +335,7 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
         } else if (h1) {
           cur = c1;
         } else {
-          cur = st.sp ? st.pop() : kRayDone;
+          cur = SHARE ? st.pop_live() : (st.sp ? st.pop() : kRayDone);
         }
       }
       if (__popcll(__ballot(cur < 0)) >= kLeafQuorum) break;
@@ -272,18 +357,41 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
       float t, u, v;
       bool finished = false;
       if (ray_triangle(tr, o, d, tmin, t, u, v) && t < tmax) {
-        const bool better = best.leaf == 0xFFFFFFFFu ? true : (t < best.t || (t == best.t && tr.world_id < best_id));
+        const bool better = best.leaf == kNone ? true : (t < best.t || (t == best.t && tr.world_id < best_id));
         if (better && (!(tr.prim_flags >> 31) || alpha_test(S, tr, u, v))) {
           best = HitRecord{t, u, v, leaf};
           best_id = tr.world_id;
           finished = ANY;
         }
       }
-      cur = (finished || st.sp == 0) ? kRayDone : st.pop();
+      cur = finished ? kRayDone : (SHARE ? st.pop_live() : (st.sp ? st.pop() : kRayDone));
+    }
+    // ---- merge: finished helpers hand their result to the owner of the ray ----
+    if (SHARE) {
+      unsigned long long fin = __ballot(helper && cur == kRayDone);
+      while (fin != 0ull) {
+        const int h = __ffsll((long long)fin) - 1;
+        fin &= fin - 1ull;
+        const int ow = __shfl((int)ray, h);
+        const float bt = __shfl(best.t, h), bu = __shfl(best.u, h), bv = __shfl(best.v, h);
+        const uint32_t bl = (uint32_t)__shfl((int)best.leaf, h), bi = (uint32_t)__shfl((int)best_id, h);
+        if (lane == ow && bl != kNone) {
+          const bool better = best.leaf == kNone ? true : (bt < best.t || (bt == best.t && bi < best_id));
+          if (better) {
+            best = HitRecord{bt, bu, bv, bl};
+            best_id = bi;
+          }
+          if (ANY) cur = kRayDone;   // occluded: the rest of the owner's stack does not matter
+        }
+        if (lane == h) {
+          helper = false;
+          atomicSub(&aux_out[ow], 1);
+        }
+      }
     }
     // ---- retire ----
-    if (open && cur == kRayDone) {
-      if (COUNT) tally.hits += best.leaf != 0xFFFFFFFFu;
+    if (open && cur == kRayDone && (!SHARE || aux_out[lane] == 0)) {
+      if (COUNT) tally.hits += best.leaf != kNone;
       sink.store(ray, best);
       open = false;
     }
@@ -366,25 +474,13 @@ struct ClosestSink {
   }
 };
 
-template <bool COUNT>
-__global__ void __launch_bounds__(kBlock, GLZ_TRACE_WAVES) k_trace_closest(const LaunchArgs A) {
-  __shared__ int s_stack[kLdsStack * kBlock];
-  if (blockIdx.x == 0 && threadIdx.x < kQueueShards) A.st.queue_count[threadIdx.x * kCounterStride] = 0;   // drained by the previous launch's k_shadow_queue; k_shade refills it
-  TraceTally tally;
-  ClosestSource src{A, tally};
-  ClosestSink sink{A};
-  trace_wave<false, COUNT>(A.scene, src, sink, &s_stack[threadIdx.x], A.st.overflow, A.st.overflow_depth, A.map.n_local_pixels, wave_index(), wave_count(),
-                           tally);
-  if (COUNT) flush_counters(A.counters, false, tally);
-}
-
 // update_count() + update_result() of path_trace.rgen:119-133 for one pixel
-__device__ __forceinline__ void accumulate_pixel(const LaunchArgs& A, uint32_t lid, vec3 c, bool add, bool update) {
+__device__ __forceinline__ void accumulate_pixel(const LaunchArgs& A, uint32_t lid, vec3 c, bool add, bool update, float exposure) {
   float4 cum = A.st.cumulative[lid];
   cum.w += 1.0f;
   if (update) {
     if (add) { cum.x += c.x; cum.y += c.y; cum.z += c.z; }
-    A.st.result[lid] = make_float4(cum.x * A.frame.exposure / cum.w, cum.y * A.frame.exposure / cum.w, cum.z * A.frame.exposure / cum.w, 1.0f);
+    A.st.result[lid] = make_float4(cum.x * exposure / cum.w, cum.y * exposure / cum.w, cum.z * exposure / cum.w, 1.0f);
   }
   A.st.cumulative[lid] = cum;
 }
@@ -513,7 +609,7 @@ __global__ void __launch_bounds__(kBlock, GLZ_SHADE_WAVES) k_shade(const LaunchA
       c = spec_to_rgb(spec_mul(importance, from_illuminant_color(texel)));
       flags = kFlagUpdate;
     }
-    accumulate_pixel(A, lid, c, true, flags != 0);
+    accumulate_pixel(A, lid, c, true, flags != 0, A.frame.exposure);
     if (!F.direct_only) A.st.ray_o[lid] = make_float4(ro.x, ro.y, ro.z, 0.0f);   // RESET_PATH
     return;
   }
@@ -599,17 +695,17 @@ __global__ void __launch_bounds__(kBlock, GLZ_SHADE_WAVES) k_shade(const LaunchA
     }
     // shadow-ray queue (consumed by k_shadow_queue); pixels without a shadow ray are accumulated right here
     const bool push = (flags & kFlagShadow) != 0;
-    const uint32_t slot = queue_slot(A.st.queue_count, A.map.n_local_pixels, push);
+    const uint32_t slot = queue_slot(A.st.queue_count + A.shade_set * kQueueSetWords, A.map.n_local_pixels, push);
     if (push) {
       A.st.sh_o[slot] = make_float4(point.x, point.y, point.z, sh_tmax);
       A.st.sh_d[slot] = make_float4(sh_dir.x, sh_dir.y, sh_dir.z, __uint_as_float(lid));
       A.st.contrib[slot] = make_float4(c.x, c.y, c.z, __uint_as_float(flags));
     } else {
-      accumulate_pixel(A, lid, c, true, true);
+      accumulate_pixel(A, lid, c, true, true, A.frame.exposure);
     }
     spec_flag = 0.0f;
   } else {
-    accumulate_pixel(A, lid, mk3(0.0f, 0.0f, 0.0f), false, false);
+    accumulate_pixel(A, lid, mk3(0.0f, 0.0f, 0.0f), false, false, A.frame.exposure);
     spec_flag = 1.0f;
   }
   if (F.direct_only) return;
@@ -645,9 +741,8 @@ __global__ void __launch_bounds__(kBlock, GLZ_SHADE_WAVES) k_shade(const LaunchA
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_shadow_queue: the shadow traceRayEXT (path_trace.rgen:106-110) for the compacted queue written by
-// k_shade, followed by update_count / update_result (:119-133) of the owning pixel.  Persistent grid: each
-// thread strides over the queue, so every wave traverses with (almost) all lanes active.
+// Shadow rays: the shadow traceRayEXT (path_trace.rgen:106-110) for the compacted queue written by k_shade,
+// followed by update_count / update_result (:119-133) of the owning pixel (source / sink of k_trace's second phase).
 // ---------------------------------------------------------------------------------------------
 struct ShadowSource {
   const LaunchArgs& A;
@@ -683,24 +778,55 @@ struct ShadowSink {
       c = mk3(nan, nan, nan);
       add = true;
     }
-    accumulate_pixel(A, src.lid, c, add, true);
+    accumulate_pixel(A, src.lid, c, add, true, A.shadow_exposure);
   }
 };
 
+// ---------------------------------------------------------------------------------------------
+// k_trace: ONE persistent traversal kernel per launch.  Every wave first works through its share of the closest-hit
+// rays of launch L (ray generation / resume + traversal -> hit[lid]), then through its share of the shadow rays that
+// launch L-1's k_shade queued (any-hit traversal, then update_count / update_result of the owning pixel).  The shadow
+// test of a launch only gates an accumulation -- the path itself continues from k_shade's output -- so deferring it
+// into the next launch's traversal changes no result, takes one kernel and one dependent drain off every launch's
+// critical path, and lets waves that finish their closest-hit share early start on shadow rays instead of idling
+// (strong scaling: at 1/8 of a 1080p frame per GPU the launch was 0.146 + 0.073 + 0.183 ms with three kernels).
+// k_shade of launch L runs after this kernel, so the accumulations of launch L-1 land before those of launch L:
+// the per-pixel order of `cum += c` is the reference's.
+// Two counter sets: this kernel drains set shade_set ^ 1 and clears set shade_set for the k_shade that follows.
+// ---------------------------------------------------------------------------------------------
 template <bool COUNT>
-__global__ void __launch_bounds__(kBlock, GLZ_TRACE_WAVES) k_shadow_queue(const LaunchArgs A) {
+__global__ void __launch_bounds__(kBlock, GLZ_TRACE_WAVES) k_trace(const LaunchArgs A) {
   __shared__ int s_stack[kLdsStack * kBlock];
-  // prefix sums of the eight shard counts (final: k_shade has completed)
-  uint32_t start[kQueueShards + 1];
-  start[0] = 0;
+  __shared__ int s_aux[(kBlock / 64) * kAuxPerWave];
+  int* aux = &s_aux[(threadIdx.x >> 6) * kAuxPerWave];
+  if (blockIdx.x == 0 && threadIdx.x < kQueueShards) A.st.queue_count[A.shade_set * kQueueSetWords + threadIdx.x * kCounterStride] = 0;
+  if (A.do_closest) {
+    TraceTally tally;
+    ClosestSource src{A, tally};
+    ClosestSink sink{A};
+    trace_wave<false, COUNT>(A.scene, src, sink, &s_stack[threadIdx.x], aux, A.st.overflow, A.st.overflow_depth, A.map.n_local_pixels, wave_index(),
+                             wave_count(), tally);
+    if (COUNT) flush_counters(A.counters, false, tally);
+  }
+  if (A.do_shadow) {
+    // prefix sums of the eight shard counts (final: the k_shade that filled them has completed)
+    const uint32_t* counts = A.st.queue_count + (A.shade_set ^ 1u) * kQueueSetWords;
+    uint32_t start[kQueueShards + 1];
+    start[0] = 0;
 #pragma unroll
-  for (uint32_t k = 0; k < kQueueShards; ++k) start[k + 1] = start[k] + A.st.queue_count[k * kCounterStride];
-  TraceTally tally;
-  ShadowSource src{A, start, queue_capacity(A.map.n_local_pixels), 0u, make_float4(0.0f, 0.0f, 0.0f, 0.0f)};
-  ShadowSink sink{A, src};
-  // the spill area is indexed by queue position here (each position is in flight at most once)
-  trace_wave<true, COUNT>(A.scene, src, sink, &s_stack[threadIdx.x], A.st.overflow, A.st.overflow_depth, start[kQueueShards], wave_index(), wave_count(), tally);
-  if (COUNT) flush_counters(A.counters, true, tally);
+    for (uint32_t k = 0; k < kQueueShards; ++k) start[k + 1] = start[k] + counts[k * kCounterStride];
+    TraceTally tally;
+    ShadowSource src{A, start, queue_capacity(A.map.n_local_pixels), 0u, make_float4(0.0f, 0.0f, 0.0f, 0.0f)};
+    ShadowSink sink{A, src};
+    // The shadow groups are dealt out starting at the wave after the one that received the last closest-hit group: with
+    // fewer groups than waves (a small tile share per GPU) every group of either kind gets a wave of its own, with more
+    // the per-wave totals stay level.
+    const uint32_t n_waves = wave_count();
+    const uint32_t closest_groups = A.do_closest ? (A.map.n_local_pixels + 63u) / 64u : 0u;
+    const uint32_t wave = (wave_index() + n_waves - closest_groups % n_waves) % n_waves;
+    trace_wave<true, COUNT>(A.scene, src, sink, &s_stack[threadIdx.x], aux, A.st.overflow, A.st.overflow_depth, start[kQueueShards], wave, n_waves, tally);
+    if (COUNT) flush_counters(A.counters, true, tally);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -763,19 +889,21 @@ __global__ void __launch_bounds__(kBlock) k_debug_closest(const DeviceScene S, c
                                                           float tmin, float* t, uint32_t* tri, uint32_t* inst, float* u, float* v,
                                                           uint32_t* overflow, uint32_t overflow_depth) {
   __shared__ int s_stack[kLdsStack * kBlock];
+  __shared__ int s_aux[(kBlock / 64) * kAuxPerWave];
   TraceTally tally;
   DebugSource src{o, d, nullptr, tmin};
   DebugClosestSink sink{S, t, tri, inst, u, v};
-  trace_wave<false, false>(S, src, sink, &s_stack[threadIdx.x], overflow, overflow_depth, n, wave_index(), wave_count(), tally);
+  trace_wave<false, false>(S, src, sink, &s_stack[threadIdx.x], &s_aux[(threadIdx.x >> 6) * kAuxPerWave], overflow, overflow_depth, n, wave_index(), wave_count(), tally);
 }
 __global__ void __launch_bounds__(kBlock) k_debug_any(const DeviceScene S, const float* __restrict__ o, const float* __restrict__ d,
                                                       const float* __restrict__ tmax, uint32_t n, float tmin, uint8_t* out, uint32_t* overflow,
                                                       uint32_t overflow_depth) {
   __shared__ int s_stack[kLdsStack * kBlock];
+  __shared__ int s_aux[(kBlock / 64) * kAuxPerWave];
   TraceTally tally;
   DebugSource src{o, d, tmax, tmin};
   DebugAnySink sink{out};
-  trace_wave<true, false>(S, src, sink, &s_stack[threadIdx.x], overflow, overflow_depth, n, wave_index(), wave_count(), tally);
+  trace_wave<true, false>(S, src, sink, &s_stack[threadIdx.x], &s_aux[(threadIdx.x >> 6) * kAuxPerWave], overflow, overflow_depth, n, wave_index(), wave_count(), tally);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -806,25 +934,19 @@ static dim3 cached_grid(Kernel kernel, uint32_t n_rays, uint32_t& cache_n, dim3&
   return cache_grid;
 }
 
-hipError_t launch_trace_closest(hipStream_t st, const LaunchArgs& a) {
+hipError_t launch_trace(hipStream_t st, const LaunchArgs& a) {
   if (a.map.n_local_pixels == 0) return hipSuccess;
-  static thread_local uint32_t n0 = 0, n1 = 0;
-  static thread_local dim3 g0(0), g1(0);
-  if (a.counters) hipLaunchKernelGGL(k_trace_closest<true>, cached_grid(k_trace_closest<true>, a.map.n_local_pixels, n1, g1), dim3(kBlock), 0, st, a);
-  else hipLaunchKernelGGL(k_trace_closest<false>, cached_grid(k_trace_closest<false>, a.map.n_local_pixels, n0, g0), dim3(kBlock), 0, st, a);
+  static uint32_t n0 = 0, n1 = 0;
+  static dim3 g0, g1;
+  // up to one closest-hit and one shadow ray per pixel: a small tile share still gets a wave per 64-ray group of either kind
+  const uint32_t rays = 2u * a.map.n_local_pixels;
+  if (a.counters) hipLaunchKernelGGL(k_trace<true>, cached_grid(k_trace<true>, rays, n1, g1), dim3(kBlock), 0, st, a);
+  else hipLaunchKernelGGL(k_trace<false>, cached_grid(k_trace<false>, rays, n0, g0), dim3(kBlock), 0, st, a);
   return hipGetLastError();
 }
 hipError_t launch_shade(hipStream_t st, const LaunchArgs& a) {
   if (a.map.n_local_pixels == 0) return hipSuccess;
   hipLaunchKernelGGL(k_shade, grid_for(a.map.n_local_pixels), dim3(kBlock), 0, st, a);
-  return hipGetLastError();
-}
-hipError_t launch_shadow_accumulate(hipStream_t st, const LaunchArgs& a) {
-  if (a.map.n_local_pixels == 0) return hipSuccess;
-  static thread_local uint32_t n0 = 0, n1 = 0;
-  static thread_local dim3 g0(0), g1(0);
-  if (a.counters) hipLaunchKernelGGL(k_shadow_queue<true>, cached_grid(k_shadow_queue<true>, a.map.n_local_pixels, n1, g1), dim3(kBlock), 0, st, a);
-  else hipLaunchKernelGGL(k_shadow_queue<false>, cached_grid(k_shadow_queue<false>, a.map.n_local_pixels, n0, g0), dim3(kBlock), 0, st, a);
   return hipGetLastError();
 }
 hipError_t launch_export(hipStream_t st, const TileMap& map, const float4* tiled, float4* frame, bool zero_first) {

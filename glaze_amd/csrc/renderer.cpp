@@ -66,11 +66,12 @@ bool Renderer::allocate(Error& err) {
   for (auto* b : bufs)
     if (!hip_ok(b->alloc((b == &sh_o_ || b == &sh_d_ || b == &contrib_) ? n_queue : n), "alloc path state", err)) return false;
   const uint32_t od = scene_->stack_overflow_depth;
-  if (!hip_ok(overflow_.alloc(n * od), "alloc traversal spill", err)) return false;
+  if (!hip_ok(overflow_.alloc((2 * n + 512) * od), "alloc traversal spill", err)) return false;   // one slot per lane of the largest k_trace grid
   if (!hip_ok(frame_tmp_.alloc((size_t)w_ * h_), "alloc frame", err)) return false;
   if (!hip_ok(rgba8_.alloc((size_t)w_ * h_), "alloc rgba8", err)) return false;
   if (!hip_ok(counters_.alloc(1), "alloc counters", err)) return false;
-  if (!hip_ok(queue_count_.alloc(8 * 32), "alloc queue counters", err)) return false;
+  if (!hip_ok(queue_count_.alloc(2 * kQueueSetWords), "alloc queue counters", err)) return false;
+  shadow_pending_ = false;
   request_new_frame_ = true;
   return true;
 }
@@ -83,7 +84,8 @@ bool Renderer::reset_buffers(Error& err) {
   for (auto* b : zero)
     if (bytes && !hip_ok(hipMemsetAsync(b->ptr, 0, bytes, st), "clear path state", err)) return false;
   if (!hip_ok(hipMemsetAsync(counters_.ptr, 0, sizeof(TraceCounters), st), "clear counters", err)) return false;
-  if (!hip_ok(hipMemsetAsync(queue_count_.ptr, 0, sizeof(uint32_t) * 8 * 32, st), "clear queue counters", err)) return false;
+  if (!hip_ok(hipMemsetAsync(queue_count_.ptr, 0, sizeof(uint32_t) * 2 * kQueueSetWords, st), "clear queue counters", err)) return false;
+  shadow_pending_ = false;   // queued shadow rays of the abandoned frame are dropped with it
   sched_.rewind();
   rng_.reseed(seed_);   // build-defined: a restart replays the same seed stream (the reference keeps drawing from entropy)
   launches_ = 0;
@@ -111,6 +113,64 @@ void Renderer::fill_args(LaunchArgs& a) const {
   a.map = map_;
   a.cam = cam_;
   a.counters = counting_ ? counters_.ptr : nullptr;
+  a.do_closest = a.do_shadow = 0;
+  a.shade_set = pending_set_ ^ 1u;
+  a.shadow_exposure = pending_exposure_;
+}
+
+bool Renderer::acquire_events(EventSet& ev, Error& err) {
+  if (free_events_.empty()) {
+    if (pending_events_.size() >= 64) {
+      // resolve and recycle the pending sets (without the flush get_stats would do)
+      if (!hip_ok(hipEventSynchronize(pending_events_.back().e[pending_events_.back().flush ? 1 : 2]), "hipEventSynchronize", err)) return false;
+      for (auto& s : pending_events_) {
+        float a = 0, b = 0;
+        (void)hipEventElapsedTime(&a, s.e[0], s.e[1]);
+        if (s.flush) {
+          shadow_ms_ += a;
+        } else {
+          (void)hipEventElapsedTime(&b, s.e[1], s.e[2]);
+          closest_ms_ += a;
+          shade_ms_ += b;
+        }
+        render_ms_ += (double)a + b;
+        free_events_.push_back(s);
+      }
+      pending_events_.clear();
+    }
+    if (free_events_.empty()) {
+      EventSet fresh{};
+      for (auto& e : fresh.e)
+        if (!hip_ok(hipEventCreate(&e), "hipEventCreate", err)) return false;
+      free_events_.push_back(fresh);
+    }
+  }
+  ev = free_events_.back();
+  free_events_.pop_back();
+  return true;
+}
+
+// Stand-alone shadow pass for the rays the last launch queued: run before anything observes the accumulators.
+bool Renderer::flush_shadows(Error& err) {
+  if (!shadow_pending_) return true;
+  hipStream_t st = inst_->stream;
+  LaunchArgs a;
+  fill_args(a);
+  memset(&a.frame, 0, sizeof(a.frame));
+  a.do_shadow = 1;
+  EventSet ev{};
+  if (profile_kernels_) {
+    if (!acquire_events(ev, err)) return false;
+    ev.flush = true;
+    (void)hipEventRecord(ev.e[0], st);
+  }
+  if (!hip_ok(launch_trace(st, a), "k_trace (shadow pass)", err)) return false;
+  if (profile_kernels_) {
+    (void)hipEventRecord(ev.e[1], st);
+    pending_events_.push_back(ev);
+  }
+  shadow_pending_ = false;
+  return true;
 }
 
 // draw_frame (raytracer.rs:369-613): one path segment per pixel
@@ -134,49 +194,43 @@ bool Renderer::one_launch(Error& err) {
   fd.direct_only = integrator_ == GLZ_DIRECT ? 1u : 0u;
   ++launches_;
   if (fd.lights_no == 0) return true;   // the raygen shader returns before touching anything (path_trace.rgen:137-141)
+  a.do_closest = 1;
+  a.do_shadow = shadow_pending_ ? 1u : 0u;   // the previous launch's shadow rays ride in this launch's traversal kernel
   EventSet ev{};
   if (profile_kernels_) {
-    if (free_events_.empty()) {
-      if (pending_events_.size() >= 64) {
-        Error ignored;
-        glz_render_stats tmp;
-        if (!get_stats(&tmp, ignored)) return false;   // resolves and recycles the pending sets
-      }
-      if (free_events_.empty()) {
-        for (auto& e : ev.e)
-          if (!hip_ok(hipEventCreate(&e), "hipEventCreate", err)) return false;
-        free_events_.push_back(ev);
-      }
-    }
-    ev = free_events_.back();
-    free_events_.pop_back();
+    if (!acquire_events(ev, err)) return false;
+    ev.flush = false;
     (void)hipEventRecord(ev.e[0], st);
   }
-  if (!hip_ok(launch_trace_closest(st, a), "k_trace_closest", err)) return false;
+  if (!hip_ok(launch_trace(st, a), "k_trace", err)) return false;
   if (profile_kernels_) (void)hipEventRecord(ev.e[1], st);
   if (!hip_ok(launch_shade(st, a), "k_shade", err)) return false;
-  if (profile_kernels_) (void)hipEventRecord(ev.e[2], st);
-  if (!hip_ok(launch_shadow_accumulate(st, a), "k_shadow_accum", err)) return false;
   if (profile_kernels_) {
-    (void)hipEventRecord(ev.e[3], st);
+    (void)hipEventRecord(ev.e[2], st);
     pending_events_.push_back(ev);
   }
+  shadow_pending_ = true;
+  pending_set_ = a.shade_set;
+  pending_exposure_ = exposure_;
   return true;
 }
 
 bool Renderer::get_stats(glz_render_stats* out, Error& err) {
   if (!hip_ok(hipSetDevice(inst_->device), "hipSetDevice", err)) return false;
+  if (!flush_shadows(err)) return false;   // the counters and timings of the last launch's shadow rays belong to it
   if (!pending_events_.empty()) {
-    if (!hip_ok(hipEventSynchronize(pending_events_.back().e[3]), "hipEventSynchronize", err)) return false;
+    if (!hip_ok(hipEventSynchronize(pending_events_.back().e[pending_events_.back().flush ? 1 : 2]), "hipEventSynchronize", err)) return false;
     for (auto& s : pending_events_) {
-      float a = 0, b = 0, c = 0;
+      float a = 0, b = 0;
       (void)hipEventElapsedTime(&a, s.e[0], s.e[1]);
-      (void)hipEventElapsedTime(&b, s.e[1], s.e[2]);
-      (void)hipEventElapsedTime(&c, s.e[2], s.e[3]);
-      closest_ms_ += a;
-      shade_ms_ += b;
-      shadow_ms_ += c;
-      render_ms_ += (double)a + b + c;
+      if (s.flush) {
+        shadow_ms_ += a;
+      } else {
+        (void)hipEventElapsedTime(&b, s.e[1], s.e[2]);
+        closest_ms_ += a;
+        shade_ms_ += b;
+      }
+      render_ms_ += (double)a + b;
       free_events_.push_back(s);
     }
     pending_events_.clear();
@@ -284,6 +338,7 @@ bool Renderer::refresh_binded_textures(const glz_texture* t, uint32_t nt, Error&
 
 bool Renderer::wait_idle(Error& err) {
   if (!hip_ok(hipSetDevice(inst_->device), "hipSetDevice", err)) return false;
+  if (!flush_shadows(err)) return false;
   return hip_ok(hipStreamSynchronize(inst_->stream), "wait_idle", err);
 }
 
@@ -318,6 +373,7 @@ bool Renderer::draw(size_t spp, void (*cb)(void*), void* user, uint8_t* rgba8_ou
 bool Renderer::read_frame(bool result, float* out, Error& err) {
   if (!hip_ok(hipSetDevice(inst_->device), "hipSetDevice", err)) return false;
   if (request_new_frame_ && !reset_buffers(err)) return false;
+  if (!flush_shadows(err)) return false;
   hipStream_t st = inst_->stream;
   if (!hip_ok(launch_export(st, map_, result ? result_.ptr : cumulative_.ptr, frame_tmp_.ptr, true), "k_export", err)) return false;
   if (!hip_ok(hipMemcpyAsync(out, frame_tmp_.ptr, sizeof(float4) * (size_t)w_ * h_, hipMemcpyDeviceToHost, st), "read frame", err)) return false;
@@ -328,6 +384,7 @@ bool Renderer::read_frame(bool result, float* out, Error& err) {
 bool Renderer::read_rgba8(uint8_t* out, Error& err) {
   if (!hip_ok(hipSetDevice(inst_->device), "hipSetDevice", err)) return false;
   if (request_new_frame_ && !reset_buffers(err)) return false;
+  if (!flush_shadows(err)) return false;
   hipStream_t st = inst_->stream;
   if (!hip_ok(launch_export(st, map_, result_.ptr, frame_tmp_.ptr, true), "k_export", err)) return false;
   if (!hip_ok(launch_tonemap(st, w_ * h_, frame_tmp_.ptr, rgba8_.ptr), "k_tonemap", err)) return false;
@@ -367,6 +424,7 @@ bool Renderer::set_partition(uint32_t rank, uint32_t world, Error& err) {
 bool Renderer::export_device(int which, void* dev, Error& err) {
   if (!hip_ok(hipSetDevice(inst_->device), "hipSetDevice", err)) return false;
   if (request_new_frame_ && !reset_buffers(err)) return false;
+  if (!flush_shadows(err)) return false;
   if (!hip_ok(launch_export(inst_->stream, map_, which ? result_.ptr : cumulative_.ptr, static_cast<float4*>(dev), true), "k_export", err)) return false;
   return hip_ok(hipStreamSynchronize(inst_->stream), "export_device", err);
 }

@@ -77,7 +77,15 @@ class Renderer {
   double render_ms_ = 0, closest_ms_ = 0, shade_ms_ = 0, shadow_ms_ = 0;
   struct EventSet {
     hipEvent_t e[4];
+    bool flush;   // e[0]..e[1] around a stand-alone shadow pass instead of e[0]..e[2] around k_trace, k_shade
   };
+  // shadow rays queued by the last launch's k_shade and not traced yet (they ride in the next launch's k_trace, or in a
+  // stand-alone pass as soon as anything looks at the images: flush_shadows)
+  bool shadow_pending_ = false;
+  uint32_t pending_set_ = 0;
+  float pending_exposure_ = 1.0f;
+  bool flush_shadows(Error& err);
+  bool acquire_events(EventSet& ev, Error& err);
   std::vector<EventSet> pending_events_;   // per-launch kernel boundaries, resolved lazily in get_stats
   std::vector<EventSet> free_events_;
   bool profile_kernels_ = true;

@@ -45,7 +45,7 @@ for (name, d, w, h, depth) in (("atrium1080p", None, 1920, 1080, 8), ("cube512",
     n = 64
     t = time.time(); rr.step(n); rr.wait_idle(); dt = time.time() - t
     s = rr.stats()
-    print("%s: %d launches %.3fs wall -> %.1f Msamples/s | kernels ms: closest %.2f shade %.2f shadow %.2f (per launch %.3f/%.3f/%.3f)" % (
+    print("%s: %d launches %.3fs wall -> %.1f Msamples/s | kernels ms: trace %.2f shade %.2f shadow-flush %.2f (per launch %.3f/%.3f/%.3f)" % (
         name, n, dt, w * h * n / dt / 1e6, s.trace_closest_ms, s.shade_ms, s.trace_shadow_ms, s.trace_closest_ms / n, s.shade_ms / n, s.trace_shadow_ms / n))
     rr.enable_counters(True, True); rr.restart(); rr.step(n); rr.wait_idle(); s = rr.stats()
     smp = w * h * n

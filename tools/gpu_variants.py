@@ -11,7 +11,7 @@ r.set_depth(8); r.step(16); r.wait_idle(); r.stats()
 s0 = r.stats(); n = 64
 t = time.time(); r.step(n); r.wait_idle(); dt = time.time() - t
 s = r.stats()
-print("%8.1f Msamples/s | closest %.3f shade %.3f shadow %.3f ms" % (1920*1080*n/dt/1e6, (s.trace_closest_ms-s0.trace_closest_ms)/n, (s.shade_ms-s0.shade_ms)/n, (s.trace_shadow_ms-s0.trace_shadow_ms)/n))
+print("%8.1f Msamples/s | trace %.3f shade %.3f shadow-flush %.3f ms" % (1920*1080*n/dt/1e6, (s.trace_closest_ms-s0.trace_closest_ms)/n, (s.shade_ms-s0.shade_ms)/n, (s.trace_shadow_ms-s0.trace_shadow_ms)/n))
 '''
 libs = [None] + sorted(glob.glob("variants/libglaze_hip_*.so"))
 for lib in libs:

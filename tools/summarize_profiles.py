@@ -23,7 +23,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 out_dir = os.path.join(ROOT, "profiles")
 os.makedirs(out_dir, exist_ok=True)
 
-KERNELS = ("k_trace_closest", "k_shadow_queue", "k_shadow_accum", "k_shade")
+KERNELS = ("k_trace", "k_shade")
 
 
 def short(name):
