@@ -45,15 +45,15 @@ def parse_args():
 def algorithmic_bytes(c):
     """Algorithmic bytes per SAMPLE of each kernel, from counted per-sample work.
 
-    node visit = 32 B (one quantised BVH2 node: two child boxes + two links), triangle test = 48 B (BvhTri: v0, e1, e2 and
+    node visit = 64 B (one quantised BVH4 node: four child boxes + four links), triangle test = 48 B (BvhTri: v0, e1, e2 and
     the ids the tie-break / alpha test need), hit-attribute fetch = 192 B (128-B shading record + the 64 B of RTMaterial
     scalars k_shade loads; texels are not counted), path state = 96 B (ray 32 + importance 64), hit record 16 B,
     accumulator = 32 B r/w + 16 B result, shadow-queue entry = 48 B.
     """
-    closest = 32 + 16 + 32 * c["f_fresh"] + 32 * c["nodes_closest"] + 48 * c["tris_closest"]
+    closest = 32 + 16 + 32 * c["f_fresh"] + 64 * c["nodes_closest"] + 48 * c["tris_closest"]
     shade = (16 + 32 + 64 * (1 - c["f_fresh"]) + 192 * c["f_hit"] + 48 * c["f_shadow"] + 48 * (1 - c["f_shadow"])
              + 96 * c["f_hit"])
-    shadow = 48 * c["f_shadow"] + 48 * c["f_shadow"] + 32 * c["nodes_shadow"] + 48 * c["tris_shadow"]
+    shadow = 48 * c["f_shadow"] + 48 * c["f_shadow"] + 64 * c["nodes_shadow"] + 48 * c["tris_shadow"]
     # k_trace traverses the closest-hit rays of a launch and the shadow rays of the launch before it in one kernel
     return {"k_trace": closest + shadow, "k_shade": shade}
 

@@ -374,7 +374,7 @@ class RayTraceScene:
 
     def debug_bvh(self):
         i = self.info()
-        nodes = np.zeros((max(1, i.bvh_nodes), 8), np.uint32)
+        nodes = np.zeros((max(1, i.bvh_nodes), 16), np.uint32)
         tris = np.zeros((max(1, i.n_world_triangles), 12), np.float32)
         abi.check(abi.lib().glz_debug_read_bvh(self._h, _ptr(nodes), i.bvh_nodes, _ptr(tris), i.n_world_triangles))
         return nodes[:i.bvh_nodes], tris[:i.n_world_triangles]

@@ -537,7 +537,7 @@ int64_t glz_debug_read_bvh(glz_scene* h, void* nodes_out, int64_t cap_nodes, voi
   if (!hip_ok(hipSetDevice(s->instance->device), "hipSetDevice", e)) return fail(e);
   const int64_t nn = s->info.bvh_nodes, nt = (int64_t)s->info.n_world_triangles;
   if (nodes_out && cap_nodes > 0 && nn > 0 &&
-      !hip_ok(hipMemcpy(nodes_out, s->dev.bvh_nodes, (size_t)std::min(cap_nodes, nn) * sizeof(BvhQNode), hipMemcpyDeviceToHost), "read nodes", e))
+      !hip_ok(hipMemcpy(nodes_out, s->dev.bvh_nodes, (size_t)std::min(cap_nodes, nn) * sizeof(BvhNode4), hipMemcpyDeviceToHost), "read nodes", e))
     return fail(e);
   if (tris_out && cap_tris > 0 && nt > 0 &&
       !hip_ok(hipMemcpy(tris_out, s->dev.bvh_tris, (size_t)std::min(cap_tris, nt) * sizeof(BvhTri), hipMemcpyDeviceToHost), "read tris", e))

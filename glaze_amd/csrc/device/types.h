@@ -99,19 +99,17 @@ struct TransformPair {
   float w2o[16];
 };
 
-// BVH2 node, 32 bytes = two dwordx4 fetches per visit (the tracers are bound by vector-memory transactions, not by
-// VALU: DESIGN.md section 4).  Both child boxes are quantised to 16 bits per coordinate on a global grid spanning
-// the scene bounds (lo rounded down, hi rounded up, so the boxes only grow); the ray is mapped into grid units once.
-//   w[0] = lo0.x | lo0.y << 16   w[1] = lo0.z | hi0.x << 16   w[2] = hi0.y | hi0.z << 16   w[3] = lo1.x | lo1.y << 16
-//   w[4] = lo1.z | hi1.x << 16   w[5] = hi1.y | hi1.z << 16   w[6] = child0                w[7] = child1
-// child: index of an inner node (>= 0), or ~index of a leaf in bvh_tris (< 0), as a two's complement int32
-// (Karras numbering: the children of a node are always the entries g and g+1 of the leaf or the node array).
-struct alignas(16) BvhQNode {
-  uint32_t w[8];
+// BVH4 node, 64 bytes = four dwordx4 fetches per visit.  Up to four child boxes, each quantised to 16 bits per coordinate
+// on a global grid spanning the scene bounds (lo rounded down, hi rounded up, so the boxes only grow); the ray is mapped
+// into grid units once.  The tree is the binary LBVH / PLOC hierarchy with every odd level folded into its parent: half
+// the dependent fetches per ray, which is what bounds a launch once a GPU holds few rays per wave.
+//   child k (k = 0..3):  w[3k] = lo.x | lo.y << 16   w[3k+1] = lo.z | hi.x << 16   w[3k+2] = hi.y | hi.z << 16
+//   w[12 + k] = link of child k: index of an inner node (>= 0), ~index of a leaf in bvh_tris (< 0), or kBvhEmptyChild
+//   for an unused slot (the tracer skips it by its link; its box words are lo = 65535, hi = 0).
+struct alignas(16) BvhNode4 {
+  uint32_t w[16];
 };
-static_assert(sizeof(BvhQNode) == 32, "BvhQNode is 32 bytes");
-
-// Quantisation grid of the BVH: world = lo + q * cell.
+constexpr int kBvhEmptyChild = 0x7FFFFFFF;
 struct BvhGrid {
   float lo[3];
   float cell[3];
@@ -146,7 +144,7 @@ struct DeviceScene {
   const TexDesc* tex_desc;
   const uint8_t* tex_pool;
   const float* srgb_lut;           // 256 entries
-  const BvhQNode* bvh_nodes;
+  const BvhNode4* bvh_nodes;
   BvhGrid bvh_grid;
   const BvhTri* bvh_tris;
   // per-leaf shading record, 8 x float4 = 128 bytes, in leaf order: VertexPacked x 3 (object space), then

@@ -23,10 +23,11 @@ struct LbvhInputs {
 };
 constexpr int kBvhBuilderLbvh = 0, kBvhBuilderPloc = 1;   // = GLZ_BVH_LBVH / GLZ_BVH_PLOC
 struct LbvhOutputs {
-  BvhQNode* nodes;  // max(n_world - 1, 1) entries, preallocated
+  BvhNode4* nodes;  // n_nodes entries, hipMalloc'ed by build_lbvh: the caller owns them afterwards
+  uint32_t n_nodes;
   BvhGrid grid;     // quantisation grid of the node boxes
   BvhTri* tris;     // n_world entries, preallocated, leaf order
-  uint32_t depth;   // number of inner nodes above the deepest leaf
+  uint32_t depth;   // number of 4-wide nodes above the deepest leaf (the traversal stack holds at most 3 * depth + 1 entries)
   float sah;
   uint32_t rounds;  // PLOC merge rounds (0 for the LBVH)
   float bounds_lo[3], bounds_hi[3];

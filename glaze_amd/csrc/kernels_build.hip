@@ -494,35 +494,69 @@ __device__ __forceinline__ uint32_t quant_hi(float x, float lo, float inv_cell) 
   return (uint32_t)fminf(fmaxf(g, 0.0f), 65535.0f);
 }
 
-__global__ void __launch_bounds__(256) k_emit_nodes(int n, const int2* __restrict__ children, const float4* __restrict__ node_lo,
-                                                    const float4* __restrict__ node_hi, const BvhGrid* __restrict__ grid,
-                                                    const int* __restrict__ new_id, BvhQNode* __restrict__ nodes, float* __restrict__ sah) {
+// ---- 4-wide collapse.  A binary node at even depth becomes a BVH4 node whose children are its grandchildren (or its
+// children where those are leaves); nodes at odd depth are folded away.  flags[dfs id] = 1 for the nodes that stay, so
+// an exclusive scan over the depth-first order numbers the BVH4 nodes depth-first as well.
+__global__ void __launch_bounds__(256) k_node_parity(int n, const int* __restrict__ parent, const int* __restrict__ new_id,
+                                                     unsigned long long* __restrict__ flags) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n - 1) return;
+  int depth = 0;
+  for (int p = parent[t]; p >= 0; p = parent[p]) ++depth;
+  flags[new_id[t]] = (depth & 1) ? 0ull : 1ull;
+}
+
+__global__ void __launch_bounds__(256) k_emit_nodes4(int n, const int2* __restrict__ children, const float4* __restrict__ node_lo,
+                                                     const float4* __restrict__ node_hi, const BvhGrid* __restrict__ grid,
+                                                     const int* __restrict__ new_id, const unsigned long long* __restrict__ flags,
+                                                     const unsigned long long* __restrict__ pos, BvhNode4* __restrict__ nodes,
+                                                     float* __restrict__ sah) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n - 1) return;
   const int2 c = children[i];
-  const int s0 = c.x >= 0 ? c.x : (n - 1) + ~c.x, s1 = c.y >= 0 ? c.y : (n - 1) + ~c.y;
-  const float4 l0 = node_lo[s0], h0 = node_hi[s0], l1 = node_lo[s1], h1 = node_hi[s1];
+  {
+    // SAH cost numerator of the binary hierarchy: surface areas of inner nodes (1.2) and leaves (1.0), normalised on the host
+    auto area = [](float4 l, float4 h) { float dx = h.x - l.x, dy = h.y - l.y, dz = h.z - l.z; return 2.0f * (dx * dy + dy * dz + dz * dx); };
+    float acc = 1.2f * area(node_lo[i], node_hi[i]);
+    if (c.x < 0) acc += area(node_lo[(n - 1) + ~c.x], node_hi[(n - 1) + ~c.x]);
+    if (c.y < 0) acc += area(node_lo[(n - 1) + ~c.y], node_hi[(n - 1) + ~c.y]);
+    atomicAdd(sah, acc);
+  }
+  if (!flags[new_id[i]]) return;   // odd depth: folded into the parent
+  // children in a fixed order: expansions of child 0 first, then of child 1 (the order breaks distance ties in the tracer)
+  int kids[4] = {kBvhEmptyChild, kBvhEmptyChild, kBvhEmptyChild, kBvhEmptyChild};
+  int nk = 0;
+  for (int side = 0; side < 2; ++side) {
+    const int ch = side ? c.y : c.x;
+    if (ch < 0) {
+      kids[nk++] = ch;
+    } else {
+      const int2 g = children[ch];
+      kids[nk++] = g.x;
+      kids[nk++] = g.y;
+    }
+  }
   const BvhGrid g = *grid;
-  const uint32_t q0[6] = {quant_lo(l0.x, g.lo[0], g.inv_cell[0]), quant_lo(l0.y, g.lo[1], g.inv_cell[1]), quant_lo(l0.z, g.lo[2], g.inv_cell[2]),
-                          quant_hi(h0.x, g.lo[0], g.inv_cell[0]), quant_hi(h0.y, g.lo[1], g.inv_cell[1]), quant_hi(h0.z, g.lo[2], g.inv_cell[2])};
-  const uint32_t q1[6] = {quant_lo(l1.x, g.lo[0], g.inv_cell[0]), quant_lo(l1.y, g.lo[1], g.inv_cell[1]), quant_lo(l1.z, g.lo[2], g.inv_cell[2]),
-                          quant_hi(h1.x, g.lo[0], g.inv_cell[0]), quant_hi(h1.y, g.lo[1], g.inv_cell[1]), quant_hi(h1.z, g.lo[2], g.inv_cell[2])};
-  BvhQNode nd;
-  nd.w[0] = q0[0] | (q0[1] << 16);
-  nd.w[1] = q0[2] | (q0[3] << 16);
-  nd.w[2] = q0[4] | (q0[5] << 16);
-  nd.w[3] = q1[0] | (q1[1] << 16);
-  nd.w[4] = q1[2] | (q1[3] << 16);
-  nd.w[5] = q1[4] | (q1[5] << 16);
-  nd.w[6] = (uint32_t)(c.x >= 0 ? new_id[c.x] : c.x);   // child links: inner node index (in the final layout) >= 0, or ~leaf
-  nd.w[7] = (uint32_t)(c.y >= 0 ? new_id[c.y] : c.y);
-  nodes[new_id[i]] = nd;
-  // SAH cost numerator: sum of surface areas of inner nodes (1.2) and leaves (1.0), normalised on the host
-  auto area = [](float4 l, float4 h) { float dx = h.x - l.x, dy = h.y - l.y, dz = h.z - l.z; return 2.0f * (dx * dy + dy * dz + dz * dx); };
-  float acc = 1.2f * area(node_lo[i], node_hi[i]);
-  if (c.x < 0) acc += area(l0, h0);
-  if (c.y < 0) acc += area(l1, h1);
-  atomicAdd(sah, acc);
+  BvhNode4 nd;
+  for (int k = 0; k < 4; ++k) {
+    const int ch = kids[k];
+    if (k >= nk) {
+      nd.w[3 * k] = 65535u | (65535u << 16);   // inverted box: never entered
+      nd.w[3 * k + 1] = 65535u;
+      nd.w[3 * k + 2] = 0u;
+      nd.w[12 + k] = (uint32_t)kBvhEmptyChild;
+      continue;
+    }
+    const int slot = ch >= 0 ? ch : (n - 1) + ~ch;
+    const float4 l = node_lo[slot], h = node_hi[slot];
+    const uint32_t q[6] = {quant_lo(l.x, g.lo[0], g.inv_cell[0]), quant_lo(l.y, g.lo[1], g.inv_cell[1]), quant_lo(l.z, g.lo[2], g.inv_cell[2]),
+                           quant_hi(h.x, g.lo[0], g.inv_cell[0]), quant_hi(h.y, g.lo[1], g.inv_cell[1]), quant_hi(h.z, g.lo[2], g.inv_cell[2])};
+    nd.w[3 * k] = q[0] | (q[1] << 16);
+    nd.w[3 * k + 1] = q[2] | (q[3] << 16);
+    nd.w[3 * k + 2] = q[4] | (q[5] << 16);
+    nd.w[12 + k] = (uint32_t)(ch >= 0 ? (int)pos[new_id[ch]] : ch);   // inner: its number among the BVH4 nodes; leaf: ~leaf
+  }
+  nodes[pos[new_id[i]]] = nd;
 }
 
 // Per-leaf shading records: everything raytrace_hit.rchit reads for a hit (3 packed vertices, the triangle's
@@ -584,6 +618,8 @@ hipError_t build_lbvh(hipStream_t st, const LbvhInputs& in, LbvhOutputs& out) {
   out.depth = 0;
   out.sah = 0.0f;
   out.rounds = 0;
+  out.nodes = nullptr;
+  out.n_nodes = 0;
   if (n == 0) return hipSuccess;
   const uint32_t np = std::max<uint32_t>(next_pow2(n), kSortTile);
   hipError_t e;
@@ -618,6 +654,13 @@ hipError_t build_lbvh(hipStream_t st, const LbvhInputs& in, LbvhOutputs& out) {
   GLZ_TRY(hipMalloc(&sah, sizeof(float)));
   GLZ_TRY(hipMalloc(&grid, sizeof(BvhGrid)));
   GLZ_TRY(hipMalloc(&counts, sizeof(int) * n));
+  {
+    const size_t tiles = ((size_t)n + kScanTile - 1) / kScanTile;
+    GLZ_TRY(hipMalloc(&flags, sizeof(unsigned long long) * n));
+    GLZ_TRY(hipMalloc(&pos, sizeof(unsigned long long) * n));
+    GLZ_TRY(hipMalloc(&scan_tmp, sizeof(unsigned long long) * (2 * tiles + 4096)));
+    GLZ_TRY(hipMalloc(&scan_total, sizeof(unsigned long long)));
+  }
   GLZ_TRY(hipMalloc(&new_id, sizeof(int) * n));
   GLZ_TRY(hipMemsetAsync(arrivals, 0, sizeof(int) * n, st));
   GLZ_TRY(hipMemsetAsync(sah, 0, sizeof(float), st));
@@ -654,14 +697,9 @@ hipError_t build_lbvh(hipStream_t st, const LbvhInputs& in, LbvhOutputs& out) {
       GLZ_TRY(hipGetLastError());
       GLZ_TRY(hipMemsetAsync(arrivals, 0, sizeof(int) * n, st));
     } else {
-      const size_t tiles = ((size_t)n + kScanTile - 1) / kScanTile;
       GLZ_TRY(hipMalloc(&refs_a, sizeof(int) * n));
       GLZ_TRY(hipMalloc(&refs_b, sizeof(int) * n));
       GLZ_TRY(hipMalloc(&nearest, sizeof(int) * n));
-      GLZ_TRY(hipMalloc(&flags, sizeof(unsigned long long) * n));
-      GLZ_TRY(hipMalloc(&pos, sizeof(unsigned long long) * n));
-      GLZ_TRY(hipMalloc(&scan_tmp, sizeof(unsigned long long) * (2 * tiles + 4096)));
-      GLZ_TRY(hipMalloc(&scan_total, sizeof(unsigned long long)));
       hipLaunchKernelGGL(k_ploc_init, grd, blk, 0, st, (int)n, refs_a, parent);
       GLZ_TRY(hipGetLastError());
       int m = (int)n, next_free = (int)n - 2;
@@ -698,7 +736,18 @@ hipError_t build_lbvh(hipStream_t st, const LbvhInputs& in, LbvhOutputs& out) {
     GLZ_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_grid_params, dim3(1), dim3(64), 0, st, node_lo, node_hi, grid);
     GLZ_TRY(hipGetLastError());
-    hipLaunchKernelGGL(k_emit_nodes, grd, blk, 0, st, (int)n, children, node_lo, node_hi, grid, new_id, out.nodes, sah);
+    // 4-wide collapse: number the even-depth nodes in depth-first order, then emit them
+    hipLaunchKernelGGL(k_node_parity, grd, blk, 0, st, (int)n, parent, new_id, flags);
+    GLZ_TRY(hipGetLastError());
+    GLZ_TRY(scan_exclusive(st, (int)n - 1, flags, pos, scan_tmp));
+    hipLaunchKernelGGL(k_scan_total, dim3(1), dim3(64), 0, st, (int)n - 1, flags, pos, scan_total);
+    GLZ_TRY(hipGetLastError());
+    unsigned long long n4 = 0;
+    GLZ_TRY(hipMemcpyAsync(&n4, scan_total, sizeof(n4), hipMemcpyDeviceToHost, st));
+    GLZ_TRY(hipStreamSynchronize(st));
+    out.n_nodes = (uint32_t)n4;
+    GLZ_TRY(hipMalloc(&out.nodes, sizeof(BvhNode4) * (size_t)n4));
+    hipLaunchKernelGGL(k_emit_nodes4, grd, blk, 0, st, (int)n, children, node_lo, node_hi, grid, new_id, flags, pos, out.nodes, sah);
     GLZ_TRY(hipGetLastError());
   }
   int host_scalars[8];
@@ -710,26 +759,27 @@ hipError_t build_lbvh(hipStream_t st, const LbvhInputs& in, LbvhOutputs& out) {
   GLZ_TRY(hipMemcpyAsync(&root_hi, node_hi, sizeof(float4), hipMemcpyDeviceToHost, st));
   GLZ_TRY(hipStreamSynchronize(st));
   if (n == 1) {
-    // single triangle: the leaf array (allocated with two entries) gets a second copy of the triangle, and the one inner
-    // node holds leaf 0 and leaf 1, each with a box spanning the whole grid (testing the same triangle twice is harmless:
-    // same world id, same result)
+    // single triangle: one node whose first child is leaf 0 with a box spanning the whole grid
     hipLaunchKernelGGL(k_grid_params, dim3(1), dim3(64), 0, st, node_lo, node_hi, grid);   // slot (n-1)+0 = 0 is the leaf box
     GLZ_TRY(hipGetLastError());
-    GLZ_TRY(hipMemcpyAsync(out.tris + 1, out.tris, sizeof(BvhTri), hipMemcpyDeviceToDevice, st));
-    BvhQNode nd{};
+    BvhNode4 nd{};
+    for (int k = 0; k < 4; ++k) {
+      nd.w[3 * k] = 65535u | (65535u << 16);
+      nd.w[3 * k + 1] = 65535u;
+      nd.w[3 * k + 2] = 0u;
+      nd.w[12 + k] = (uint32_t)kBvhEmptyChild;
+    }
     nd.w[0] = 0u;
     nd.w[1] = 0u | (65535u << 16);
     nd.w[2] = 65535u | (65535u << 16);
-    nd.w[3] = 0u;
-    nd.w[4] = 0u | (65535u << 16);
-    nd.w[5] = 65535u | (65535u << 16);
-    nd.w[6] = ~0u;   // leaf 0
-    nd.w[7] = ~1u;   // leaf 1 (the copy)
+    nd.w[12] = ~0u;   // leaf 0
+    GLZ_TRY(hipMalloc(&out.nodes, sizeof(BvhNode4)));
+    out.n_nodes = 1;
     GLZ_TRY(hipMemcpyAsync(out.nodes, &nd, sizeof(nd), hipMemcpyHostToDevice, st));
     GLZ_TRY(hipStreamSynchronize(st));
     out.depth = 1;
   } else {
-    out.depth = (uint32_t)host_scalars[6];
+    out.depth = ((uint32_t)host_scalars[6] + 1u) / 2u;   // levels of 4-wide nodes above the deepest leaf
     const float dx = root_hi.x - root_lo.x, dy = root_hi.y - root_lo.y, dz = root_hi.z - root_lo.z;
     const float ra = 2.0f * (dx * dy + dy * dz + dz * dx);
     out.sah = ra > 0.0f ? host_sah / ra : 0.0f;

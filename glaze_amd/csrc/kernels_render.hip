@@ -177,7 +177,7 @@ struct TraceTally {
 // lds_col: this lane's stack column; aux: this WAVE's 3 x 64 ints of LDS scratch (helpers per owner, donor list, stack bottoms)
 // ---------------------------------------------------------------------------------------------
 #ifndef GLZ_TRACE_WAVES
-#define GLZ_TRACE_WAVES 7   // waves per SIMD the tracers are compiled for (__launch_bounds__): 72 VGPRs, no spills
+#define GLZ_TRACE_WAVES 6   // waves per SIMD the tracers are compiled for (__launch_bounds__): 80 VGPRs; 7 waves (72 VGPRs) spills 40 registers with the 64-byte nodes and measured 5 % slower
 #endif
 #ifndef GLZ_REFILL
 #define GLZ_REFILL 16
@@ -189,12 +189,26 @@ constexpr int kRefill = GLZ_REFILL;
 constexpr int kLeafQuorum = GLZ_LEAF_QUORUM;
 constexpr int kAuxPerWave = 3 * 64;
 
+__device__ __forceinline__ uint32_t child_key(float entry, uint32_t link, uint32_t k) {
+  // (the slab test is symmetric in lo / hi, so an unused child slot cannot be excluded through its box: its link says so)
+  return (entry < INFINITY && link != (uint32_t)kBvhEmptyChild) ? ((__float_as_uint(entry) & 0xFFFFFFFCu) | k) : 0xFFFFFFFFu;
+}
+__device__ __forceinline__ void sort2(uint32_t& a, uint32_t& b) {
+  const uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
+  a = lo;
+  b = hi;
+}
+__device__ __forceinline__ int child_link(const uint4& links, uint32_t key) {
+  const uint32_t k = key & 3u;
+  return (int)(k == 0u ? links.x : (k == 1u ? links.y : (k == 2u ? links.z : links.w)));
+}
+
 template <bool ANY, bool COUNT, class Source, class Sink>
 __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Sink& sink, int* __restrict__ lds_col, int* aux, uint32_t* __restrict__ spill,
                                            uint32_t spill_depth, uint32_t total, uint32_t wave, uint32_t n_waves, TraceTally& tally) {
   constexpr bool SHARE = !COUNT;
   constexpr uint32_t kNone = 0xFFFFFFFFu;
-  const BvhQNode* __restrict__ nodes = S.bvh_nodes;
+  const BvhNode4* __restrict__ nodes = S.bvh_nodes;
   const BvhGrid grid = S.bvh_grid;
   const BvhTri* __restrict__ tris = S.bvh_tris;
   const int lane = threadIdx.x & 63;
@@ -316,26 +330,30 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
       if (m_node == 0ull) break;
       if (COUNT && lane == 0) { tally.node_iters += 1; tally.node_lanes += (unsigned)__popcll(m_node); }
       if (at_node) {
-        // 32-byte node = 2 x dwordx4; boxes are 16-bit grid coordinates, the ray was mapped into grid units at refill
+        // 64-byte node = 4 x dwordx4: four child boxes in 16-bit grid coordinates (the ray was mapped into grid units at
+        // refill) and four links.  Children are entered nearest first; the others are pushed farthest first.
         const uint4* np = reinterpret_cast<const uint4*>(nodes + cur);
-        const uint4 w0 = np[0], w1 = np[1];
+        const uint4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
         if (COUNT) tally.nodes += 1;
         const float e0 = box_entry((float)(w0.x & 0xFFFFu), (float)(w0.x >> 16), (float)(w0.y & 0xFFFFu), (float)(w0.y >> 16), (float)(w0.z & 0xFFFFu),
                                    (float)(w0.z >> 16), ig, cg, tmin, best.t);
         const float e1 = box_entry((float)(w0.w & 0xFFFFu), (float)(w0.w >> 16), (float)(w1.x & 0xFFFFu), (float)(w1.x >> 16), (float)(w1.y & 0xFFFFu),
                                    (float)(w1.y >> 16), ig, cg, tmin, best.t);
-        const int c0 = (int)w1.z, c1 = (int)w1.w;   // child links: inner node index, or ~leaf
-        const bool h0 = e0 < INFINITY, h1 = e1 < INFINITY;
-        if (h0 && h1) {
-          const bool swap = e1 < e0;   // near child first; ties -> child0
-          st.push(swap ? c0 : c1);
-          cur = swap ? c1 : c0;
-        } else if (h0) {
-          cur = c0;
-        } else if (h1) {
-          cur = c1;
-        } else {
+        const float e2 = box_entry((float)(w1.z & 0xFFFFu), (float)(w1.z >> 16), (float)(w1.w & 0xFFFFu), (float)(w1.w >> 16), (float)(w2.x & 0xFFFFu),
+                                   (float)(w2.x >> 16), ig, cg, tmin, best.t);
+        const float e3 = box_entry((float)(w2.y & 0xFFFFu), (float)(w2.y >> 16), (float)(w2.z & 0xFFFFu), (float)(w2.z >> 16), (float)(w2.w & 0xFFFFu),
+                                   (float)(w2.w >> 16), ig, cg, tmin, best.t);
+        // sort keys: entry distance (a positive float, so its bits order like the value) with the child index in the two
+        // lowest bits -- nearer first, ties (to 2 ulp) by child index; a missed child sorts last
+        uint32_t k0 = child_key(e0, w3.x, 0u), k1 = child_key(e1, w3.y, 1u), k2 = child_key(e2, w3.z, 2u), k3 = child_key(e3, w3.w, 3u);
+        sort2(k0, k1); sort2(k2, k3); sort2(k0, k2); sort2(k1, k3); sort2(k1, k2);
+        if (k0 == 0xFFFFFFFFu) {
           cur = SHARE ? st.pop_live() : (st.sp ? st.pop() : kRayDone);
+        } else {
+          if (k3 != 0xFFFFFFFFu) st.push(child_link(w3, k3));
+          if (k2 != 0xFFFFFFFFu) st.push(child_link(w3, k2));
+          if (k1 != 0xFFFFFFFFu) st.push(child_link(w3, k1));
+          cur = child_link(w3, k0);
         }
       }
       if (__popcll(__ballot(cur < 0)) >= kLeafQuorum) break;

@@ -399,12 +399,11 @@ bool Scene::build_lights_and_sky(Error& err) {
 bool Scene::build_bvh(Error& err) {
   hipStream_t st = instance->stream;
   const uint32_t n = (uint32_t)info.n_world_triangles;
-  if (!hip_ok(d_nodes_.alloc(n > 1 ? n - 1 : 1), "alloc BVH nodes", err)) return false;
-  if (!hip_ok(d_tris_.alloc(n == 1 ? 2 : n), "alloc BVH triangles", err)) return false;   // n == 1: see build_lbvh
+  d_nodes_.release();
+  if (!hip_ok(d_tris_.alloc(n), "alloc BVH triangles", err)) return false;
   LbvhInputs in{d_vertices_.ptr, d_indices_.ptr, d_instances_.ptr, d_inst_base_.ptr, (uint32_t)h_instances.size(), d_transforms_.ptr,
                 d_materials_.ptr, n, instance->bvh_builder};
   LbvhOutputs out{};
-  out.nodes = d_nodes_.ptr;
   out.tris = d_tris_.ptr;
   hipEvent_t e0, e1;
   if (!hip_ok(hipEventCreate(&e0), "event", err) || !hip_ok(hipEventCreate(&e1), "event", err)) return false;
@@ -417,7 +416,9 @@ bool Scene::build_bvh(Error& err) {
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   if (!hip_ok(be, "LBVH build", err)) return false;
-  info.bvh_nodes = n > 1 ? n - 1 : (n == 1 ? 1 : 0);
+  d_nodes_.ptr = out.nodes;       // allocated by the build once the number of 4-wide nodes is known
+  d_nodes_.count = out.n_nodes;
+  info.bvh_nodes = out.n_nodes;
   info.bvh_depth = out.depth;
   info.bvh_sah_cost = out.sah;
   info.build_ms = ms;
@@ -426,7 +427,9 @@ bool Scene::build_bvh(Error& err) {
     info.bounds_max[k] = out.bounds_hi[k];
   }
   // traversal stack: kTraversalLdsStack levels live in LDS, the rest spills to a per-pixel HBM area
-  stack_overflow_depth = out.depth > (uint32_t)kTraversalLdsStack ? out.depth - kTraversalLdsStack + 1 : 1;
+  // (a 4-wide visit pushes up to three siblings, so the bound is 3 entries per level)
+  const uint32_t stack_bound = 3u * out.depth + 1u;
+  stack_overflow_depth = stack_bound > (uint32_t)kTraversalLdsStack ? stack_bound - kTraversalLdsStack + 1 : 1;
   dev.bvh_nodes = d_nodes_.ptr;
   dev.bvh_grid = out.grid;
   for (int k = 0; k < 3; ++k) {
@@ -441,8 +444,8 @@ bool Scene::build_bvh(Error& err) {
     ident[i] = memcmp(data.transforms[i].m, id, 64) == 0 ? 1u : 0u;   // bitwise: -0.0 does not count
   }
   if (!hip_ok(d_xf_identity_.upload(ident.data(), ident.size(), st), "upload transform flags", err)) return false;
-  if (!hip_ok(d_shade_tris_.alloc((size_t)(n == 1 ? 2 : n) * 8), "alloc shading records", err)) return false;
-  if (!hip_ok(launch_shade_records(st, n == 1 ? 2 : n, d_tris_.ptr, d_instances_.ptr, d_indices_.ptr, d_vertices_.ptr, d_derivatives_.ptr, d_xf_identity_.ptr,
+  if (!hip_ok(d_shade_tris_.alloc((size_t)n * 8), "alloc shading records", err)) return false;
+  if (!hip_ok(launch_shade_records(st, n, d_tris_.ptr, d_instances_.ptr, d_indices_.ptr, d_vertices_.ptr, d_derivatives_.ptr, d_xf_identity_.ptr,
                                    d_shade_tris_.ptr), "k_shade_records", err))
     return false;
   if (!hip_ok(hipStreamSynchronize(st), "shading records", err)) return false;

@@ -364,7 +364,7 @@ int64_t glz_debug_read_derivatives(glz_scene*, float* out12, int64_t cap_triangl
 int64_t glz_debug_read_rt_materials(glz_scene*, void* out, int64_t cap_bytes); /* 208-byte RTMaterial records */
 int64_t glz_debug_read_rt_lights(glz_scene*, void* out, int64_t cap_bytes);    /* 112-byte RTLight records */
 int64_t glz_debug_read_sky(glz_scene*, float* out, int64_t cap_floats);        /* RTSky(36 f32) | header(4) | marginal arrays */
-/* LBVH as traversed by the kernels: 32-byte quantised nodes (returns the node count) and 48-byte leaf
+/* BVH as traversed by the kernels: 64-byte quantised 4-wide nodes (returns the node count) and 48-byte leaf
  * triangles in leaf order (n_world_triangles of them); see DESIGN.md for the layouts. */
 int64_t glz_debug_read_bvh(glz_scene*, void* nodes_out, int64_t cap_nodes, void* tris_out, int64_t cap_tris);
 

@@ -451,7 +451,7 @@ struct Scene {
   std::vector<Tri> tris;                 // in BVH order
   std::vector<BNode> nodes;
   // optional externally supplied BVH2 (the product's LBVH) for work counting
-  std::vector<uint32_t> ext_nodes;       // 8 words per node (BvhQNode layout)
+  std::vector<uint32_t> ext_nodes;       // 16 words per node (BvhNode4 layout)
   std::vector<float> ext_tris;           // 12 floats per tri (BvhTri layout)
   float ext_grid[9] = {0};               // BvhGrid: lo[3], cell[3], inv_cell[3]
 };
@@ -870,7 +870,8 @@ bool trace_any(const Scene& sc, V3 o, V3 d, float tmin, float tmax) {
 // DESIGN.md section 2), counting node and triangle visits: the "counted on the shared LBVH" figures of SURVEY 8(d).
 // Ordered (near child first, ties -> child0) traversal with pruning against the current best t -- exactly the visit
 // rule of the HIP tracer, so the instrumented kernels' counters must equal these counts.
-struct ExtNode { uint32_t w[8]; };
+inline uint32_t fbits(float f);
+struct ExtNode { uint32_t w[16]; };   // BvhNode4
 struct ExtTri { float v0[3]; uint32_t world_id; float e1[3]; uint32_t instance; float e2[3]; uint32_t prim_flags; };
 inline float box_entry_q(float lox, float loy, float loz, float hix, float hiy, float hiz, V3 ig, V3 cg, float tmin, float tmax) {
   // plane distances as one correctly rounded fma each (kernels_render.hip box_entry: v_pk_fma_f32)
@@ -896,24 +897,24 @@ void ext_trace(const Scene& sc, V3 o, V3 d, float tmin, float tmax, bool any, Co
   const V3 ig = v3(inv_dir(d.x) * G[3], inv_dir(d.y) * G[4], inv_dir(d.z) * G[5]);
   const V3 cg = v3(-(og.x * ig.x), -(og.y * ig.y), -(og.z * ig.z));
   float best = tmax; uint32_t best_id = 0xFFFFFFFFu; bool found = false;
-  int stack[128]; int sp = 0; int cur = 0;
+  int stack[512]; int sp = 0; int cur = 0;
   for (;;) {
     if (cur >= 0) {
       const uint32_t* w = nodes[cur].w;
       c.nodes++;
-      const float e0 = box_entry_q((float)(w[0] & 0xFFFFu), (float)(w[0] >> 16), (float)(w[1] & 0xFFFFu), (float)(w[1] >> 16), (float)(w[2] & 0xFFFFu),
-                                   (float)(w[2] >> 16), ig, cg, tmin, best);
-      const float e1 = box_entry_q((float)(w[3] & 0xFFFFu), (float)(w[3] >> 16), (float)(w[4] & 0xFFFFu), (float)(w[4] >> 16), (float)(w[5] & 0xFFFFu),
-                                   (float)(w[5] >> 16), ig, cg, tmin, best);
-      const int c0 = (int)w[6], c1 = (int)w[7];
-      const bool h0 = e0 < INF, h1 = e1 < INF;
-      if (h0 && h1) {
-        const bool swap = e1 < e0;
-        stack[sp++] = swap ? c0 : c1;
-        cur = swap ? c1 : c0;
+      uint32_t key[4];
+      for (uint32_t k = 0; k < 4; ++k) {
+        const float e = box_entry_q((float)(w[3 * k] & 0xFFFFu), (float)(w[3 * k] >> 16), (float)(w[3 * k + 1] & 0xFFFFu), (float)(w[3 * k + 1] >> 16),
+                                    (float)(w[3 * k + 2] & 0xFFFFu), (float)(w[3 * k + 2] >> 16), ig, cg, tmin, best);
+        key[k] = (e < INF && w[12 + k] != 0x7FFFFFFFu) ? ((fbits(e) & 0xFFFFFFFCu) | k) : 0xFFFFFFFFu;   // child_key, kernels_render.hip
+      }
+      std::sort(key, key + 4);
+      if (key[0] != 0xFFFFFFFFu) {
+        for (int k = 3; k >= 1; --k)
+          if (key[k] != 0xFFFFFFFFu) stack[sp++] = (int)w[12 + (key[k] & 3u)];
+        cur = (int)w[12 + (key[0] & 3u)];
         continue;
-      } else if (h0) { cur = c0; continue; }
-      else if (h1) { cur = c1; continue; }
+      }
     } else {
       const ExtTri& et = tris[~cur];
       c.tris++;
@@ -1854,7 +1855,7 @@ int64_t orc_read_sky_cond(void* s, float* values, float* cdf) {
 // product LBVH import for work counting (nodes: 8 words each, tris: 12 floats each, grid: lo[3], cell[3])
 void orc_scene_set_ext_bvh(void* s, const uint32_t* nodes, uint64_t n_nodes, const float* tris, uint64_t n_tris, const float* grid_lo, const float* grid_cell) {
   Scene* sc = (Scene*)s;
-  sc->ext_nodes.assign(nodes, nodes + n_nodes * 8);
+  sc->ext_nodes.assign(nodes, nodes + n_nodes * 16);
   sc->ext_tris.assign(tris, tris + n_tris * 12);
   for (int k = 0; k < 3; ++k) {
     sc->ext_grid[k] = grid_lo[k];

@@ -115,7 +115,7 @@ class OracleScene:
         return out
 
     def set_ext_bvh(self, nodes, tris, grid_lo, grid_cell):
-        nodes = np.ascontiguousarray(nodes).view(np.uint32).reshape(-1, 8)
+        nodes = np.ascontiguousarray(nodes).view(np.uint32).reshape(-1, 16)
         tris = np.ascontiguousarray(tris).view(np.float32).reshape(-1, 12)
         glo = np.ascontiguousarray(grid_lo, np.float32)
         gcell = np.ascontiguousarray(grid_cell, np.float32)
