@@ -439,6 +439,10 @@ class RayTraceRenderer:
         t, nt = _texture_array(textures, keep)
         abi.check(abi.lib().glz_renderer_refresh_binded_textures(self._h, t, nt))
 
+    def set_chains(self, n):
+        """Concurrent launch chains over this rank's tiles (0 = automatic); the image does not depend on it."""
+        abi.check(abi.lib().glz_renderer_set_chains(self._h, n))
+
     def wait_idle(self):
         abi.check(abi.lib().glz_renderer_wait_idle(self._h))
 

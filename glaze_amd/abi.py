@@ -156,6 +156,7 @@ PROTOTYPES = {
     "glz_renderer_launch_constants": (C.c_int, [_P, C.c_uint32, _P, _P]),
     "glz_renderer_push_constants": (C.c_int, [_P, _P]),
     "glz_renderer_set_partition": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
+    "glz_renderer_set_chains": (C.c_int, [_P, C.c_uint32]),
     "glz_renderer_export_device": (C.c_int, [_P, C.c_int, _P]),
     "glz_renderer_tonemap_device": (C.c_int, [_P, _P, _P]),
     "glz_renderer_enable_counters": (C.c_int, [_P, C.c_int]),

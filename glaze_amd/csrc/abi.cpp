@@ -401,6 +401,7 @@ int glz_renderer_push_constants(glz_renderer* h, float out[32]) {
   return GLZ_OK;
 }
 int glz_renderer_set_partition(glz_renderer* h, uint32_t rank, uint32_t world) { GLZ_GUARD_BEGIN GLZ_R(h); GLZ_RET(h->r->set_partition(rank, world, e)); GLZ_GUARD_END(GLZ_E_IO) }
+int glz_renderer_set_chains(glz_renderer* h, uint32_t n) { GLZ_GUARD_BEGIN GLZ_R(h); GLZ_RET(h->r->set_chains(n, e)); GLZ_GUARD_END(GLZ_E_IO) }
 int glz_renderer_export_device(glz_renderer* h, int which, void* dev) {
   GLZ_GUARD_BEGIN GLZ_R(h);
   if (!dev) return fail(GLZ_E_ARG, "device buffer is null");

@@ -33,8 +33,6 @@ Renderer* Renderer::create(Instance* inst, Scene* scene, uint32_t w, uint32_t h,
   }
   r->w_ = w;
   r->h_ = h;
-  r->map_.rank = 0;
-  r->map_.world = 1;
   r->camera_ = scene->data.camera;
   r->exposure_ = scene->data.meta.exposure;
   host::push_constants(r->camera_, w, h, r->cam_.camera2world, r->cam_.screen2camera);
@@ -42,144 +40,186 @@ Renderer* Renderer::create(Instance* inst, Scene* scene, uint32_t w, uint32_t h,
   return r.release();
 }
 
+void Renderer::release_chains() {
+  for (auto& c : chains_) {
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto& s : c->pending_events)
+      for (auto& e : s.e) (void)hipEventDestroy(e);
+    for (auto& s : c->free_events)
+      for (auto& e : s.e) (void)hipEventDestroy(e);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+  }
+  chains_.clear();
+}
+
 Renderer::~Renderer() {
   if (inst_) (void)hipSetDevice(inst_->device);
-  if (inst_ && inst_->stream) (void)hipStreamSynchronize(inst_->stream);
-  for (auto& s : pending_events_)
-    for (auto& e : s.e) (void)hipEventDestroy(e);
-  for (auto& s : free_events_)
-    for (auto& e : s.e) (void)hipEventDestroy(e);
+  release_chains();
+}
+
+// Number of concurrent chains, from the pixels this rank owns (measured on the atrium, ms per launch of one rank's share of
+// a 1080p frame with 1 / 2 / 3 chains): 2.07 M pixels 1.29 / 1.36 / 1.42, 1.04 M 0.72 / 0.72 / 0.71, 518 k 0.43 / 0.38 / 0.38,
+// 259 k 0.26 / 0.25 / 0.23.  A launch over a million pixels is throughput bound and wants one chain; below that it is bound
+// by the latency of its longest rays and concurrent chains fill the machine.  Four chains were slower again (host enqueue).
+uint32_t Renderer::pick_chains() const {
+  const uint32_t tiles_x = (w_ + kTile - 1) / kTile, tiles_y = (h_ + kTile - 1) / kTile, tiles = tiles_x * tiles_y;
+  const uint32_t local_tiles = tiles > rank_ ? (tiles - rank_ + world_ - 1) / world_ : 0;
+  const uint64_t pixels = (uint64_t)local_tiles * kTile * kTile;
+  uint32_t want = chains_wanted_;
+  if (want == 0) want = pixels >= 1000000u ? 1u : (pixels >= 400000u ? 2u : 3u);
+  if (want > local_tiles) want = local_tiles;
+  return want ? want : 1u;
 }
 
 bool Renderer::allocate(Error& err) {
-  map_.width = w_;
-  map_.height = h_;
-  map_.tiles_x = (w_ + kTile - 1) / kTile;
-  map_.tiles_y = (h_ + kTile - 1) / kTile;
-  const uint32_t tiles = map_.tiles_x * map_.tiles_y;
-  map_.n_local_tiles = tiles > map_.rank ? (tiles - map_.rank + map_.world - 1) / map_.world : 0;
-  map_.n_local_pixels = map_.n_local_tiles * kTile * kTile;
-  const size_t n = map_.n_local_pixels;
-  // shadow-ray queue: 8 shards of ceil(blocks/8)*256 entries (kernels_render.hip, queue_capacity)
-  const size_t n_queue = (((n + 255) / 256 + 7) / 8) * 256 * 8;
-  DeviceBuffer<float4>* bufs[] = {&ray_o_, &ray_d_, &imp_[0], &imp_[1], &imp_[2], &imp_[3], &hit_, &sh_o_, &sh_d_, &contrib_, &cumulative_, &result_};
-  for (auto* b : bufs)
-    if (!hip_ok(b->alloc((b == &sh_o_ || b == &sh_d_ || b == &contrib_) ? n_queue : n), "alloc path state", err)) return false;
+  release_chains();
+  const uint32_t S = pick_chains();
   const uint32_t od = scene_->stack_overflow_depth;
-  if (!hip_ok(overflow_.alloc((2 * n + 512) * od), "alloc traversal spill", err)) return false;   // one slot per lane of the largest k_trace grid
+  for (uint32_t s = 0; s < S; ++s) {
+    std::unique_ptr<Chain> c(new Chain());
+    if (s == 0) {
+      c->stream = inst_->stream;   // glz_instance_stream keeps naming a stream the renderer works on
+    } else {
+      if (!hip_ok(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate", err)) return false;
+      c->own_stream = true;
+    }
+    TileMap& m = c->map;
+    m.width = w_;
+    m.height = h_;
+    m.tiles_x = (w_ + kTile - 1) / kTile;
+    m.tiles_y = (h_ + kTile - 1) / kTile;
+    m.rank = rank_ + s * world_;   // chain s of S = the finer partition (rank + s * world, world * S)
+    m.world = world_ * S;
+    const uint32_t tiles = m.tiles_x * m.tiles_y;
+    m.n_local_tiles = tiles > m.rank ? (tiles - m.rank + m.world - 1) / m.world : 0;
+    m.n_local_pixels = m.n_local_tiles * kTile * kTile;
+    const size_t n = m.n_local_pixels;
+    // shadow-ray queue: 8 shards of ceil(blocks/8)*256 entries (kernels_render.hip, queue_capacity)
+    const size_t n_queue = (((n + 255) / 256 + 7) / 8) * 256 * 8;
+    DeviceBuffer<float4>* bufs[] = {&c->ray_o, &c->ray_d, &c->imp[0], &c->imp[1], &c->imp[2], &c->imp[3], &c->hit, &c->sh_o, &c->sh_d, &c->contrib,
+                                    &c->cumulative, &c->result};
+    for (auto* b : bufs)
+      if (!hip_ok(b->alloc((b == &c->sh_o || b == &c->sh_d || b == &c->contrib) ? n_queue : n), "alloc path state", err)) return false;
+    if (!hip_ok(c->overflow.alloc((2 * n + 512) * od), "alloc traversal spill", err)) return false;   // one slot per lane of the largest k_trace grid
+    if (!hip_ok(c->queue_count.alloc(2 * kQueueSetWords), "alloc queue counters", err)) return false;
+    chains_.push_back(std::move(c));
+  }
   if (!hip_ok(frame_tmp_.alloc((size_t)w_ * h_), "alloc frame", err)) return false;
   if (!hip_ok(rgba8_.alloc((size_t)w_ * h_), "alloc rgba8", err)) return false;
   if (!hip_ok(counters_.alloc(1), "alloc counters", err)) return false;
-  if (!hip_ok(queue_count_.alloc(2 * kQueueSetWords), "alloc queue counters", err)) return false;
-  shadow_pending_ = false;
   request_new_frame_ = true;
   return true;
 }
 
 // the fill_buffer / clear_color_image of a new frame (raytracer.rs:506-532) + scheduler rewind (:483-485)
 bool Renderer::reset_buffers(Error& err) {
-  hipStream_t st = inst_->stream;
-  const size_t bytes = sizeof(float4) * (size_t)map_.n_local_pixels;
-  DeviceBuffer<float4>* zero[] = {&ray_o_, &ray_d_, &imp_[0], &imp_[1], &imp_[2], &imp_[3], &cumulative_, &result_, &contrib_};
-  for (auto* b : zero)
-    if (bytes && !hip_ok(hipMemsetAsync(b->ptr, 0, bytes, st), "clear path state", err)) return false;
-  if (!hip_ok(hipMemsetAsync(counters_.ptr, 0, sizeof(TraceCounters), st), "clear counters", err)) return false;
-  if (!hip_ok(hipMemsetAsync(queue_count_.ptr, 0, sizeof(uint32_t) * 2 * kQueueSetWords, st), "clear queue counters", err)) return false;
-  shadow_pending_ = false;   // queued shadow rays of the abandoned frame are dropped with it
+  // work of the abandoned frame may still be running on the chains' streams
+  for (auto& c : chains_)
+    if (!hip_ok(hipStreamSynchronize(c->stream), "reset", err)) return false;
+  for (auto& cp : chains_) {
+    Chain& c = *cp;
+    const size_t bytes = sizeof(float4) * (size_t)c.map.n_local_pixels;
+    DeviceBuffer<float4>* zero[] = {&c.ray_o, &c.ray_d, &c.imp[0], &c.imp[1], &c.imp[2], &c.imp[3], &c.cumulative, &c.result, &c.contrib};
+    for (auto* b : zero)
+      if (bytes && !hip_ok(hipMemsetAsync(b->ptr, 0, bytes, c.stream), "clear path state", err)) return false;
+    if (!hip_ok(hipMemsetAsync(c.queue_count.ptr, 0, sizeof(uint32_t) * 2 * kQueueSetWords, c.stream), "clear queue counters", err)) return false;
+    c.shadow_pending = false;   // queued shadow rays of the abandoned frame are dropped with it
+    c.trace_ms = c.shade_ms = c.flush_ms = 0;
+    for (auto& s : c.pending_events) c.free_events.push_back(s);
+    c.pending_events.clear();
+  }
+  if (!hip_ok(hipMemsetAsync(counters_.ptr, 0, sizeof(TraceCounters), chains_[0]->stream), "clear counters", err)) return false;
+  if (chains_.size() > 1 && !hip_ok(hipStreamSynchronize(chains_[0]->stream), "clear counters", err)) return false;   // the other chains add to them too
   sched_.rewind();
   rng_.reseed(seed_);   // build-defined: a restart replays the same seed stream (the reference keeps drawing from entropy)
   launches_ = 0;
-  render_ms_ = closest_ms_ = shade_ms_ = shadow_ms_ = 0;
-  for (auto& s : pending_events_) free_events_.push_back(s);
-  pending_events_.clear();
   request_new_frame_ = false;
   return true;
 }
 
-void Renderer::fill_args(LaunchArgs& a) const {
+void Renderer::fill_args(const Chain& c, LaunchArgs& a) const {
   a.scene = scene_->dev;
-  a.st.ray_o = ray_o_.ptr;
-  a.st.ray_d = ray_d_.ptr;
-  for (int q = 0; q < 4; ++q) a.st.imp[q] = imp_[q].ptr;
-  a.st.hit = hit_.ptr;
-  a.st.sh_o = sh_o_.ptr;
-  a.st.sh_d = sh_d_.ptr;
-  a.st.contrib = contrib_.ptr;
-  a.st.queue_count = queue_count_.ptr;
-  a.st.cumulative = cumulative_.ptr;
-  a.st.result = result_.ptr;
-  a.st.overflow = overflow_.ptr;
+  a.st.ray_o = c.ray_o.ptr;
+  a.st.ray_d = c.ray_d.ptr;
+  for (int q = 0; q < 4; ++q) a.st.imp[q] = c.imp[q].ptr;
+  a.st.hit = c.hit.ptr;
+  a.st.sh_o = c.sh_o.ptr;
+  a.st.sh_d = c.sh_d.ptr;
+  a.st.contrib = c.contrib.ptr;
+  a.st.queue_count = c.queue_count.ptr;
+  a.st.cumulative = c.cumulative.ptr;
+  a.st.result = c.result.ptr;
+  a.st.overflow = c.overflow.ptr;
   a.st.overflow_depth = scene_->stack_overflow_depth;
-  a.map = map_;
+  a.map = c.map;
   a.cam = cam_;
   a.counters = counting_ ? counters_.ptr : nullptr;
   a.do_closest = a.do_shadow = 0;
-  a.shade_set = pending_set_ ^ 1u;
-  a.shadow_exposure = pending_exposure_;
+  a.shade_set = c.pending_set ^ 1u;
+  a.shadow_exposure = c.pending_exposure;
 }
 
-bool Renderer::acquire_events(EventSet& ev, Error& err) {
-  if (free_events_.empty()) {
-    if (pending_events_.size() >= 64) {
-      // resolve and recycle the pending sets (without the flush get_stats would do)
-      if (!hip_ok(hipEventSynchronize(pending_events_.back().e[pending_events_.back().flush ? 1 : 2]), "hipEventSynchronize", err)) return false;
-      for (auto& s : pending_events_) {
-        float a = 0, b = 0;
-        (void)hipEventElapsedTime(&a, s.e[0], s.e[1]);
-        if (s.flush) {
-          shadow_ms_ += a;
-        } else {
-          (void)hipEventElapsedTime(&b, s.e[1], s.e[2]);
-          closest_ms_ += a;
-          shade_ms_ += b;
-        }
-        render_ms_ += (double)a + b;
-        free_events_.push_back(s);
-      }
-      pending_events_.clear();
+void Renderer::resolve_events(Chain& c) {
+  for (auto& s : c.pending_events) {
+    float a = 0, b = 0;
+    (void)hipEventElapsedTime(&a, s.e[0], s.e[1]);
+    if (s.flush) {
+      c.flush_ms += a;
+    } else {
+      (void)hipEventElapsedTime(&b, s.e[1], s.e[2]);
+      c.trace_ms += a;
+      c.shade_ms += b;
     }
-    if (free_events_.empty()) {
+    c.free_events.push_back(s);
+  }
+  c.pending_events.clear();
+}
+
+bool Renderer::acquire_events(Chain& c, EventSet& ev, Error& err) {
+  if (c.free_events.empty()) {
+    if (c.pending_events.size() >= 64) {
+      // resolve and recycle the pending sets (without the flush get_stats would do)
+      if (!hip_ok(hipEventSynchronize(c.pending_events.back().e[c.pending_events.back().flush ? 1 : 2]), "hipEventSynchronize", err)) return false;
+      resolve_events(c);
+    }
+    if (c.free_events.empty()) {
       EventSet fresh{};
       for (auto& e : fresh.e)
         if (!hip_ok(hipEventCreate(&e), "hipEventCreate", err)) return false;
-      free_events_.push_back(fresh);
+      c.free_events.push_back(fresh);
     }
   }
-  ev = free_events_.back();
-  free_events_.pop_back();
+  ev = c.free_events.back();
+  c.free_events.pop_back();
   return true;
 }
 
 // Stand-alone shadow pass for the rays the last launch queued: run before anything observes the accumulators.
-bool Renderer::flush_shadows(Error& err) {
-  if (!shadow_pending_) return true;
-  hipStream_t st = inst_->stream;
+bool Renderer::flush_shadows(Chain& c, Error& err) {
+  if (!c.shadow_pending) return true;
   LaunchArgs a;
-  fill_args(a);
+  fill_args(c, a);
   memset(&a.frame, 0, sizeof(a.frame));
   a.do_shadow = 1;
   EventSet ev{};
   if (profile_kernels_) {
-    if (!acquire_events(ev, err)) return false;
+    if (!acquire_events(c, ev, err)) return false;
     ev.flush = true;
-    (void)hipEventRecord(ev.e[0], st);
+    (void)hipEventRecord(ev.e[0], c.stream);
   }
-  if (!hip_ok(launch_trace(st, a), "k_trace (shadow pass)", err)) return false;
+  if (!hip_ok(launch_trace(c.stream, a), "k_trace (shadow pass)", err)) return false;
   if (profile_kernels_) {
-    (void)hipEventRecord(ev.e[1], st);
-    pending_events_.push_back(ev);
+    (void)hipEventRecord(ev.e[1], c.stream);
+    c.pending_events.push_back(ev);
   }
-  shadow_pending_ = false;
+  c.shadow_pending = false;
   return true;
 }
 
 // draw_frame (raytracer.rs:369-613): one path segment per pixel
 bool Renderer::one_launch(Error& err) {
   if (request_new_frame_ && !reset_buffers(err)) return false;
-  hipStream_t st = inst_->stream;
-  LaunchArgs a;
-  fill_args(a);
-  FrameData& fd = a.frame;
+  FrameData fd;
   memset(&fd, 0, sizeof(fd));
   fd.seed = rng_.next();                  // rng.gen::<u32>(), raytracer.rs:487
   fd.lights_no = scene_->lights_no;
@@ -194,63 +234,68 @@ bool Renderer::one_launch(Error& err) {
   fd.direct_only = integrator_ == GLZ_DIRECT ? 1u : 0u;
   ++launches_;
   if (fd.lights_no == 0) return true;   // the raygen shader returns before touching anything (path_trace.rgen:137-141)
-  a.do_closest = 1;
-  a.do_shadow = shadow_pending_ ? 1u : 0u;   // the previous launch's shadow rays ride in this launch's traversal kernel
-  EventSet ev{};
-  if (profile_kernels_) {
-    if (!acquire_events(ev, err)) return false;
-    ev.flush = false;
-    (void)hipEventRecord(ev.e[0], st);
+  for (auto& cp : chains_) {
+    Chain& c = *cp;
+    hipStream_t st = c.stream;
+    LaunchArgs a;
+    fill_args(c, a);
+    a.frame = fd;
+    a.do_closest = 1;
+    a.do_shadow = c.shadow_pending ? 1u : 0u;   // the previous launch's shadow rays ride in this launch's traversal kernel
+    EventSet ev{};
+    if (profile_kernels_) {
+      if (!acquire_events(c, ev, err)) return false;
+      ev.flush = false;
+      (void)hipEventRecord(ev.e[0], st);
+    }
+    if (!hip_ok(launch_trace(st, a), "k_trace", err)) return false;
+    if (profile_kernels_) (void)hipEventRecord(ev.e[1], st);
+    if (!hip_ok(launch_shade(st, a), "k_shade", err)) return false;
+    if (profile_kernels_) {
+      (void)hipEventRecord(ev.e[2], st);
+      c.pending_events.push_back(ev);
+    }
+    c.shadow_pending = true;
+    c.pending_set = a.shade_set;
+    c.pending_exposure = exposure_;
   }
-  if (!hip_ok(launch_trace(st, a), "k_trace", err)) return false;
-  if (profile_kernels_) (void)hipEventRecord(ev.e[1], st);
-  if (!hip_ok(launch_shade(st, a), "k_shade", err)) return false;
-  if (profile_kernels_) {
-    (void)hipEventRecord(ev.e[2], st);
-    pending_events_.push_back(ev);
-  }
-  shadow_pending_ = true;
-  pending_set_ = a.shade_set;
-  pending_exposure_ = exposure_;
   return true;
 }
 
 bool Renderer::get_stats(glz_render_stats* out, Error& err) {
   if (!hip_ok(hipSetDevice(inst_->device), "hipSetDevice", err)) return false;
-  if (!flush_shadows(err)) return false;   // the counters and timings of the last launch's shadow rays belong to it
-  if (!pending_events_.empty()) {
-    if (!hip_ok(hipEventSynchronize(pending_events_.back().e[pending_events_.back().flush ? 1 : 2]), "hipEventSynchronize", err)) return false;
-    for (auto& s : pending_events_) {
-      float a = 0, b = 0;
-      (void)hipEventElapsedTime(&a, s.e[0], s.e[1]);
-      if (s.flush) {
-        shadow_ms_ += a;
-      } else {
-        (void)hipEventElapsedTime(&b, s.e[1], s.e[2]);
-        closest_ms_ += a;
-        shade_ms_ += b;
-      }
-      render_ms_ += (double)a + b;
-      free_events_.push_back(s);
+  double trace_ms = 0, shade_ms = 0, flush_ms = 0;
+  for (auto& cp : chains_) {
+    Chain& c = *cp;
+    if (!flush_shadows(c, err)) return false;   // the counters and timings of the last launch's shadow rays belong to it
+    if (!c.pending_events.empty()) {
+      if (!hip_ok(hipEventSynchronize(c.pending_events.back().e[c.pending_events.back().flush ? 1 : 2]), "hipEventSynchronize", err)) return false;
+      resolve_events(c);
     }
-    pending_events_.clear();
+    trace_ms += c.trace_ms;
+    shade_ms += c.shade_ms;
+    flush_ms += c.flush_ms;
   }
+  // concurrent chains overlap in time: the mean over chains is the time the rank spent in S concurrent instances of a kernel
+  const double inv = chains_.empty() ? 0.0 : 1.0 / (double)chains_.size();
   memset(out, 0, sizeof(*out));
   out->launches = launches_;
   uint64_t owned = 0;
-  for (uint32_t t = map_.rank; t < map_.tiles_x * map_.tiles_y; t += map_.world) {
-    const uint32_t tx = t % map_.tiles_x, ty = t / map_.tiles_x;
+  const uint32_t tiles_x = (w_ + kTile - 1) / kTile, tiles_y = (h_ + kTile - 1) / kTile;
+  for (uint32_t t = rank_; t < tiles_x * tiles_y; t += world_) {
+    const uint32_t tx = t % tiles_x, ty = t / tiles_x;
     const uint32_t tw = std::min(kTile, w_ - tx * kTile), th = std::min(kTile, h_ - ty * kTile);
     owned += (uint64_t)tw * th;
   }
   out->samples = owned * launches_;
-  out->render_ms = render_ms_;
-  out->trace_closest_ms = closest_ms_;
-  out->shade_ms = shade_ms_;
-  out->trace_shadow_ms = shadow_ms_;
+  out->trace_closest_ms = trace_ms * inv;
+  out->shade_ms = shade_ms * inv;
+  out->trace_shadow_ms = flush_ms * inv;
+  out->render_ms = out->trace_closest_ms + out->shade_ms + out->trace_shadow_ms;
+  for (auto& c : chains_)
+    if (!hip_ok(hipStreamSynchronize(c->stream), "read counters", err)) return false;
   TraceCounters c{};
-  if (!hip_ok(hipMemcpyAsync(&c, counters_.ptr, sizeof(c), hipMemcpyDeviceToHost, inst_->stream), "read counters", err)) return false;
-  if (!hip_ok(hipStreamSynchronize(inst_->stream), "read counters", err)) return false;
+  if (!hip_ok(hipMemcpy(&c, counters_.ptr, sizeof(c), hipMemcpyDeviceToHost), "read counters", err)) return false;
   out->closest_rays = c.closest_rays;
   out->shadow_rays = c.shadow_rays;
   out->closest_nodes = c.closest_nodes;
@@ -338,8 +383,11 @@ bool Renderer::refresh_binded_textures(const glz_texture* t, uint32_t nt, Error&
 
 bool Renderer::wait_idle(Error& err) {
   if (!hip_ok(hipSetDevice(inst_->device), "hipSetDevice", err)) return false;
-  if (!flush_shadows(err)) return false;
-  return hip_ok(hipStreamSynchronize(inst_->stream), "wait_idle", err);
+  for (auto& c : chains_)
+    if (!flush_shadows(*c, err)) return false;
+  for (auto& c : chains_)
+    if (!hip_ok(hipStreamSynchronize(c->stream), "wait_idle", err)) return false;
+  return true;
 }
 
 bool Renderer::restart() {
@@ -370,12 +418,24 @@ bool Renderer::draw(size_t spp, void (*cb)(void*), void* user, uint8_t* rgba8_ou
   return true;
 }
 
+// every chain scatters its tiles into the full-frame buffer `dst` (the first one clears it); all on the first chain's
+// stream after the chains have drained
+bool Renderer::gather(bool result, float4* dst, Error& err) {
+  if (request_new_frame_ && !reset_buffers(err)) return false;
+  if (!wait_idle(err)) return false;
+  hipStream_t st = chains_[0]->stream;
+  bool first = true;
+  for (auto& c : chains_) {
+    if (!hip_ok(launch_export(st, c->map, result ? c->result.ptr : c->cumulative.ptr, dst, first), "k_export", err)) return false;
+    first = false;
+  }
+  return true;
+}
+
 bool Renderer::read_frame(bool result, float* out, Error& err) {
   if (!hip_ok(hipSetDevice(inst_->device), "hipSetDevice", err)) return false;
-  if (request_new_frame_ && !reset_buffers(err)) return false;
-  if (!flush_shadows(err)) return false;
-  hipStream_t st = inst_->stream;
-  if (!hip_ok(launch_export(st, map_, result ? result_.ptr : cumulative_.ptr, frame_tmp_.ptr, true), "k_export", err)) return false;
+  if (!gather(result, frame_tmp_.ptr, err)) return false;
+  hipStream_t st = chains_[0]->stream;
   if (!hip_ok(hipMemcpyAsync(out, frame_tmp_.ptr, sizeof(float4) * (size_t)w_ * h_, hipMemcpyDeviceToHost, st), "read frame", err)) return false;
   return hip_ok(hipStreamSynchronize(st), "read frame", err);
 }
@@ -383,10 +443,8 @@ bool Renderer::read_frame(bool result, float* out, Error& err) {
 // blit out32 -> out8 (R8G8B8A8_SRGB) + export (raytracer.rs:576-584, memory.rs:269-483)
 bool Renderer::read_rgba8(uint8_t* out, Error& err) {
   if (!hip_ok(hipSetDevice(inst_->device), "hipSetDevice", err)) return false;
-  if (request_new_frame_ && !reset_buffers(err)) return false;
-  if (!flush_shadows(err)) return false;
-  hipStream_t st = inst_->stream;
-  if (!hip_ok(launch_export(st, map_, result_.ptr, frame_tmp_.ptr, true), "k_export", err)) return false;
+  if (!gather(true, frame_tmp_.ptr, err)) return false;
+  hipStream_t st = chains_[0]->stream;
   if (!hip_ok(launch_tonemap(st, w_ * h_, frame_tmp_.ptr, rgba8_.ptr), "k_tonemap", err)) return false;
   if (!hip_ok(hipMemcpyAsync(out, rgba8_.ptr, (size_t)w_ * h_ * 4, hipMemcpyDeviceToHost, st), "read rgba8", err)) return false;
   return hip_ok(hipStreamSynchronize(st), "read rgba8", err);
@@ -416,22 +474,31 @@ bool Renderer::set_partition(uint32_t rank, uint32_t world, Error& err) {
     return false;
   }
   if (!wait_idle(err)) return false;
-  map_.rank = rank;
-  map_.world = world;
+  rank_ = rank;
+  world_ = world;
+  return allocate(err);
+}
+
+bool Renderer::set_chains(uint32_t n, Error& err) {
+  if (n > 16) {
+    err.code = GLZ_E_ARG;
+    err.msg = "at most 16 chains";
+    return false;
+  }
+  if (!wait_idle(err)) return false;
+  chains_wanted_ = n;
   return allocate(err);
 }
 
 bool Renderer::export_device(int which, void* dev, Error& err) {
   if (!hip_ok(hipSetDevice(inst_->device), "hipSetDevice", err)) return false;
-  if (request_new_frame_ && !reset_buffers(err)) return false;
-  if (!flush_shadows(err)) return false;
-  if (!hip_ok(launch_export(inst_->stream, map_, which ? result_.ptr : cumulative_.ptr, static_cast<float4*>(dev), true), "k_export", err)) return false;
-  return hip_ok(hipStreamSynchronize(inst_->stream), "export_device", err);
+  if (!gather(which != 0, static_cast<float4*>(dev), err)) return false;
+  return hip_ok(hipStreamSynchronize(chains_[0]->stream), "export_device", err);
 }
 
 bool Renderer::tonemap_device(const void* dev_result, uint8_t* out, Error& err) {
   if (!hip_ok(hipSetDevice(inst_->device), "hipSetDevice", err)) return false;
-  hipStream_t st = inst_->stream;
+  hipStream_t st = chains_[0]->stream;
   if (!hip_ok(launch_tonemap(st, w_ * h_, static_cast<const float4*>(dev_result), rgba8_.ptr), "k_tonemap", err)) return false;
   if (!hip_ok(hipMemcpyAsync(out, rgba8_.ptr, (size_t)w_ * h_ * 4, hipMemcpyDeviceToHost, st), "read rgba8", err)) return false;
   return hip_ok(hipStreamSynchronize(st), "tonemap_device", err);

@@ -34,6 +34,8 @@ class Renderer {
   bool set_seed(uint64_t s);
   bool set_depth(uint32_t d, Error& err);
   bool set_partition(uint32_t rank, uint32_t world, Error& err);
+  bool set_chains(uint32_t n, Error& err);   // 0 = automatic
+  uint32_t chains() const { return (uint32_t)chains_.size(); }
   bool export_device(int which, void* dev_rgba32f, Error& err);
   bool tonemap_device(const void* dev_result, uint8_t* out, Error& err);
   bool launch_constants(uint32_t launch, uint32_t* seed, float off[2]);
@@ -51,7 +53,7 @@ class Renderer {
   bool allocate(Error& err);
   bool reset_buffers(Error& err);
   bool one_launch(Error& err);
-  void fill_args(LaunchArgs& a) const;
+  bool gather(bool result, float4* dst, Error& err);
 
   Instance* inst_ = nullptr;
   std::unique_ptr<Scene> scene_;
@@ -65,29 +67,47 @@ class Renderer {
   host::SeedStream rng_;
   host::WorkScheduler sched_;
   bool request_new_frame_ = true;
-  TileMap map_{};
-  // state
-  DeviceBuffer<float4> ray_o_, ray_d_, imp_[4], hit_, sh_o_, sh_d_, contrib_, cumulative_, result_, frame_tmp_;
-  DeviceBuffer<uint32_t> overflow_, queue_count_;
+  uint32_t rank_ = 0, world_ = 1;   // tile partition of this process (glz_renderer_set_partition)
+  uint32_t chains_wanted_ = 0;      // 0 = automatic (pick_chains)
+
+  // One chain = one independent sequence of launches over a subset of this rank's tiles, on its own HIP stream.
+  // Pixels never interact, so the tiles of a rank can advance as several concurrent chains: chain s of S renders the
+  // tiles of the finer partition (rank + s * world, world * S).  With few pixels per GPU a launch is bound by the
+  // latency of its longest rays, not by throughput; concurrent chains fill the machine during those tails (strong
+  // scaling of the 1080p frame over 8 GPUs).  Results are bit-identical for every S.
+  struct EventSet {
+    hipEvent_t e[4];
+    bool flush;   // e[0]..e[1] around a stand-alone shadow pass instead of e[0]..e[2] around k_trace, k_shade
+  };
+  struct Chain {
+    TileMap map{};
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    DeviceBuffer<float4> ray_o, ray_d, imp[4], hit, sh_o, sh_d, contrib, cumulative, result;
+    DeviceBuffer<uint32_t> overflow, queue_count;
+    // shadow rays queued by the last launch's k_shade and not traced yet (they ride in the next launch's k_trace, or in
+    // a stand-alone pass as soon as anything looks at the images: flush_shadows)
+    bool shadow_pending = false;
+    uint32_t pending_set = 0;
+    float pending_exposure = 1.0f;
+    std::vector<EventSet> pending_events;   // per-launch kernel boundaries, resolved lazily in get_stats
+    std::vector<EventSet> free_events;
+    double trace_ms = 0, shade_ms = 0, flush_ms = 0;
+  };
+  std::vector<std::unique_ptr<Chain>> chains_;
+  uint32_t pick_chains() const;
+  void release_chains();
+  bool flush_shadows(Chain& c, Error& err);
+  bool acquire_events(Chain& c, EventSet& ev, Error& err);
+  void resolve_events(Chain& c);
+  void fill_args(const Chain& c, LaunchArgs& a) const;
+
+  DeviceBuffer<float4> frame_tmp_;
   DeviceBuffer<uchar4> rgba8_;
   DeviceBuffer<TraceCounters> counters_;
   // stats
   bool counting_ = false;
   uint64_t launches_ = 0;
-  double render_ms_ = 0, closest_ms_ = 0, shade_ms_ = 0, shadow_ms_ = 0;
-  struct EventSet {
-    hipEvent_t e[4];
-    bool flush;   // e[0]..e[1] around a stand-alone shadow pass instead of e[0]..e[2] around k_trace, k_shade
-  };
-  // shadow rays queued by the last launch's k_shade and not traced yet (they ride in the next launch's k_trace, or in a
-  // stand-alone pass as soon as anything looks at the images: flush_shadows)
-  bool shadow_pending_ = false;
-  uint32_t pending_set_ = 0;
-  float pending_exposure_ = 1.0f;
-  bool flush_shadows(Error& err);
-  bool acquire_events(EventSet& ev, Error& err);
-  std::vector<EventSet> pending_events_;   // per-launch kernel boundaries, resolved lazily in get_stats
-  std::vector<EventSet> free_events_;
   bool profile_kernels_ = true;
 };
 

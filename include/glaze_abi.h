@@ -331,6 +331,11 @@ int glz_renderer_set_partition(glz_renderer*, uint32_t rank, uint32_t world);
  * (which = 1) into a caller-provided DEVICE buffer of W*H*4 floats, zero elsewhere, on the instance
  * stream (synchronised before returning): the operand of ncclReduce(sum).  Tiles are disjoint, so
  * the sum over ranks is bit-identical to a single-GPU render. */
+/* Concurrent chains: the tiles of this process advance as `n` independent launch sequences on `n` HIP streams (0 = automatic:
+
+ * one chain while the rank owns a million pixels, two down to 400 k, three below).  Pixels never interact, so the image does not depend on n; with a small
+ * tile share per GPU the chains fill the machine while the longest rays of a launch finish. */
+int glz_renderer_set_chains(glz_renderer*, uint32_t n);
 int glz_renderer_export_device(glz_renderer*, int which, void* dev_rgba32f);
 /* Tonemaps a full-frame DEVICE result image (e.g. the reduced one on rank 0) to RGBA8 sRGB host memory. */
 int glz_renderer_tonemap_device(glz_renderer*, const void* dev_result_rgba32f, uint8_t* rgba8_out);

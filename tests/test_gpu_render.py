@@ -301,6 +301,34 @@ def test_tile_partition_sums_to_single_gpu(instance):
     assert np.array_equal(total.view(np.uint32), ref.view(np.uint32))
 
 
+def test_concurrent_chains_do_not_change_the_image(instance, mattest_desc):
+    """glz_renderer_set_chains: the rank's tiles advance as n independent launch sequences on n streams; bit-identical for every n,
+    also under a tile partition (chain s of S is the finer partition (rank + s * world, world * S))."""
+    scene = glaze_amd.RayTraceScene.from_desc(instance, mattest_desc)
+    r = glaze_amd.RayTraceRenderer.new(instance, scene, 200, 136)             # 4 x 3 tiles, ragged right and bottom edges
+    r.set_depth(5)
+    r.set_chains(1)
+    r.step(23)
+    ref, ref_result = r.read_hdr(), r.read_result()
+    for n in (2, 3, 5, 12, 16, 0):
+        r.set_chains(n)
+        r.step(10)
+        r.set_exposure(2.0 * mattest_desc.meta.exposure)                       # queued shadow rays keep the exposure of their launch
+        r.set_exposure(mattest_desc.meta.exposure)
+        r.step(13)
+        assert np.array_equal(r.read_hdr().view(np.uint32), ref.view(np.uint32)), "chains=%d" % n
+        assert np.array_equal(r.read_result().view(np.uint32), ref_result.view(np.uint32)), "chains=%d" % n
+    total = np.zeros_like(ref)
+    for rank in range(3):
+        r.set_partition(rank, 3)
+        r.set_chains(2)
+        r.step(23)
+        total += r.read_hdr()
+    assert np.array_equal(total.view(np.uint32), ref.view(np.uint32))
+    s = r.stats()
+    assert s.launches == 23 and s.trace_closest_ms > 0 and s.shade_ms > 0
+
+
 def test_full_size_properties_atrium(instance):
     """BASELINE config 4 shape (1920x1080, synthetic atrium): size-independent properties at full size."""
     desc = atrium_scene()

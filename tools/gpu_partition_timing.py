@@ -7,10 +7,13 @@ from glaze_amd.scenes import atrium_scene
 inst = glaze_amd.RayTraceInstance.new()
 scene = glaze_amd.RayTraceScene.from_desc(inst, atrium_scene())
 base = None
-for world in (1, 2, 4, 8, 16, 32):
+import os
+chains = int(os.environ.get('CHAINS', '0'))
+for world in (1, 2, 3, 4, 6, 8, 16):
     r = glaze_amd.RayTraceRenderer.new(inst, scene, 1920, 1080) if world == 1 else r
     r.set_depth(8)
     r.set_partition(0, world)
+    r.set_chains(chains)
     r.restart(); r.step(16); r.wait_idle(); r.stats()
     s0 = r.stats(); n = 128
     t = time.time(); r.step(n); r.wait_idle(); dt = (time.time() - t) / n * 1e3
