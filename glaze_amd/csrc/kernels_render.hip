@@ -1,11 +1,11 @@
 // Wavefront path-tracing kernels for gfx950 (wave64).  One reference "launch" (one
 // vkCmdTraceRaysKHR of path_trace.rgen = one path segment per pixel, raytracer.rs:553-562) is
-// three kernels over the SoA path state in HBM:
+// two kernels over the SoA path state in HBM:
 //
-//   k_trace_closest   ray generation / resume + closest-hit LBVH traversal      -> hit record
-//   k_shade           hit attributes, light sample, BSDF eval, Russian roulette,
-//                     BSDF sample, state update                                 -> shadow ray + contribution
-//   k_shadow_queue    any-hit traversal of the compacted shadow-ray queue (persistent grid), update_count/update_result
+//   k_trace   (persistent) ray generation / resume + closest-hit BVH4 traversal -> hit record; then the any-hit
+//             traversal of the shadow rays the previous launch queued + update_count / update_result
+//   k_shade   hit attributes, light sample, BSDF eval, Russian roulette, BSDF sample, state update
+//             -> next ray + queued shadow ray with its contribution
 //
 // A wave owns one 8x8 pixel block of a 64x64 tile, so primary rays of a wave are coherent and all
 // per-pixel arrays are read and written as one contiguous 1 KiB (float4) line per wave.
@@ -446,7 +446,7 @@ __device__ __forceinline__ uint32_t wave_index() { return blockIdx.x * (kBlock /
 __device__ __forceinline__ uint32_t wave_count() { return gridDim.x * (kBlock / 64); }
 
 // ---------------------------------------------------------------------------------------------
-// k_trace_closest: path_trace.rgen:143-169
+// closest-hit phase of k_trace: path_trace.rgen:143-169
 // ---------------------------------------------------------------------------------------------
 struct ClosestSource {
   const LaunchArgs& A;
@@ -711,7 +711,7 @@ __global__ void __launch_bounds__(kBlock, GLZ_SHADE_WAVES) k_shade(const LaunchA
       GLZ_BINS probe += 0.0f * importance.w[i];
       if (probe != probe) c = spec_to_rgb(spec_scale(importance, 0.0f * (float)F.lights_no));
     }
-    // shadow-ray queue (consumed by k_shadow_queue); pixels without a shadow ray are accumulated right here
+    // shadow-ray queue (consumed by the next launch's k_trace); pixels without a shadow ray are accumulated right here
     const bool push = (flags & kFlagShadow) != 0;
     const uint32_t slot = queue_slot(A.st.queue_count + A.shade_set * kQueueSetWords, A.map.n_local_pixels, push);
     if (push) {
