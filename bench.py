@@ -39,6 +39,7 @@ def parse_args():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-launches", type=int, default=16, help="launches of the bounded CPU-baseline sample")
+    ap.add_argument("--verify", action="store_true", help="N > 1: rank 0 re-renders the whole frame alone and compares it bit for bit")
     return ap.parse_args()
 
 
@@ -77,10 +78,18 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda is not available (there is no CPU fallback)")
+    # GLAZE_BENCH_REHEARSAL=1: every rank shares GPU 0 and the reduce goes through gloo on host tensors -- lets the N > 1
+    # code path (partition, chains, reduce, max-over-ranks timing) be run on a one-GPU box.  Not a measurement.
+    rehearsal = os.environ.get("GLAZE_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     inst = glaze_amd.RayTraceInstance.new(local_rank)
     if inst is None:
@@ -105,12 +114,21 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    def reduce_to_rank0():
+        """export this rank's tiles (zero elsewhere) and sum them onto rank 0: RCCL over xGMI, or gloo in a rehearsal"""
+        renderer.export_device(0, frame.data_ptr())
+        if rehearsal:
+            host = frame.cpu()
+            reduce_frame(host)
+            frame.copy_(host)
+        else:
+            reduce_frame(frame)
+
     # ---- warmup (untimed): same accumulation continues afterwards, like the interactive draw_frame loop
     renderer.restart()
     renderer.step(args.warmup)
     if world > 1:
-        renderer.export_device(0, frame.data_ptr())
-        reduce_frame(frame)
+        reduce_to_rank0()
     sync_all()
     renderer.stats()            # drains the warmup's kernel events
     s0 = renderer.stats()
@@ -120,13 +138,12 @@ def main():
     t_start = time.perf_counter()
     renderer.step(args.steps)
     if world > 1:
-        renderer.export_device(0, frame.data_ptr())
-        reduce_frame(frame)
+        reduce_to_rank0()
     sync_all()
     elapsed = time.perf_counter() - t_start
     s1 = renderer.stats()
 
-    t_all = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    t_all = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
     if world > 1:
         dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
     elapsed = float(t_all.item())
@@ -161,7 +178,7 @@ def main():
         achieved = bytes_per_sample[dominant] * owned / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         traffic = None
         prof = os.path.join(ROOT, "profiles", "pmc_summary.json")
-        if os.path.exists(prof):
+        if os.path.exists(prof) and world == 1:      # the committed PMC passes profiled the N = 1 command
             try:
                 traffic = json.load(open(prof)).get(dominant, {}).get("hbm_bytes_per_launch")
             except Exception:
@@ -196,13 +213,24 @@ def main():
             "config": {"workload": "Sponza-class synthetic atrium (262140 tris) %dx%d, path tracer depth %d, %d steps = %.1f spp"
                                    % (W, H, args.depth, args.steps, args.steps / args.depth),
                        "width": W, "height": H, "depth": args.depth, "triangles": int(info.n_world_triangles),
-                       "sharding": "64x64 tiles round-robin over %d rank(s), RCCL reduce of the RGBA32F accumulator" % world,
+                       "sharding": "64x64 tiles round-robin over %d rank(s), %s reduce of the RGBA32F accumulator" % (world, "gloo (rehearsal on one GPU)" if rehearsal else "RCCL"),
                        "bvh": {"nodes": int(info.bvh_nodes), "depth": int(info.bvh_depth), "build_ms": round(float(info.build_ms), 3)},
                        "setup_s": round(setup_s, 3)},
             "roofline": roofline, "cpu_baseline": cpu,
             "mpaths_per_s": round(value / args.depth, 2),
             "grays_per_s": round(value * (1 + counted["f_shadow"]) / 1e3, 3),
         }
+    if world > 1 and args.verify and rank == 0:
+        # the reduced frame against the whole frame rendered by this rank alone, same seed and launch count
+        reduced = frame.cpu().numpy().copy()
+        renderer.set_partition(0, 1)
+        renderer.restart()
+        renderer.step(args.warmup + args.steps)
+        alone = renderer.read_hdr()
+        same = bool(np.array_equal(np.nan_to_num(reduced, nan=-1.0).view(np.uint32), np.nan_to_num(alone, nan=-1.0).view(np.uint32)))
+        out["verify"] = {"bit_identical_to_one_gpu": same, "launches": args.warmup + args.steps}
+        if not same:
+            raise SystemExit("multi-GPU frame differs from the single-GPU frame")
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
