@@ -90,6 +90,7 @@ struct LaunchArgs {
   uint32_t do_closest, do_shadow;
   uint32_t shade_set;        // which of the two shadow-queue counter sets this launch's k_shade fills (the other one is drained)
   float shadow_exposure;     // exposure of the launch that queued the shadow rays (update_result uses it)
+  uint32_t grid_share;       // host side: concurrent chains sharing the GPU (k_trace's persistent grid is 1 / grid_share of the resident blocks)
 };
 constexpr uint32_t kQueueSetWords = 8 * 32;   // 8 shard counters, 128 bytes apart
 

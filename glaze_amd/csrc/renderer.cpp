@@ -8,6 +8,7 @@ namespace glz {
 
 namespace {
 constexpr uint32_t kTile = 64;
+constexpr uint64_t kEventStride = 8;   // with several chains: every 8th launch is timed (see one_launch)
 }
 
 Renderer* Renderer::create(Instance* inst, Scene* scene, uint32_t w, uint32_t h, Error& err) {
@@ -157,6 +158,7 @@ void Renderer::fill_args(const Chain& c, LaunchArgs& a) const {
   a.do_closest = a.do_shadow = 0;
   a.shade_set = c.pending_set ^ 1u;
   a.shadow_exposure = c.pending_exposure;
+  a.grid_share = (uint32_t)chains_.size();
 }
 
 void Renderer::resolve_events(Chain& c) {
@@ -167,8 +169,9 @@ void Renderer::resolve_events(Chain& c) {
       c.flush_ms += a;
     } else {
       (void)hipEventElapsedTime(&b, s.e[1], s.e[2]);
-      c.trace_ms += a;
-      c.shade_ms += b;
+      const double weight = chains_.size() == 1 ? 1.0 : (double)kEventStride;
+      c.trace_ms += a * weight;
+      c.shade_ms += b * weight;
     }
     c.free_events.push_back(s);
   }
@@ -242,16 +245,20 @@ bool Renderer::one_launch(Error& err) {
     a.frame = fd;
     a.do_closest = 1;
     a.do_shadow = c.shadow_pending ? 1u : 0u;   // the previous launch's shadow rays ride in this launch's traversal kernel
+    // Kernel boundaries are timed with HIP events on every launch of a single chain; with several chains the three
+    // records per chain and launch cost 10 % of a small launch, so every kEventStride-th launch is timed and counted
+    // kEventStride times (get_stats reports the estimate).
+    const bool timed = profile_kernels_ && (chains_.size() == 1 || launches_ % kEventStride == 0);
     EventSet ev{};
-    if (profile_kernels_) {
+    if (timed) {
       if (!acquire_events(c, ev, err)) return false;
       ev.flush = false;
       (void)hipEventRecord(ev.e[0], st);
     }
     if (!hip_ok(launch_trace(st, a), "k_trace", err)) return false;
-    if (profile_kernels_) (void)hipEventRecord(ev.e[1], st);
+    if (timed) (void)hipEventRecord(ev.e[1], st);
     if (!hip_ok(launch_shade(st, a), "k_shade", err)) return false;
-    if (profile_kernels_) {
+    if (timed) {
       (void)hipEventRecord(ev.e[2], st);
       c.pending_events.push_back(ev);
     }
