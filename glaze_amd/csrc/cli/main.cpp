@@ -186,7 +186,7 @@ int main(int argc, char** argv) {
     const uint32_t steps = glz_renderer_steps_per_sample(renderer);
     printf("{\"input\": \"%s\", \"width\": %lu, \"height\": %lu, \"spp\": %zu, \"steps_per_sample\": %u, \"launches\": %llu, "
            "\"triangles\": %llu, \"bvh_nodes\": %u, \"bvh_depth\": %u, \"bvh_build_ms\": %.3f, \"setup_ms\": %.1f, \"render_ms\": %.1f, "
-           "\"kernel_ms\": {\"trace_closest\": %.2f, \"shade\": %.2f, \"shadow_accum\": %.2f}, \"msamples_per_s\": %.2f}\n",
+           "\"kernel_ms\": {\"trace\": %.2f, \"shade\": %.2f, \"shadow_flush\": %.2f}, \"msamples_per_s\": %.2f}\n",
            input.c_str(), width, height, spp, steps, (unsigned long long)st.launches, (unsigned long long)info.n_world_triangles, info.bvh_nodes,
            info.bvh_depth, info.build_ms, setup_ms, render_ms, st.trace_closest_ms, st.shade_ms, st.trace_shadow_ms,
            render_ms > 0 ? (double)st.samples / render_ms / 1e3 : 0.0);
