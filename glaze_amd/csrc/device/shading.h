@@ -84,13 +84,18 @@ GLZ_D Spec from_illuminant_color(vec3 c) { return rgb_to_spec(c, kIllum, 0.86445
 struct vec4 {
   float x, y, z, w;
 };
+// Texels are stored in 128-byte tiles (one cache line): 8 x 4 RGBA texels or 16 x 8 gray texels, tiles row-major.  The 2 x 2
+// footprint of a bilinear fetch then touches 1.4 lines on average instead of the 2.06 of a row-major image (k_shade sits
+// at the memory system's random-access rate and half of what it fetches is texels).
 GLZ_D vec4 fetch_texel(const DeviceScene& S, const TexDesc& t, int x, int y) {
-  if (t.format == GLZ_TEX_GRAY) {
-    float g = (float)S.tex_pool[t.offset + (uint32_t)y * t.width + (uint32_t)x] / 255.0f;
+  const uint32_t format = t.format & 0xFFu, tiles_x = t.format >> 8;
+  const uint32_t ux = (uint32_t)x, uy = (uint32_t)y;
+  if (format == GLZ_TEX_GRAY) {
+    float g = (float)S.tex_pool[t.offset + ((uy >> 3) * tiles_x + (ux >> 4)) * 128u + (uy & 7u) * 16u + (ux & 15u)] / 255.0f;
     return vec4{g, 0.0f, 0.0f, 1.0f};
   }
-  const uchar4 p = *reinterpret_cast<const uchar4*>(S.tex_pool + t.offset + ((uint32_t)y * t.width + (uint32_t)x) * 4u);
-  if (t.format == GLZ_TEX_RGBA_SRGB) return vec4{S.srgb_lut[p.x], S.srgb_lut[p.y], S.srgb_lut[p.z], (float)p.w / 255.0f};
+  const uchar4 p = *reinterpret_cast<const uchar4*>(S.tex_pool + t.offset + (((uy >> 2) * tiles_x + (ux >> 3)) * 32u + (uy & 3u) * 8u + (ux & 7u)) * 4u);
+  if (format == GLZ_TEX_RGBA_SRGB) return vec4{S.srgb_lut[p.x], S.srgb_lut[p.y], S.srgb_lut[p.z], (float)p.w / 255.0f};
   return vec4{(float)p.x / 255.0f, (float)p.y / 255.0f, (float)p.z / 255.0f, (float)p.w / 255.0f};
 }
 GLZ_D int wrap_coord(int i, int n) {
@@ -107,7 +112,12 @@ GLZ_D vec4 texture2d(const DeviceScene& S, uint32_t id, float u, float v) {
   float ax = fu - iu, ay = fv - iv;
   int x0 = wrap_coord((int)iu, (int)t.width), y0 = wrap_coord((int)iv, (int)t.height);
   int x1 = wrap_coord((int)iu + 1, (int)t.width), y1 = wrap_coord((int)iv + 1, (int)t.height);
-  vec4 a = fetch_texel(S, t, x0, y0), b = fetch_texel(S, t, x1, y0), c = fetch_texel(S, t, x0, y1), d = fetch_texel(S, t, x1, y1);
+  vec4 a = fetch_texel(S, t, x0, y0), b = a, c = a, d = a;
+  if (t.width != 1u || t.height != 1u) {   // the default 1 x 1 textures (roughness / metalness / opacity of most materials): one load; same arithmetic below
+    b = fetch_texel(S, t, x1, y0);
+    c = fetch_texel(S, t, x0, y1);
+    d = fetch_texel(S, t, x1, y1);
+  }
   vec4 r;
   r.x = lerp_ab(lerp_ab(a.x, b.x, ax), lerp_ab(c.x, d.x, ax), ay);
   r.y = lerp_ab(lerp_ab(a.y, b.y, ax), lerp_ab(c.y, d.y, ax), ay);

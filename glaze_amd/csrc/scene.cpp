@@ -217,14 +217,25 @@ bool Scene::upload_textures(Error& err) {
       err.msg = "texture has inconsistent dimensions";
       return false;
     }
-    pool.resize((pool.size() + 15) & ~size_t(15));
-    if (pool.size() + bytes > 0xFFFFFFFFull) {
+    // 128-byte tiles: 8 x 4 RGBA texels or 16 x 8 gray texels (device/shading.h fetch_texel); ragged edges are padded
+    const bool gray = t.info.format == GLZ_TEX_GRAY;
+    const uint32_t tw = gray ? 16u : 8u, th = gray ? 8u : 4u, bpp = gray ? 1u : 4u;
+    const uint32_t tiles_x = (t.info.width + tw - 1) / tw, tiles_y = (t.info.height + th - 1) / th;
+    const size_t tiled_bytes = (size_t)tiles_x * tiles_y * 128u;
+    pool.resize((pool.size() + 127) & ~size_t(127));
+    if (pool.size() + tiled_bytes > 0xFFFFFFFFull || tiles_x >= (1u << 24)) {
       err.code = GLZ_E_UNSUPPORTED;
       err.msg = "texture pool larger than 4 GiB";
       return false;
     }
-    desc[i] = TexDesc{(uint32_t)pool.size(), t.info.width, t.info.height, t.info.format};
-    pool.insert(pool.end(), t.level0.begin(), t.level0.begin() + bytes);
+    desc[i] = TexDesc{(uint32_t)pool.size(), t.info.width, t.info.height, t.info.format | (tiles_x << 8)};
+    const size_t base = pool.size();
+    pool.resize(base + tiled_bytes, 0);
+    for (uint32_t y = 0; y < t.info.height; ++y)
+      for (uint32_t x = 0; x < t.info.width; ++x) {
+        const size_t dst = base + ((size_t)(y / th) * tiles_x + x / tw) * 128u + ((size_t)(y % th) * tw + x % tw) * bpp;
+        memcpy(&pool[dst], &t.level0[((size_t)y * t.info.width + x) * bpp], bpp);
+      }
   }
   if (!hip_ok(d_tex_desc_.upload(desc.data(), desc.size(), st), "upload texture descriptors", err)) return false;
   if (!hip_ok(d_tex_pool_.upload(pool.data(), pool.size(), st), "upload texture pool", err)) return false;
