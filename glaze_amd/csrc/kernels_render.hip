@@ -355,9 +355,15 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
         if (k0 == 0xFFFFFFFFu) {
           cur = SHARE ? st.pop_live() : (st.sp ? st.pop() : kRayDone);
         } else {
-          if (k3 != 0xFFFFFFFFu) st.push(child_link(w3, k3));
-          if (k2 != 0xFFFFFFFFu) st.push(child_link(w3, k2));
-          if (k1 != 0xFFFFFFFFu) st.push(child_link(w3, k1));
+          if (__ballot(st.sp + 3 > kLdsStack) == 0ull) {   // wave-uniform: every lane stays inside the LDS part of its stack (no spill branches)
+            if (k3 != 0xFFFFFFFFu) { st.lds[st.sp * kBlock] = child_link(w3, k3); ++st.sp; }
+            if (k2 != 0xFFFFFFFFu) { st.lds[st.sp * kBlock] = child_link(w3, k2); ++st.sp; }
+            if (k1 != 0xFFFFFFFFu) { st.lds[st.sp * kBlock] = child_link(w3, k1); ++st.sp; }
+          } else {
+            if (k3 != 0xFFFFFFFFu) st.push(child_link(w3, k3));
+            if (k2 != 0xFFFFFFFFu) st.push(child_link(w3, k2));
+            if (k1 != 0xFFFFFFFFu) st.push(child_link(w3, k1));
+          }
           cur = child_link(w3, k0);
         }
       }
