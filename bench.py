@@ -205,6 +205,14 @@ def main():
             dt = time.perf_counter() - tc
             cpu = {"value": round(W * H * args.cpu_launches / dt / 1e6, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
                    "sample": "%dx%d atrium, depth %d, %d launches (%.1f s)" % (W, H, args.depth, args.cpu_launches, dt)}
+            # the same port on ONE core (SURVEY 8d asks for both): one launch of the same frame
+            o.set_threads(1)
+            o.restart()
+            tc = time.perf_counter()
+            o.step(1)
+            dt1 = time.perf_counter() - tc
+            cpu["single_thread"] = {"value": round(W * H / dt1 / 1e6, 3), "unit": "Msamples/s", "cores": 1,
+                                    "sample": "1 launch (%.1f s)" % dt1}
         out = {
             "metric": "Msamples/s + achieved HBM GB/s, Sponza 1080p, 1/2/4/8xMI355X",
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
