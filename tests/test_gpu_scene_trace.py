@@ -178,6 +178,43 @@ def test_ploc_tiny_scenes():
         assert same.all() and np.isfinite(t).any()
 
 
+@pytest.mark.parametrize("builder", ["lbvh", "ploc"])
+def test_triangle_soup_with_duplicates_and_degenerates(builder):
+    """Random soup: exact duplicates (equal Morton codes -> the index tie-break of the hierarchy), zero-area and needle triangles,
+    one triangle spanning the whole scene, clusters far apart (deep, unbalanced tree).  Hits must equal the oracle's."""
+    from glaze_amd.scene_desc import MESH_DTYPE, VERTEX_DTYPE, SceneDesc
+    rng = np.random.default_rng(11)
+    n = 60000
+    centres = np.concatenate([rng.normal(size=(n // 2, 3)) * 0.3, rng.normal(size=(n // 2, 3)) * 0.02 + [40.0, -25.0, 10.0]]).astype(np.float32)
+    tri = centres[:, None, :] + (rng.normal(size=(n, 3, 3)) * 0.05).astype(np.float32)
+    tri[100:2100] = tri[100]                                     # 2000 exact copies of one triangle
+    tri[3000:3500, 2] = tri[3000:3500, 1]                        # zero area (two equal vertices)
+    tri[4000:4200, 1] = tri[4000:4200, 0] + np.float32(1e-7)     # needles
+    tri[5000] = [[-60, -60, -3], [60, -60, -3], [0, 90, -3]]     # one huge triangle under everything
+    verts = np.zeros((n * 3, 8), np.float32)
+    verts[:, :3] = tri.reshape(-1, 3)
+    verts[:, 3:6] = [0, 0, 1]
+    verts[:, 6:8] = rng.random((n * 3, 2))
+    desc = cube_scene()
+    desc = SceneDesc(verts.view(VERTEX_DTYPE).reshape(-1), np.arange(n * 3, dtype=np.uint32), np.array([(0, 1, 0, n * 3)], MESH_DTYPE), None, desc.instances, desc.materials,
+                     desc.lights, desc.textures, desc.camera, desc.meta)
+    inst = glaze_amd.RayTraceInstance.new()
+    inst.set_bvh_builder(builder)
+    gpu, orc = glaze_amd.RayTraceScene.from_desc(inst, desc), OracleScene(desc)
+    i = gpu.info()
+    assert i.n_world_triangles == n and i.bvh_nodes >= n // 3
+    m = 30000
+    o = np.concatenate([rng.normal(size=(m // 2, 3)) * 0.5, rng.normal(size=(m // 2, 3)) * 0.1 + [40.0, -25.0, 10.0]]).astype(np.float32)
+    d = rng.normal(size=(m, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d[:50] = [0, 0, -1]                                           # straight down onto the big triangle
+    same, (t, _), _ = _check_closest(gpu, orc, o, d)
+    assert same.all(), "mismatching rays: %d" % (~same).sum()
+    assert np.isfinite(t[:50]).all() and 0.01 < np.isfinite(t).mean() < 1.0      # the straight-down rays all land on the big triangle
+    tmax = (rng.random(m) * 5.0).astype(np.float32)
+    assert np.array_equal(gpu.debug_trace_any(o, d, tmax), orc.trace_any(o, d, tmax))
+
+
 def test_oracle_bvh_against_brute_force(mattest):
     """The oracle's own BVH must agree with testing every triangle (checks the checker)."""
     _, _, orc = mattest
