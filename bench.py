@@ -26,6 +26,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# a rank with a small tile share renders with up to three concurrent launch chains (HIP streams) next to torch's and RCCL's own
+# streams; the runtime's default of four hardware queues would make some of them share one
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 
 def parse_args():
