@@ -170,6 +170,7 @@ PROTOTYPES = {
     "glz_debug_read_bvh": (C.c_int64, [_P, _P, C.c_int64, _P, C.c_int64]),
     "glz_host_launch_constants": (C.c_int, [C.c_uint64, C.c_uint32, _P, _P]),
     "glz_host_push_constants": (C.c_int, [_P, C.c_uint32, C.c_uint32, _P]),
+    "glz_host_chain_owner": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _P]),
     "glz_host_tile_owner": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, _P]),
 }
 

@@ -577,5 +577,17 @@ int glz_host_tile_owner(uint32_t width, uint32_t height, uint32_t world, uint16_
     for (uint32_t x = 0; x < width; ++x) owner_out[(size_t)y * width + x] = (uint16_t)(((y / 64) * tiles_x + x / 64) % world);
   return GLZ_OK;
 }
+int glz_host_chain_owner(uint32_t width, uint32_t height, uint32_t rank, uint32_t world, uint32_t chains, uint16_t* owner_out) {
+  if (world == 0 || rank >= world || chains > 16 || !width || !height) return fail(GLZ_E_ARG, "bad argument");
+  const uint32_t S = Renderer::chains_for(width, height, rank, world, chains);
+  const uint32_t tiles_x = (width + 63) / 64;
+  if (owner_out)
+    for (uint32_t y = 0; y < height; ++y)
+      for (uint32_t x = 0; x < width; ++x) {
+        const uint32_t t = (y / 64) * tiles_x + x / 64;
+        owner_out[(size_t)y * width + x] = t % world == rank ? (uint16_t)((t % (world * S)) / world) : (uint16_t)0xFFFF;
+      }
+  return (int)S;
+}
 
 }  // extern "C"

@@ -62,15 +62,16 @@ Renderer::~Renderer() {
 // a 1080p frame with 1 / 2 / 3 chains): 2.07 M pixels 1.29 / 1.36 / 1.42, 1.04 M 0.72 / 0.72 / 0.71, 518 k 0.43 / 0.38 / 0.38,
 // 259 k 0.26 / 0.25 / 0.23.  A launch over a million pixels is throughput bound and wants one chain; below that it is bound
 // by the latency of its longest rays and concurrent chains fill the machine.  Four chains were slower again (host enqueue).
-uint32_t Renderer::pick_chains() const {
-  const uint32_t tiles_x = (w_ + kTile - 1) / kTile, tiles_y = (h_ + kTile - 1) / kTile, tiles = tiles_x * tiles_y;
-  const uint32_t local_tiles = tiles > rank_ ? (tiles - rank_ + world_ - 1) / world_ : 0;
+uint32_t Renderer::chains_for(uint32_t w, uint32_t h, uint32_t rank, uint32_t world, uint32_t wanted) {
+  const uint32_t tiles_x = (w + kTile - 1) / kTile, tiles_y = (h + kTile - 1) / kTile, tiles = tiles_x * tiles_y;
+  const uint32_t local_tiles = tiles > rank ? (tiles - rank + world - 1) / world : 0;
   const uint64_t pixels = (uint64_t)local_tiles * kTile * kTile;
-  uint32_t want = chains_wanted_;
+  uint32_t want = wanted;
   if (want == 0) want = pixels >= 1000000u ? 1u : (pixels >= 400000u ? 2u : 3u);
   if (want > local_tiles) want = local_tiles;
   return want ? want : 1u;
 }
+uint32_t Renderer::pick_chains() const { return chains_for(w_, h_, rank_, world_, chains_wanted_); }
 
 bool Renderer::allocate(Error& err) {
   release_chains();

@@ -36,6 +36,7 @@ class Renderer {
   bool set_partition(uint32_t rank, uint32_t world, Error& err);
   bool set_chains(uint32_t n, Error& err);   // 0 = automatic
   uint32_t chains() const { return (uint32_t)chains_.size(); }
+  static uint32_t chains_for(uint32_t w, uint32_t h, uint32_t rank, uint32_t world, uint32_t wanted);
   bool export_device(int which, void* dev_rgba32f, Error& err);
   bool tonemap_device(const void* dev_result, uint8_t* out, Error& err);
   bool launch_constants(uint32_t launch, uint32_t* seed, float off[2]);

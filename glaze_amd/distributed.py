@@ -19,6 +19,13 @@ def tile_owner(width, height, world):
     return out
 
 
+def chain_owner(width, height, rank, world, chains=0):
+    """(number of launch chains, uint16 HxW map of the chain rendering each pixel of `rank`; 0xFFFF = another rank's pixel)."""
+    out = np.zeros((height, width), np.uint16)
+    n = abi.check(abi.lib().glz_host_chain_owner(width, height, rank, world, chains, out.ctypes.data))
+    return n, out
+
+
 def reduce_frame(frame, dst=0, group=None):
     """Sum-reduces a full-frame RGBA32F torch tensor (zero outside the caller's tiles) onto `dst`.
 

@@ -381,6 +381,9 @@ int glz_host_launch_constants(uint64_t seed, uint32_t launch, uint32_t* seed_out
 int glz_host_push_constants(const glz_camera* camera, uint32_t width, uint32_t height, float out32[32]);
 /* rank owning each pixel under glz_renderer_set_partition(., world): 64x64 tiles, tile t -> t % world */
 int glz_host_tile_owner(uint32_t width, uint32_t height, uint32_t world, uint16_t* owner_out);
+/* launch chains a renderer of this size and partition runs with (chains = 0: the automatic choice of glz_renderer_set_chains), and the
+ * chain rendering each pixel of rank `rank` (0xFFFF for pixels of other ranks): chain s of S owns tiles t with t % (world*S) == rank + s*world */
+int glz_host_chain_owner(uint32_t width, uint32_t height, uint32_t rank, uint32_t world, uint32_t chains, uint16_t* owner_out);
 
 #ifdef __cplusplus
 }

@@ -114,3 +114,29 @@ def test_scene_desc_round_trips_through_ctypes():
     d2 = d.copy()
     d2.materials[2].mtype = abi.MAT_GLASS
     assert d.materials[2].mtype == abi.MAT_LAMBERT
+
+
+def test_launch_chains_partition_a_ranks_tiles():
+    """glz_host_chain_owner: chain s of S renders the finer partition (rank + s * world, world * S); together the chains cover the
+    rank's tiles exactly once, and the automatic count follows the pixels per rank (1 chain from a million pixels, 2 from 400 k, else 3)."""
+    from glaze_amd.distributed import chain_owner, tile_owner
+    W, H = 1920, 1080
+    expect = {1: 1, 2: 1, 4: 2, 8: 3}
+    for world, chains in expect.items():
+        ranks = tile_owner(W, H, world)
+        seen = np.zeros((H, W), np.int32)
+        for rank in range(world):
+            n, own = chain_owner(W, H, rank, world)
+            assert n == chains, (world, n)
+            mine = own != 0xFFFF
+            assert np.array_equal(mine, ranks == rank)
+            assert set(np.unique(own[mine]).tolist()) == set(range(n))
+            # a chain's tiles are whole 64x64 tiles
+            t = own[::64, ::64]
+            assert np.array_equal(np.repeat(np.repeat(t, 64, 0), 64, 1)[:H, :W], own)
+            seen += mine
+        assert (seen == 1).all()
+    assert chain_owner(3840, 2160, 3, 8)[0] == 1                      # 4K over 8 GPUs: a million pixels per rank
+    assert chain_owner(W, H, 0, 8, chains=5)[0] == 5 and chain_owner(64, 64, 0, 1, chains=4)[0] == 1    # never more chains than tiles
+    n, own = chain_owner(200, 136, 1, 3, chains=2)                     # ragged edges
+    assert n == 2 and (own[tile_owner(200, 136, 3) == 1] != 0xFFFF).all()
