@@ -215,6 +215,16 @@ def test_triangle_soup_with_duplicates_and_degenerates(builder):
     assert np.array_equal(gpu.debug_trace_any(o, d, tmax), orc.trace_any(o, d, tmax))
 
 
+def test_transform_memory_layout_kat_on_device(instance):
+    """geometry/mesh.rs:110-119 (column-major Transform = row-major 3x4 Vulkan transform): world-space leaf of the flattened instance."""
+    from test_oracle_kats import LAYOUT_KAT_WORLD, _layout_kat_scene
+    gpu = glaze_amd.RayTraceScene.from_desc(instance, _layout_kat_scene())
+    _, tris = gpu.debug_bvh()
+    w = LAYOUT_KAT_WORLD
+    assert tris.shape[0] == 1
+    assert np.array_equal(tris[0, 0:3], w[0]) and np.array_equal(tris[0, 4:7], w[1] - w[0]) and np.array_equal(tris[0, 8:11], w[2] - w[0])
+
+
 def test_oracle_bvh_against_brute_force(mattest):
     """The oracle's own BVH must agree with testing every triangle (checks the checker)."""
     _, _, orc = mattest

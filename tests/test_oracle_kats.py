@@ -184,3 +184,35 @@ def test_cube_scene_counts_and_render_sanity():
     r0 = OracleRenderer(OracleScene(cube_scene(light=False)), 16, 16, threads=1)
     r0.draw(1)
     assert not r0.read_hdr().any()
+
+
+def _layout_kat_scene():
+    """One triangle under the matrix of the reference's `cgmath_vktransform_memory_layout` test (geometry/mesh.rs:110-119):
+    Matrix4::new takes COLUMNS, so the 16 stored floats 0,4,8,12, 1,5,9,13, ... are the row-major 3x4 Vulkan transform
+    [0,1,2,3; 4,5,6,7; 8,9,10,11]: world = M * (x, y, z, 1)."""
+    from glaze_amd.scene_desc import MESH_DTYPE, VERTEX_DTYPE, SceneDesc
+    from glaze_amd.scenes import cube_scene
+    base = cube_scene()
+    verts = np.zeros(3, VERTEX_DTYPE)
+    verts["vv"] = [[0, 0, 0], [1, 0, 0], [0, 1, 0]]
+    verts["vn"] = [0, 0, 1]
+    m = np.array([0.0, 4.0, 8.0, 12.0, 1.0, 5.0, 9.0, 13.0, 2.0, 6.0, 10.0, 14.0, 3.0, 7.0, 11.0, 15.0], np.float32)
+    return SceneDesc(verts, np.array([0, 1, 2], np.uint32), np.array([(0, 1, 0, 3)], MESH_DTYPE), m.reshape(1, 16), base.instances, base.materials,
+                     base.lights, base.textures, base.camera, base.meta)
+
+
+LAYOUT_KAT_WORLD = np.array([[3, 7, 11], [3 + 0, 7 + 4, 11 + 8], [3 + 1, 7 + 5, 11 + 9]], np.float32)     # rows of [0..11] applied to (x, y, z, 1)
+
+
+def test_transform_memory_layout_kat():
+    from oracle.pyoracle import OracleScene
+    sc = OracleScene(_layout_kat_scene())
+    w = LAYOUT_KAT_WORLD
+    centre = w.mean(0)
+    n = np.cross(w[1] - w[0], w[2] - w[0])
+    n /= np.linalg.norm(n)
+    o = (centre + 2.0 * n).astype(np.float32)[None]
+    t, tri, *_ = sc.trace_closest(o, (-n).astype(np.float32)[None])
+    assert tri[0] == 0 and abs(float(t[0]) - 2.0) < 1e-4            # the world triangle is where the row-major reading puts it
+    t, tri, *_ = sc.trace_closest(np.array([[0.25, 0.25, 1.0]], np.float32), np.array([[0, 0, -1]], np.float32))
+    assert not np.isfinite(t[0])                                    # and not where the object-space triangle was
