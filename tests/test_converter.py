@@ -89,6 +89,22 @@ def test_converted_cube_renders_like_the_builtin_cube(tmp_path):
     assert a == b and len(a) == 12
 
 
+def test_mipmaps_nonuniform(tmp_path):
+    """materials/texture.rs:329-360: checker_nu.jpg is 64 x 512 -> 10 levels, the width stays 1 once it got there."""
+    shutil = __import__("shutil")
+    for f in ("checker_nu.jpg",):
+        shutil.copy(os.path.join(GOLDEN, f), tmp_path / f)
+    _write(tmp_path / "nu.mtl", "newmtl m\nmap_Kd checker_nu.jpg\n")
+    _write(tmp_path / "nu.obj", "mtllib nu.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nusemtl m\nf 1 2 3\n")
+    out = str(tmp_path / "nu.glaze")
+    glaze_amd.convert_obj(str(tmp_path / "nu.obj"), out, gen_mipmaps=True)
+    levels = glaze_v1.parse(out).textures()[1]["levels"]
+    assert [l.shape[1] for l in levels] == [64, 32, 16, 8, 4, 2, 1, 1, 1, 1]
+    assert [l.shape[0] for l in levels] == [512, 256, 128, 64, 32, 16, 8, 4, 2, 1]
+    ref = np.asarray(Image.open(os.path.join(GOLDEN, "checker_nu.jpg")).convert("RGBA"))
+    assert np.abs(levels[0].astype(int) - ref.astype(int)).max() <= 4          # 4:2:0 baseline JPEG, vs libjpeg
+
+
 def _write(path, text):
     with open(path, "w") as f:
         f.write(text)

@@ -10,6 +10,7 @@ import ctypes
 
 import numpy as np
 import pytest
+from PIL import Image as PILImage
 
 import glaze_amd
 import glaze_amd.distributed
@@ -244,6 +245,26 @@ def test_refresh_binded_textures_keeps_accumulating(instance):
     o.set_depth(2)
     o.step(8)
     assert_parity(r, o, "fresh frame on the refreshed textures")
+
+
+def test_reference_raytracer_unit_tests(instance, tmp_path):
+    """lib/src/vulkan/raytracer.rs:1230-1290: load_raytrace (no scene), draw_outlive, save_to_disk, change_resolution."""
+    r = glaze_amd.RayTraceRenderer.new(instance, None, 2, 2)                   # RayTraceRenderer::new(instance, None, 2, 2)
+    img = r.draw(1)
+    assert img.shape == (2, 2, 4)
+    scene = glaze_amd.RayTraceScene.from_desc(instance, cube_scene())
+    r = glaze_amd.RayTraceRenderer.new(instance, scene, 2, 2)
+    ticks = []
+    img = r.draw(1, callback=lambda: ticks.append(1))                          # draw_outlive
+    assert img.shape == (2, 2, 4) and len(ticks) == 1
+    glaze_amd.save_image(tmp_path / "save.png", img)                           # save_to_disk
+    assert (tmp_path / "save.png").exists() and np.array_equal(np.asarray(PILImage.open(tmp_path / "save.png")), img)
+    r.change_resolution(4, 4)                                                  # change_resolution
+    img = r.draw(1)
+    assert img.shape == (4, 4, 4)
+    o = OracleRenderer(OracleScene(cube_scene()), 4, 4)
+    o.draw(1)
+    assert_parity(r, o, "cube 4x4 after change_resolution")
 
 
 def test_progressive_step_equals_draw(instance):
