@@ -37,8 +37,8 @@ hipError_t build_lbvh(hipStream_t st, const LbvhInputs& in, LbvhOutputs& out);
 hipError_t launch_shade_records(hipStream_t st, uint32_t n, const BvhTri* tris, const RTInstance* instances, const uint32_t* indices,
                                 const float4* vertices, const float4* derivatives, const uint32_t* xf_identity, float4* out);
 
-// Traversal stack entries each lane keeps in LDS (the deepest simultaneous stack of a near-first BVH2
-// traversal is bounded by the tree depth; what does not fit spills to a per-pixel HBM area).
+// Traversal stack entries each lane keeps in LDS (a near-first 4-wide traversal holds at most three entries per
+// level of the tree; what does not fit spills to a per-lane HBM area).
 constexpr int kTraversalLdsStack = 18;
 
 // ---- rendering ------------------------------------------------------------------------------------
@@ -56,7 +56,7 @@ struct PathState {
   uint32_t* queue_count;
   float4* cumulative;// accumulate_image (xyz = sum rgb, w = launches)
   float4* result;    // result_image (out32)
-  uint32_t* overflow;// traversal stack spill, `overflow_depth` words per pixel
+  uint32_t* overflow;// traversal stack spill, `overflow_depth` words per lane slot of the k_trace grid
   uint32_t overflow_depth;
 };
 

@@ -437,7 +437,7 @@ bool Scene::build_bvh(Error& err) {
     info.bounds_min[k] = out.bounds_lo[k];
     info.bounds_max[k] = out.bounds_hi[k];
   }
-  // traversal stack: kTraversalLdsStack levels live in LDS, the rest spills to a per-pixel HBM area
+  // traversal stack: kTraversalLdsStack levels live in LDS, the rest spills to a per-lane HBM area
   // (a 4-wide visit pushes up to three siblings, so the bound is 3 entries per level)
   const uint32_t stack_bound = 3u * out.depth + 1u;
   stack_overflow_depth = stack_bound > (uint32_t)kTraversalLdsStack ? stack_bound - kTraversalLdsStack + 1 : 1;

@@ -450,7 +450,7 @@ struct Scene {
   // acceleration
   std::vector<Tri> tris;                 // in BVH order
   std::vector<BNode> nodes;
-  // optional externally supplied BVH2 (the product's LBVH) for work counting
+  // optional externally supplied BVH4 (the product's tree) for work counting
   std::vector<uint32_t> ext_nodes;       // 16 words per node (BvhNode4 layout)
   std::vector<float> ext_tris;           // 12 floats per tri (BvhTri layout)
   float ext_grid[9] = {0};               // BvhGrid: lo[3], cell[3], inv_cell[3]
@@ -866,7 +866,7 @@ bool trace_any(const Scene& sc, V3 o, V3 d, float tmin, float tmax) {
   return false;
 }
 
-// Traversal of an externally supplied BVH2 in the product's node/leaf layout (32-byte nodes with 16-bit grid boxes,
+// Traversal of an externally supplied BVH4 in the product's node/leaf layout (64-byte nodes with 16-bit grid boxes,
 // DESIGN.md section 2), counting node and triangle visits: the "counted on the shared LBVH" figures of SURVEY 8(d).
 // Ordered (near child first, ties -> child0) traversal with pruning against the current best t -- exactly the visit
 // rule of the HIP tracer, so the instrumented kernels' counters must equal these counts.
