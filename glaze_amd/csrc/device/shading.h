@@ -86,17 +86,23 @@ struct vec4 {
 };
 // Texels are stored in 128-byte tiles (one cache line): 8 x 4 RGBA texels or 16 x 8 gray texels, tiles row-major.  The 2 x 2
 // footprint of a bilinear fetch then touches 1.4 lines on average instead of the 2.06 of a row-major image (k_shade sits
-// at the memory system's random-access rate and half of what it fetches is texels).
-GLZ_D vec4 fetch_texel(const DeviceScene& S, const TexDesc& t, int x, int y) {
-  const uint32_t format = t.format & 0xFFu, tiles_x = t.format >> 8;
-  const uint32_t ux = (uint32_t)x, uy = (uint32_t)y;
-  if (format == GLZ_TEX_GRAY) {
-    float g = (float)S.tex_pool[t.offset + ((uy >> 3) * tiles_x + (ux >> 4)) * 128u + (uy & 7u) * 16u + (ux & 15u)] / 255.0f;
-    return vec4{g, 0.0f, 0.0f, 1.0f};
-  }
-  const uchar4 p = *reinterpret_cast<const uchar4*>(S.tex_pool + t.offset + (((uy >> 2) * tiles_x + (ux >> 3)) * 32u + (uy & 3u) * 8u + (ux & 7u)) * 4u);
-  if (format == GLZ_TEX_RGBA_SRGB) return vec4{S.srgb_lut[p.x], S.srgb_lut[p.y], S.srgb_lut[p.z], (float)p.w / 255.0f};
-  return vec4{(float)p.x / 255.0f, (float)p.y / 255.0f, (float)p.z / 255.0f, (float)p.w / 255.0f};
+// at the memory system's random-access rate; with every texel fetch removed it ran 30 % faster).  A 1 x 1 texture (the
+// default roughness / metalness / opacity maps of most materials) carries its texel in the descriptor: no texel load at all.
+constexpr uint32_t kTexInline = 0x80u;   // TexDesc.format flag: `offset` holds the single RGBA8 / gray texel
+GLZ_D vec4 decode_texel(const DeviceScene& S, uint32_t format, uint32_t bits) {
+  if (format == GLZ_TEX_GRAY) return vec4{(float)(bits & 0xFFu) / 255.0f, 0.0f, 0.0f, 1.0f};
+  const uint32_t r = bits & 0xFFu, g = (bits >> 8) & 0xFFu, b = (bits >> 16) & 0xFFu, a = bits >> 24;
+  if (format == GLZ_TEX_RGBA_SRGB) return vec4{S.srgb_lut[r], S.srgb_lut[g], S.srgb_lut[b], (float)a / 255.0f};
+  return vec4{(float)r / 255.0f, (float)g / 255.0f, (float)b / 255.0f, (float)a / 255.0f};
+}
+GLZ_D uint32_t texel_address(const TexDesc& t, uint32_t format, uint32_t ux, uint32_t uy) {
+  const uint32_t tiles_x = t.format >> 8;
+  if (format == GLZ_TEX_GRAY) return t.offset + ((uy >> 3) * tiles_x + (ux >> 4)) * 128u + (uy & 7u) * 16u + (ux & 15u);
+  return t.offset + (((uy >> 2) * tiles_x + (ux >> 3)) * 32u + (uy & 3u) * 8u + (ux & 7u)) * 4u;
+}
+GLZ_D uint32_t load_texel(const DeviceScene& S, const TexDesc& t, uint32_t format, uint32_t ux, uint32_t uy) {
+  const uint32_t addr = texel_address(t, format, ux, uy);
+  return format == GLZ_TEX_GRAY ? (uint32_t)S.tex_pool[addr] : *reinterpret_cast<const uint32_t*>(S.tex_pool + addr);
 }
 GLZ_D int wrap_coord(int i, int n) {
   int r = i % n;
@@ -104,20 +110,32 @@ GLZ_D int wrap_coord(int i, int n) {
 }
 GLZ_D float lerp_ab(float a, float b, float t) { return a + (b - a) * t; }
 GLZ_D vec4 texture2d(const DeviceScene& S, uint32_t id, float u, float v) {
-  // one dwordx4 for the whole descriptor (the shade kernel is bound by vector-memory transactions)
+  // one dwordx4 for the whole descriptor
   const uint4 td = reinterpret_cast<const uint4*>(S.tex_desc)[id];
   const TexDesc t{td.x, td.y, td.z, td.w};
+  const uint32_t format = t.format & 0x7Fu;
   float fu = u * (float)t.width - 0.5f, fv = v * (float)t.height - 0.5f;
   float iu = glz_floorf(fu), iv = glz_floorf(fv);
   float ax = fu - iu, ay = fv - iv;
-  int x0 = wrap_coord((int)iu, (int)t.width), y0 = wrap_coord((int)iv, (int)t.height);
-  int x1 = wrap_coord((int)iu + 1, (int)t.width), y1 = wrap_coord((int)iv + 1, (int)t.height);
-  vec4 a = fetch_texel(S, t, x0, y0), b = a, c = a, d = a;
-  if (t.width != 1u || t.height != 1u) {   // the default 1 x 1 textures (roughness / metalness / opacity of most materials): one load; same arithmetic below
-    b = fetch_texel(S, t, x1, y0);
-    c = fetch_texel(S, t, x0, y1);
-    d = fetch_texel(S, t, x1, y1);
+  uint32_t ta, tb, tc, tdx;
+  if (t.format & kTexInline) {
+    ta = tb = tc = tdx = t.offset;   // same arithmetic below, so NaN coordinates still give what four equal texels give
+  } else {
+    const int x0 = wrap_coord((int)iu, (int)t.width), y0 = wrap_coord((int)iv, (int)t.height);
+    const int x1 = wrap_coord((int)iu + 1, (int)t.width), y1 = wrap_coord((int)iv + 1, (int)t.height);
+    if (format != GLZ_TEX_GRAY && x1 == x0 + 1 && (x0 & 7) != 7) {
+      // the two texels of a row are neighbours inside one tile row: one 8-byte load per row
+      const uint2 r0 = *reinterpret_cast<const uint2*>(S.tex_pool + texel_address(t, format, (uint32_t)x0, (uint32_t)y0));
+      const uint2 r1 = *reinterpret_cast<const uint2*>(S.tex_pool + texel_address(t, format, (uint32_t)x0, (uint32_t)y1));
+      ta = r0.x; tb = r0.y; tc = r1.x; tdx = r1.y;
+    } else {
+      ta = load_texel(S, t, format, (uint32_t)x0, (uint32_t)y0);
+      tb = load_texel(S, t, format, (uint32_t)x1, (uint32_t)y0);
+      tc = load_texel(S, t, format, (uint32_t)x0, (uint32_t)y1);
+      tdx = load_texel(S, t, format, (uint32_t)x1, (uint32_t)y1);
+    }
   }
+  const vec4 a = decode_texel(S, format, ta), b = decode_texel(S, format, tb), c = decode_texel(S, format, tc), d = decode_texel(S, format, tdx);
   vec4 r;
   r.x = lerp_ab(lerp_ab(a.x, b.x, ax), lerp_ab(c.x, d.x, ax), ay);
   r.y = lerp_ab(lerp_ab(a.y, b.y, ax), lerp_ab(c.y, d.y, ax), ay);

@@ -89,7 +89,7 @@ enum : uint32_t {
 struct TexDesc {
   uint32_t offset;    // byte offset of level 0 in the pool
   uint32_t width, height;
-  uint32_t format;    // bits 0..7: GLZ_TEX_GRAY / RGBA_SRGB / RGBA_NORM; bits 8..31: tiles per row of the tiled layout (shading.h fetch_texel)
+  uint32_t format;    // bits 0..6: GLZ_TEX_GRAY / RGBA_SRGB / RGBA_NORM; bit 7: 1x1 texture whose texel is in `offset`; bits 8..31: tiles per row (shading.h)
 };
 
 // Object<->world matrices of one transform: column-major mat4 (as uploaded by the reference,

@@ -228,6 +228,13 @@ bool Scene::upload_textures(Error& err) {
       err.msg = "texture pool larger than 4 GiB";
       return false;
     }
+    if (t.info.width == 1 && t.info.height == 1) {
+      // the texel travels in the descriptor (device/shading.h kTexInline): materials' default maps cost no texel load
+      uint32_t bits = 0;
+      memcpy(&bits, t.level0.data(), bpp);
+      desc[i] = TexDesc{bits, 1u, 1u, t.info.format | 0x80u | (1u << 8)};
+      continue;
+    }
     desc[i] = TexDesc{(uint32_t)pool.size(), t.info.width, t.info.height, t.info.format | (tiles_x << 8)};
     const size_t base = pool.size();
     pool.resize(base + tiled_bytes, 0);
