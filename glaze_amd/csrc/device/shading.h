@@ -298,6 +298,11 @@ struct SurfacePoint {
   vec2 uv;
   Frame frame;
   MatScalars mat;
+  // texture values of this hit, fetched once (fetch_material_textures) for both the NEE evaluation and the BSDF sample --
+  // the reference's value and sample_value callables each call texture() for themselves, with the same uv and result
+  vec3 tint;           // texture(diffuse).rgb * diffuse_mul      (Lambert, Uber)
+  float rough_tex;     // texture(roughness).r                     (Metal, Frosted, Uber)
+  float metal_tex;     // texture(metalness).r                     (Uber)
 };
 
 GLZ_D void dielectric_etas(const MatScalars& m, float woz, float& etai, float& etat) {
@@ -339,10 +344,18 @@ GLZ_D float oren_nayar(float roughness, vec3 wo, vec3 wi) {
   return kInvPi * (A + B * maxcos * sinalpha * tanbeta);
 }
 
-GLZ_D vec3 diffuse_tint(const DeviceScene& S, const SurfacePoint& P) {
-  vec3 tx = texture_rgb(S, P.mat.diffuse, P.uv);
-  return tx * mk3(P.mat.diffuse_mul[0], P.mat.diffuse_mul[1], P.mat.diffuse_mul[2]);
+GLZ_D void fetch_material_textures(const DeviceScene& S, SurfacePoint& P) {
+  const uint32_t kind = P.mat.bsdf_index;
+  P.tint = mk3(0.0f, 0.0f, 0.0f);
+  P.rough_tex = P.metal_tex = 0.0f;
+  if (kind == kBsdfLambert || kind == kBsdfUber) {
+    const vec3 tx = texture_rgb(S, P.mat.diffuse, P.uv);
+    P.tint = tx * mk3(P.mat.diffuse_mul[0], P.mat.diffuse_mul[1], P.mat.diffuse_mul[2]);
+  }
+  if (kind == kBsdfMetal || kind == kBsdfFrosted || kind == kBsdfUber) P.rough_tex = texture_r(S, P.mat.roughness, P.uv);
+  if (kind == kBsdfUber) P.metal_tex = texture_r(S, P.mat.metalness, P.uv);
 }
+GLZ_D vec3 diffuse_tint(const DeviceScene&, const SurfacePoint& P) { return P.tint; }
 
 // BSDF evaluation for next-event estimation; returns the pdf (0 = no contribution).
 GLZ_D float bsdf_eval(const DeviceScene& S, const SurfacePoint& P, vec3 wiW, float xi, Spec& value) {
@@ -359,7 +372,7 @@ GLZ_D float bsdf_eval(const DeviceScene& S, const SurfacePoint& P, vec3 wiW, flo
     vec3 wh = normalize3(wo + wi);
     if (!(wo.z * wi.z > 0.0f)) return 0.0f;
     Spec F = fresnel_conductor(dot3(wi, wh), m.spectra->metal_ior, m.spectra->metal_fresnel);
-    vec2 a = anisotropic_alpha(texture_r(S, m.roughness, P.uv) * m.roughness_mul, m.anisotropy);
+    vec2 a = anisotropic_alpha(P.rough_tex * m.roughness_mul, m.anisotropy);
     float d = ggx_d(wh, a);
     float g = ggx_g(wo, wi, a);
     float term = d * g / (4.0f * fabsf(wo.z) * fabsf(wi.z));
@@ -368,7 +381,7 @@ GLZ_D float bsdf_eval(const DeviceScene& S, const SurfacePoint& P, vec3 wiW, flo
     return check_nan(pdf);
   }
   if (kind == kBsdfFrosted) {   // mat_frosted_value.rcall:19-66
-    vec2 a = anisotropic_alpha(texture_r(S, m.roughness, P.uv) * m.roughness_mul, m.anisotropy);
+    vec2 a = anisotropic_alpha(P.rough_tex * m.roughness_mul, m.anisotropy);
     float etai, etat;
     dielectric_etas(m, wo.z, etai, etat);
     float eta = etai / etat;
@@ -392,12 +405,12 @@ GLZ_D float bsdf_eval(const DeviceScene& S, const SurfacePoint& P, vec3 wiW, flo
     return check_nan(pdf);
   }
   // Uber: mat_uber_value.rcall:20-77
-  float roughness = texture_r(S, m.roughness, P.uv) * m.roughness_mul;
+  float roughness = P.rough_tex * m.roughness_mul;
   float same = gl_step(0.0f, wo.z * wi.z);
   if (xi < 0.5f) {
     vec2 a = anisotropic_alpha(roughness * m.roughness_mul, m.anisotropy);   // roughness_mul applied twice (Q5)
     vec3 wh = normalize3(wo + wi);
-    float metalness = texture_r(S, m.metalness, P.uv) * m.metalness_mul;
+    float metalness = P.metal_tex * m.metalness_mul;
     float etai, etat;
     dielectric_etas(m, wo.z, etai, etat);
     Lobe L = reflect_lobe(wo, wi, wh, a);
@@ -461,7 +474,7 @@ GLZ_D float bsdf_sample(const DeviceScene& S, const SurfacePoint& P, vec3 xi, Sp
     return pdf;
   }
   if (kind == kBsdfMetal) {   // mat_metal_sample_value.rcall:21-49
-    vec2 a = anisotropic_alpha(texture_r(S, m.roughness, P.uv) * m.roughness_mul, m.anisotropy);
+    vec2 a = anisotropic_alpha(P.rough_tex * m.roughness_mul, m.anisotropy);
     vec3 wh = normalize3(ggx_sample_wh(wo, vec2{xi.x, xi.y}, a));
     vec3 wi = -normalize3(gl_reflect(wo, wh));
     if (!(wo.z * wi.z > 0.0f)) return 0.0f;
@@ -476,7 +489,7 @@ GLZ_D float bsdf_sample(const DeviceScene& S, const SurfacePoint& P, vec3 xi, Sp
     return check_nan(pdf);
   }
   if (kind == kBsdfFrosted) {   // mat_frosted_sample_value.rcall:21-71
-    vec2 a = anisotropic_alpha(texture_r(S, m.roughness, P.uv) * m.roughness_mul, m.anisotropy);
+    vec2 a = anisotropic_alpha(P.rough_tex * m.roughness_mul, m.anisotropy);
     vec3 wh = normalize3(ggx_sample_wh(wo, vec2{xi.x, xi.y}, a));
     float etai, etat;
     dielectric_etas(m, wo.z, etai, etat);
@@ -505,13 +518,13 @@ GLZ_D float bsdf_sample(const DeviceScene& S, const SurfacePoint& P, vec3 xi, Sp
     return pdf;
   }
   // Uber: mat_uber_sample_value.rcall:21-86
-  float roughness = texture_r(S, m.roughness, P.uv) * m.roughness_mul;
+  float roughness = P.rough_tex * m.roughness_mul;
   vec3 wi;
   float pdf;
   if (xi.z < 0.5f) {
     vec2 a = anisotropic_alpha(roughness * m.roughness_mul, m.anisotropy);
     vec3 wh = normalize3(ggx_sample_wh(wo, vec2{xi.x, xi.y}, a));
-    float metalness = texture_r(S, m.metalness, P.uv) * m.metalness_mul;
+    float metalness = P.metal_tex * m.metalness_mul;
     float etai, etat;
     dielectric_etas(m, wo.z, etai, etat);
     wi = -normalize3(gl_reflect(wo, wh));

@@ -682,6 +682,7 @@ __global__ void __launch_bounds__(kBlock, GLZ_SHADE_WAVES) k_shade(const LaunchA
   P.uv = uv;
   P.frame = make_frame(dpdu, ns);
   P.mat = mat;
+  fetch_material_textures(S, P);
   float spec_flag;
   if (mat.is_specular == 0) {
     // direct_light(), :84-117
