@@ -103,14 +103,15 @@ __device__ __forceinline__ bool ray_triangle(const BvhTri& tr, vec3 o, vec3 d, f
 }
 
 // raytrace_hit.rahit:24-39 -- candidates on non-opaque geometry are dropped when opacity.r < 0.5
-__device__ __forceinline__ bool alpha_test(const DeviceScene& S, const BvhTri& tr, float u, float v) {
-  const RTInstance in = S.instances[tr.instance];
-  const uint32_t prim = tr.prim_flags & 0x7FFFFFFFu;
-  const uint32_t* ix = S.indices + (in.index_offset / 3u + prim) * 3u;
-  const float4 a = S.vertices[2u * ix[0] + 1u], b = S.vertices[2u * ix[1] + 1u], c = S.vertices[2u * ix[2] + 1u];
+__device__ __forceinline__ bool alpha_test(const DeviceScene& S, uint32_t leaf, float u, float v) {
+  // uv of the three vertices and the material id come from the leaf's 128-byte shading record (the same values the
+  // reference's any-hit shader reads through instance -> indices -> vertices)
+  const float4* rec = S.shade_tris + 8u * (size_t)leaf;
+  const float4 a = rec[1], b = rec[3], c = rec[5];
+  const uint32_t material_id = __float_as_uint(rec[6].w);
   const float w = 1.0f - u - v;
   const float tu = (a.z * w + b.z * u) + c.z * v, tv = (a.w * w + b.w * u) + c.w * v;
-  return !(texture_r(S, S.materials[in.material_id].opacity, vec2{tu, tv}) < 0.5f);
+  return !(texture_r(S, S.materials[material_id].opacity, vec2{tu, tv}) < 0.5f);
 }
 
 struct HitRecord {
@@ -388,7 +389,7 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
       bool finished = false;
       if (ray_triangle(tr, o, d, tmin, t, u, v) && t < tmax) {
         const bool better = best.leaf == kNone ? true : (t < best.t || (t == best.t && tr.world_id < best_id));
-        if (better && (!(tr.prim_flags >> 31) || alpha_test(S, tr, u, v))) {
+        if (better && (!(tr.prim_flags >> 31) || alpha_test(S, leaf, u, v))) {
           best = HitRecord{t, u, v, leaf};
           best_id = tr.world_id;
           finished = ANY;
