@@ -103,7 +103,8 @@ struct TransformPair {
 // on a global grid spanning the scene bounds (lo rounded down, hi rounded up, so the boxes only grow); the ray is mapped
 // into grid units once.  The tree is the binary LBVH / PLOC hierarchy with every odd level folded into its parent: half
 // the dependent fetches per ray, which is what bounds a launch once a GPU holds few rays per wave.
-//   child k (k = 0..3):  w[3k] = lo.x | lo.y << 16   w[3k+1] = lo.z | hi.x << 16   w[3k+2] = hi.y | hi.z << 16
+//   child k (k = 0..3):  w[3k] = lo.x | hi.x << 16   w[3k+1] = lo.y | hi.y << 16   w[3k+2] = lo.z | hi.z << 16
+//   (one word per axis, so that a per-ray byte permutation puts the plane the ray meets first into the low half)
 //   w[12 + k] = link of child k: index of an inner node (>= 0), ~index of a leaf in bvh_tris (< 0), or kBvhEmptyChild
 //   for an unused slot (the tracer skips it by its link; its box words are lo = 65535, hi = 0).
 struct alignas(16) BvhNode4 {

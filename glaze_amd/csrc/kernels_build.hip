@@ -541,9 +541,7 @@ __global__ void __launch_bounds__(256) k_emit_nodes4(int n, const int2* __restri
   for (int k = 0; k < 4; ++k) {
     const int ch = kids[k];
     if (k >= nk) {
-      nd.w[3 * k] = 65535u | (65535u << 16);   // inverted box: never entered
-      nd.w[3 * k + 1] = 65535u;
-      nd.w[3 * k + 2] = 0u;
+      nd.w[3 * k] = nd.w[3 * k + 1] = nd.w[3 * k + 2] = 65535u;   // lo = 65535, hi = 0 (the tracer skips the slot by its link)
       nd.w[12 + k] = (uint32_t)kBvhEmptyChild;
       continue;
     }
@@ -551,9 +549,9 @@ __global__ void __launch_bounds__(256) k_emit_nodes4(int n, const int2* __restri
     const float4 l = node_lo[slot], h = node_hi[slot];
     const uint32_t q[6] = {quant_lo(l.x, g.lo[0], g.inv_cell[0]), quant_lo(l.y, g.lo[1], g.inv_cell[1]), quant_lo(l.z, g.lo[2], g.inv_cell[2]),
                            quant_hi(h.x, g.lo[0], g.inv_cell[0]), quant_hi(h.y, g.lo[1], g.inv_cell[1]), quant_hi(h.z, g.lo[2], g.inv_cell[2])};
-    nd.w[3 * k] = q[0] | (q[1] << 16);
-    nd.w[3 * k + 1] = q[2] | (q[3] << 16);
-    nd.w[3 * k + 2] = q[4] | (q[5] << 16);
+    nd.w[3 * k] = q[0] | (q[3] << 16);       // one word per axis: lo | hi << 16
+    nd.w[3 * k + 1] = q[1] | (q[4] << 16);
+    nd.w[3 * k + 2] = q[2] | (q[5] << 16);
     nd.w[12 + k] = (uint32_t)(ch >= 0 ? (int)pos[new_id[ch]] : ch);   // inner: its number among the BVH4 nodes; leaf: ~leaf
   }
   nodes[pos[new_id[i]]] = nd;
@@ -764,14 +762,10 @@ hipError_t build_lbvh(hipStream_t st, const LbvhInputs& in, LbvhOutputs& out) {
     GLZ_TRY(hipGetLastError());
     BvhNode4 nd{};
     for (int k = 0; k < 4; ++k) {
-      nd.w[3 * k] = 65535u | (65535u << 16);
-      nd.w[3 * k + 1] = 65535u;
-      nd.w[3 * k + 2] = 0u;
+      nd.w[3 * k] = nd.w[3 * k + 1] = nd.w[3 * k + 2] = 65535u;
       nd.w[12 + k] = (uint32_t)kBvhEmptyChild;
     }
-    nd.w[0] = 0u;
-    nd.w[1] = 0u | (65535u << 16);
-    nd.w[2] = 65535u | (65535u << 16);
+    nd.w[0] = nd.w[1] = nd.w[2] = 0u | (65535u << 16);   // lo 0, hi 65535 on every axis
     nd.w[12] = ~0u;   // leaf 0
     GLZ_TRY(hipMalloc(&out.nodes, sizeof(BvhNode4)));
     out.n_nodes = 1;

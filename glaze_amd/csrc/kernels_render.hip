@@ -54,22 +54,24 @@ __device__ __forceinline__ PixelId pixel_of(const TileMap& m, uint32_t lid) {
 // intersector ([ext]).  Ties on t are broken by the smaller world triangle id so that the result
 // does not depend on traversal order.
 // ---------------------------------------------------------------------------------------------
-// Slab test on a quantised box.  It only prunes: boxes are padded by 1/16 cell when they are quantised and the exit distance
-// is scaled by 1 + 4 ulp, so it never rejects a box whose triangle the exact Moeller-Trumbore test below accepts.
-// The ray is mapped into grid units once (ig = cell / d, cg = -(origin_grid * ig)), each plane distance is then one
-// fma(q, ig, cg); the (lo, hi) planes of an axis go through one packed v_pk_fma_f32.  The tracers are VALU-issue bound
-// (profiles/r01_pmc.json: SQ_INSTS_VALU * 4 cycles / 1024 SIMDs is 80 % of the kernel time), so instructions per node
-// visit are what counts.  ig is kept finite (grid_inv_dir), so no plane distance is ever NaN: a ray parallel to a slab
-// gets +-1e30-scale distances whose signs still say on which side of each plane the origin lies.
+// Slab test on a quantised box.  It only prunes: boxes are padded by 1/16 cell when they are quantised, which covers the
+// rounding of the plane distances (< 0.01 cell), so it never rejects a box whose triangle the exact Moeller-Trumbore test
+// below accepts.  The ray is mapped into grid units once (ig = cell / d, cg = -(origin_grid * ig)); a node word holds
+// lo | hi << 16 of one axis, and a per-ray byte permutation (sel: identity for ig >= 0, halves swapped for ig < 0) moves the
+// plane the ray meets first into the low half -- no min / max per axis.  Both plane distances of an axis then come from one
+// packed v_pk_fma_f32.  The tracers are VALU-issue bound, so instructions per node visit are what counts.  ig is kept
+// finite (grid_inv_dir), so no plane distance is ever NaN: a ray parallel to a slab gets +-1e30-scale distances whose signs
+// still say on which side of each plane the origin lies.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float box_entry(float lox, float loy, float loz, float hix, float hiy, float hiz, vec3 ig, vec3 cg, float tmin,
-                                           float tmax) {
-  const f32x2 tx = __builtin_elementwise_fma(f32x2{lox, hix}, f32x2{ig.x, ig.x}, f32x2{cg.x, cg.x});
-  const f32x2 ty = __builtin_elementwise_fma(f32x2{loy, hiy}, f32x2{ig.y, ig.y}, f32x2{cg.y, cg.y});
-  const f32x2 tz = __builtin_elementwise_fma(f32x2{loz, hiz}, f32x2{ig.z, ig.z}, f32x2{cg.z, cg.z});
-  const float t0 = fmaxf(fmaxf(fminf(tx.x, tx.y), fminf(ty.x, ty.y)), fmaxf(fminf(tz.x, tz.y), tmin));
-  const float t1 = fminf(fminf(fmaxf(tx.x, tx.y), fmaxf(ty.x, ty.y)), fmaxf(tz.x, tz.y)) * 1.0000005f;
-  return t0 <= fminf(t1, tmax) ? t0 : INFINITY;
+struct SlabSel { uint32_t x, y, z; };   // v_perm_b32 selectors per axis
+__device__ __forceinline__ float box_entry(uint32_t wx, uint32_t wy, uint32_t wz, SlabSel sel, vec3 ig, vec3 cg, float tmin, float tmax) {
+  const uint32_t px = __builtin_amdgcn_perm(wx, wx, sel.x), py = __builtin_amdgcn_perm(wy, wy, sel.y), pz = __builtin_amdgcn_perm(wz, wz, sel.z);
+  const f32x2 tx = __builtin_elementwise_fma(f32x2{(float)(px & 0xFFFFu), (float)(px >> 16)}, f32x2{ig.x, ig.x}, f32x2{cg.x, cg.x});
+  const f32x2 ty = __builtin_elementwise_fma(f32x2{(float)(py & 0xFFFFu), (float)(py >> 16)}, f32x2{ig.y, ig.y}, f32x2{cg.y, cg.y});
+  const f32x2 tz = __builtin_elementwise_fma(f32x2{(float)(pz & 0xFFFFu), (float)(pz >> 16)}, f32x2{ig.z, ig.z}, f32x2{cg.z, cg.z});
+  const float t0 = fmaxf(fmaxf(tx.x, ty.x), fmaxf(tz.x, tmin));
+  const float t1 = fminf(fminf(tx.y, ty.y), fminf(tz.y, tmax));
+  return t0 <= t1 ? t0 : INFINITY;
 }
 
 // 1 / d clamped to +-1e30: zero (or denormal) direction components must not produce inf - inf in the fma above --
@@ -235,6 +237,7 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
   uint32_t ray = 0;                                         // ray index (open) or owner lane (helper)
   vec3 o = mk3(0.0f, 0.0f, 0.0f), d = mk3(0.0f, 0.0f, 1.0f);
   vec3 ig = mk3(0.0f, 0.0f, 0.0f), cg = mk3(0.0f, 0.0f, 0.0f);   // grid-space ray: plane q is crossed at t = q * ig + cg
+  SlabSel sel{0x03020100u, 0x03020100u, 0x03020100u};          // near-plane selectors, from the signs of ig
   float tmin = 0.0f, tmax = 0.0f;
   HitRecord best{0.0f, 0.0f, 0.0f, kNone};
   uint32_t best_id = kNone;
@@ -261,6 +264,7 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
             const vec3 og = mk3((o.x - grid.lo[0]) * grid.inv_cell[0], (o.y - grid.lo[1]) * grid.inv_cell[1], (o.z - grid.lo[2]) * grid.inv_cell[2]);
             ig = mk3(grid_inv_dir(d.x) * grid.cell[0], grid_inv_dir(d.y) * grid.cell[1], grid_inv_dir(d.z) * grid.cell[2]);
             cg = mk3(-(og.x * ig.x), -(og.y * ig.y), -(og.z * ig.z));
+            sel = SlabSel{ig.x < 0.0f ? 0x01000302u : 0x03020100u, ig.y < 0.0f ? 0x01000302u : 0x03020100u, ig.z < 0.0f ? 0x01000302u : 0x03020100u};
             st.sp = 0;
             if (SHARE) aux_sb[lane] = 0;
             cur = 0;
@@ -315,6 +319,7 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
           d.x = __shfl(d.x, donor); d.y = __shfl(d.y, donor); d.z = __shfl(d.z, donor);
           ig.x = __shfl(ig.x, donor); ig.y = __shfl(ig.y, donor); ig.z = __shfl(ig.z, donor);
           cg.x = __shfl(cg.x, donor); cg.y = __shfl(cg.y, donor); cg.z = __shfl(cg.z, donor);
+          sel = SlabSel{ig.x < 0.0f ? 0x01000302u : 0x03020100u, ig.y < 0.0f ? 0x01000302u : 0x03020100u, ig.z < 0.0f ? 0x01000302u : 0x03020100u};
           tmin = __shfl(tmin, donor); tmax = __shfl(tmax, donor);
           best.t = __shfl(best.t, donor); best.u = __shfl(best.u, donor); best.v = __shfl(best.v, donor);
           best.leaf = (uint32_t)__shfl((int)best.leaf, donor);
@@ -342,14 +347,10 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
         const uint4* np = reinterpret_cast<const uint4*>(nodes + cur);
         const uint4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
         if (COUNT) tally.nodes += 1;
-        const float e0 = box_entry((float)(w0.x & 0xFFFFu), (float)(w0.x >> 16), (float)(w0.y & 0xFFFFu), (float)(w0.y >> 16), (float)(w0.z & 0xFFFFu),
-                                   (float)(w0.z >> 16), ig, cg, tmin, best.t);
-        const float e1 = box_entry((float)(w0.w & 0xFFFFu), (float)(w0.w >> 16), (float)(w1.x & 0xFFFFu), (float)(w1.x >> 16), (float)(w1.y & 0xFFFFu),
-                                   (float)(w1.y >> 16), ig, cg, tmin, best.t);
-        const float e2 = box_entry((float)(w1.z & 0xFFFFu), (float)(w1.z >> 16), (float)(w1.w & 0xFFFFu), (float)(w1.w >> 16), (float)(w2.x & 0xFFFFu),
-                                   (float)(w2.x >> 16), ig, cg, tmin, best.t);
-        const float e3 = box_entry((float)(w2.y & 0xFFFFu), (float)(w2.y >> 16), (float)(w2.z & 0xFFFFu), (float)(w2.z >> 16), (float)(w2.w & 0xFFFFu),
-                                   (float)(w2.w >> 16), ig, cg, tmin, best.t);
+        const float e0 = box_entry(w0.x, w0.y, w0.z, sel, ig, cg, tmin, best.t);
+        const float e1 = box_entry(w0.w, w1.x, w1.y, sel, ig, cg, tmin, best.t);
+        const float e2 = box_entry(w1.z, w1.w, w2.x, sel, ig, cg, tmin, best.t);
+        const float e3 = box_entry(w2.y, w2.z, w2.w, sel, ig, cg, tmin, best.t);
         // sort keys: entry distance (a positive float, so its bits order like the value) with the child index in the two
         // lowest bits -- nearer first, ties (to 2 ulp) by child index; a missed child sorts last
         uint32_t k0 = child_key(e0, w3.x, 0u), k1 = child_key(e1, w3.y, 1u), k2 = child_key(e2, w3.z, 2u), k3 = child_key(e3, w3.w, 3u);

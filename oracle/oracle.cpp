@@ -879,7 +879,7 @@ inline float box_entry_q(float lox, float loy, float loz, float hix, float hiy, 
   const float ay = fmaf(loy, ig.y, cg.y), by = fmaf(hiy, ig.y, cg.y);
   const float az = fmaf(loz, ig.z, cg.z), bz = fmaf(hiz, ig.z, cg.z);
   const float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin));
-  const float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)) * 1.0000005f;
+  const float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));   // (the kernel picks the near / far plane by the sign of ig: same values)
   return t0 <= fminf(t1, tmax) ? t0 : INF;
 }
 void ext_trace(const Scene& sc, V3 o, V3 d, float tmin, float tmax, bool any, Counters& c, float& t_out, uint32_t& id_out) {
@@ -904,8 +904,9 @@ void ext_trace(const Scene& sc, V3 o, V3 d, float tmin, float tmax, bool any, Co
       c.nodes++;
       uint32_t key[4];
       for (uint32_t k = 0; k < 4; ++k) {
-        const float e = box_entry_q((float)(w[3 * k] & 0xFFFFu), (float)(w[3 * k] >> 16), (float)(w[3 * k + 1] & 0xFFFFu), (float)(w[3 * k + 1] >> 16),
-                                    (float)(w[3 * k + 2] & 0xFFFFu), (float)(w[3 * k + 2] >> 16), ig, cg, tmin, best);
+        // one word per axis: lo | hi << 16
+        const float e = box_entry_q((float)(w[3 * k] & 0xFFFFu), (float)(w[3 * k + 1] & 0xFFFFu), (float)(w[3 * k + 2] & 0xFFFFu), (float)(w[3 * k] >> 16),
+                                    (float)(w[3 * k + 1] >> 16), (float)(w[3 * k + 2] >> 16), ig, cg, tmin, best);
         key[k] = (e < INF && w[12 + k] != 0x7FFFFFFFu) ? ((fbits(e) & 0xFFFFFFFCu) | k) : 0xFFFFFFFFu;   // child_key, kernels_render.hip
       }
       std::sort(key, key + 4);

@@ -87,8 +87,8 @@ def test_bvh_structure(builder, mattest, mattest_ploc):
 
     u = lambda x, hi: ((x >> 16) if hi else (x & 0xFFFF)).astype(np.int64)
     w = nodes[:, :12].reshape(n4, 4, 3)
-    lo = np.stack([u(w[..., 0], 0), u(w[..., 0], 1), u(w[..., 1], 0)], -1)     # (n4, 4, 3) grid units
-    hi = np.stack([u(w[..., 1], 1), u(w[..., 2], 0), u(w[..., 2], 1)], -1)
+    lo = np.stack([u(w[..., 0], 0), u(w[..., 1], 0), u(w[..., 2], 0)], -1)     # (n4, 4, 3) grid units; one word per axis: lo | hi << 16
+    hi = np.stack([u(w[..., 0], 1), u(w[..., 1], 1), u(w[..., 2], 1)], -1)
     assert (lo[~empty] <= hi[~empty]).all()
     # the box stored for an inner child contains every box stored in that child (quantisation only grows boxes, and
     # the same world box is quantised to the same grid cell everywhere)
