@@ -64,14 +64,18 @@ __device__ __forceinline__ PixelId pixel_of(const TileMap& m, uint32_t lid) {
 // still say on which side of each plane the origin lies.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 struct SlabSel { uint32_t x, y, z; };   // v_perm_b32 selectors per axis
-__device__ __forceinline__ float box_entry(uint32_t wx, uint32_t wy, uint32_t wz, SlabSel sel, vec3 ig, vec3 cg, float tmin, float tmax) {
+// returns the sort key of the child: entry distance (a positive float, so its bits order like the value) with the child index in
+// the two lowest bits -- nearer first, ties (to 2 ulp) by child index; 0xFFFFFFFF for a missed child or an unused slot
+// (the slab test is symmetric in lo / hi, so an unused slot cannot be excluded through its box: its link says so)
+__device__ __forceinline__ uint32_t box_key(uint32_t wx, uint32_t wy, uint32_t wz, uint32_t link, uint32_t k, SlabSel sel, vec3 ig, vec3 cg,
+                                            float tmin, float tmax) {
   const uint32_t px = __builtin_amdgcn_perm(wx, wx, sel.x), py = __builtin_amdgcn_perm(wy, wy, sel.y), pz = __builtin_amdgcn_perm(wz, wz, sel.z);
   const f32x2 tx = __builtin_elementwise_fma(f32x2{(float)(px & 0xFFFFu), (float)(px >> 16)}, f32x2{ig.x, ig.x}, f32x2{cg.x, cg.x});
   const f32x2 ty = __builtin_elementwise_fma(f32x2{(float)(py & 0xFFFFu), (float)(py >> 16)}, f32x2{ig.y, ig.y}, f32x2{cg.y, cg.y});
   const f32x2 tz = __builtin_elementwise_fma(f32x2{(float)(pz & 0xFFFFu), (float)(pz >> 16)}, f32x2{ig.z, ig.z}, f32x2{cg.z, cg.z});
   const float t0 = fmaxf(fmaxf(tx.x, ty.x), fmaxf(tz.x, tmin));
   const float t1 = fminf(fminf(tx.y, ty.y), fminf(tz.y, tmax));
-  return t0 <= t1 ? t0 : INFINITY;
+  return (t0 <= t1 && link != (uint32_t)kBvhEmptyChild) ? ((__float_as_uint(t0) & 0xFFFFFFFCu) | k) : 0xFFFFFFFFu;
 }
 
 // 1 / d clamped to +-1e30: zero (or denormal) direction components must not produce inf - inf in the fma above --
@@ -193,10 +197,6 @@ constexpr int kRefill = GLZ_REFILL;
 constexpr int kLeafQuorum = GLZ_LEAF_QUORUM;
 constexpr int kAuxPerWave = 3 * 64;
 
-__device__ __forceinline__ uint32_t child_key(float entry, uint32_t link, uint32_t k) {
-  // (the slab test is symmetric in lo / hi, so an unused child slot cannot be excluded through its box: its link says so)
-  return (entry < INFINITY && link != (uint32_t)kBvhEmptyChild) ? ((__float_as_uint(entry) & 0xFFFFFFFCu) | k) : 0xFFFFFFFFu;
-}
 __device__ __forceinline__ void sort2(uint32_t& a, uint32_t& b) {
   const uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
   a = lo;
@@ -347,13 +347,8 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
         const uint4* np = reinterpret_cast<const uint4*>(nodes + cur);
         const uint4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
         if (COUNT) tally.nodes += 1;
-        const float e0 = box_entry(w0.x, w0.y, w0.z, sel, ig, cg, tmin, best.t);
-        const float e1 = box_entry(w0.w, w1.x, w1.y, sel, ig, cg, tmin, best.t);
-        const float e2 = box_entry(w1.z, w1.w, w2.x, sel, ig, cg, tmin, best.t);
-        const float e3 = box_entry(w2.y, w2.z, w2.w, sel, ig, cg, tmin, best.t);
-        // sort keys: entry distance (a positive float, so its bits order like the value) with the child index in the two
-        // lowest bits -- nearer first, ties (to 2 ulp) by child index; a missed child sorts last
-        uint32_t k0 = child_key(e0, w3.x, 0u), k1 = child_key(e1, w3.y, 1u), k2 = child_key(e2, w3.z, 2u), k3 = child_key(e3, w3.w, 3u);
+        uint32_t k0 = box_key(w0.x, w0.y, w0.z, w3.x, 0u, sel, ig, cg, tmin, best.t), k1 = box_key(w0.w, w1.x, w1.y, w3.y, 1u, sel, ig, cg, tmin, best.t);
+        uint32_t k2 = box_key(w1.z, w1.w, w2.x, w3.z, 2u, sel, ig, cg, tmin, best.t), k3 = box_key(w2.y, w2.z, w2.w, w3.w, 3u, sel, ig, cg, tmin, best.t);
         sort2(k0, k1); sort2(k2, k3); sort2(k0, k2); sort2(k1, k3); sort2(k1, k2);
         if (k0 == 0xFFFFFFFFu) {
           cur = SHARE ? st.pop_live() : (st.sp ? st.pop() : kRayDone);
