@@ -487,14 +487,63 @@ __device__ __forceinline__ uint32_t quant_hi(float x, float lo, float inv_cell) 
   return (uint32_t)fminf(fmaxf(g, 0.0f), 65535.0f);
 }
 
-// ---- 4-wide collapse.  A binary node at even depth becomes a BVH4 node whose children are its grandchildren (or its
-// children where those are leaves); nodes at odd depth are folded away.  flags[dfs id] = 1 for the nodes that stay, so
-// an exclusive scan over the depth-first order numbers the BVH4 nodes depth-first as well.
-__global__ void __launch_bounds__(256) k_node_parity(int n, const int* __restrict__ node_depth, const int* __restrict__ new_id,
-                                                     unsigned long long* __restrict__ flags) {
+// ---- 4-wide collapse.  A BVH4 node starts from the two children of a binary node and keeps opening the inner child
+// with the LARGEST surface area (the one a ray is most likely to enter anyway) until it has four children or only leaves
+// are left; an opened child's two children take its place, so the children stay in the left-to-right order of the binary
+// hierarchy (the order that breaks distance ties in the tracer).  The binary nodes that head a BVH4 node are found top
+// down, one launch per level of the binary hierarchy (a node marks its final children, which lie 1-3 levels below).
+// flags[dfs id] = 1 for those heads, so an exclusive scan over the depth-first order numbers the BVH4 nodes depth-first.
+// (Folding every odd level instead -- children = grandchildren -- left 3.0 children per node; this leaves 3.4+.)
+struct Kids4 {
+  int link[4];
+  int n;
+};
+__device__ __forceinline__ float box_area(const float4* __restrict__ node_lo, const float4* __restrict__ node_hi, int slot) {
+  const float4 l = node_lo[slot], h = node_hi[slot];
+  const float dx = h.x - l.x, dy = h.y - l.y, dz = h.z - l.z;
+  return 2.0f * (dx * dy + dy * dz + dz * dx);
+}
+__device__ __forceinline__ Kids4 collapse4(int node, const int2* __restrict__ children, const float4* __restrict__ node_lo,
+                                           const float4* __restrict__ node_hi) {
+  Kids4 k;
+  const int2 c = children[node];
+  k.link[0] = c.x; k.link[1] = c.y; k.link[2] = k.link[3] = kBvhEmptyChild;
+  k.n = 2;
+  float area[4] = {c.x >= 0 ? box_area(node_lo, node_hi, c.x) : -1.0f, c.y >= 0 ? box_area(node_lo, node_hi, c.y) : -1.0f, -1.0f, -1.0f};
+  while (k.n < 4) {
+    int j = -1;
+    float best = -1.0f;
+    for (int i = 0; i < 4; ++i)
+      if (i < k.n && k.link[i] >= 0 && area[i] > best) { best = area[i]; j = i; }   // ties: the leftmost
+    if (j < 0) break;   // only leaves left
+    const int2 g = children[k.link[j]];
+    for (int i = 3; i > 0; --i)
+      if (i > j + 1) { k.link[i] = k.link[i - 1]; area[i] = area[i - 1]; }
+    k.link[j] = g.x; area[j] = g.x >= 0 ? box_area(node_lo, node_hi, g.x) : -1.0f;
+    k.link[j + 1] = g.y; area[j + 1] = g.y >= 0 ? box_area(node_lo, node_hi, g.y) : -1.0f;
+    ++k.n;
+  }
+  return k;
+}
+// head[t] = level of the BVH4 node headed by binary node t (root = 1), 0 = folded into an ancestor
+__global__ void __launch_bounds__(256) k_mark_heads(int n, int level, const int* __restrict__ node_depth, const int2* __restrict__ children,
+                                                    const float4* __restrict__ node_lo, const float4* __restrict__ node_hi,
+                                                    int* head, int* __restrict__ max_level) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n - 1 || node_depth[t] != level) return;
+  const int mine = t == 0 ? 1 : head[t];
+  if (t == 0) head[0] = 1;
+  if (mine == 0) return;
+  const Kids4 k = collapse4(t, children, node_lo, node_hi);
+  for (int i = 0; i < 4; ++i)
+    if (i < k.n && k.link[i] >= 0) head[k.link[i]] = mine + 1;
+  atomicMax(max_level, mine);
+}
+__global__ void __launch_bounds__(256) k_head_flags(int n, const int* __restrict__ head, const int* __restrict__ new_id,
+                                                    unsigned long long* __restrict__ flags) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n - 1) return;
-  flags[new_id[t]] = (node_depth[t] & 1) ? 0ull : 1ull;
+  flags[new_id[t]] = head[t] ? 1ull : 0ull;
 }
 
 __global__ void __launch_bounds__(256) k_emit_nodes4(int n, const int2* __restrict__ children, const float4* __restrict__ node_lo,
@@ -513,20 +562,10 @@ __global__ void __launch_bounds__(256) k_emit_nodes4(int n, const int2* __restri
     if (c.y < 0) acc += area(node_lo[(n - 1) + ~c.y], node_hi[(n - 1) + ~c.y]);
     atomicAdd(sah, acc);   // reported only (the sum's order is not fixed)
   }
-  if (!flags[new_id[i]]) return;   // odd depth: folded into the parent
-  // children in a fixed order: expansions of child 0 first, then of child 1 (the order breaks distance ties in the tracer)
-  int kids[4] = {kBvhEmptyChild, kBvhEmptyChild, kBvhEmptyChild, kBvhEmptyChild};
-  int nk = 0;
-  for (int side = 0; side < 2; ++side) {
-    const int ch = side ? c.y : c.x;
-    if (ch < 0) {
-      kids[nk++] = ch;
-    } else {
-      const int2 g = children[ch];
-      kids[nk++] = g.x;
-      kids[nk++] = g.y;
-    }
-  }
+  if (!flags[new_id[i]]) return;   // folded into an ancestor
+  const Kids4 kk = collapse4(i, children, node_lo, node_hi);
+  const int nk = kk.n;
+  const int* kids = kk.link;
   const BvhGrid g = *grid;
   BvhNode4 nd;
   for (int k = 0; k < 4; ++k) {
@@ -730,8 +769,15 @@ hipError_t build_lbvh(hipStream_t st, const LbvhInputs& in, LbvhOutputs& out) {
     GLZ_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_grid_params, dim3(1), dim3(64), 0, st, node_lo, node_hi, grid);
     GLZ_TRY(hipGetLastError());
-    // 4-wide collapse: number the even-depth nodes in depth-first order, then emit them
-    hipLaunchKernelGGL(k_node_parity, grd, blk, 0, st, (int)n, node_depth, new_id, flags);
+    // 4-wide collapse: find the heads of the BVH4 nodes top down, number them in depth-first order, then emit them
+    int* head = counts;   // k_dfs_ids was the last reader of the subtree sizes
+    GLZ_TRY(hipMemsetAsync(head, 0, sizeof(int) * n, st));
+    GLZ_TRY(hipMemsetAsync(scalars + 7, 0, sizeof(int), st));
+    for (int level = 0; level <= inner_depth; ++level) {
+      hipLaunchKernelGGL(k_mark_heads, grd, blk, 0, st, (int)n, level, node_depth, children, node_lo, node_hi, head, scalars + 7);
+      GLZ_TRY(hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_head_flags, grd, blk, 0, st, (int)n, head, new_id, flags);
     GLZ_TRY(hipGetLastError());
     GLZ_TRY(scan_exclusive(st, (int)n - 1, flags, pos, scan_tmp));
     hipLaunchKernelGGL(k_scan_total, dim3(1), dim3(64), 0, st, (int)n - 1, flags, pos, scan_total);
@@ -769,7 +815,7 @@ hipError_t build_lbvh(hipStream_t st, const LbvhInputs& in, LbvhOutputs& out) {
     GLZ_TRY(hipStreamSynchronize(st));
     out.depth = 1;
   } else {
-    out.depth = ((uint32_t)host_scalars[6] + 1u) / 2u;   // levels of 4-wide nodes above the deepest leaf
+    out.depth = (uint32_t)host_scalars[7];   // levels of 4-wide nodes above the deepest leaf
     const float dx = root_hi.x - root_lo.x, dy = root_hi.y - root_lo.y, dz = root_hi.z - root_lo.z;
     const float ra = 2.0f * (dx * dy + dy * dz + dz * dx);
     out.sah = ra > 0.0f ? host_sah / ra : 0.0f;
