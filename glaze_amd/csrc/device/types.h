@@ -101,7 +101,7 @@ struct TransformPair {
 
 // BVH4 node, 64 bytes = four dwordx4 fetches per visit.  Up to four child boxes, each quantised to 16 bits per coordinate
 // on a global grid spanning the scene bounds (lo rounded down, hi rounded up, so the boxes only grow); the ray is mapped
-// into grid units once.  The tree is the binary LBVH / PLOC hierarchy with every odd level folded into its parent: half
+// into grid units once.  The tree is the binary LBVH / PLOC hierarchy collapsed four wide (kernels_build.hip, collapse4): half
 // the dependent fetches per ray, which is what bounds a launch once a GPU holds few rays per wave.
 //   child k (k = 0..3):  w[3k] = lo.x | hi.x << 16   w[3k+1] = lo.y | hi.y << 16   w[3k+2] = lo.z | hi.z << 16
 //   (one word per axis, so that a per-ray byte permutation puts the plane the ray meets first into the low half)
