@@ -90,11 +90,11 @@ struct LaunchArgs {
   uint32_t do_closest, do_shadow;
   uint32_t shade_set;        // which of the two shadow-queue counter sets this launch's k_shade fills (the other one is drained)
   float shadow_exposure;     // exposure of the launch that queued the shadow rays (update_result uses it)
-  uint32_t grid_share;       // host side: concurrent chains sharing the GPU (k_trace's persistent grid is 1 / grid_share of the resident blocks)
 };
 constexpr uint32_t kQueueSetWords = 8 * 32;   // 8 shard counters, 128 bytes apart
 
-hipError_t launch_trace(hipStream_t st, const LaunchArgs& a);
+uint32_t trace_grid_blocks(uint32_t n_local_pixels, bool counting);   // persistent grid of k_trace (device must be current)
+hipError_t launch_trace(hipStream_t st, const LaunchArgs& a, uint32_t blocks);
 hipError_t launch_shade(hipStream_t st, const LaunchArgs& a);
 // scatter the tile-major cumulative / result images into full-frame row-major RGBA32F buffers
 hipError_t launch_export(hipStream_t st, const TileMap& map, const float4* tiled, float4* frame, bool zero_first);

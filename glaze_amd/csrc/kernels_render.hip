@@ -942,7 +942,7 @@ static inline dim3 grid_for(uint32_t n) { return dim3((n + kBlock - 1) / kBlock)
 // most 8), and never more waves than there are 64-ray groups.  A block that had to wait for a slot would serialise
 // behind a whole persistent block (cdna_hip_programming.md section 1: size persistent grids by residency).
 template <class Kernel>
-static dim3 persistent_grid(Kernel kernel, uint32_t n_rays, uint32_t share = 1) {
+static dim3 persistent_grid(Kernel kernel, uint32_t n_rays) {
   int dev = 0, cus = 256, per_cu = 8;
   if (hipGetDevice(&dev) == hipSuccess) {
     hipDeviceProp_t prop;
@@ -951,30 +951,24 @@ static dim3 persistent_grid(Kernel kernel, uint32_t n_rays, uint32_t share = 1) 
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0) != hipSuccess || per_cu < 1) per_cu = 4;
   per_cu = std::min(per_cu, 8);
   // (splitting the resident blocks between concurrent chains measured slower: a chain's blocks fill in as another's retire)
-  (void)share;
   const uint32_t resident = (uint32_t)cus * (uint32_t)per_cu;
   return dim3(std::max<uint32_t>(1u, std::min<uint32_t>((n_rays + kBlock - 1) / kBlock, resident)));
 }
-template <class Kernel>
-static dim3 cached_grid(Kernel kernel, uint32_t n_rays, uint32_t share, uint32_t& cache_n, uint32_t& cache_share, dim3& cache_grid) {
-  if (cache_n != n_rays || cache_share != share || cache_grid.x == 0) {
-    cache_grid = persistent_grid(kernel, n_rays, share);
-    cache_n = n_rays;
-    cache_share = share;
-  }
-  return cache_grid;
+
+// Blocks of k_trace's persistent grid for a chain of n_local_pixels (the renderer asks once per allocation and passes the
+// answer to every launch_trace; needs the device current).  Up to one closest-hit and one shadow ray per pixel: a small
+// tile share still gets a wave per 64-ray group of either kind (fewer, longer-lived waves -- 2 to 4 groups per wave --
+// measured 25-50 % slower for small shares: spread as wide as possible).
+uint32_t trace_grid_blocks(uint32_t n_local_pixels, bool counting) {
+  const uint32_t rays = 2u * n_local_pixels;
+  return counting ? persistent_grid(k_trace<true>, rays).x : persistent_grid(k_trace<false>, rays).x;
 }
 
-hipError_t launch_trace(hipStream_t st, const LaunchArgs& a) {
+hipError_t launch_trace(hipStream_t st, const LaunchArgs& a, uint32_t blocks) {
   if (a.map.n_local_pixels == 0) return hipSuccess;
-  static uint32_t n0 = 0, n1 = 0, s0 = 0, s1 = 0;
-  static dim3 g0, g1;
-  // up to one closest-hit and one shadow ray per pixel: a small tile share still gets a wave per 64-ray group of either kind;
-  // concurrent chains split the resident blocks between them so that all their persistent grids are on the machine at once
-  // (fewer, longer-lived waves -- 2 to 4 groups per wave -- measured 25-50 % slower for small shares: spread as wide as possible)
-  const uint32_t rays = 2u * a.map.n_local_pixels;
-  if (a.counters) hipLaunchKernelGGL(k_trace<true>, cached_grid(k_trace<true>, rays, a.grid_share, n1, s1, g1), dim3(kBlock), 0, st, a);
-  else hipLaunchKernelGGL(k_trace<false>, cached_grid(k_trace<false>, rays, a.grid_share, n0, s0, g0), dim3(kBlock), 0, st, a);
+  if (blocks == 0 || (uint64_t)blocks * kBlock > 2ull * a.map.n_local_pixels + kBlock) return hipErrorInvalidValue;   // the spill area holds one slot per lane of this bound
+  if (a.counters) hipLaunchKernelGGL(k_trace<true>, dim3(blocks), dim3(kBlock), 0, st, a);
+  else hipLaunchKernelGGL(k_trace<false>, dim3(blocks), dim3(kBlock), 0, st, a);
   return hipGetLastError();
 }
 hipError_t launch_shade(hipStream_t st, const LaunchArgs& a) {

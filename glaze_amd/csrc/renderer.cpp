@@ -104,6 +104,8 @@ bool Renderer::allocate(Error& err) {
       if (!hip_ok(b->alloc((b == &c->sh_o || b == &c->sh_d || b == &c->contrib) ? n_queue : n), "alloc path state", err)) return false;
     if (!hip_ok(c->overflow.alloc((2 * n + 512) * od), "alloc traversal spill", err)) return false;   // one slot per lane of the largest k_trace grid
     if (!hip_ok(c->queue_count.alloc(2 * kQueueSetWords), "alloc queue counters", err)) return false;
+    c->grid = trace_grid_blocks(m.n_local_pixels, false);
+    c->grid_counting = trace_grid_blocks(m.n_local_pixels, true);
     chains_.push_back(std::move(c));
   }
   if (!hip_ok(frame_tmp_.alloc((size_t)w_ * h_), "alloc frame", err)) return false;
@@ -159,7 +161,6 @@ void Renderer::fill_args(const Chain& c, LaunchArgs& a) const {
   a.do_closest = a.do_shadow = 0;
   a.shade_set = c.pending_set ^ 1u;
   a.shadow_exposure = c.pending_exposure;
-  a.grid_share = (uint32_t)chains_.size();
 }
 
 void Renderer::resolve_events(Chain& c) {
@@ -211,7 +212,7 @@ bool Renderer::flush_shadows(Chain& c, Error& err) {
     ev.flush = true;
     (void)hipEventRecord(ev.e[0], c.stream);
   }
-  if (!hip_ok(launch_trace(c.stream, a), "k_trace (shadow pass)", err)) return false;
+  if (!hip_ok(launch_trace(c.stream, a, counting_ ? c.grid_counting : c.grid), "k_trace (shadow pass)", err)) return false;
   if (profile_kernels_) {
     (void)hipEventRecord(ev.e[1], c.stream);
     c.pending_events.push_back(ev);
@@ -256,7 +257,7 @@ bool Renderer::one_launch(Error& err) {
       ev.flush = false;
       (void)hipEventRecord(ev.e[0], st);
     }
-    if (!hip_ok(launch_trace(st, a), "k_trace", err)) return false;
+    if (!hip_ok(launch_trace(st, a, counting_ ? c.grid_counting : c.grid), "k_trace", err)) return false;
     if (timed) (void)hipEventRecord(ev.e[1], st);
     if (!hip_ok(launch_shade(st, a), "k_shade", err)) return false;
     if (timed) {

@@ -86,6 +86,7 @@ class Renderer {
     bool own_stream = false;
     DeviceBuffer<float4> ray_o, ray_d, imp[4], hit, sh_o, sh_d, contrib, cumulative, result;
     DeviceBuffer<uint32_t> overflow, queue_count;
+    uint32_t grid = 0, grid_counting = 0;   // blocks of k_trace's persistent grid (plain / instrumented kernel)
     // shadow rays queued by the last launch's k_shade and not traced yet (they ride in the next launch's k_trace, or in
     // a stand-alone pass as soon as anything looks at the images: flush_shadows)
     bool shadow_pending = false;
