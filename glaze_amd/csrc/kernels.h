@@ -91,6 +91,7 @@ struct LaunchArgs {
   uint32_t shade_set;        // which of the two shadow-queue counter sets this launch's k_shade fills (the other one is drained)
   float shadow_exposure;     // exposure of the launch that queued the shadow rays (update_result uses it)
 };
+constexpr uint32_t kTraceBlock = 256;          // threads per block of the render kernels (4 waves)
 constexpr uint32_t kQueueSetWords = 8 * 32;   // 8 shard counters, 128 bytes apart
 
 uint32_t trace_grid_blocks(uint32_t n_local_pixels, bool counting);   // persistent grid of k_trace (device must be current)

@@ -22,7 +22,7 @@
 namespace glz {
 using namespace dev;
 
-constexpr int kBlock = 256;       // 4 waves
+constexpr int kBlock = (int)kTraceBlock;   // 4 waves
 constexpr int kLdsStack = kTraversalLdsStack;   // stack entries kept in LDS per lane (18 KB per block -> 8 blocks per CU); deeper levels spill to HBM
 constexpr uint32_t kQueueShards = 8;     // shadow-ray sub-queues (see queue_slot)
 constexpr uint32_t kCounterStride = 32;  // uint32 words between shard counters (128 bytes)

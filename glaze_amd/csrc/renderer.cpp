@@ -1,6 +1,7 @@
 // RayTraceRenderer on HIP -- see renderer.h.  Reference: lib/src/vulkan/raytracer.rs.
 #include "renderer.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 
@@ -102,10 +103,11 @@ bool Renderer::allocate(Error& err) {
                                     &c->cumulative, &c->result};
     for (auto* b : bufs)
       if (!hip_ok(b->alloc((b == &c->sh_o || b == &c->sh_d || b == &c->contrib) ? n_queue : n), "alloc path state", err)) return false;
-    if (!hip_ok(c->overflow.alloc((2 * n + 512) * od), "alloc traversal spill", err)) return false;   // one slot per lane of the largest k_trace grid
-    if (!hip_ok(c->queue_count.alloc(2 * kQueueSetWords), "alloc queue counters", err)) return false;
     c->grid = trace_grid_blocks(m.n_local_pixels, false);
     c->grid_counting = trace_grid_blocks(m.n_local_pixels, true);
+    // traversal spill: one slot of `od` entries per lane of the larger of the two persistent grids
+    if (!hip_ok(c->overflow.alloc((size_t)std::max(c->grid, c->grid_counting) * kTraceBlock * od), "alloc traversal spill", err)) return false;
+    if (!hip_ok(c->queue_count.alloc(2 * kQueueSetWords), "alloc queue counters", err)) return false;
     chains_.push_back(std::move(c));
   }
   if (!hip_ok(frame_tmp_.alloc((size_t)w_ * h_), "alloc frame", err)) return false;
