@@ -9,7 +9,18 @@ namespace glz {
 
 namespace {
 constexpr uint32_t kTile = 64;
-constexpr uint64_t kEventStride = 8;   // with several chains: every 8th launch is timed (see one_launch)
+// Kernel boundaries are timed with HIP events on one launch of every kEventStride, at a pseudo-random place inside each
+// group of kEventStride consecutive launches, and counted kEventStride times (three event records per launch cost 1-3 % of
+// a 1080p launch and 10 % of a small one).  A fixed place would beat against the path depth: launch i traces bounce
+// i mod depth of most pixels and the bounces differ in cost.
+constexpr uint64_t kEventStride = 4;
+inline bool timed_launch(uint64_t i /* 1-based */) {
+  const uint64_t group = (i - 1) / kEventStride;
+  uint32_t x = (uint32_t)group * 747796405u + 2891336453u;   // PCG-RXS-M-XS-32
+  x = ((x >> ((x >> 28) + 4u)) ^ x) * 277803737u;
+  x ^= x >> 22;
+  return (i - 1) % kEventStride == x % kEventStride;
+}
 }
 
 Renderer* Renderer::create(Instance* inst, Scene* scene, uint32_t w, uint32_t h, Error& err) {
@@ -173,7 +184,7 @@ void Renderer::resolve_events(Chain& c) {
       c.flush_ms += a;
     } else {
       (void)hipEventElapsedTime(&b, s.e[1], s.e[2]);
-      const double weight = chains_.size() == 1 ? 1.0 : (double)kEventStride;
+      const double weight = (double)kEventStride;
       c.trace_ms += a * weight;
       c.shade_ms += b * weight;
     }
@@ -249,10 +260,7 @@ bool Renderer::one_launch(Error& err) {
     a.frame = fd;
     a.do_closest = 1;
     a.do_shadow = c.shadow_pending ? 1u : 0u;   // the previous launch's shadow rays ride in this launch's traversal kernel
-    // Kernel boundaries are timed with HIP events on every launch of a single chain; with several chains the three
-    // records per chain and launch cost 10 % of a small launch, so every kEventStride-th launch is timed and counted
-    // kEventStride times (get_stats reports the estimate).
-    const bool timed = profile_kernels_ && (chains_.size() == 1 || launches_ % kEventStride == 0);
+    const bool timed = profile_kernels_ && timed_launch(launches_);
     EventSet ev{};
     if (timed) {
       if (!acquire_events(c, ev, err)) return false;
