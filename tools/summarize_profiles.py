@@ -35,12 +35,18 @@ def short(name):
     return None
 
 
-stats = glob.glob(os.path.join(ROOT, "gpurun_out", "prof_trace", "*", "*_kernel_stats.csv"))
+def newest(pattern):
+    """gpurun merges every call's files into gpurun_out/ and never deletes: only the latest run of a directory counts"""
+    files = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return files[-1:]
+
+
+stats = newest(os.path.join(ROOT, "gpurun_out", "prof_trace", "*", "*_kernel_stats.csv"))
 if stats:
     shutil.copy(stats[0], os.path.join(out_dir, tag + "_kernel_stats.csv"))
 summary = defaultdict(dict)
 for counter, sub in (("FETCH_SIZE", "prof_fetch"), ("WRITE_SIZE", "prof_write")):
-    files = glob.glob(os.path.join(ROOT, "gpurun_out", sub, "*", "*_counter_collection.csv"))
+    files = newest(os.path.join(ROOT, "gpurun_out", sub, "*", "*_counter_collection.csv"))
     acc = defaultdict(list)
     dur = defaultdict(list)
     for f in files:
