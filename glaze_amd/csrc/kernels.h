@@ -19,9 +19,12 @@ struct LbvhInputs {
   const TransformPair* transforms;
   const RTMaterial* materials;
   uint32_t n_world;
-  int builder;                 // kBvhBuilderLbvh (default) or kBvhBuilderPloc
+  int builder;                 // kBvhBuilder*
 };
-constexpr int kBvhBuilderLbvh = 0, kBvhBuilderPloc = 1;   // = GLZ_BVH_LBVH / GLZ_BVH_PLOC
+constexpr int kBvhBuilderLbvh = 0, kBvhBuilderPloc = 1, kBvhBuilderSah = 2, kBvhBuilderAuto = 3;   // = GLZ_BVH_LBVH / _PLOC / _SAH / _AUTO
+constexpr uint32_t kBvhAutoSahLimit = 2000000;   // GLZ_BVH_AUTO: SAH up to this many triangles (build <= 0.35 s), LBVH above
+// host side of the SAH builder (bvh_sah.cpp): binary hierarchy over n leaf boxes -> children / parent arrays
+void build_sah_host(uint32_t n, const float4* lo, const float4* hi, int2* children, int* parent);
 struct LbvhOutputs {
   BvhNode4* nodes;  // n_nodes entries, hipMalloc'ed by build_lbvh: the caller owns them afterwards
   uint32_t n_nodes;

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <vector>
 
 #include "device/math.h"
 #include "device/types.h"
@@ -643,6 +644,7 @@ hipError_t launch_shade_records(hipStream_t st, uint32_t n, const BvhTri* tris, 
 
 hipError_t build_lbvh(hipStream_t st, const LbvhInputs& in, LbvhOutputs& out) {
   const uint32_t n = in.n_world;
+  const int builder = in.builder == kBvhBuilderAuto ? (n <= kBvhAutoSahLimit ? kBvhBuilderSah : kBvhBuilderLbvh) : in.builder;
   out.depth = 0;
   out.sah = 0.0f;
   out.rounds = 0;
@@ -717,9 +719,21 @@ hipError_t build_lbvh(hipStream_t st, const LbvhInputs& in, LbvhOutputs& out) {
   hipLaunchKernelGGL(k_gather_leaves, grd, blk, 0, st, vals, n, tris_unsorted, lo, hi, out.tris, node_lo, node_hi);
   GLZ_TRY(hipGetLastError());
   if (n >= 2) {
-    if (in.builder == kBvhBuilderLbvh) {
+    if (builder == kBvhBuilderLbvh) {
       hipLaunchKernelGGL(k_hierarchy, grd, blk, 0, st, keys, (int)n, children, parent);
       GLZ_TRY(hipGetLastError());
+    } else if (builder == kBvhBuilderSah) {
+      // binned SAH on the host over the leaf boxes (node_lo / node_hi slots (n-1)+i, leaf order), boxes fitted below
+      std::vector<float4> h_lo(n), h_hi(n);
+      std::vector<int2> h_children(n);
+      std::vector<int> h_parent(2 * (size_t)n);
+      GLZ_TRY(hipMemcpyAsync(h_lo.data(), node_lo + (n - 1), sizeof(float4) * n, hipMemcpyDeviceToHost, st));
+      GLZ_TRY(hipMemcpyAsync(h_hi.data(), node_hi + (n - 1), sizeof(float4) * n, hipMemcpyDeviceToHost, st));
+      GLZ_TRY(hipStreamSynchronize(st));
+      build_sah_host(n, h_lo.data(), h_hi.data(), h_children.data(), h_parent.data());
+      GLZ_TRY(hipMemcpyAsync(children, h_children.data(), sizeof(int2) * (n - 1), hipMemcpyHostToDevice, st));
+      GLZ_TRY(hipMemcpyAsync(parent, h_parent.data(), sizeof(int) * (2 * (size_t)n - 1), hipMemcpyHostToDevice, st));
+      GLZ_TRY(hipStreamSynchronize(st));
     } else {
       GLZ_TRY(hipMalloc(&refs_a, sizeof(int) * n));
       GLZ_TRY(hipMalloc(&refs_b, sizeof(int) * n));
@@ -758,7 +772,7 @@ hipError_t build_lbvh(hipStream_t st, const LbvhInputs& in, LbvhOutputs& out) {
     GLZ_TRY(hipMemcpyAsync(&inner_depth, scalars + 7, sizeof(int), hipMemcpyDeviceToHost, st));
     GLZ_TRY(hipStreamSynchronize(st));
     for (int level = inner_depth; level >= 0; --level) {
-      if (in.builder == kBvhBuilderLbvh)
+      if (builder != kBvhBuilderPloc)
         hipLaunchKernelGGL(k_level_up<true>, grd, blk, 0, st, (int)n, level, node_depth, children, node_lo, node_hi, counts);
       else
         hipLaunchKernelGGL(k_level_up<false>, grd, blk, 0, st, (int)n, level, node_depth, children, node_lo, node_hi, counts);

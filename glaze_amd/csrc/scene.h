@@ -17,7 +17,7 @@ struct Instance {
   int device = -1;
   hipStream_t stream = nullptr;
   std::string arch;
-  int bvh_builder = 0;   // kBvhBuilderLbvh / kBvhBuilderPloc for scenes created afterwards (glz_instance_set_bvh_builder)
+  int bvh_builder = 3;   // kBvhBuilder* for scenes created afterwards (glz_instance_set_bvh_builder); 3 = kBvhBuilderAuto
   ~Instance();
   static Instance* create(int hip_device, Error& err);
 };

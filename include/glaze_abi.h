@@ -236,11 +236,17 @@ int glz_instance_device(const glz_instance*);
 /* stream all of this instance's kernels run on (a hipStream_t), for event timing by the caller */
 void* glz_instance_stream(const glz_instance*);
 /* [extension] acceleration-structure builder for scenes created afterwards (the reference leaves the choice to the
- * Vulkan driver, acceleration.rs:253-257 asks for PREFER_FAST_TRACE): GLZ_BVH_LBVH (default; Karras 2012, fastest
- * build) or GLZ_BVH_PLOC (parallel locally-ordered clustering, Meister & Bittner 2018: a few more milliseconds of
- * build; on the atrium it trades closest-hit visits +10 % for shadow-ray visits -15 %).  Hits do not depend on it. */
+ * Vulkan driver, acceleration.rs:253-257 asks for PREFER_FAST_TRACE).  Hits do not depend on it.
+ *   GLZ_BVH_LBVH  Karras 2012 on the GPU: fastest build (3 ms for 262 k triangles, 38 ms for 21 M)
+ *   GLZ_BVH_PLOC  parallel locally-ordered clustering on the GPU (Meister & Bittner 2018): a few more milliseconds; on
+ *                 the atrium it trades closest-hit visits +10 % for shadow-ray visits -15 %
+ *   GLZ_BVH_SAH   top-down binned SAH on the host cores (38 ms for 262 k triangles, 0.3 s for 1.8 M, 1.5 s for 7 M):
+ *                 SAH cost -11 %, 5 % more samples per second
+ *   GLZ_BVH_AUTO  (default) SAH up to 2 M world triangles, LBVH above */
 #define GLZ_BVH_LBVH 0
 #define GLZ_BVH_PLOC 1
+#define GLZ_BVH_SAH 2
+#define GLZ_BVH_AUTO 3
 int glz_instance_set_bvh_builder(glz_instance*, int builder);
 
 /* ------------------------------------------------------------------------------------------

@@ -59,16 +59,19 @@ def test_rt_tables_bit_exact(which, cube, mattest):
 
 
 @pytest.fixture(scope="module")
-def mattest_ploc(mattest):
-    """Same scene built with the optional PLOC builder (glz_instance_set_bvh_builder) on its own instance."""
-    inst = glaze_amd.RayTraceInstance.new()
-    inst.set_bvh_builder("ploc")
-    return glaze_amd.RayTraceScene.new(inst, glaze_amd.parse(MATTEST))
+def mattest_by_builder(mattest):
+    """The same scene built by every acceleration-structure builder (glz_instance_set_bvh_builder), each on its own instance."""
+    out = {}
+    for name in ("lbvh", "ploc", "sah"):
+        inst = glaze_amd.RayTraceInstance.new()
+        inst.set_bvh_builder(name)
+        out[name] = glaze_amd.RayTraceScene.new(inst, glaze_amd.parse(MATTEST))
+    return out
 
 
-@pytest.mark.parametrize("builder", ["lbvh", "ploc"])
-def test_bvh_structure(builder, mattest, mattest_ploc):
-    gpu = mattest[1] if builder == "lbvh" else mattest_ploc
+@pytest.mark.parametrize("builder", ["lbvh", "ploc", "sah"])
+def test_bvh_structure(builder, mattest_by_builder):
+    gpu = mattest_by_builder[builder]
     nodes, tris = gpu.debug_bvh()
     info = gpu.info()
     n, n4 = tris.shape[0], nodes.shape[0]
@@ -145,26 +148,29 @@ def test_closest_hit_mattest_camera_and_random(mattest, instance):
     assert same.all(), "mismatching rays: %d" % (~same).sum()
 
 
-def test_ploc_builder_same_hits(mattest, mattest_ploc):
-    """Hits must not depend on the acceleration structure: PLOC-built scene vs the oracle."""
+@pytest.mark.parametrize("builder", ["lbvh", "ploc", "sah"])
+def test_builders_same_hits(builder, mattest, mattest_by_builder):
+    """Hits must not depend on the acceleration structure: every builder's scene vs the oracle."""
     _, _, orc = mattest
+    gpu = mattest_by_builder[builder]
     rng = np.random.default_rng(7)
-    i = mattest_ploc.info()
+    i = gpu.info()
     assert 138480 // 3 <= i.bvh_nodes <= 138479 and 9 <= i.bvh_depth <= 48
     lo, hi = np.array(i.bounds_min), np.array(i.bounds_max)
     o = (lo + rng.random((50000, 3)) * (hi - lo)).astype(np.float32)
     d = rng.normal(size=(50000, 3)).astype(np.float32)
     d /= np.linalg.norm(d, axis=1, keepdims=True)
-    same, _, _ = _check_closest(mattest_ploc, orc, o, d)
+    same, _, _ = _check_closest(gpu, orc, o, d)
     assert same.all(), "mismatching rays: %d" % (~same).sum()
     tmax = (rng.random(50000) * 3.0).astype(np.float32)
-    assert np.array_equal(mattest_ploc.debug_trace_any(o, d, tmax), orc.trace_any(o, d, tmax))
+    assert np.array_equal(gpu.debug_trace_any(o, d, tmax), orc.trace_any(o, d, tmax))
 
 
-def test_ploc_tiny_scenes():
-    """1, 2 and 3 triangles: the merge loop's smallest cases."""
+@pytest.mark.parametrize("builder", ["lbvh", "ploc", "sah"])
+def test_tiny_scenes(builder):
+    """1, 2 and 3 triangles: the builders' smallest cases."""
     inst = glaze_amd.RayTraceInstance.new()
-    inst.set_bvh_builder("ploc")
+    inst.set_bvh_builder(builder)
     for ntri in (1, 2, 3):
         desc = cube_scene()
         desc.indices = desc.indices[: 3 * ntri].copy()
@@ -178,7 +184,7 @@ def test_ploc_tiny_scenes():
         assert same.all() and np.isfinite(t).any()
 
 
-@pytest.mark.parametrize("builder", ["lbvh", "ploc"])
+@pytest.mark.parametrize("builder", ["lbvh", "ploc", "sah"])
 def test_triangle_soup_with_duplicates_and_degenerates(builder):
     """Random soup: exact duplicates (equal Morton codes -> the index tie-break of the hierarchy), zero-area and needle triangles,
     one triangle spanning the whole scene, clusters far apart (deep, unbalanced tree).  Hits must equal the oracle's."""
@@ -213,6 +219,20 @@ def test_triangle_soup_with_duplicates_and_degenerates(builder):
     assert np.isfinite(t[:50]).all() and 0.01 < np.isfinite(t).mean() < 1.0      # the straight-down rays all land on the big triangle
     tmax = (rng.random(m) * 5.0).astype(np.float32)
     assert np.array_equal(gpu.debug_trace_any(o, d, tmax), orc.trace_any(o, d, tmax))
+
+
+def test_sah_build_is_deterministic_and_default(mattest, mattest_by_builder):
+    """The host SAH builder runs on several threads; node ids are fixed by the ranges, so two builds give the same array.
+    'auto' (the default) picks SAH below 2 M triangles."""
+    inst = glaze_amd.RayTraceInstance.new()
+    inst.set_bvh_builder("sah")
+    again = glaze_amd.RayTraceScene.new(inst, glaze_amd.parse(MATTEST))
+    n0, t0 = mattest_by_builder["sah"].debug_bvh()
+    n1, t1 = again.debug_bvh()
+    assert np.array_equal(n0, n1) and np.array_equal(t0.view(np.uint32), t1.view(np.uint32))
+    n2, _ = mattest[1].debug_bvh()                              # built by the default instance
+    assert np.array_equal(n0, n2)
+    assert mattest_by_builder["sah"].info().bvh_sah_cost < mattest_by_builder["lbvh"].info().bvh_sah_cost
 
 
 def test_transform_memory_layout_kat_on_device(instance):

@@ -12,7 +12,7 @@ for det in details:
     desc = atrium_scene(detail=det, texture_size=256)
     ntri = sum(int(x) for x in desc.meshes["index_count"]) // 3
     imgs = {}
-    for builder in ("lbvh", "ploc"):
+    for builder in ("lbvh", "ploc", "sah"):
         inst = glaze_amd.RayTraceInstance.new()
         inst.set_bvh_builder(builder)
         scene = glaze_amd.RayTraceScene.from_desc(inst, desc); del scene   # first build of a process pays module load
