@@ -171,6 +171,7 @@ PROTOTYPES = {
     "glz_host_launch_constants": (C.c_int, [C.c_uint64, C.c_uint32, _P, _P]),
     "glz_host_push_constants": (C.c_int, [_P, C.c_uint32, C.c_uint32, _P]),
     "glz_host_chain_owner": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _P]),
+    "glz_host_build_sah": (C.c_int, [C.c_uint32, _P, _P, _P, _P]),
     "glz_host_tile_owner": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, _P]),
 }
 

@@ -591,3 +591,12 @@ int glz_host_chain_owner(uint32_t width, uint32_t height, uint32_t rank, uint32_
 }
 
 }  // extern "C"
+
+int glz_host_build_sah(uint32_t n, const float* box_lo, const float* box_hi, int32_t* children_out, int32_t* parent_out) {
+  GLZ_GUARD_BEGIN
+  if (n < 2 || !box_lo || !box_hi || !children_out || !parent_out) return fail(GLZ_E_ARG, "glz_host_build_sah: bad argument");
+  static_assert(sizeof(float4) == 16 && sizeof(int2) == 8, "layout");
+  build_sah_host(n, reinterpret_cast<const float4*>(box_lo), reinterpret_cast<const float4*>(box_hi), reinterpret_cast<int2*>(children_out), parent_out);
+  return GLZ_OK;
+  GLZ_GUARD_END(GLZ_E_IO)
+}

@@ -61,8 +61,8 @@ struct Builder {
   unsigned threads;
 
   static int bin_of(float c, float lo, float scale) {
-    const int b = (int)((c - lo) * scale);
-    return b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+    const float f = (c - lo) * scale;   // NaN centroids (degenerate input) land in bin 0
+    return f >= 0.0f ? (f < (float)kBins ? (int)f : kBins - 1) : 0;
   }
   void centroid_bounds(uint32_t b, uint32_t e, float clo[3], float chi[3]) const {
     for (int k = 0; k < 3; ++k) { clo[k] = INFINITY; chi[k] = -INFINITY; }

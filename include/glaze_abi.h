@@ -390,6 +390,10 @@ int glz_host_tile_owner(uint32_t width, uint32_t height, uint32_t world, uint16_
 /* launch chains a renderer of this size and partition runs with (chains = 0: the automatic choice of glz_renderer_set_chains), and the
  * chain rendering each pixel of rank `rank` (0xFFFF for pixels of other ranks): chain s of S owns tiles t with t % (world*S) == rank + s*world */
 int glz_host_chain_owner(uint32_t width, uint32_t height, uint32_t rank, uint32_t world, uint32_t chains, uint16_t* owner_out);
+/* the host side of GLZ_BVH_SAH on its own (no GPU): binary hierarchy over n >= 2 leaf boxes (box_lo / box_hi: 4 floats per leaf,
+ * xyz used).  children_out[2 * i], [2 * i + 1] for inner node i < n - 1: link >= 0 inner node, < 0 ~leaf; parent_out[i] for
+ * inner node i (root 0: -1), parent_out[n - 1 + l] for leaf l. */
+int glz_host_build_sah(uint32_t n, const float* box_lo, const float* box_hi, int32_t* children_out, int32_t* parent_out);
 
 #ifdef __cplusplus
 }

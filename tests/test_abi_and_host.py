@@ -140,3 +140,60 @@ def test_launch_chains_partition_a_ranks_tiles():
     assert chain_owner(W, H, 0, 8, chains=5)[0] == 5 and chain_owner(64, 64, 0, 1, chains=4)[0] == 1    # never more chains than tiles
     n, own = chain_owner(200, 136, 1, 3, chains=2)                     # ragged edges
     assert n == 2 and (own[tile_owner(200, 136, 3) == 1] != 0xFFFF).all()
+
+
+def _sah_tree(lo, hi):
+    import ctypes as C
+    n = lo.shape[0]
+    lo4 = np.zeros((n, 4), np.float32); lo4[:, :3] = lo
+    hi4 = np.zeros((n, 4), np.float32); hi4[:, :3] = hi
+    children = np.full((n - 1, 2), 0x7FFFFFF0, np.int32)
+    parent = np.full(2 * n - 1, 0x7FFFFFF0, np.int32)
+    abi.check(abi.lib().glz_host_build_sah(n, lo4.ctypes.data, hi4.ctypes.data, children.ctypes.data, parent.ctypes.data))
+    return children, parent
+
+
+def _check_tree(children, parent, n):
+    """every leaf and every inner node but the root has exactly one parent, links and parents agree, ids are the pre-order"""
+    assert parent[0] == -1
+    links = children.reshape(-1).astype(np.int64)
+    leaf, inner = ~links[links < 0], links[links >= 0]
+    assert np.array_equal(np.sort(leaf), np.arange(n)) and np.array_equal(np.sort(inner), np.arange(1, n - 1))
+    for side in (0, 1):
+        l = children[:, side].astype(np.int64)
+        slot = np.where(l >= 0, l, (n - 1) + ~l)
+        assert np.array_equal(parent[slot], np.arange(n - 1))
+    # a subtree over c leaves owns c - 1 consecutive ids: the left child of node i is i + 1, the right one follows the left subtree
+    left = children[:, 0]
+    assert (left[left >= 0] == np.nonzero(left >= 0)[0] + 1).all()
+
+
+def test_host_sah_builder_structure_and_determinism():
+    """bvh_sah.cpp without a GPU: random boxes, clustered boxes, all boxes equal (no split by binning: halving), two leaves."""
+    rng = np.random.default_rng(3)
+    n = 70000                                                      # above the threshold where the top ranges are binned in parallel
+    c = np.concatenate([rng.random((n // 2, 3)) * 10, rng.normal(size=(n - n // 2, 3)) * 0.01 + [50, -20, 5]]).astype(np.float32)
+    ext = (rng.random((n, 3)) * 0.05).astype(np.float32)
+    ch, pa = _sah_tree(c - ext, c + ext)
+    _check_tree(ch, pa, n)
+    ch2, pa2 = _sah_tree(c - ext, c + ext)
+    assert np.array_equal(ch, ch2) and np.array_equal(pa, pa2)     # threads do not change the tree
+    # the split of the root separates the two clusters
+    def leaves_under(link):
+        stack, out = [link], []
+        while stack:
+            l = stack.pop()
+            if l < 0: out.append(~l)
+            else: stack.extend(ch[l].tolist())
+        return np.array(out)
+    a, b = leaves_under(int(ch[0, 0])), leaves_under(int(ch[0, 1]))
+    first, second = (a, b) if a.min() < n // 2 else (b, a)
+    assert len(a) + len(b) == n and (first < n // 2).all() and (second >= n // 2).all()
+    same = np.tile(np.array([[1.0, 2.0, 3.0]], np.float32), (257, 1))
+    ch, pa = _sah_tree(same, same + 1)
+    _check_tree(ch, pa, 257)
+    ch, pa = _sah_tree(np.zeros((2, 3), np.float32), np.ones((2, 3), np.float32))
+    assert sorted((~ch[0]).tolist()) == [0, 1] and pa.tolist() == [-1, 0, 0]
+    nan = c[:1000].copy(); nan[::7] = np.nan                      # degenerate input must still give a tree
+    ch, pa = _sah_tree(nan, nan)
+    _check_tree(ch, pa, 1000)
