@@ -107,6 +107,10 @@ struct TransformPair {
 //   (one word per axis, so that a per-ray byte permutation puts the plane the ray meets first into the low half)
 //   w[12 + k] = link of child k: index of an inner node (>= 0), ~index of a leaf in bvh_tris (< 0), or kBvhEmptyChild
 //   for an unused slot (the tracer skips it by its link; its box words are lo = 65535, hi = 0).
+constexpr uint32_t kTriNonOpaque = 0x80000000u;   // BvhTri::prim_flags: candidates on this triangle go through the alpha test
+constexpr uint32_t kTriHasPartner = 0x40000000u;  // the next triangle in bvh_tris belongs to the same leaf
+constexpr uint32_t kTriPrimMask = 0x3FFFFFFFu;
+constexpr float kPairAreaRatio = 0.75f;           // two triangles share a leaf when area(joint box) <= ratio * (area(a) + area(b))
 struct alignas(16) BvhNode4 {
   uint32_t w[16];
 };
@@ -121,7 +125,7 @@ struct BvhGrid {
 struct alignas(16) BvhTri {
   float v0[3]; uint32_t world_id;   // instance-major id: tie-break key for equal t
   float e1[3]; uint32_t instance;
-  float e2[3]; uint32_t prim_flags; // bit 31: non-opaque (alpha tested), bits 0-30: primitive in instance
+  float e2[3]; uint32_t prim_flags; // kTriNonOpaque | kTriHasPartner | primitive in instance
 };
 static_assert(sizeof(BvhTri) == 48, "BvhTri is 48 bytes");
 

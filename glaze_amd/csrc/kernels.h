@@ -20,6 +20,7 @@ struct LbvhInputs {
   const RTMaterial* materials;
   uint32_t n_world;
   int builder;                 // kBvhBuilder*
+  bool pair_leaves;            // two triangles per leaf where they qualify (kernels_build.hip, k_pair_triangles)
 };
 constexpr int kBvhBuilderLbvh = 0, kBvhBuilderPloc = 1, kBvhBuilderSah = 2, kBvhBuilderAuto = 3;   // = GLZ_BVH_LBVH / _PLOC / _SAH / _AUTO
 constexpr uint32_t kBvhAutoSahLimit = 2000000;   // GLZ_BVH_AUTO: SAH up to this many triangles (build <= 0.35 s), LBVH above
@@ -29,7 +30,8 @@ struct LbvhOutputs {
   BvhNode4* nodes;  // n_nodes entries, hipMalloc'ed by build_lbvh: the caller owns them afterwards
   uint32_t n_nodes;
   BvhGrid grid;     // quantisation grid of the node boxes
-  BvhTri* tris;     // n_world entries, preallocated, leaf order
+  BvhTri* tris;     // n_world + 1 entries (the tracer reads one past a leaf's first triangle), preallocated; leaf order, a leaf's triangles adjacent
+  uint32_t n_leaves;
   uint32_t depth;   // number of 4-wide nodes above the deepest leaf (the traversal stack holds at most 3 * depth + 1 entries)
   float sah;
   uint32_t rounds;  // PLOC merge rounds (0 for the LBVH)

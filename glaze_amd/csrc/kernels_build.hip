@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(256) k_world_tris(const float4* __restrict__ v
     t.v0[0] = v[0].x; t.v0[1] = v[0].y; t.v0[2] = v[0].z; t.world_id = w;
     t.e1[0] = e1.x; t.e1[1] = e1.y; t.e1[2] = e1.z; t.instance = inst;
     t.e2[0] = e2.x; t.e2[1] = e2.y; t.e2[2] = e2.z;
-    t.prim_flags = prim | (materials[in.material_id].opacity != 0 ? 0x80000000u : 0u);   // acceleration.rs:136-141
+    t.prim_flags = prim | (materials[in.material_id].opacity != 0 ? kTriNonOpaque : 0u);   // acceleration.rs:136-141
     tris[w] = t;
     const float* A = &v[0].x; const float* B = &v[1].x; const float* C = &v[2].x;
     float l[3], h[3];
@@ -216,17 +216,88 @@ __global__ void __launch_bounds__(1024) k_bitonic_lds(uint64_t* __restrict__ key
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Leaves.  Two triangles of one instance that follow each other in the index buffer, share an edge and have largely the
+// same box (the two halves of a quad: what tessellated grids and triangulated quad meshes consist of) form ONE leaf: the
+// hierarchy is built over half as many primitives and the tracer tests both triangles in one leaf round.  A leaf's
+// triangles are adjacent in bvh_tris (the first one carries kTriHasPartner); leaf links point at the first.
+// Pairs start at even primitives first, then at odd ones between triangles that are still single.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float box_area3(float4 l, float4 h) {
+  const float dx = h.x - l.x, dy = h.y - l.y, dz = h.z - l.z;
+  return 2.0f * (dx * dy + dy * dz + dz * dx);
+}
+__global__ void __launch_bounds__(256) k_pair_triangles(uint32_t n_world, uint32_t parity, const BvhTri* __restrict__ tris,
+                                                        const uint32_t* __restrict__ indices, const RTInstance* __restrict__ instances,
+                                                        const float4* __restrict__ box_lo, const float4* __restrict__ box_hi,
+                                                        uint8_t* role /* 0 single, 1 first of a pair, 2 second of a pair */) {
+  const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w + 1 >= n_world) return;
+  const BvhTri a = tris[w], b = tris[w + 1];
+  const uint32_t prim = a.prim_flags & kTriPrimMask;
+  if ((prim & 1u) != parity || a.instance != b.instance) return;
+  if (parity == 1u && (role[w] != 0 || role[w + 1] != 0)) return;
+  const RTInstance in = instances[a.instance];
+  const uint32_t* ia = indices + in.index_offset + 3 * prim;
+  const uint32_t* ib = ia + 3;
+  int shared = 0;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) shared += ia[i] == ib[j] ? 1 : 0;
+  if (shared != 2) return;
+  const float4 la = box_lo[w], ha = box_hi[w], lb = box_lo[w + 1], hb = box_hi[w + 1];
+  const float4 lm = make_float4(fminf(la.x, lb.x), fminf(la.y, lb.y), fminf(la.z, lb.z), 0.0f);
+  const float4 hm = make_float4(fmaxf(ha.x, hb.x), fmaxf(ha.y, hb.y), fmaxf(ha.z, hb.z), 0.0f);
+  // one box for both must not cost more than it saves: identical boxes give 0.5, two squares side by side 0.83
+  if (!(box_area3(lm, hm) <= kPairAreaRatio * (box_area3(la, ha) + box_area3(lb, hb)))) return;
+  role[w] = 1;
+  role[w + 1] = 2;
+}
+__global__ void __launch_bounds__(256) k_leaf_flags(uint32_t n_world, const uint8_t* __restrict__ role, unsigned long long* __restrict__ flags) {
+  const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w < n_world) flags[w] = role[w] != 2 ? 1ull : 0ull;
+}
+// leaf l (numbered in world-triangle order) -> its first triangle and its box
+__global__ void __launch_bounds__(256) k_leaf_boxes(uint32_t n_world, const uint8_t* __restrict__ role, const unsigned long long* __restrict__ pos,
+                                                    const float4* __restrict__ box_lo, const float4* __restrict__ box_hi,
+                                                    uint32_t* __restrict__ leaf_first, float4* __restrict__ leaf_lo, float4* __restrict__ leaf_hi) {
+  const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n_world || role[w] == 2) return;
+  const uint32_t l = (uint32_t)pos[w];
+  float4 lo = box_lo[w], hi = box_hi[w];
+  if (role[w] == 1) {
+    const float4 l2 = box_lo[w + 1], h2 = box_hi[w + 1];
+    lo = make_float4(fminf(lo.x, l2.x), fminf(lo.y, l2.y), fminf(lo.z, l2.z), 0.0f);
+    hi = make_float4(fmaxf(hi.x, h2.x), fmaxf(hi.y, h2.y), fmaxf(hi.z, h2.z), 0.0f);
+  }
+  leaf_first[l] = w;
+  leaf_lo[l] = lo;
+  leaf_hi[l] = hi;
+}
+// triangles of the leaf at sorted place j (for the prefix sum that gives its first slot in bvh_tris)
+__global__ void __launch_bounds__(256) k_leaf_sizes(uint32_t n, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ leaf_first,
+                                                    const uint8_t* __restrict__ role, unsigned long long* __restrict__ sizes) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n) sizes[j] = role[leaf_first[vals[j]]] == 1 ? 2ull : 1ull;
+}
+
 // gathers triangles and boxes into leaf (sorted) order
-__global__ void __launch_bounds__(256) k_gather_leaves(const uint32_t* __restrict__ vals, uint32_t n, const BvhTri* __restrict__ tris_in,
-                                                       const float4* __restrict__ lo_in, const float4* __restrict__ hi_in,
-                                                       BvhTri* __restrict__ tris_out, float4* __restrict__ node_lo,
+__global__ void __launch_bounds__(256) k_gather_leaves(const uint32_t* __restrict__ vals, uint32_t n, const uint32_t* __restrict__ leaf_first,
+                                                       const uint8_t* __restrict__ role, const unsigned long long* __restrict__ slot,
+                                                       const BvhTri* __restrict__ tris_in, const float4* __restrict__ lo_in,
+                                                       const float4* __restrict__ hi_in, BvhTri* __restrict__ tris_out, float4* __restrict__ node_lo,
                                                        float4* __restrict__ node_hi) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const uint32_t src = vals[i];
-  tris_out[i] = tris_in[src];
-  node_lo[(n - 1) + i] = lo_in[src];   // leaf j's box lives at slot (n-1)+j, inner node i's at slot i
-  node_hi[(n - 1) + i] = hi_in[src];
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const uint32_t leaf = vals[j], first = leaf_first[leaf];
+  const uint32_t s = (uint32_t)slot[j];
+  BvhTri t = tris_in[first];
+  if (role[first] == 1) {
+    t.prim_flags |= kTriHasPartner;
+    tris_out[s + 1] = tris_in[first + 1];
+  }
+  tris_out[s] = t;
+  node_lo[(n - 1) + j] = lo_in[leaf];   // leaf j's box lives at slot (n-1)+j, inner node i's at slot i
+  node_hi[(n - 1) + j] = hi_in[leaf];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -550,8 +621,8 @@ __global__ void __launch_bounds__(256) k_head_flags(int n, const int* __restrict
 __global__ void __launch_bounds__(256) k_emit_nodes4(int n, const int2* __restrict__ children, const float4* __restrict__ node_lo,
                                                      const float4* __restrict__ node_hi, const BvhGrid* __restrict__ grid,
                                                      const int* __restrict__ new_id, const unsigned long long* __restrict__ flags,
-                                                     const unsigned long long* __restrict__ pos, BvhNode4* __restrict__ nodes,
-                                                     float* __restrict__ sah) {
+                                                     const unsigned long long* __restrict__ pos, const unsigned long long* __restrict__ slot,
+                                                     BvhNode4* __restrict__ nodes, float* __restrict__ sah) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n - 1) return;
   const int2 c = children[i];
@@ -576,14 +647,15 @@ __global__ void __launch_bounds__(256) k_emit_nodes4(int n, const int2* __restri
       nd.w[12 + k] = (uint32_t)kBvhEmptyChild;
       continue;
     }
-    const int slot = ch >= 0 ? ch : (n - 1) + ~ch;
-    const float4 l = node_lo[slot], h = node_hi[slot];
+    const int box = ch >= 0 ? ch : (n - 1) + ~ch;
+    const float4 l = node_lo[box], h = node_hi[box];
     const uint32_t q[6] = {quant_lo(l.x, g.lo[0], g.inv_cell[0]), quant_lo(l.y, g.lo[1], g.inv_cell[1]), quant_lo(l.z, g.lo[2], g.inv_cell[2]),
                            quant_hi(h.x, g.lo[0], g.inv_cell[0]), quant_hi(h.y, g.lo[1], g.inv_cell[1]), quant_hi(h.z, g.lo[2], g.inv_cell[2])};
     nd.w[3 * k] = q[0] | (q[3] << 16);       // one word per axis: lo | hi << 16
     nd.w[3 * k + 1] = q[1] | (q[4] << 16);
     nd.w[3 * k + 2] = q[2] | (q[5] << 16);
-    nd.w[12 + k] = (uint32_t)(ch >= 0 ? (int)pos[new_id[ch]] : ch);   // inner: its number among the BVH4 nodes; leaf: ~leaf
+    // inner: its number among the BVH4 nodes; leaf: ~(first slot of the leaf in bvh_tris)
+    nd.w[12 + k] = (uint32_t)(ch >= 0 ? (int)pos[new_id[ch]] : ~(int)slot[~ch]);
   }
   nodes[pos[new_id[i]]] = nd;
 }
@@ -600,7 +672,7 @@ __global__ void __launch_bounds__(256) k_shade_records(uint32_t n, const BvhTri*
   if (leaf >= n) return;
   const BvhTri t = tris[leaf];
   const RTInstance in = instances[t.instance];
-  const uint32_t tri_id = in.index_offset / 3u + (t.prim_flags & 0x7FFFFFFFu);
+  const uint32_t tri_id = in.index_offset / 3u + (t.prim_flags & kTriPrimMask);
   float4* r = out + 8 * (size_t)leaf;
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
@@ -643,67 +715,97 @@ hipError_t launch_shade_records(hipStream_t st, uint32_t n, const BvhTri* tris, 
 }
 
 hipError_t build_lbvh(hipStream_t st, const LbvhInputs& in, LbvhOutputs& out) {
-  const uint32_t n = in.n_world;
-  const int builder = in.builder == kBvhBuilderAuto ? (n <= kBvhAutoSahLimit ? kBvhBuilderSah : kBvhBuilderLbvh) : in.builder;
+  const uint32_t nw = in.n_world;   // world triangles; n (below) = leaves of the hierarchy <= nw
+  const int builder = in.builder == kBvhBuilderAuto ? (nw <= kBvhAutoSahLimit ? kBvhBuilderSah : kBvhBuilderLbvh) : in.builder;
   out.depth = 0;
   out.sah = 0.0f;
   out.rounds = 0;
   out.nodes = nullptr;
   out.n_nodes = 0;
-  if (n == 0) return hipSuccess;
-  const uint32_t np = std::max<uint32_t>(next_pow2(n), kSortTile);
+  out.n_leaves = 0;
+  if (nw == 0) return hipSuccess;
+  const uint32_t np_max = std::max<uint32_t>(next_pow2(nw), kSortTile);
   hipError_t e;
   BvhTri* tris_unsorted = nullptr;
-  float4 *lo = nullptr, *hi = nullptr, *node_lo = nullptr, *node_hi = nullptr;
+  float4 *lo = nullptr, *hi = nullptr, *leaf_lo = nullptr, *leaf_hi = nullptr, *node_lo = nullptr, *node_hi = nullptr;
   uint64_t* keys = nullptr;
-  uint32_t* vals = nullptr;
+  uint32_t *vals = nullptr, *leaf_first = nullptr;
+  uint8_t* role = nullptr;
   int2* children = nullptr;
   int *parent = nullptr, *node_depth = nullptr, *scalars = nullptr, *counts = nullptr, *new_id = nullptr;
   int *refs_a = nullptr, *refs_b = nullptr, *nearest = nullptr;
-  unsigned long long *flags = nullptr, *pos = nullptr, *scan_tmp = nullptr, *scan_total = nullptr;
+  unsigned long long *flags = nullptr, *pos = nullptr, *slot = nullptr, *scan_tmp = nullptr, *scan_total = nullptr;
   float* sah = nullptr;
   BvhGrid* grid = nullptr;
   auto cleanup = [&]() {
-    void* bufs[] = {tris_unsorted, lo, hi, node_lo, node_hi, keys, vals, children, parent, node_depth, scalars, sah, grid, counts, new_id,
-                    refs_a, refs_b, nearest, flags, pos, scan_tmp, scan_total};
+    void* bufs[] = {tris_unsorted, lo, hi, leaf_lo, leaf_hi, leaf_first, role, node_lo, node_hi, keys, vals, children, parent, node_depth, scalars, sah,
+                    grid, counts, new_id, refs_a, refs_b, nearest, flags, pos, slot, scan_tmp, scan_total};
     for (void* b : bufs)
       if (b) (void)hipFree(b);
   };
 #define GLZ_TRY(x) do { e = (x); if (e != hipSuccess) { cleanup(); return e; } } while (0)
-  GLZ_TRY(hipMalloc(&tris_unsorted, sizeof(BvhTri) * n));
-  GLZ_TRY(hipMalloc(&lo, sizeof(float4) * n));
-  GLZ_TRY(hipMalloc(&hi, sizeof(float4) * n));
-  GLZ_TRY(hipMalloc(&node_lo, sizeof(float4) * (2 * (size_t)n)));
-  GLZ_TRY(hipMalloc(&node_hi, sizeof(float4) * (2 * (size_t)n)));
-  GLZ_TRY(hipMalloc(&keys, sizeof(uint64_t) * np));
-  GLZ_TRY(hipMalloc(&vals, sizeof(uint32_t) * np));
-  GLZ_TRY(hipMalloc(&children, sizeof(int2) * n));
-  GLZ_TRY(hipMalloc(&parent, sizeof(int) * (2 * (size_t)n)));
-  GLZ_TRY(hipMalloc(&node_depth, sizeof(int) * n));
+  GLZ_TRY(hipMalloc(&tris_unsorted, sizeof(BvhTri) * nw));
+  GLZ_TRY(hipMalloc(&lo, sizeof(float4) * nw));
+  GLZ_TRY(hipMalloc(&hi, sizeof(float4) * nw));
+  GLZ_TRY(hipMalloc(&leaf_lo, sizeof(float4) * nw));
+  GLZ_TRY(hipMalloc(&leaf_hi, sizeof(float4) * nw));
+  GLZ_TRY(hipMalloc(&leaf_first, sizeof(uint32_t) * nw));
+  GLZ_TRY(hipMalloc(&role, nw));
+  GLZ_TRY(hipMalloc(&node_lo, sizeof(float4) * (2 * (size_t)nw)));
+  GLZ_TRY(hipMalloc(&node_hi, sizeof(float4) * (2 * (size_t)nw)));
+  GLZ_TRY(hipMalloc(&keys, sizeof(uint64_t) * np_max));
+  GLZ_TRY(hipMalloc(&vals, sizeof(uint32_t) * np_max));
+  GLZ_TRY(hipMalloc(&children, sizeof(int2) * nw));
+  GLZ_TRY(hipMalloc(&parent, sizeof(int) * (2 * (size_t)nw)));
+  GLZ_TRY(hipMalloc(&node_depth, sizeof(int) * nw));
   GLZ_TRY(hipMalloc(&scalars, sizeof(int) * 8));
   GLZ_TRY(hipMalloc(&sah, sizeof(float)));
   GLZ_TRY(hipMalloc(&grid, sizeof(BvhGrid)));
-  GLZ_TRY(hipMalloc(&counts, sizeof(int) * n));
+  GLZ_TRY(hipMalloc(&counts, sizeof(int) * nw));
   {
-    const size_t tiles = ((size_t)n + kScanTile - 1) / kScanTile;
-    GLZ_TRY(hipMalloc(&flags, sizeof(unsigned long long) * n));
-    GLZ_TRY(hipMalloc(&pos, sizeof(unsigned long long) * n));
+    const size_t tiles = ((size_t)nw + kScanTile - 1) / kScanTile;
+    GLZ_TRY(hipMalloc(&flags, sizeof(unsigned long long) * nw));
+    GLZ_TRY(hipMalloc(&pos, sizeof(unsigned long long) * nw));
+    GLZ_TRY(hipMalloc(&slot, sizeof(unsigned long long) * nw));
     GLZ_TRY(hipMalloc(&scan_tmp, sizeof(unsigned long long) * (2 * tiles + 4096)));
     GLZ_TRY(hipMalloc(&scan_total, sizeof(unsigned long long)));
   }
-  GLZ_TRY(hipMalloc(&new_id, sizeof(int) * n));
+  GLZ_TRY(hipMalloc(&new_id, sizeof(int) * nw));
   GLZ_TRY(hipMemsetAsync(sah, 0, sizeof(float), st));
+  GLZ_TRY(hipMemsetAsync(role, 0, nw, st));
   {
     // ordered-int encodings of +inf / -inf, then depth counter
     const int init[8] = {0x7F800000, 0x7F800000, 0x7F800000, (int)0xFF800000 ^ 0x7FFFFFFF, (int)0xFF800000 ^ 0x7FFFFFFF,
                          (int)0xFF800000 ^ 0x7FFFFFFF, 0, 0};
     GLZ_TRY(hipMemcpyAsync(scalars, init, sizeof(init), hipMemcpyHostToDevice, st));
   }
-  const dim3 blk(256), grd((n + 255) / 256);
-  hipLaunchKernelGGL(k_world_tris, grd, blk, 0, st, in.vertices, in.indices, in.instances, in.inst_base, in.n_instances, in.transforms,
-                     in.materials, n, tris_unsorted, lo, hi, scalars);
+  const dim3 blk(256), grdw((nw + 255) / 256);
+  hipLaunchKernelGGL(k_world_tris, grdw, blk, 0, st, in.vertices, in.indices, in.instances, in.inst_base, in.n_instances, in.transforms,
+                     in.materials, nw, tris_unsorted, lo, hi, scalars);
   GLZ_TRY(hipGetLastError());
-  hipLaunchKernelGGL(k_morton, dim3((np + 255) / 256), blk, 0, st, lo, hi, scalars, n, np, keys, vals);
+  // leaves: pairs of triangles where they qualify, single triangles otherwise
+  if (in.pair_leaves) {
+    for (uint32_t parity = 0; parity < 2; ++parity) {
+      hipLaunchKernelGGL(k_pair_triangles, grdw, blk, 0, st, nw, parity, tris_unsorted, in.indices, in.instances, lo, hi, role);
+      GLZ_TRY(hipGetLastError());
+    }
+  }
+  hipLaunchKernelGGL(k_leaf_flags, grdw, blk, 0, st, nw, role, flags);
+  GLZ_TRY(hipGetLastError());
+  GLZ_TRY(scan_exclusive(st, (int)nw, flags, pos, scan_tmp));
+  hipLaunchKernelGGL(k_scan_total, dim3(1), dim3(64), 0, st, (int)nw, flags, pos, scan_total);
+  GLZ_TRY(hipGetLastError());
+  unsigned long long n_leaves = 0;
+  GLZ_TRY(hipMemcpyAsync(&n_leaves, scan_total, sizeof(n_leaves), hipMemcpyDeviceToHost, st));
+  GLZ_TRY(hipStreamSynchronize(st));
+  const uint32_t n = (uint32_t)n_leaves;
+  if (n == 0 || n > nw) { cleanup(); return hipErrorUnknown; }
+  out.n_leaves = n;
+  hipLaunchKernelGGL(k_leaf_boxes, grdw, blk, 0, st, nw, role, pos, lo, hi, leaf_first, leaf_lo, leaf_hi);
+  GLZ_TRY(hipGetLastError());
+  const uint32_t np = std::max<uint32_t>(next_pow2(n), kSortTile);
+  const dim3 grd((n + 255) / 256);
+  hipLaunchKernelGGL(k_morton, dim3((np + 255) / 256), blk, 0, st, leaf_lo, leaf_hi, scalars, n, np, keys, vals);
   GLZ_TRY(hipGetLastError());
   // bitonic network: stages k = 2..np; strides j = k/2..1
   hipLaunchKernelGGL(k_bitonic_lds, dim3(np / kSortTile), dim3(1024), 0, st, keys, vals, np, 2u, kSortTile, 0u);
@@ -716,7 +818,11 @@ hipError_t build_lbvh(hipStream_t st, const LbvhInputs& in, LbvhOutputs& out) {
     hipLaunchKernelGGL(k_bitonic_lds, dim3(np / kSortTile), dim3(1024), 0, st, keys, vals, np, k, k, kSortTile / 2);
     GLZ_TRY(hipGetLastError());
   }
-  hipLaunchKernelGGL(k_gather_leaves, grd, blk, 0, st, vals, n, tris_unsorted, lo, hi, out.tris, node_lo, node_hi);
+  // first slot of every leaf in bvh_tris (leaf order, one or two triangles each)
+  hipLaunchKernelGGL(k_leaf_sizes, grd, blk, 0, st, n, vals, leaf_first, role, flags);
+  GLZ_TRY(hipGetLastError());
+  GLZ_TRY(scan_exclusive(st, (int)n, flags, slot, scan_tmp));
+  hipLaunchKernelGGL(k_gather_leaves, grd, blk, 0, st, vals, n, leaf_first, role, slot, tris_unsorted, leaf_lo, leaf_hi, out.tris, node_lo, node_hi);
   GLZ_TRY(hipGetLastError());
   if (n >= 2) {
     if (builder == kBvhBuilderLbvh) {
@@ -801,7 +907,7 @@ hipError_t build_lbvh(hipStream_t st, const LbvhInputs& in, LbvhOutputs& out) {
     GLZ_TRY(hipStreamSynchronize(st));
     out.n_nodes = (uint32_t)n4;
     GLZ_TRY(hipMalloc(&out.nodes, sizeof(BvhNode4) * (size_t)n4));
-    hipLaunchKernelGGL(k_emit_nodes4, grd, blk, 0, st, (int)n, children, node_lo, node_hi, grid, new_id, flags, pos, out.nodes, sah);
+    hipLaunchKernelGGL(k_emit_nodes4, grd, blk, 0, st, (int)n, children, node_lo, node_hi, grid, new_id, flags, pos, slot, out.nodes, sah);
     GLZ_TRY(hipGetLastError());
   }
   int host_scalars[8];

@@ -1,5 +1,6 @@
 // RayTraceInstance / RayTraceScene equivalents: device selection, scene upload, LBVH build.
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 
 #include <memory>
@@ -17,6 +18,7 @@ struct Instance {
   int device = -1;
   hipStream_t stream = nullptr;
   std::string arch;
+  bool bvh_pair_leaves = getenv("GLAZE_BVH_PAIRS") ? atoi(getenv("GLAZE_BVH_PAIRS")) != 0 : true;   // tuning switch: two triangles per leaf where they qualify
   int bvh_builder = 3;   // kBvhBuilder* for scenes created afterwards (glz_instance_set_bvh_builder); 3 = kBvhBuilderAuto
   ~Instance();
   static Instance* create(int hip_device, Error& err);

@@ -917,18 +917,25 @@ void ext_trace(const Scene& sc, V3 o, V3 d, float tmin, float tmax, bool any, Co
         continue;
       }
     } else {
-      const ExtTri& et = tris[~cur];
-      c.tris++;
-      Tri tr; tr.v0 = v3(et.v0[0], et.v0[1], et.v0[2]); tr.e1 = v3(et.e1[0], et.e1[1], et.e1[2]); tr.e2 = v3(et.e2[0], et.e2[1], et.e2[2]);
-      tr.instance = et.instance; tr.prim = et.prim_flags & 0x7FFFFFFFu; tr.non_opaque = (et.prim_flags >> 31) != 0;
-      float t, u, v;
-      if (ray_tri(tr, o, d, tmin, INF, t, u, v) && t < tmax) {
-        bool better = !found ? true : (t < best || (t == best && et.world_id < best_id));
-        if (better && (!tr.non_opaque || alpha_pass(sc, tr, u, v))) {
-          found = true; best = t; best_id = et.world_id;
-          if (any) break;
+      // a leaf is one triangle or two adjacent ones (bit 30 of the first one's flags, kTriHasPartner): both are tested in one visit
+      const uint32_t first = (uint32_t)~cur;
+      const uint32_t count = (tris[first].prim_flags & 0x40000000u) ? 2u : 1u;
+      bool stop = false;
+      for (uint32_t s = first; s < first + count; ++s) {
+        const ExtTri& et = tris[s];
+        c.tris++;
+        Tri tr; tr.v0 = v3(et.v0[0], et.v0[1], et.v0[2]); tr.e1 = v3(et.e1[0], et.e1[1], et.e1[2]); tr.e2 = v3(et.e2[0], et.e2[1], et.e2[2]);
+        tr.instance = et.instance; tr.prim = et.prim_flags & 0x3FFFFFFFu; tr.non_opaque = (et.prim_flags >> 31) != 0;
+        float t, u, v;
+        if (ray_tri(tr, o, d, tmin, INF, t, u, v) && t < tmax) {
+          bool better = !found ? true : (t < best || (t == best && et.world_id < best_id));
+          if (better && (!tr.non_opaque || alpha_pass(sc, tr, u, v))) {
+            found = true; best = t; best_id = et.world_id;
+            if (any) stop = true;
+          }
         }
       }
+      if (stop) break;
     }
     if (!sp) break;
     cur = stack[--sp];

@@ -37,7 +37,7 @@ def test_scene_info(cube, mattest):
     # SURVEY F10 / BASELINE config 1
     assert (i.n_vertices, i.n_triangles, i.n_world_triangles) == (70876, 138480, 138480)
     assert (i.n_instances, i.n_materials, i.n_textures, i.n_lights, i.n_rt_lights) == (3, 5, 3, 1, 1)
-    assert 138480 // 3 <= i.bvh_nodes <= 138479 and 9 <= i.bvh_depth <= 48
+    assert 138480 // 6 <= i.bvh_nodes <= 138479 and 8 <= i.bvh_depth <= 48      # leaves hold one or two triangles
 
 
 @pytest.mark.parametrize("which", ["cube", "mattest"])
@@ -75,9 +75,9 @@ def test_bvh_structure(builder, mattest_by_builder):
     nodes, tris = gpu.debug_bvh()
     info = gpu.info()
     n, n4 = tris.shape[0], nodes.shape[0]
-    assert nodes.shape == (info.bvh_nodes, 16) and nodes.dtype == np.uint32 and n // 3 <= n4 <= n - 1      # 64-byte 4-wide nodes
+    assert nodes.shape == (info.bvh_nodes, 16) and nodes.dtype == np.uint32                                  # 64-byte 4-wide nodes
     ids = tris.view(np.uint32)[:, 3]
-    assert np.array_equal(np.sort(ids), np.arange(n, dtype=np.uint32))         # every world triangle is a leaf exactly once
+    assert np.array_equal(np.sort(ids), np.arange(n, dtype=np.uint32))         # every world triangle is in the leaf array exactly once
     EMPTY = 0x7FFFFFFF
     links = nodes[:, 12:16].view(np.int32).astype(np.int64)                    # (n4, 4)
     empty = links == EMPTY
@@ -86,7 +86,18 @@ def test_bvh_structure(builder, mattest_by_builder):
     assert (~empty[:, :2]).all()                                               # at least two children, packed to the front
     assert ((~empty).astype(int)[:, :-1] >= (~empty).astype(int)[:, 1:]).all()
     assert np.array_equal(np.sort(links[inner]), np.arange(1, n4))             # every inner node but the root has one parent
-    assert np.array_equal(np.sort(~links[leaf]), np.arange(n))
+    # a leaf is one triangle or two adjacent ones (bit 30 of the first one's flags); leaf links point at the first:
+    # the linked slots and their partners cover the triangle array exactly once
+    first = np.sort(~links[leaf])
+    partner = (tris.view(np.uint32)[:, 11] & 0x40000000) != 0
+    covered = np.sort(np.concatenate([first, first[partner[first]] + 1]))
+    assert np.array_equal(covered, np.arange(n)) and not partner[first[partner[first]] + 1].any()
+    n_leaves = first.size
+    assert n_leaves // 3 <= n4 <= max(1, n_leaves - 1) and n_leaves >= n // 2
+    # both triangles of a pair belong to one instance, follow each other in its index buffer and share an edge
+    p0 = first[partner[first]]
+    assert (tris.view(np.uint32)[p0, 7] == tris.view(np.uint32)[p0 + 1, 7]).all()
+    assert ((tris.view(np.uint32)[p0 + 1, 11] & 0x3FFFFFFF) == (tris.view(np.uint32)[p0, 11] & 0x3FFFFFFF) + 1).all()
 
     u = lambda x, hi: ((x >> 16) if hi else (x & 0xFFFF)).astype(np.int64)
     w = nodes[:, :12].reshape(n4, 4, 3)
@@ -104,9 +115,10 @@ def test_bvh_structure(builder, mattest_by_builder):
     glo, cell = np.array(info.bvh_grid_lo, np.float64), np.array(info.bvh_grid_cell, np.float64)
     v0 = tris[:, 0:3].astype(np.float64)
     t = ~links[leaf]
-    for v in (v0, v0 + tris[:, 4:7], v0 + tris[:, 8:11]):
-        q = (v[t] - glo) / cell
-        assert (lo[leaf] <= q + 1e-6).all() and (hi[leaf] >= q - 1e-6).all()
+    for slot, sel in ((t, np.ones(t.size, bool)), (np.minimum(t + 1, n - 1), partner[t])):   # the leaf's first triangle, then its partner
+        for v in (v0, v0 + tris[:, 4:7], v0 + tris[:, 8:11]):
+            q = (v[slot[sel]] - glo) / cell
+            assert (lo[leaf][sel] <= q + 1e-6).all() and (hi[leaf][sel] >= q - 1e-6).all()
     assert 2 <= info.bvh_depth <= 48
 
 
@@ -155,7 +167,7 @@ def test_builders_same_hits(builder, mattest, mattest_by_builder):
     gpu = mattest_by_builder[builder]
     rng = np.random.default_rng(7)
     i = gpu.info()
-    assert 138480 // 3 <= i.bvh_nodes <= 138479 and 9 <= i.bvh_depth <= 48
+    assert 138480 // 6 <= i.bvh_nodes <= 138479 and 8 <= i.bvh_depth <= 48      # leaves hold one or two triangles
     lo, hi = np.array(i.bounds_min), np.array(i.bounds_max)
     o = (lo + rng.random((50000, 3)) * (hi - lo)).astype(np.float32)
     d = rng.normal(size=(50000, 3)).astype(np.float32)
@@ -208,7 +220,7 @@ def test_triangle_soup_with_duplicates_and_degenerates(builder):
     inst.set_bvh_builder(builder)
     gpu, orc = glaze_amd.RayTraceScene.from_desc(inst, desc), OracleScene(desc)
     i = gpu.info()
-    assert i.n_world_triangles == n and i.bvh_nodes >= n // 3
+    assert i.n_world_triangles == n and i.bvh_nodes >= n // 6
     m = 30000
     o = np.concatenate([rng.normal(size=(m // 2, 3)) * 0.5, rng.normal(size=(m // 2, 3)) * 0.1 + [40.0, -25.0, 10.0]]).astype(np.float32)
     d = rng.normal(size=(m, 3)).astype(np.float32)
