@@ -110,7 +110,7 @@ struct TransformPair {
 constexpr uint32_t kTriNonOpaque = 0x80000000u;   // BvhTri::prim_flags: candidates on this triangle go through the alpha test
 constexpr uint32_t kTriHasPartner = 0x40000000u;  // the next triangle in bvh_tris belongs to the same leaf
 constexpr uint32_t kTriPrimMask = 0x3FFFFFFFu;
-constexpr float kPairAreaRatio = 0.75f;           // two triangles share a leaf when area(joint box) <= ratio * (area(a) + area(b))
+constexpr float kPairAreaRatio = 0.85f;           // two triangles share a leaf when area(joint box) <= ratio * (area(a) + area(b)); 0.55 ... 2: 2146 ... 2193 ... 2184 Msamples/s
 struct alignas(16) BvhNode4 {
   uint32_t w[16];
 };

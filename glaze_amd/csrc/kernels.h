@@ -20,7 +20,7 @@ struct LbvhInputs {
   const RTMaterial* materials;
   uint32_t n_world;
   int builder;                 // kBvhBuilder*
-  bool pair_leaves;            // two triangles per leaf where they qualify (kernels_build.hip, k_pair_triangles)
+  float pair_area_ratio;       // two triangles share a leaf when area(joint box) <= ratio * (area(a) + area(b)); 0 = never (k_pair_triangles)
 };
 constexpr int kBvhBuilderLbvh = 0, kBvhBuilderPloc = 1, kBvhBuilderSah = 2, kBvhBuilderAuto = 3;   // = GLZ_BVH_LBVH / _PLOC / _SAH / _AUTO
 constexpr uint32_t kBvhAutoSahLimit = 2000000;   // GLZ_BVH_AUTO: SAH up to this many triangles (build <= 0.35 s), LBVH above

@@ -230,7 +230,7 @@ __device__ __forceinline__ float box_area3(float4 l, float4 h) {
 __global__ void __launch_bounds__(256) k_pair_triangles(uint32_t n_world, uint32_t parity, const BvhTri* __restrict__ tris,
                                                         const uint32_t* __restrict__ indices, const RTInstance* __restrict__ instances,
                                                         const float4* __restrict__ box_lo, const float4* __restrict__ box_hi,
-                                                        uint8_t* role /* 0 single, 1 first of a pair, 2 second of a pair */) {
+                                                        float area_ratio, uint8_t* role /* 0 single, 1 first of a pair, 2 second of a pair */) {
   const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
   if (w + 1 >= n_world) return;
   const BvhTri a = tris[w], b = tris[w + 1];
@@ -248,7 +248,7 @@ __global__ void __launch_bounds__(256) k_pair_triangles(uint32_t n_world, uint32
   const float4 lm = make_float4(fminf(la.x, lb.x), fminf(la.y, lb.y), fminf(la.z, lb.z), 0.0f);
   const float4 hm = make_float4(fmaxf(ha.x, hb.x), fmaxf(ha.y, hb.y), fmaxf(ha.z, hb.z), 0.0f);
   // one box for both must not cost more than it saves: identical boxes give 0.5, two squares side by side 0.83
-  if (!(box_area3(lm, hm) <= kPairAreaRatio * (box_area3(la, ha) + box_area3(lb, hb)))) return;
+  if (!(box_area3(lm, hm) <= area_ratio * (box_area3(la, ha) + box_area3(lb, hb)))) return;
   role[w] = 1;
   role[w + 1] = 2;
 }
@@ -784,9 +784,9 @@ hipError_t build_lbvh(hipStream_t st, const LbvhInputs& in, LbvhOutputs& out) {
                      in.materials, nw, tris_unsorted, lo, hi, scalars);
   GLZ_TRY(hipGetLastError());
   // leaves: pairs of triangles where they qualify, single triangles otherwise
-  if (in.pair_leaves) {
+  if (in.pair_area_ratio > 0.0f) {
     for (uint32_t parity = 0; parity < 2; ++parity) {
-      hipLaunchKernelGGL(k_pair_triangles, grdw, blk, 0, st, nw, parity, tris_unsorted, in.indices, in.instances, lo, hi, role);
+      hipLaunchKernelGGL(k_pair_triangles, grdw, blk, 0, st, nw, parity, tris_unsorted, in.indices, in.instances, lo, hi, in.pair_area_ratio, role);
       GLZ_TRY(hipGetLastError());
     }
   }

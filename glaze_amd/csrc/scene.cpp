@@ -421,7 +421,7 @@ bool Scene::build_bvh(Error& err) {
   if (!hip_ok(d_tris_.alloc((size_t)n + 1), "alloc BVH triangles", err)) return false;   // + 1: the tracer loads a leaf's partner slot unconditionally
   if (!hip_ok(hipMemsetAsync(d_tris_.ptr + n, 0, sizeof(BvhTri), st), "clear BVH triangle padding", err)) return false;
   LbvhInputs in{d_vertices_.ptr, d_indices_.ptr, d_instances_.ptr, d_inst_base_.ptr, (uint32_t)h_instances.size(), d_transforms_.ptr,
-                d_materials_.ptr, n, instance->bvh_builder, instance->bvh_pair_leaves};
+                d_materials_.ptr, n, instance->bvh_builder, instance->bvh_pair_area_ratio};
   LbvhOutputs out{};
   out.tris = d_tris_.ptr;
   hipEvent_t e0, e1;

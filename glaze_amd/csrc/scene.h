@@ -18,7 +18,8 @@ struct Instance {
   int device = -1;
   hipStream_t stream = nullptr;
   std::string arch;
-  bool bvh_pair_leaves = getenv("GLAZE_BVH_PAIRS") ? atoi(getenv("GLAZE_BVH_PAIRS")) != 0 : true;   // tuning switch: two triangles per leaf where they qualify
+  // two triangles share a leaf when area(joint box) <= ratio * (area(a) + area(b)); tuning switch GLAZE_BVH_PAIRS=<ratio>, 0 = never
+  float bvh_pair_area_ratio = getenv("GLAZE_BVH_PAIRS") ? (float)atof(getenv("GLAZE_BVH_PAIRS")) : kPairAreaRatio;
   int bvh_builder = 3;   // kBvhBuilder* for scenes created afterwards (glz_instance_set_bvh_builder); 3 = kBvhBuilderAuto
   ~Instance();
   static Instance* create(int hip_device, Error& err);
