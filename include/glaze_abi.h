@@ -376,7 +376,8 @@ int64_t glz_debug_read_rt_materials(glz_scene*, void* out, int64_t cap_bytes); /
 int64_t glz_debug_read_rt_lights(glz_scene*, void* out, int64_t cap_bytes);    /* 112-byte RTLight records */
 int64_t glz_debug_read_sky(glz_scene*, float* out, int64_t cap_floats);        /* RTSky(36 f32) | header(4) | marginal arrays */
 /* BVH as traversed by the kernels: 64-byte quantised 4-wide nodes (returns the node count) and 48-byte leaf
- * triangles in leaf order (n_world_triangles of them); see DESIGN.md for the layouts. */
+ * triangles in leaf order (n_world_triangles of them; a leaf is one triangle or two adjacent ones, bit 30 of the
+ * first one's last word says which, and leaf links name the first); see DESIGN.md for the layouts. */
 int64_t glz_debug_read_bvh(glz_scene*, void* nodes_out, int64_t cap_nodes, void* tris_out, int64_t cap_tris);
 
 /* ---- host logic, callable without a device (used by the CPU test-suite and by bindings) ------ */
