@@ -285,7 +285,7 @@ class RayTraceInstance:
         return abi.lib().glz_instance_stream(self._h)
 
     def set_bvh_builder(self, name):
-        """'auto' (default: 'sah' up to 2 M triangles, else 'lbvh'), 'lbvh', 'ploc' or 'sah' for scenes created afterwards."""
+        """'auto' (default: 'sah' up to 8 M triangles, else 'lbvh'), 'lbvh', 'ploc' or 'sah' for scenes created afterwards."""
         abi.check(abi.lib().glz_instance_set_bvh_builder(self._h, {"lbvh": 0, "ploc": 1, "sah": 2, "auto": 3}[name]))
 
     def __del__(self):

@@ -58,6 +58,7 @@ struct Builder {
   int* parent;
   std::vector<uint32_t> idx;
   std::vector<float> cen;   // 3 per leaf
+  std::vector<uint32_t> scratch;   // parallel partition of the large ranges at the top
   unsigned threads;
 
   static int bin_of(float c, float lo, float scale) {
@@ -154,9 +155,36 @@ struct Builder {
       }
       if (best_axis >= 0) {
         const float l = clo[best_axis], s = scale[best_axis];
-        auto it = std::stable_partition(idx.begin() + t.b, idx.begin() + t.e,
-                                        [&](uint32_t p) { return bin_of(cen[3 * (size_t)p + best_axis], l, s) <= best_bin; });
-        mid = (uint32_t)(it - idx.begin());
+        auto left = [&](uint32_t p) { return bin_of(cen[3 * (size_t)p + best_axis], l, s) <= best_bin; };
+        if (parallel) {
+          // stable partition in chunks: every thread splits its chunk into the scratch array, then the pieces are
+          // copied back side by side (left pieces in chunk order, then right pieces): the result of the serial algorithm
+          if (scratch.size() < n) scratch.resize(n);
+          std::vector<uint32_t> n_left(threads, 0), cb(threads, 0), ce(threads, 0);
+          chunks(t.b, t.e, true, [&](unsigned c, uint32_t b0, uint32_t e0) {
+            cb[c] = b0; ce[c] = e0;
+            uint32_t lpos = b0, rpos = e0;   // left elements grow up from b0, right elements down from e0 (reversed)
+            for (uint32_t i = b0; i < e0; ++i) {
+              const uint32_t p = idx[i];
+              if (left(p)) scratch[lpos++] = p; else scratch[--rpos] = p;
+            }
+            n_left[c] = lpos - b0;
+          });
+          uint32_t total_left = 0;
+          for (unsigned c = 0; c < threads; ++c) total_left += n_left[c];
+          std::vector<uint32_t> lbase(threads), rbase(threads);
+          uint32_t lacc = t.b, racc = t.b + total_left;
+          for (unsigned c = 0; c < threads; ++c) { lbase[c] = lacc; rbase[c] = racc; lacc += n_left[c]; racc += (ce[c] - cb[c]) - n_left[c]; }
+          chunks(t.b, t.e, true, [&](unsigned c, uint32_t, uint32_t) {
+            for (uint32_t i = 0; i < n_left[c]; ++i) idx[lbase[c] + i] = scratch[cb[c] + i];
+            const uint32_t nr = (ce[c] - cb[c]) - n_left[c];
+            for (uint32_t i = 0; i < nr; ++i) idx[rbase[c] + i] = scratch[ce[c] - 1 - i];   // undo the reversal
+          });
+          mid = t.b + total_left;
+        } else {
+          auto it = std::stable_partition(idx.begin() + t.b, idx.begin() + t.e, left);
+          mid = (uint32_t)(it - idx.begin());
+        }
         found = mid > t.b && mid < t.e;
       }
     }

@@ -240,9 +240,9 @@ void* glz_instance_stream(const glz_instance*);
  *   GLZ_BVH_LBVH  Karras 2012 on the GPU: fastest build (3 ms for 262 k triangles, 38 ms for 21 M)
  *   GLZ_BVH_PLOC  parallel locally-ordered clustering on the GPU (Meister & Bittner 2018): a few more milliseconds; on
  *                 the atrium it trades closest-hit visits +10 % for shadow-ray visits -15 %
- *   GLZ_BVH_SAH   top-down binned SAH on the host cores (38 ms for 262 k triangles, 0.3 s for 1.8 M, 1.5 s for 7 M):
- *                 SAH cost -11 %, 5 % more samples per second
- *   GLZ_BVH_AUTO  (default) SAH up to 2 M world triangles, LBVH above */
+ *   GLZ_BVH_SAH   top-down binned SAH on the host cores (21 ms for 262 k triangles, 0.15 s for 1.8 M, 0.8 s for 7 M,
+ *                 2 s for 21 M): SAH cost -11 %, 5-13 % more samples per second
+ *   GLZ_BVH_AUTO  (default) SAH up to 8 M world triangles, LBVH above */
 #define GLZ_BVH_LBVH 0
 #define GLZ_BVH_PLOC 1
 #define GLZ_BVH_SAH 2
