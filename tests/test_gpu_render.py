@@ -88,6 +88,21 @@ def test_cube_every_bsdf(instance, mtype):
     assert_parity(r, o, "cube mtype %d" % mtype)
 
 
+@pytest.mark.parametrize("mtype", [abi.MAT_METAL, abi.MAT_FROSTED, abi.MAT_UBER])
+def test_roughness_and_metalness_textures(instance, mtype):
+    """Gray roughness / metalness maps next to the sRGB diffuse map (material.rs:17-342: every scalar is texture x multiplier):
+    the three material textures are fetched once per hit and shared by the NEE evaluation and the BSDF sample."""
+    desc = cube_scene(material_type=mtype)
+    rng = np.random.default_rng(mtype)
+    desc.textures.append((abi.TEX_GRAY, rng.integers(20, 256, (32, 48), dtype=np.uint8), "rough"))     # not square, not a power of two
+    desc.textures.append((abi.TEX_GRAY, rng.integers(0, 256, (64, 64), dtype=np.uint8), "metal"))
+    m = desc.materials[2]
+    m.roughness, m.metalness, m.roughness_mul, m.metalness_mul, m.metal, m.anisotropy = 2, 3, 0.8, 0.9, 1, 0.1
+    desc.lights.append(make_light(abi.LIGHT_SUN, "sun", direction=(0.3, -0.6, 0.5), intensity=0.6))
+    r, o, _ = render_both(instance, desc, 64, 64, spp=6, depth=5, seed=20 + mtype)
+    assert_parity(r, o, "rough/metal maps mtype %d" % mtype)
+
+
 def test_cube_all_light_types(instance):
     desc = cube_scene()
     desc.materials.append(make_material("emitter", diffuse_mul=(255, 200, 150)))
