@@ -103,6 +103,19 @@ def test_roughness_and_metalness_textures(instance, mtype):
     assert_parity(r, o, "rough/metal maps mtype %d" % mtype)
 
 
+@pytest.mark.parametrize("shape", [(1, 7), (5, 1), (3, 129), (37, 5), (130, 66)])
+def test_odd_texture_sizes(instance, shape):
+    """Textures live in 128-byte tiles (8 x 4 RGBA / 16 x 8 gray texels) on the device: sizes that end inside a tile, single rows
+    and columns, and REPEAT wrapping across the ragged edge must sample exactly like the oracle's row-major images."""
+    desc = cube_scene(material_type=abi.MAT_UBER)
+    rng = np.random.default_rng(shape[0] * 1000 + shape[1])
+    desc.textures[1] = (abi.TEX_RGBA_SRGB, rng.integers(0, 256, shape + (4,), dtype=np.uint8), "odd rgba")
+    desc.textures.append((abi.TEX_GRAY, rng.integers(30, 256, shape[::-1], dtype=np.uint8), "odd gray"))
+    desc.materials[2].roughness = 2
+    r, o, _ = render_both(instance, desc, 48, 48, spp=4, depth=3, seed=shape[0])
+    assert_parity(r, o, "texture %dx%d" % shape)
+
+
 def test_cube_all_light_types(instance):
     desc = cube_scene()
     desc.materials.append(make_material("emitter", diffuse_mul=(255, 200, 150)))
