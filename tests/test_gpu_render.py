@@ -158,6 +158,7 @@ def test_instance_transforms(instance):
     desc.transforms = np.stack([_col_major(m) for m in mats])
     desc.instances = np.array([(0, 0), (0, 1), (0, 2)], INSTANCE_DTYPE)
     desc.lights.append(make_light(abi.LIGHT_SUN, "sun", direction=(0.2, -0.7, 0.4), intensity=0.5))
+    desc.lights.append(make_light(abi.LIGHT_AREA, "area", resource_id=2, intensity=0.6))   # one RTLight per instance, sampled through its transform
     r, o, _ = render_both(instance, desc, 96, 96, spp=6, depth=5, seed=11)
     assert_parity(r, o, "instance transforms")
     hdr = r.read_hdr()
