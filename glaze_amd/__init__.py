@@ -285,8 +285,8 @@ class RayTraceInstance:
         return abi.lib().glz_instance_stream(self._h)
 
     def set_bvh_builder(self, name):
-        """'auto' (default: 'sah' up to 8 M triangles, else 'lbvh'), 'lbvh', 'ploc' or 'sah' for scenes created afterwards."""
-        abi.check(abi.lib().glz_instance_set_bvh_builder(self._h, {"lbvh": 0, "ploc": 1, "sah": 2, "auto": 3}[name]))
+        """'auto' (default, = 'sah': binned SAH on the GPU), 'lbvh', 'ploc' or 'sah_host' (the SAH builder's host reference) for scenes created afterwards."""
+        abi.check(abi.lib().glz_instance_set_bvh_builder(self._h, {"lbvh": 0, "ploc": 1, "sah": 2, "auto": 3, "sah_host": 4}[name]))
 
     def __del__(self):
         if getattr(self, "_h", None):

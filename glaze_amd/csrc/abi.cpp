@@ -237,7 +237,7 @@ void glz_instance_destroy(glz_instance* h) { delete h; }
 int glz_instance_device(const glz_instance* h) { return h ? h->i->device : -1; }
 void* glz_instance_stream(const glz_instance* h) { return h ? (void*)h->i->stream : nullptr; }
 int glz_instance_set_bvh_builder(glz_instance* h, int builder) {
-  if (!h || (builder < GLZ_BVH_LBVH || builder > GLZ_BVH_AUTO)) return fail(GLZ_E_INVALID_INPUT, "glz_instance_set_bvh_builder: bad argument");
+  if (!h || (builder < GLZ_BVH_LBVH || builder > GLZ_BVH_SAH_HOST)) return fail(GLZ_E_INVALID_INPUT, "glz_instance_set_bvh_builder: bad argument");
   h->i->bvh_builder = builder;
   return GLZ_OK;
 }

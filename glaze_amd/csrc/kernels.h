@@ -22,8 +22,7 @@ struct LbvhInputs {
   int builder;                 // kBvhBuilder*
   float pair_area_ratio;       // two triangles share a leaf when area(joint box) <= ratio * (area(a) + area(b)); 0 = never (k_pair_triangles)
 };
-constexpr int kBvhBuilderLbvh = 0, kBvhBuilderPloc = 1, kBvhBuilderSah = 2, kBvhBuilderAuto = 3;   // = GLZ_BVH_LBVH / _PLOC / _SAH / _AUTO
-constexpr uint32_t kBvhAutoSahLimit = 8000000;   // GLZ_BVH_AUTO: SAH up to this many triangles (build <= 1 s), LBVH above
+constexpr int kBvhBuilderLbvh = 0, kBvhBuilderPloc = 1, kBvhBuilderSah = 2, kBvhBuilderAuto = 3, kBvhBuilderSahHost = 4;   // = GLZ_BVH_LBVH / _PLOC / _SAH / _AUTO / _SAH_HOST
 // host side of the SAH builder (bvh_sah.cpp): binary hierarchy over n leaf boxes -> children / parent arrays
 void build_sah_host(uint32_t n, const float4* lo, const float4* hi, int2* children, int* parent);
 struct LbvhOutputs {

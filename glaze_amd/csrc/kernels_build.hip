@@ -519,6 +519,195 @@ __global__ void __launch_bounds__(256) k_ploc_init(int n, int* __restrict__ refs
   if (i == 0) parent[0] = -1;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Top-down binned SAH on the GPU (GLZ_BVH_SAH): the same algorithm, arithmetic and tie-breaks as the host reference in
+// bvh_sah.cpp, so both give the same tree node for node (tests/test_gpu_scene_trace.py).  One launch per level, one block
+// per node of the level: centroid bounds of the node's range (LDS reduction) -> 3 x 16 bins (LDS atomics on ordered-int
+// box coordinates) -> thread 0 walks the 45 candidate splits exactly as the host does -> stable partition of the range
+// into the other index array (block-wide prefix sums over tiles) -> children.  A subtree over c leaves owns c - 1
+// consecutive node ids (left child id + 1, right child id + c_left), so ids do not depend on which block runs when.
+// The top levels are few blocks over long ranges (level 0 of 131 k leaves: 1.5 ms), the rest is wide and short.
+// ---------------------------------------------------------------------------------------------
+constexpr int kSahBins = 16;
+struct SahTask {
+  uint32_t b, e;
+  int node;
+};
+__device__ __forceinline__ int sah_bin_of(float c, float lo, float scale) {
+  const float f = (c - lo) * scale;
+  return f >= 0.0f ? (f < (float)kSahBins ? (int)f : kSahBins - 1) : 0;
+}
+__device__ __forceinline__ float sah_area(const float* lo, const float* hi) {
+  const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+  return dx < 0.0f ? 0.0f : 2.0f * (dx * dy + dy * dz + dz * dx);
+}
+template <int kSahBlock>
+__global__ void __launch_bounds__(kSahBlock) k_sah_level(const SahTask* __restrict__ queue_in, const uint32_t* __restrict__ n_in,
+                                                         const uint32_t* __restrict__ idx_in, uint32_t* __restrict__ idx_out,
+                                                         SahTask* __restrict__ queue_out, uint32_t* __restrict__ n_out, int n_leaves,
+                                                         const float4* __restrict__ leaf_lo, const float4* __restrict__ leaf_hi,
+                                                         int2* __restrict__ children, int* __restrict__ parent) {
+  if (blockIdx.x >= *n_in) return;
+  const SahTask t = queue_in[blockIdx.x];
+  const uint32_t cnt = t.e - t.b;
+  const int tid = threadIdx.x;
+  __shared__ float s_red[6][kSahBlock / 64];
+  __shared__ float s_clo[3], s_chi[3], s_scale[3];
+  __shared__ int s_box[3][kSahBins][6];      // ordered-int lo xyz, hi xyz
+  __shared__ uint32_t s_count[3][kSahBins];
+  __shared__ int s_axis, s_bin;
+  __shared__ uint32_t s_n_left, s_wave_sum[kSahBlock / 64], s_done_left, s_done_right;
+  uint32_t mid = t.b + cnt / 2;
+  bool found = false;
+  if (cnt > 2) {
+    // ---- centroid bounds ----
+    float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t i = t.b + tid; i < t.e; i += kSahBlock) {
+      const uint32_t p = idx_in[i];
+      const float4 l = leaf_lo[p], h = leaf_hi[p];
+      const float c[3] = {0.5f * (l.x + h.x), 0.5f * (l.y + h.y), 0.5f * (l.z + h.z)};
+      for (int k = 0; k < 3; ++k) { clo[k] = fminf(clo[k], c[k]); chi[k] = fmaxf(chi[k], c[k]); }
+    }
+    for (int off = 32; off > 0; off >>= 1)
+      for (int k = 0; k < 3; ++k) { clo[k] = fminf(clo[k], __shfl_xor(clo[k], off)); chi[k] = fmaxf(chi[k], __shfl_xor(chi[k], off)); }
+    if ((tid & 63) == 0)
+      for (int k = 0; k < 3; ++k) { s_red[k][tid >> 6] = clo[k]; s_red[3 + k][tid >> 6] = chi[k]; }
+    for (int i = tid; i < 3 * kSahBins * 6; i += kSahBlock) (&s_box[0][0][0])[i] = (i % 6) < 3 ? float_to_ordered(INFINITY) : float_to_ordered(-INFINITY);
+    for (int i = tid; i < 3 * kSahBins; i += kSahBlock) (&s_count[0][0])[i] = 0;
+    __syncthreads();
+    if (tid < 3) {
+      float l = INFINITY, h = -INFINITY;
+      for (int w = 0; w < kSahBlock / 64; ++w) { l = fminf(l, s_red[tid][w]); h = fmaxf(h, s_red[3 + tid][w]); }
+      s_clo[tid] = l;
+      s_chi[tid] = h;
+      s_scale[tid] = h - l > 0.0f ? (float)kSahBins / (h - l) : 0.0f;
+    }
+    __syncthreads();
+    // ---- binning ----
+    for (uint32_t i = t.b + tid; i < t.e; i += kSahBlock) {
+      const uint32_t p = idx_in[i];
+      const float4 l = leaf_lo[p], h = leaf_hi[p];
+      const float c[3] = {0.5f * (l.x + h.x), 0.5f * (l.y + h.y), 0.5f * (l.z + h.z)};
+      for (int a = 0; a < 3; ++a) {
+        if (!(s_scale[a] > 0.0f)) continue;
+        const int k = sah_bin_of(c[a], s_clo[a], s_scale[a]);
+        atomicMin(&s_box[a][k][0], float_to_ordered(l.x)); atomicMin(&s_box[a][k][1], float_to_ordered(l.y)); atomicMin(&s_box[a][k][2], float_to_ordered(l.z));
+        atomicMax(&s_box[a][k][3], float_to_ordered(h.x)); atomicMax(&s_box[a][k][4], float_to_ordered(h.y)); atomicMax(&s_box[a][k][5], float_to_ordered(h.z));
+        atomicAdd(&s_count[a][k], 1u);
+      }
+    }
+    __syncthreads();
+    // ---- the split: bvh_sah.cpp, Builder::split, statement for statement ----
+    if (tid == 0) {
+      float best_cost = INFINITY;
+      int best_axis = -1, best_bin = -1;
+      for (int a = 0; a < 3; ++a) {
+        if (!(s_scale[a] > 0.0f)) continue;
+        float right_area[kSahBins];
+        uint32_t right_cnt[kSahBins];
+        float alo[3] = {INFINITY, INFINITY, INFINITY}, ahi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        uint32_t c = 0;
+        for (int k = kSahBins - 1; k > 0; --k) {
+          for (int d = 0; d < 3; ++d) { alo[d] = fminf(alo[d], ordered_to_float(s_box[a][k][d])); ahi[d] = fmaxf(ahi[d], ordered_to_float(s_box[a][k][3 + d])); }
+          c += s_count[a][k];
+          right_area[k] = sah_area(alo, ahi);
+          right_cnt[k] = c;
+        }
+        for (int d = 0; d < 3; ++d) { alo[d] = INFINITY; ahi[d] = -INFINITY; }
+        c = 0;
+        for (int k = 0; k < kSahBins - 1; ++k) {
+          for (int d = 0; d < 3; ++d) { alo[d] = fminf(alo[d], ordered_to_float(s_box[a][k][d])); ahi[d] = fmaxf(ahi[d], ordered_to_float(s_box[a][k][3 + d])); }
+          c += s_count[a][k];
+          if (c == 0 || right_cnt[k + 1] == 0) continue;
+          const float cost = sah_area(alo, ahi) * (float)c + right_area[k + 1] * (float)right_cnt[k + 1];
+          if (cost < best_cost) { best_cost = cost; best_axis = a; best_bin = k; }
+        }
+      }
+      uint32_t n_left = 0;
+      if (best_axis >= 0)
+        for (int k = 0; k <= best_bin; ++k) n_left += s_count[best_axis][k];
+      s_axis = best_axis;
+      s_bin = best_bin;
+      s_n_left = n_left;
+      s_done_left = 0;
+      s_done_right = 0;
+    }
+    __syncthreads();
+    found = s_axis >= 0 && s_n_left > 0 && s_n_left < cnt;
+  }
+  if (found) {
+    // ---- stable partition into idx_out, a tile of kSahBlock elements at a time ----
+    mid = t.b + s_n_left;
+    const int axis = s_axis, bin = s_bin;
+    const float lo_a = s_clo[axis], scale_a = s_scale[axis];
+    for (uint32_t base = t.b; base < t.e; base += kSahBlock) {
+      const uint32_t i = base + tid;
+      uint32_t p = 0;
+      bool left = false, valid = i < t.e;
+      if (valid) {
+        p = idx_in[i];
+        const float4 l = leaf_lo[p], h = leaf_hi[p];
+        const float c = axis == 0 ? 0.5f * (l.x + h.x) : (axis == 1 ? 0.5f * (l.y + h.y) : 0.5f * (l.z + h.z));
+        left = sah_bin_of(c, lo_a, scale_a) <= bin;
+      }
+      const unsigned long long m = __ballot(valid && left);
+      const uint32_t in_wave = (uint32_t)__popcll(m & ((1ull << (tid & 63)) - 1ull));
+      if ((tid & 63) == 0) s_wave_sum[tid >> 6] = (uint32_t)__popcll(m);
+      __syncthreads();
+      uint32_t before = 0, tile_left = 0;
+      for (int w = 0; w < kSahBlock / 64; ++w) {
+        if (w < (tid >> 6)) before += s_wave_sum[w];
+        tile_left += s_wave_sum[w];
+      }
+      const uint32_t lpos = before + in_wave;                 // lefts of the tile before this element
+      if (valid) {
+        if (left) idx_out[t.b + s_done_left + lpos] = p;
+        else idx_out[mid + s_done_right + ((uint32_t)tid - lpos)] = p;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        const uint32_t tile = min((uint32_t)kSahBlock, t.e - base);
+        s_done_left += tile_left;
+        s_done_right += tile - tile_left;
+      }
+      __syncthreads();
+    }
+  } else {
+    for (uint32_t i = t.b + tid; i < t.e; i += kSahBlock) idx_out[i] = idx_in[i];   // two leaves, or every centroid in one place: halve the range as it stands
+    __syncthreads();
+  }
+  // ---- children ----
+  if (tid == 0) {
+    int link[2];
+    const uint32_t rb[2] = {t.b, mid}, re[2] = {mid, t.e};
+    int next_id = t.node + 1;
+    for (int s = 0; s < 2; ++s) {
+      const uint32_t c = re[s] - rb[s];
+      if (c == 1) {
+        const uint32_t leaf = idx_out[rb[s]];
+        link[s] = ~(int)leaf;
+        parent[(n_leaves - 1) + (int)leaf] = t.node;
+      } else {
+        link[s] = next_id;
+        parent[next_id] = t.node;
+        queue_out[atomicAdd(n_out, 1u)] = SahTask{rb[s], re[s], next_id};
+        next_id += (int)c - 1;
+      }
+    }
+    children[t.node] = make_int2(link[0], link[1]);
+  }
+}
+__global__ void k_sah_init(uint32_t n, uint32_t* __restrict__ idx, SahTask* __restrict__ queue, uint32_t* __restrict__ counts, int* __restrict__ parent) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) idx[i] = i;
+  if (i == 0) {
+    queue[0] = SahTask{0u, n, 0};
+    counts[0] = 1;
+    counts[1] = 0;
+    parent[0] = -1;
+  }
+}
+
 // ---- layout: depth-first (pre-order) numbering, so every subtree is one contiguous run of nodes and a node's left
 // child is its neighbour.  counts[t] = inner nodes in the subtree of t (k_level_up).
 __global__ void __launch_bounds__(256) k_dfs_ids(int n, const int2* __restrict__ children, const int* __restrict__ parent,
@@ -716,7 +905,7 @@ hipError_t launch_shade_records(hipStream_t st, uint32_t n, const BvhTri* tris, 
 
 hipError_t build_lbvh(hipStream_t st, const LbvhInputs& in, LbvhOutputs& out) {
   const uint32_t nw = in.n_world;   // world triangles; n (below) = leaves of the hierarchy <= nw
-  const int builder = in.builder == kBvhBuilderAuto ? (nw <= kBvhAutoSahLimit ? kBvhBuilderSah : kBvhBuilderLbvh) : in.builder;
+  const int builder = in.builder == kBvhBuilderAuto ? kBvhBuilderSah : in.builder;
   out.depth = 0;
   out.sah = 0.0f;
   out.rounds = 0;
@@ -734,12 +923,14 @@ hipError_t build_lbvh(hipStream_t st, const LbvhInputs& in, LbvhOutputs& out) {
   int2* children = nullptr;
   int *parent = nullptr, *node_depth = nullptr, *scalars = nullptr, *counts = nullptr, *new_id = nullptr;
   int *refs_a = nullptr, *refs_b = nullptr, *nearest = nullptr;
+  uint32_t *sah_idx_a = nullptr, *sah_idx_b = nullptr, *sah_counts = nullptr;
+  SahTask *sah_queue_a = nullptr, *sah_queue_b = nullptr;
   unsigned long long *flags = nullptr, *pos = nullptr, *slot = nullptr, *scan_tmp = nullptr, *scan_total = nullptr;
   float* sah = nullptr;
   BvhGrid* grid = nullptr;
   auto cleanup = [&]() {
     void* bufs[] = {tris_unsorted, lo, hi, leaf_lo, leaf_hi, leaf_first, role, node_lo, node_hi, keys, vals, children, parent, node_depth, scalars, sah,
-                    grid, counts, new_id, refs_a, refs_b, nearest, flags, pos, slot, scan_tmp, scan_total};
+                    grid, counts, new_id, refs_a, refs_b, nearest, flags, pos, slot, scan_tmp, scan_total, sah_idx_a, sah_idx_b, sah_counts, sah_queue_a, sah_queue_b};
     for (void* b : bufs)
       if (b) (void)hipFree(b);
   };
@@ -829,7 +1020,39 @@ hipError_t build_lbvh(hipStream_t st, const LbvhInputs& in, LbvhOutputs& out) {
       hipLaunchKernelGGL(k_hierarchy, grd, blk, 0, st, keys, (int)n, children, parent);
       GLZ_TRY(hipGetLastError());
     } else if (builder == kBvhBuilderSah) {
-      // binned SAH on the host over the leaf boxes (node_lo / node_hi slots (n-1)+i, leaf order), boxes fitted below
+      // binned SAH, one launch per level (k_sah_level); the leaf boxes are node_lo / node_hi slots (n-1)+j
+      const size_t qcap = (size_t)n / 2 + 2;
+      GLZ_TRY(hipMalloc(&sah_idx_a, sizeof(uint32_t) * n));
+      GLZ_TRY(hipMalloc(&sah_idx_b, sizeof(uint32_t) * n));
+      GLZ_TRY(hipMalloc(&sah_queue_a, sizeof(SahTask) * qcap));
+      GLZ_TRY(hipMalloc(&sah_queue_b, sizeof(SahTask) * qcap));
+      GLZ_TRY(hipMalloc(&sah_counts, sizeof(uint32_t) * 2));
+      hipLaunchKernelGGL(k_sah_init, grd, blk, 0, st, n, sah_idx_a, sah_queue_a, sah_counts, parent);
+      GLZ_TRY(hipGetLastError());
+      uint32_t active = 1;
+      uint32_t *idx_in = sah_idx_a, *idx_out = sah_idx_b;
+      SahTask *q_in = sah_queue_a, *q_out = sah_queue_b;
+      for (int level = 0, in = 0; active > 0; ++level, in ^= 1) {
+        if (level > 4096) { cleanup(); return hipErrorUnknown; }   // cannot happen: every level at least halves the ranges it cannot split
+        // block size by the mean range of the level: long ranges at the top want many threads (a range is one block's
+        // loop), the wide bottom levels want cheap blocks (one wave: its barriers cost nothing)
+        const uint32_t mean = n / active;
+#define GLZ_SAH_LAUNCH(B) hipLaunchKernelGGL(k_sah_level<B>, dim3(active), dim3(B), 0, st, q_in, sah_counts + in, idx_in, idx_out, q_out, \
+                                             sah_counts + (in ^ 1), (int)n, node_lo + (n - 1), node_hi + (n - 1), children, parent)
+        if (mean >= 4096) GLZ_SAH_LAUNCH(1024);
+        else if (mean >= 128) GLZ_SAH_LAUNCH(256);
+        else GLZ_SAH_LAUNCH(64);
+#undef GLZ_SAH_LAUNCH
+        GLZ_TRY(hipGetLastError());
+        GLZ_TRY(hipMemcpyAsync(&active, sah_counts + (in ^ 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        GLZ_TRY(hipMemsetAsync(sah_counts + in, 0, sizeof(uint32_t), st));   // this level's input counter is the output counter of the level after next
+        GLZ_TRY(hipStreamSynchronize(st));
+        std::swap(idx_in, idx_out);
+        std::swap(q_in, q_out);
+        ++out.rounds;
+      }
+    } else if (builder == kBvhBuilderSahHost) {
+      // the same builder on the host cores (bvh_sah.cpp): the reference the GPU builder is tested against
       std::vector<float4> h_lo(n), h_hi(n);
       std::vector<int2> h_children(n);
       std::vector<int> h_parent(2 * (size_t)n);

@@ -62,7 +62,7 @@ def test_rt_tables_bit_exact(which, cube, mattest):
 def mattest_by_builder(mattest):
     """The same scene built by every acceleration-structure builder (glz_instance_set_bvh_builder), each on its own instance."""
     out = {}
-    for name in ("lbvh", "ploc", "sah"):
+    for name in ("lbvh", "ploc", "sah", "sah_host"):
         inst = glaze_amd.RayTraceInstance.new()
         inst.set_bvh_builder(name)
         out[name] = glaze_amd.RayTraceScene.new(inst, glaze_amd.parse(MATTEST))
@@ -234,8 +234,8 @@ def test_triangle_soup_with_duplicates_and_degenerates(builder):
 
 
 def test_sah_build_is_deterministic_and_default(mattest, mattest_by_builder):
-    """The host SAH builder runs on several threads; node ids are fixed by the ranges, so two builds give the same array.
-    'auto' (the default) picks SAH below 2 M triangles."""
+    """The GPU SAH builder (one launch per level, node ids fixed by the ranges) gives the same array every time, it is what
+    'auto' (the default) builds, and it is the tree of the host reference implementation node for node."""
     inst = glaze_amd.RayTraceInstance.new()
     inst.set_bvh_builder("sah")
     again = glaze_amd.RayTraceScene.new(inst, glaze_amd.parse(MATTEST))
@@ -244,7 +244,44 @@ def test_sah_build_is_deterministic_and_default(mattest, mattest_by_builder):
     assert np.array_equal(n0, n1) and np.array_equal(t0.view(np.uint32), t1.view(np.uint32))
     n2, _ = mattest[1].debug_bvh()                              # built by the default instance
     assert np.array_equal(n0, n2)
+    n3, t3 = mattest_by_builder["sah_host"].debug_bvh()
+    assert np.array_equal(n0, n3) and np.array_equal(t0.view(np.uint32), t3.view(np.uint32))
     assert mattest_by_builder["sah"].info().bvh_sah_cost < mattest_by_builder["lbvh"].info().bvh_sah_cost
+
+
+@pytest.mark.parametrize("case", ["atrium", "equal centroids", "tiny"])
+def test_gpu_sah_builder_equals_its_host_reference(case):
+    """k_sah_level restates bvh_sah.cpp statement for statement (bins, candidate order, tie-breaks, stable partition): the two
+    builders must emit identical node and triangle arrays -- also where binning finds no split and ranges are halved."""
+    from glaze_amd.scene_desc import MESH_DTYPE, VERTEX_DTYPE, SceneDesc
+    if case == "atrium":
+        from glaze_amd.scenes import atrium_scene
+        descs = [atrium_scene(detail=0.2, texture_size=16, sky_size=(64, 32))]
+    elif case == "equal centroids":
+        rng = np.random.default_rng(5)
+        n = 3000
+        tri = np.tile((rng.normal(size=(1, 3, 3)) * 0.3).astype(np.float32), (n, 1, 1))      # n copies of one triangle ...
+        tri[n // 2:] += (rng.normal(size=(n - n // 2, 1, 3)) * 2.0).astype(np.float32)        # ... and n/2 scattered ones
+        verts = np.zeros((n * 3, 8), np.float32)
+        verts[:, :3] = tri.reshape(-1, 3)
+        verts[:, 3:6] = [0, 0, 1]
+        base = cube_scene()
+        descs = [SceneDesc(verts.view(VERTEX_DTYPE).reshape(-1), np.arange(n * 3, dtype=np.uint32), np.array([(0, 1, 0, n * 3)], MESH_DTYPE), None,
+                           base.instances, base.materials, base.lights, base.textures, base.camera, base.meta)]
+    else:
+        descs = []
+        for ntri in (1, 2, 3, 5, 12):
+            d = cube_scene()
+            d.indices = d.indices[: 3 * ntri].copy()
+            d.meshes["index_count"][0] = 3 * ntri
+            descs.append(d)
+    for desc in descs:
+        out = []
+        for b in ("sah", "sah_host"):
+            inst = glaze_amd.RayTraceInstance.new()
+            inst.set_bvh_builder(b)
+            out.append(glaze_amd.RayTraceScene.from_desc(inst, desc).debug_bvh())
+        assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1].view(np.uint32), out[1][1].view(np.uint32))
 
 
 def test_transform_memory_layout_kat_on_device(instance):
