@@ -541,6 +541,107 @@ __device__ __forceinline__ float sah_area(const float* lo, const float* hi) {
   const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
   return dx < 0.0f ? 0.0f : 2.0f * (dx * dy + dy * dz + dz * dx);
 }
+// The split of a node from its bins: bvh_sah.cpp, Builder::split, statement for statement (candidate order, strict '<').
+// box: [3][kSahBins][6] ordered-int lo xyz / hi xyz, count: [3][kSahBins]; axis < 0 when binning separates nothing.
+__device__ inline void sah_pick_split(const int* box, const uint32_t* count, const float* scale, int& axis_out, int& bin_out, uint32_t& n_left_out) {
+  float best_cost = INFINITY;
+  int best_axis = -1, best_bin = -1;
+  for (int a = 0; a < 3; ++a) {
+    if (!(scale[a] > 0.0f)) continue;
+    const int* bx = box + a * kSahBins * 6;
+    const uint32_t* cn = count + a * kSahBins;
+    float right_area[kSahBins];
+    uint32_t right_cnt[kSahBins];
+    float alo[3] = {INFINITY, INFINITY, INFINITY}, ahi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    uint32_t c = 0;
+    for (int k = kSahBins - 1; k > 0; --k) {
+      for (int d = 0; d < 3; ++d) { alo[d] = fminf(alo[d], ordered_to_float(bx[k * 6 + d])); ahi[d] = fmaxf(ahi[d], ordered_to_float(bx[k * 6 + 3 + d])); }
+      c += cn[k];
+      right_area[k] = sah_area(alo, ahi);
+      right_cnt[k] = c;
+    }
+    for (int d = 0; d < 3; ++d) { alo[d] = INFINITY; ahi[d] = -INFINITY; }
+    c = 0;
+    for (int k = 0; k < kSahBins - 1; ++k) {
+      for (int d = 0; d < 3; ++d) { alo[d] = fminf(alo[d], ordered_to_float(bx[k * 6 + d])); ahi[d] = fmaxf(ahi[d], ordered_to_float(bx[k * 6 + 3 + d])); }
+      c += cn[k];
+      if (c == 0 || right_cnt[k + 1] == 0) continue;
+      const float cost = sah_area(alo, ahi) * (float)c + right_area[k + 1] * (float)right_cnt[k + 1];
+      if (cost < best_cost) { best_cost = cost; best_axis = a; best_bin = k; }
+    }
+  }
+  uint32_t n_left = 0;
+  if (best_axis >= 0)
+    for (int k = 0; k <= best_bin; ++k) n_left += count[best_axis * kSahBins + k];
+  axis_out = best_axis;
+  bin_out = best_bin;
+  n_left_out = n_left;
+}
+// Children of node t once its range is in order in idx_out: leaves are linked, longer ranges queued for the next level.
+__device__ inline void sah_emit_children(const SahTask& t, uint32_t mid, const uint32_t* idx_out, int n_leaves, int2* children, int* parent,
+                                         SahTask* queue_out, uint32_t* n_out) {
+  int link[2];
+  const uint32_t rb[2] = {t.b, mid}, re[2] = {mid, t.e};
+  int next_id = t.node + 1;
+  for (int s = 0; s < 2; ++s) {
+    const uint32_t c = re[s] - rb[s];
+    if (c == 1) {
+      const uint32_t leaf = idx_out[rb[s]];
+      link[s] = ~(int)leaf;
+      parent[(n_leaves - 1) + (int)leaf] = t.node;
+    } else {
+      link[s] = next_id;
+      parent[next_id] = t.node;
+      queue_out[atomicAdd(n_out, 1u)] = SahTask{rb[s], re[s], next_id};
+      next_id += (int)c - 1;
+    }
+  }
+  children[t.node] = make_int2(link[0], link[1]);
+}
+// Stable partition of the elements [begin, end) of node t (a whole range or one chunk of it) into idx_out: lefts go to
+// t.b + done_left..., rights to mid + done_right..., a tile of B elements at a time.  s_wave_sum: B / 64 words, s_done: 2.
+template <int B>
+__device__ inline void sah_scatter(uint32_t begin, uint32_t end, uint32_t node_b, uint32_t mid, int axis, int bin, float lo_a, float scale_a,
+                                   uint32_t done_left, uint32_t done_right, const uint32_t* __restrict__ idx_in, uint32_t* __restrict__ idx_out,
+                                   const float4* __restrict__ leaf_lo, const float4* __restrict__ leaf_hi, uint32_t* s_wave_sum, uint32_t* s_done) {
+  const int tid = threadIdx.x;
+  if (tid == 0) { s_done[0] = done_left; s_done[1] = done_right; }
+  __syncthreads();
+  for (uint32_t base = begin; base < end; base += B) {
+    const uint32_t i = base + tid;
+    uint32_t p = 0;
+    bool left = false;
+    const bool valid = i < end;
+    if (valid) {
+      p = idx_in[i];
+      const float4 l = leaf_lo[p], h = leaf_hi[p];
+      const float c = axis == 0 ? 0.5f * (l.x + h.x) : (axis == 1 ? 0.5f * (l.y + h.y) : 0.5f * (l.z + h.z));
+      left = sah_bin_of(c, lo_a, scale_a) <= bin;
+    }
+    const unsigned long long m = __ballot(valid && left);
+    const uint32_t in_wave = (uint32_t)__popcll(m & ((1ull << (tid & 63)) - 1ull));
+    if ((tid & 63) == 0) s_wave_sum[tid >> 6] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t before = 0, tile_left = 0;
+    for (int w = 0; w < B / 64; ++w) {
+      if (w < (tid >> 6)) before += s_wave_sum[w];
+      tile_left += s_wave_sum[w];
+    }
+    const uint32_t lpos = before + in_wave;                 // lefts of the tile before this element
+    if (valid) {
+      if (left) idx_out[node_b + s_done[0] + lpos] = p;
+      else idx_out[mid + s_done[1] + ((uint32_t)tid - lpos)] = p;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      const uint32_t tile = min((uint32_t)B, end - base);
+      s_done[0] += tile_left;
+      s_done[1] += tile - tile_left;
+    }
+    __syncthreads();
+  }
+}
+
 template <int kSahBlock>
 __global__ void __launch_bounds__(kSahBlock) k_sah_level(const SahTask* __restrict__ queue_in, const uint32_t* __restrict__ n_in,
                                                          const uint32_t* __restrict__ idx_in, uint32_t* __restrict__ idx_out,
@@ -556,7 +657,7 @@ __global__ void __launch_bounds__(kSahBlock) k_sah_level(const SahTask* __restri
   __shared__ int s_box[3][kSahBins][6];      // ordered-int lo xyz, hi xyz
   __shared__ uint32_t s_count[3][kSahBins];
   __shared__ int s_axis, s_bin;
-  __shared__ uint32_t s_n_left, s_wave_sum[kSahBlock / 64], s_done_left, s_done_right;
+  __shared__ uint32_t s_n_left, s_wave_sum[kSahBlock / 64], s_done[2];
   uint32_t mid = t.b + cnt / 2;
   bool found = false;
   if (cnt > 2) {
@@ -597,106 +698,237 @@ __global__ void __launch_bounds__(kSahBlock) k_sah_level(const SahTask* __restri
       }
     }
     __syncthreads();
-    // ---- the split: bvh_sah.cpp, Builder::split, statement for statement ----
     if (tid == 0) {
-      float best_cost = INFINITY;
-      int best_axis = -1, best_bin = -1;
-      for (int a = 0; a < 3; ++a) {
-        if (!(s_scale[a] > 0.0f)) continue;
-        float right_area[kSahBins];
-        uint32_t right_cnt[kSahBins];
-        float alo[3] = {INFINITY, INFINITY, INFINITY}, ahi[3] = {-INFINITY, -INFINITY, -INFINITY};
-        uint32_t c = 0;
-        for (int k = kSahBins - 1; k > 0; --k) {
-          for (int d = 0; d < 3; ++d) { alo[d] = fminf(alo[d], ordered_to_float(s_box[a][k][d])); ahi[d] = fmaxf(ahi[d], ordered_to_float(s_box[a][k][3 + d])); }
-          c += s_count[a][k];
-          right_area[k] = sah_area(alo, ahi);
-          right_cnt[k] = c;
-        }
-        for (int d = 0; d < 3; ++d) { alo[d] = INFINITY; ahi[d] = -INFINITY; }
-        c = 0;
-        for (int k = 0; k < kSahBins - 1; ++k) {
-          for (int d = 0; d < 3; ++d) { alo[d] = fminf(alo[d], ordered_to_float(s_box[a][k][d])); ahi[d] = fmaxf(ahi[d], ordered_to_float(s_box[a][k][3 + d])); }
-          c += s_count[a][k];
-          if (c == 0 || right_cnt[k + 1] == 0) continue;
-          const float cost = sah_area(alo, ahi) * (float)c + right_area[k + 1] * (float)right_cnt[k + 1];
-          if (cost < best_cost) { best_cost = cost; best_axis = a; best_bin = k; }
-        }
-      }
-      uint32_t n_left = 0;
-      if (best_axis >= 0)
-        for (int k = 0; k <= best_bin; ++k) n_left += s_count[best_axis][k];
-      s_axis = best_axis;
-      s_bin = best_bin;
+      int axis, bin;
+      uint32_t n_left;
+      sah_pick_split(&s_box[0][0][0], &s_count[0][0], s_scale, axis, bin, n_left);
+      s_axis = axis;
+      s_bin = bin;
       s_n_left = n_left;
-      s_done_left = 0;
-      s_done_right = 0;
     }
     __syncthreads();
     found = s_axis >= 0 && s_n_left > 0 && s_n_left < cnt;
   }
   if (found) {
-    // ---- stable partition into idx_out, a tile of kSahBlock elements at a time ----
     mid = t.b + s_n_left;
-    const int axis = s_axis, bin = s_bin;
-    const float lo_a = s_clo[axis], scale_a = s_scale[axis];
-    for (uint32_t base = t.b; base < t.e; base += kSahBlock) {
-      const uint32_t i = base + tid;
-      uint32_t p = 0;
-      bool left = false, valid = i < t.e;
-      if (valid) {
-        p = idx_in[i];
-        const float4 l = leaf_lo[p], h = leaf_hi[p];
-        const float c = axis == 0 ? 0.5f * (l.x + h.x) : (axis == 1 ? 0.5f * (l.y + h.y) : 0.5f * (l.z + h.z));
-        left = sah_bin_of(c, lo_a, scale_a) <= bin;
-      }
-      const unsigned long long m = __ballot(valid && left);
-      const uint32_t in_wave = (uint32_t)__popcll(m & ((1ull << (tid & 63)) - 1ull));
-      if ((tid & 63) == 0) s_wave_sum[tid >> 6] = (uint32_t)__popcll(m);
-      __syncthreads();
-      uint32_t before = 0, tile_left = 0;
-      for (int w = 0; w < kSahBlock / 64; ++w) {
-        if (w < (tid >> 6)) before += s_wave_sum[w];
-        tile_left += s_wave_sum[w];
-      }
-      const uint32_t lpos = before + in_wave;                 // lefts of the tile before this element
-      if (valid) {
-        if (left) idx_out[t.b + s_done_left + lpos] = p;
-        else idx_out[mid + s_done_right + ((uint32_t)tid - lpos)] = p;
-      }
-      __syncthreads();
-      if (tid == 0) {
-        const uint32_t tile = min((uint32_t)kSahBlock, t.e - base);
-        s_done_left += tile_left;
-        s_done_right += tile - tile_left;
-      }
-      __syncthreads();
-    }
+    sah_scatter<kSahBlock>(t.b, t.e, t.b, mid, s_axis, s_bin, s_clo[s_axis], s_scale[s_axis], 0u, 0u, idx_in, idx_out, leaf_lo, leaf_hi, s_wave_sum, s_done);
   } else {
     for (uint32_t i = t.b + tid; i < t.e; i += kSahBlock) idx_out[i] = idx_in[i];   // two leaves, or every centroid in one place: halve the range as it stands
     __syncthreads();
   }
-  // ---- children ----
-  if (tid == 0) {
-    int link[2];
-    const uint32_t rb[2] = {t.b, mid}, re[2] = {mid, t.e};
-    int next_id = t.node + 1;
-    for (int s = 0; s < 2; ++s) {
-      const uint32_t c = re[s] - rb[s];
-      if (c == 1) {
-        const uint32_t leaf = idx_out[rb[s]];
-        link[s] = ~(int)leaf;
-        parent[(n_leaves - 1) + (int)leaf] = t.node;
-      } else {
-        link[s] = next_id;
-        parent[next_id] = t.node;
-        queue_out[atomicAdd(n_out, 1u)] = SahTask{rb[s], re[s], next_id};
-        next_id += (int)c - 1;
-      }
-    }
-    children[t.node] = make_int2(link[0], link[1]);
+  if (tid == 0) sah_emit_children(t, mid, idx_out, n_leaves, children, parent, queue_out, n_out);
+}
+// ---- the top levels: long ranges, several blocks per node ("chunks" of kSahChunk elements) ----
+// A level whose mean range is long would leave a handful of blocks looping over millions of elements (level 0 of 3.6 M
+// leaves: 70 ms in one block).  Here every pass of the level runs over (node, chunk) pairs: centroid bounds and bins are
+// combined per node with global atomics on ordered ints (min / max / counts: the result does not depend on the order), the
+// split is picked by one thread per node with the same routine, lefts are counted per chunk, and every chunk scatters
+// its elements behind those of the chunks before it -- the stable partition of the one-block version, hence the same tree.
+constexpr uint32_t kSahChunk = 4096;
+constexpr uint32_t kSahWideMean = 16384;   // levels whose mean range is at least this long take the several-blocks-per-node path
+constexpr int kSahWideBlock = 1024;
+struct SahWideNode {
+  int bounds[6];                       // ordered-int centroid lo xyz, hi xyz
+  int box[3 * kSahBins * 6];
+  uint32_t count[3 * kSahBins];
+  int axis, bin;
+  uint32_t n_left, found;
+  uint32_t chunk_base;                 // number of the node's first chunk in the level
+};
+__device__ __forceinline__ uint32_t sah_chunks_of(const SahTask& t) { return (t.e - t.b + kSahChunk - 1) / kSahChunk; }
+// block -> (node, chunk of the node); false when the block is beyond the level's chunks
+__device__ __forceinline__ bool sah_locate(const SahWideNode* __restrict__ wide, uint32_t n_nodes, uint32_t total_chunks, uint32_t block,
+                                           uint32_t& node, uint32_t& chunk) {
+  if (block >= total_chunks) return false;
+  uint32_t lo = 0, hi = n_nodes - 1;
+  while (lo < hi) {   // last node whose first chunk is <= block
+    const uint32_t m = (lo + hi + 1) >> 1;
+    if (wide[m].chunk_base <= block) lo = m; else hi = m - 1;
+  }
+  node = lo;
+  chunk = block - wide[lo].chunk_base;
+  return true;
+}
+__global__ void __launch_bounds__(1024) k_wide_plan(const SahTask* __restrict__ queue_in, const uint32_t* __restrict__ n_in, SahWideNode* __restrict__ wide,
+                                                    uint32_t* __restrict__ total_chunks) {
+  const uint32_t n_nodes = *n_in;
+  for (uint32_t i = threadIdx.x; i < n_nodes; i += blockDim.x) {
+    SahWideNode& w = wide[i];
+    for (int k = 0; k < 3; ++k) { w.bounds[k] = float_to_ordered(INFINITY); w.bounds[3 + k] = float_to_ordered(-INFINITY); }
+    for (int k = 0; k < 3 * kSahBins * 6; ++k) w.box[k] = (k % 6) < 3 ? float_to_ordered(INFINITY) : float_to_ordered(-INFINITY);
+    for (int k = 0; k < 3 * kSahBins; ++k) w.count[k] = 0;
+    w.axis = -1; w.bin = -1; w.n_left = 0; w.found = 0;
+  }
+  if (threadIdx.x == 0) {
+    uint32_t acc = 0;
+    for (uint32_t i = 0; i < n_nodes; ++i) { wide[i].chunk_base = acc; acc += sah_chunks_of(queue_in[i]); }
+    *total_chunks = acc;
   }
 }
+__global__ void __launch_bounds__(kSahWideBlock) k_wide_bounds(const SahTask* __restrict__ queue_in, const uint32_t* __restrict__ n_in,
+                                                               const uint32_t* __restrict__ total_chunks, SahWideNode* __restrict__ wide,
+                                                               const uint32_t* __restrict__ idx_in, const float4* __restrict__ leaf_lo,
+                                                               const float4* __restrict__ leaf_hi) {
+  uint32_t node, chunk;
+  if (!sah_locate(wide, *n_in, *total_chunks, blockIdx.x, node, chunk)) return;
+  const SahTask t = queue_in[node];
+  if (t.e - t.b <= 2) return;
+  const uint32_t begin = t.b + chunk * kSahChunk, end = min(t.e, begin + kSahChunk);
+  __shared__ float s_red[6][kSahWideBlock / 64];
+  const int tid = threadIdx.x;
+  float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (uint32_t i = begin + tid; i < end; i += kSahWideBlock) {
+    const uint32_t p = idx_in[i];
+    const float4 l = leaf_lo[p], h = leaf_hi[p];
+    const float c[3] = {0.5f * (l.x + h.x), 0.5f * (l.y + h.y), 0.5f * (l.z + h.z)};
+    for (int k = 0; k < 3; ++k) { clo[k] = fminf(clo[k], c[k]); chi[k] = fmaxf(chi[k], c[k]); }
+  }
+  for (int off = 32; off > 0; off >>= 1)
+    for (int k = 0; k < 3; ++k) { clo[k] = fminf(clo[k], __shfl_xor(clo[k], off)); chi[k] = fmaxf(chi[k], __shfl_xor(chi[k], off)); }
+  if ((tid & 63) == 0)
+    for (int k = 0; k < 3; ++k) { s_red[k][tid >> 6] = clo[k]; s_red[3 + k][tid >> 6] = chi[k]; }
+  __syncthreads();
+  if (tid < 3) {
+    float l = INFINITY, h = -INFINITY;
+    for (int w = 0; w < kSahWideBlock / 64; ++w) { l = fminf(l, s_red[tid][w]); h = fmaxf(h, s_red[3 + tid][w]); }
+    atomicMin(&wide[node].bounds[tid], float_to_ordered(l));
+    atomicMax(&wide[node].bounds[3 + tid], float_to_ordered(h));
+  }
+}
+__device__ __forceinline__ void sah_wide_scale(const SahWideNode& w, float clo[3], float scale[3]) {
+  for (int a = 0; a < 3; ++a) {
+    const float l = ordered_to_float(w.bounds[a]), h = ordered_to_float(w.bounds[3 + a]);
+    clo[a] = l;
+    scale[a] = h - l > 0.0f ? (float)kSahBins / (h - l) : 0.0f;
+  }
+}
+__global__ void __launch_bounds__(kSahWideBlock) k_wide_bin(const SahTask* __restrict__ queue_in, const uint32_t* __restrict__ n_in,
+                                                            const uint32_t* __restrict__ total_chunks, SahWideNode* __restrict__ wide,
+                                                            const uint32_t* __restrict__ idx_in, const float4* __restrict__ leaf_lo,
+                                                            const float4* __restrict__ leaf_hi) {
+  uint32_t node, chunk;
+  if (!sah_locate(wide, *n_in, *total_chunks, blockIdx.x, node, chunk)) return;
+  const SahTask t = queue_in[node];
+  if (t.e - t.b <= 2) return;
+  const uint32_t begin = t.b + chunk * kSahChunk, end = min(t.e, begin + kSahChunk);
+  __shared__ int s_box[3 * kSahBins * 6];
+  __shared__ uint32_t s_count[3 * kSahBins];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 3 * kSahBins * 6; i += kSahWideBlock) s_box[i] = (i % 6) < 3 ? float_to_ordered(INFINITY) : float_to_ordered(-INFINITY);
+  for (int i = tid; i < 3 * kSahBins; i += kSahWideBlock) s_count[i] = 0;
+  float clo[3], scale[3];
+  sah_wide_scale(wide[node], clo, scale);
+  __syncthreads();
+  for (uint32_t i = begin + tid; i < end; i += kSahWideBlock) {
+    const uint32_t p = idx_in[i];
+    const float4 l = leaf_lo[p], h = leaf_hi[p];
+    const float c[3] = {0.5f * (l.x + h.x), 0.5f * (l.y + h.y), 0.5f * (l.z + h.z)};
+    for (int a = 0; a < 3; ++a) {
+      if (!(scale[a] > 0.0f)) continue;
+      int* bx = &s_box[(a * kSahBins + sah_bin_of(c[a], clo[a], scale[a])) * 6];
+      atomicMin(&bx[0], float_to_ordered(l.x)); atomicMin(&bx[1], float_to_ordered(l.y)); atomicMin(&bx[2], float_to_ordered(l.z));
+      atomicMax(&bx[3], float_to_ordered(h.x)); atomicMax(&bx[4], float_to_ordered(h.y)); atomicMax(&bx[5], float_to_ordered(h.z));
+      atomicAdd(&s_count[a * kSahBins + sah_bin_of(c[a], clo[a], scale[a])], 1u);
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < 3 * kSahBins; i += kSahWideBlock) {
+    if (s_count[i] == 0) continue;
+    atomicAdd(&wide[node].count[i], s_count[i]);
+    for (int d = 0; d < 3; ++d) { atomicMin(&wide[node].box[i * 6 + d], s_box[i * 6 + d]); atomicMax(&wide[node].box[i * 6 + 3 + d], s_box[i * 6 + 3 + d]); }
+  }
+}
+__global__ void __launch_bounds__(64) k_wide_pick(const SahTask* __restrict__ queue_in, const uint32_t* __restrict__ n_in, SahWideNode* __restrict__ wide) {
+  const uint32_t node = blockIdx.x * blockDim.x + threadIdx.x;
+  if (node >= *n_in) return;
+  const SahTask t = queue_in[node];
+  const uint32_t cnt = t.e - t.b;
+  if (cnt <= 2) return;
+  float clo[3], scale[3];
+  sah_wide_scale(wide[node], clo, scale);
+  int axis, bin;
+  uint32_t n_left;
+  sah_pick_split(wide[node].box, wide[node].count, scale, axis, bin, n_left);
+  wide[node].axis = axis;
+  wide[node].bin = bin;
+  wide[node].n_left = n_left;
+  wide[node].found = (axis >= 0 && n_left > 0 && n_left < cnt) ? 1u : 0u;
+}
+__global__ void __launch_bounds__(kSahWideBlock) k_wide_count(const SahTask* __restrict__ queue_in, const uint32_t* __restrict__ n_in,
+                                                              const uint32_t* __restrict__ total_chunks, const SahWideNode* __restrict__ wide,
+                                                              const uint32_t* __restrict__ idx_in, const float4* __restrict__ leaf_lo,
+                                                              const float4* __restrict__ leaf_hi, uint32_t* __restrict__ chunk_left) {
+  uint32_t node, chunk;
+  if (!sah_locate(wide, *n_in, *total_chunks, blockIdx.x, node, chunk)) return;
+  const SahWideNode& w = wide[node];
+  if (!w.found) return;
+  const SahTask t = queue_in[node];
+  const uint32_t begin = t.b + chunk * kSahChunk, end = min(t.e, begin + kSahChunk);
+  __shared__ uint32_t s_sum[kSahWideBlock / 64];
+  float clo[3], scale[3];
+  sah_wide_scale(w, clo, scale);
+  const int axis = w.axis, bin = w.bin, tid = threadIdx.x;
+  uint32_t mine = 0;
+  for (uint32_t i = begin + tid; i < end; i += kSahWideBlock) {
+    const uint32_t p = idx_in[i];
+    const float4 l = leaf_lo[p], h = leaf_hi[p];
+    const float c = axis == 0 ? 0.5f * (l.x + h.x) : (axis == 1 ? 0.5f * (l.y + h.y) : 0.5f * (l.z + h.z));
+    mine += sah_bin_of(c, clo[axis], scale[axis]) <= bin ? 1u : 0u;
+  }
+  for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
+  if ((tid & 63) == 0) s_sum[tid >> 6] = mine;
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t total = 0;
+    for (int k = 0; k < kSahWideBlock / 64; ++k) total += s_sum[k];
+    chunk_left[blockIdx.x] = total;
+  }
+}
+__global__ void __launch_bounds__(kSahWideBlock) k_wide_scatter(const SahTask* __restrict__ queue_in, const uint32_t* __restrict__ n_in,
+                                                                const uint32_t* __restrict__ total_chunks, const SahWideNode* __restrict__ wide,
+                                                                const uint32_t* __restrict__ chunk_left, const uint32_t* __restrict__ idx_in,
+                                                                uint32_t* __restrict__ idx_out, const float4* __restrict__ leaf_lo,
+                                                                const float4* __restrict__ leaf_hi) {
+  uint32_t node, chunk;
+  if (!sah_locate(wide, *n_in, *total_chunks, blockIdx.x, node, chunk)) return;
+  const SahWideNode& w = wide[node];
+  const SahTask t = queue_in[node];
+  const uint32_t begin = t.b + chunk * kSahChunk, end = min(t.e, begin + kSahChunk);
+  const int tid = threadIdx.x;
+  if (!w.found) {   // the range stays as it is
+    for (uint32_t i = begin + tid; i < end; i += kSahWideBlock) idx_out[i] = idx_in[i];
+    return;
+  }
+  __shared__ uint32_t s_sum[kSahWideBlock / 64], s_wave_sum[kSahWideBlock / 64], s_done[2], s_before;
+  // lefts in the chunks of this node before this one
+  uint32_t mine = 0;
+  for (uint32_t c = tid; c < chunk; c += kSahWideBlock) mine += chunk_left[w.chunk_base + c];
+  for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
+  if ((tid & 63) == 0) s_sum[tid >> 6] = mine;
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t total = 0;
+    for (int k = 0; k < kSahWideBlock / 64; ++k) total += s_sum[k];
+    s_before = total;
+  }
+  __syncthreads();
+  const uint32_t left_before = s_before, right_before = chunk * kSahChunk - left_before;
+  float clo[3], scale[3];
+  sah_wide_scale(w, clo, scale);
+  sah_scatter<kSahWideBlock>(begin, end, t.b, t.b + w.n_left, w.axis, w.bin, clo[w.axis], scale[w.axis], left_before, right_before, idx_in, idx_out, leaf_lo,
+                             leaf_hi, s_wave_sum, s_done);
+}
+__global__ void __launch_bounds__(64) k_wide_children(const SahTask* __restrict__ queue_in, const uint32_t* __restrict__ n_in,
+                                                      const SahWideNode* __restrict__ wide, const uint32_t* __restrict__ idx_out, int n_leaves,
+                                                      int2* __restrict__ children, int* __restrict__ parent, SahTask* __restrict__ queue_out,
+                                                      uint32_t* __restrict__ n_out) {
+  const uint32_t node = blockIdx.x * blockDim.x + threadIdx.x;
+  if (node >= *n_in) return;
+  const SahTask t = queue_in[node];
+  const uint32_t mid = wide[node].found ? t.b + wide[node].n_left : t.b + (t.e - t.b) / 2;
+  sah_emit_children(t, mid, idx_out, n_leaves, children, parent, queue_out, n_out);
+}
+
 __global__ void k_sah_init(uint32_t n, uint32_t* __restrict__ idx, SahTask* __restrict__ queue, uint32_t* __restrict__ counts, int* __restrict__ parent) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) idx[i] = i;
@@ -923,14 +1155,15 @@ hipError_t build_lbvh(hipStream_t st, const LbvhInputs& in, LbvhOutputs& out) {
   int2* children = nullptr;
   int *parent = nullptr, *node_depth = nullptr, *scalars = nullptr, *counts = nullptr, *new_id = nullptr;
   int *refs_a = nullptr, *refs_b = nullptr, *nearest = nullptr;
-  uint32_t *sah_idx_a = nullptr, *sah_idx_b = nullptr, *sah_counts = nullptr;
+  uint32_t *sah_idx_a = nullptr, *sah_idx_b = nullptr, *sah_counts = nullptr, *sah_total_chunks = nullptr, *sah_chunk_left = nullptr;
+  SahWideNode* sah_wide = nullptr;
   SahTask *sah_queue_a = nullptr, *sah_queue_b = nullptr;
   unsigned long long *flags = nullptr, *pos = nullptr, *slot = nullptr, *scan_tmp = nullptr, *scan_total = nullptr;
   float* sah = nullptr;
   BvhGrid* grid = nullptr;
   auto cleanup = [&]() {
     void* bufs[] = {tris_unsorted, lo, hi, leaf_lo, leaf_hi, leaf_first, role, node_lo, node_hi, keys, vals, children, parent, node_depth, scalars, sah,
-                    grid, counts, new_id, refs_a, refs_b, nearest, flags, pos, slot, scan_tmp, scan_total, sah_idx_a, sah_idx_b, sah_counts, sah_queue_a, sah_queue_b};
+                    grid, counts, new_id, refs_a, refs_b, nearest, flags, pos, slot, scan_tmp, scan_total, sah_idx_a, sah_idx_b, sah_counts, sah_queue_a, sah_queue_b, sah_total_chunks, sah_chunk_left, sah_wide};
     for (void* b : bufs)
       if (b) (void)hipFree(b);
   };
@@ -1027,6 +1260,9 @@ hipError_t build_lbvh(hipStream_t st, const LbvhInputs& in, LbvhOutputs& out) {
       GLZ_TRY(hipMalloc(&sah_queue_a, sizeof(SahTask) * qcap));
       GLZ_TRY(hipMalloc(&sah_queue_b, sizeof(SahTask) * qcap));
       GLZ_TRY(hipMalloc(&sah_counts, sizeof(uint32_t) * 2));
+      GLZ_TRY(hipMalloc(&sah_total_chunks, sizeof(uint32_t)));
+      GLZ_TRY(hipMalloc(&sah_wide, sizeof(SahWideNode) * ((size_t)n / kSahWideMean + 2)));
+      GLZ_TRY(hipMalloc(&sah_chunk_left, sizeof(uint32_t) * ((size_t)n / kSahWideMean + (size_t)n / kSahChunk + 4)));
       hipLaunchKernelGGL(k_sah_init, grd, blk, 0, st, n, sah_idx_a, sah_queue_a, sah_counts, parent);
       GLZ_TRY(hipGetLastError());
       uint32_t active = 1;
@@ -1034,15 +1270,32 @@ hipError_t build_lbvh(hipStream_t st, const LbvhInputs& in, LbvhOutputs& out) {
       SahTask *q_in = sah_queue_a, *q_out = sah_queue_b;
       for (int level = 0, in = 0; active > 0; ++level, in ^= 1) {
         if (level > 4096) { cleanup(); return hipErrorUnknown; }   // cannot happen: every level at least halves the ranges it cannot split
-        // block size by the mean range of the level: long ranges at the top want many threads (a range is one block's
-        // loop), the wide bottom levels want cheap blocks (one wave: its barriers cost nothing)
+        // by the mean range of the level: several blocks per node while the ranges are long, then one block per node --
+        // many threads for a long range (it is one block's loop), one wave for the wide bottom levels (its barriers cost nothing)
         const uint32_t mean = n / active;
+        if (mean >= kSahWideMean) {
+          const uint32_t max_chunks = active + n / kSahChunk + 1;
+          const dim3 gc(max_chunks), gn((active + 63) / 64);
+          hipLaunchKernelGGL(k_wide_plan, dim3(1), dim3(1024), 0, st, q_in, sah_counts + in, sah_wide, sah_total_chunks);
+          hipLaunchKernelGGL(k_wide_bounds, gc, dim3(kSahWideBlock), 0, st, q_in, sah_counts + in, sah_total_chunks, sah_wide, idx_in, node_lo + (n - 1),
+                             node_hi + (n - 1));
+          hipLaunchKernelGGL(k_wide_bin, gc, dim3(kSahWideBlock), 0, st, q_in, sah_counts + in, sah_total_chunks, sah_wide, idx_in, node_lo + (n - 1),
+                             node_hi + (n - 1));
+          hipLaunchKernelGGL(k_wide_pick, gn, dim3(64), 0, st, q_in, sah_counts + in, sah_wide);
+          hipLaunchKernelGGL(k_wide_count, gc, dim3(kSahWideBlock), 0, st, q_in, sah_counts + in, sah_total_chunks, sah_wide, idx_in, node_lo + (n - 1),
+                             node_hi + (n - 1), sah_chunk_left);
+          hipLaunchKernelGGL(k_wide_scatter, gc, dim3(kSahWideBlock), 0, st, q_in, sah_counts + in, sah_total_chunks, sah_wide, sah_chunk_left, idx_in, idx_out,
+                             node_lo + (n - 1), node_hi + (n - 1));
+          hipLaunchKernelGGL(k_wide_children, gn, dim3(64), 0, st, q_in, sah_counts + in, sah_wide, idx_out, (int)n, children, parent, q_out,
+                             sah_counts + (in ^ 1));
+        } else {
 #define GLZ_SAH_LAUNCH(B) hipLaunchKernelGGL(k_sah_level<B>, dim3(active), dim3(B), 0, st, q_in, sah_counts + in, idx_in, idx_out, q_out, \
                                              sah_counts + (in ^ 1), (int)n, node_lo + (n - 1), node_hi + (n - 1), children, parent)
-        if (mean >= 4096) GLZ_SAH_LAUNCH(1024);
-        else if (mean >= 128) GLZ_SAH_LAUNCH(256);
-        else GLZ_SAH_LAUNCH(64);
+          if (mean >= 4096) GLZ_SAH_LAUNCH(1024);
+          else if (mean >= 128) GLZ_SAH_LAUNCH(256);
+          else GLZ_SAH_LAUNCH(64);
 #undef GLZ_SAH_LAUNCH
+        }
         GLZ_TRY(hipGetLastError());
         GLZ_TRY(hipMemcpyAsync(&active, sah_counts + (in ^ 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         GLZ_TRY(hipMemsetAsync(sah_counts + in, 0, sizeof(uint32_t), st));   // this level's input counter is the output counter of the level after next
