@@ -642,15 +642,19 @@ __device__ inline void sah_scatter(uint32_t begin, uint32_t end, uint32_t node_b
   }
 }
 
+// One block per node of the level.  A one-wave block whose node holds at most 64 leaves finishes the whole subtree by
+// itself (children go on a stack in LDS, each reading the index array its parent wrote): the wide bottom of the tree --
+// millions of two- and three-leaf nodes over six or seven levels -- costs one level.
 template <int kSahBlock>
 __global__ void __launch_bounds__(kSahBlock) k_sah_level(const SahTask* __restrict__ queue_in, const uint32_t* __restrict__ n_in,
-                                                         const uint32_t* __restrict__ idx_in, uint32_t* __restrict__ idx_out,
+                                                         uint32_t* idx_a /* read by the level's nodes */, uint32_t* idx_b /* written */,
                                                          SahTask* __restrict__ queue_out, uint32_t* __restrict__ n_out, int n_leaves,
                                                          const float4* __restrict__ leaf_lo, const float4* __restrict__ leaf_hi,
                                                          int2* __restrict__ children, int* __restrict__ parent) {
   if (blockIdx.x >= *n_in) return;
-  const SahTask t = queue_in[blockIdx.x];
-  const uint32_t cnt = t.e - t.b;
+  constexpr int kLocalLeaves = 64;
+  SahTask t = queue_in[blockIdx.x];
+  const bool local = kSahBlock == 64 && t.e - t.b <= (uint32_t)kLocalLeaves;
   const int tid = threadIdx.x;
   __shared__ float s_red[6][kSahBlock / 64];
   __shared__ float s_clo[3], s_chi[3], s_scale[3];
@@ -658,65 +662,105 @@ __global__ void __launch_bounds__(kSahBlock) k_sah_level(const SahTask* __restri
   __shared__ uint32_t s_count[3][kSahBins];
   __shared__ int s_axis, s_bin;
   __shared__ uint32_t s_n_left, s_wave_sum[kSahBlock / 64], s_done[2];
-  uint32_t mid = t.b + cnt / 2;
-  bool found = false;
-  if (cnt > 2) {
-    // ---- centroid bounds ----
-    float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (uint32_t i = t.b + tid; i < t.e; i += kSahBlock) {
-      const uint32_t p = idx_in[i];
-      const float4 l = leaf_lo[p], h = leaf_hi[p];
-      const float c[3] = {0.5f * (l.x + h.x), 0.5f * (l.y + h.y), 0.5f * (l.z + h.z)};
-      for (int k = 0; k < 3; ++k) { clo[k] = fminf(clo[k], c[k]); chi[k] = fmaxf(chi[k], c[k]); }
-    }
-    for (int off = 32; off > 0; off >>= 1)
-      for (int k = 0; k < 3; ++k) { clo[k] = fminf(clo[k], __shfl_xor(clo[k], off)); chi[k] = fmaxf(chi[k], __shfl_xor(chi[k], off)); }
-    if ((tid & 63) == 0)
-      for (int k = 0; k < 3; ++k) { s_red[k][tid >> 6] = clo[k]; s_red[3 + k][tid >> 6] = chi[k]; }
-    for (int i = tid; i < 3 * kSahBins * 6; i += kSahBlock) (&s_box[0][0][0])[i] = (i % 6) < 3 ? float_to_ordered(INFINITY) : float_to_ordered(-INFINITY);
-    for (int i = tid; i < 3 * kSahBins; i += kSahBlock) (&s_count[0][0])[i] = 0;
-    __syncthreads();
-    if (tid < 3) {
-      float l = INFINITY, h = -INFINITY;
-      for (int w = 0; w < kSahBlock / 64; ++w) { l = fminf(l, s_red[tid][w]); h = fmaxf(h, s_red[3 + tid][w]); }
-      s_clo[tid] = l;
-      s_chi[tid] = h;
-      s_scale[tid] = h - l > 0.0f ? (float)kSahBins / (h - l) : 0.0f;
-    }
-    __syncthreads();
-    // ---- binning ----
-    for (uint32_t i = t.b + tid; i < t.e; i += kSahBlock) {
-      const uint32_t p = idx_in[i];
-      const float4 l = leaf_lo[p], h = leaf_hi[p];
-      const float c[3] = {0.5f * (l.x + h.x), 0.5f * (l.y + h.y), 0.5f * (l.z + h.z)};
-      for (int a = 0; a < 3; ++a) {
-        if (!(s_scale[a] > 0.0f)) continue;
-        const int k = sah_bin_of(c[a], s_clo[a], s_scale[a]);
-        atomicMin(&s_box[a][k][0], float_to_ordered(l.x)); atomicMin(&s_box[a][k][1], float_to_ordered(l.y)); atomicMin(&s_box[a][k][2], float_to_ordered(l.z));
-        atomicMax(&s_box[a][k][3], float_to_ordered(h.x)); atomicMax(&s_box[a][k][4], float_to_ordered(h.y)); atomicMax(&s_box[a][k][5], float_to_ordered(h.z));
-        atomicAdd(&s_count[a][k], 1u);
+  __shared__ SahTask s_stack[kSahBlock == 64 ? kLocalLeaves : 1];   // bit 31 of .node: the task reads idx_b (its parent wrote there)
+  __shared__ int s_sp;
+  if (tid == 0) s_sp = 0;
+  bool flip = false;
+  for (;;) {
+    const uint32_t* idx_in = flip ? idx_b : idx_a;
+    uint32_t* idx_out = flip ? idx_a : idx_b;
+    const uint32_t cnt = t.e - t.b;
+    uint32_t mid = t.b + cnt / 2;
+    bool found = false;
+    if (cnt > 2) {
+      // ---- centroid bounds ----
+      float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
+      for (uint32_t i = t.b + tid; i < t.e; i += kSahBlock) {
+        const uint32_t p = idx_in[i];
+        const float4 l = leaf_lo[p], h = leaf_hi[p];
+        const float c[3] = {0.5f * (l.x + h.x), 0.5f * (l.y + h.y), 0.5f * (l.z + h.z)};
+        for (int k = 0; k < 3; ++k) { clo[k] = fminf(clo[k], c[k]); chi[k] = fmaxf(chi[k], c[k]); }
       }
+      for (int off = 32; off > 0; off >>= 1)
+        for (int k = 0; k < 3; ++k) { clo[k] = fminf(clo[k], __shfl_xor(clo[k], off)); chi[k] = fmaxf(chi[k], __shfl_xor(chi[k], off)); }
+      if ((tid & 63) == 0)
+        for (int k = 0; k < 3; ++k) { s_red[k][tid >> 6] = clo[k]; s_red[3 + k][tid >> 6] = chi[k]; }
+      for (int i = tid; i < 3 * kSahBins * 6; i += kSahBlock) (&s_box[0][0][0])[i] = (i % 6) < 3 ? float_to_ordered(INFINITY) : float_to_ordered(-INFINITY);
+      for (int i = tid; i < 3 * kSahBins; i += kSahBlock) (&s_count[0][0])[i] = 0;
+      __syncthreads();
+      if (tid < 3) {
+        float l = INFINITY, h = -INFINITY;
+        for (int w = 0; w < kSahBlock / 64; ++w) { l = fminf(l, s_red[tid][w]); h = fmaxf(h, s_red[3 + tid][w]); }
+        s_clo[tid] = l;
+        s_chi[tid] = h;
+        s_scale[tid] = h - l > 0.0f ? (float)kSahBins / (h - l) : 0.0f;
+      }
+      __syncthreads();
+      // ---- binning ----
+      for (uint32_t i = t.b + tid; i < t.e; i += kSahBlock) {
+        const uint32_t p = idx_in[i];
+        const float4 l = leaf_lo[p], h = leaf_hi[p];
+        const float c[3] = {0.5f * (l.x + h.x), 0.5f * (l.y + h.y), 0.5f * (l.z + h.z)};
+        for (int a = 0; a < 3; ++a) {
+          if (!(s_scale[a] > 0.0f)) continue;
+          const int k = sah_bin_of(c[a], s_clo[a], s_scale[a]);
+          atomicMin(&s_box[a][k][0], float_to_ordered(l.x)); atomicMin(&s_box[a][k][1], float_to_ordered(l.y)); atomicMin(&s_box[a][k][2], float_to_ordered(l.z));
+          atomicMax(&s_box[a][k][3], float_to_ordered(h.x)); atomicMax(&s_box[a][k][4], float_to_ordered(h.y)); atomicMax(&s_box[a][k][5], float_to_ordered(h.z));
+          atomicAdd(&s_count[a][k], 1u);
+        }
+      }
+      __syncthreads();
+      if (tid == 0) {
+        int axis, bin;
+        uint32_t n_left;
+        sah_pick_split(&s_box[0][0][0], &s_count[0][0], s_scale, axis, bin, n_left);
+        s_axis = axis;
+        s_bin = bin;
+        s_n_left = n_left;
+      }
+      __syncthreads();
+      found = s_axis >= 0 && s_n_left > 0 && s_n_left < cnt;
     }
-    __syncthreads();
+    if (found) {
+      mid = t.b + s_n_left;
+      sah_scatter<kSahBlock>(t.b, t.e, t.b, mid, s_axis, s_bin, s_clo[s_axis], s_scale[s_axis], 0u, 0u, idx_in, idx_out, leaf_lo, leaf_hi, s_wave_sum, s_done);
+    } else {
+      for (uint32_t i = t.b + tid; i < t.e; i += kSahBlock) idx_out[i] = idx_in[i];   // two leaves, or every centroid in one place: halve the range as it stands
+      __syncthreads();
+    }
+    if (!local) {
+      if (tid == 0) sah_emit_children(t, mid, idx_out, n_leaves, children, parent, queue_out, n_out);
+      return;
+    }
+    // ---- this wave goes on with the children ----
     if (tid == 0) {
-      int axis, bin;
-      uint32_t n_left;
-      sah_pick_split(&s_box[0][0][0], &s_count[0][0], s_scale, axis, bin, n_left);
-      s_axis = axis;
-      s_bin = bin;
-      s_n_left = n_left;
+      int link[2];
+      const uint32_t rb[2] = {t.b, mid}, re[2] = {mid, t.e};
+      int next_id = t.node + 1;
+      for (int s = 0; s < 2; ++s) {
+        const uint32_t c = re[s] - rb[s];
+        if (c == 1) {
+          const uint32_t leaf = idx_out[rb[s]];
+          link[s] = ~(int)leaf;
+          parent[(n_leaves - 1) + (int)leaf] = t.node;
+        } else {
+          link[s] = next_id;
+          parent[next_id] = t.node;
+          s_stack[s_sp++] = SahTask{rb[s], re[s], next_id | (flip ? 0 : (int)0x80000000)};   // the child reads what this node wrote
+          next_id += (int)c - 1;
+        }
+      }
+      children[t.node] = make_int2(link[0], link[1]);
     }
     __syncthreads();
-    found = s_axis >= 0 && s_n_left > 0 && s_n_left < cnt;
-  }
-  if (found) {
-    mid = t.b + s_n_left;
-    sah_scatter<kSahBlock>(t.b, t.e, t.b, mid, s_axis, s_bin, s_clo[s_axis], s_scale[s_axis], 0u, 0u, idx_in, idx_out, leaf_lo, leaf_hi, s_wave_sum, s_done);
-  } else {
-    for (uint32_t i = t.b + tid; i < t.e; i += kSahBlock) idx_out[i] = idx_in[i];   // two leaves, or every centroid in one place: halve the range as it stands
+    if (s_sp == 0) return;
+    t = s_stack[s_sp - 1];
+    __syncthreads();
+    if (tid == 0) --s_sp;
+    flip = (t.node & (int)0x80000000) != 0;
+    t.node &= 0x7FFFFFFF;
     __syncthreads();
   }
-  if (tid == 0) sah_emit_children(t, mid, idx_out, n_leaves, children, parent, queue_out, n_out);
 }
 // ---- the top levels: long ranges, several blocks per node ("chunks" of kSahChunk elements) ----
 // A level whose mean range is long would leave a handful of blocks looping over millions of elements (level 0 of 3.6 M

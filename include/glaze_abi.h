@@ -237,12 +237,12 @@ int glz_instance_device(const glz_instance*);
 void* glz_instance_stream(const glz_instance*);
 /* [extension] acceleration-structure builder for scenes created afterwards (the reference leaves the choice to the
  * Vulkan driver, acceleration.rs:253-257 asks for PREFER_FAST_TRACE).  Hits do not depend on it.
- *   GLZ_BVH_SAH      (default, = GLZ_BVH_AUTO) top-down binned SAH on the GPU, one launch per level: 11 ms for 262 k
- *                    triangles, 55 ms for 1.8 M, 0.2 s for 7 M, 0.6 s for 21 M; SAH cost -11 % and 5-13 % more samples
+ *   GLZ_BVH_SAH      (default, = GLZ_BVH_AUTO) top-down binned SAH on the GPU, level by level: 7 ms for 262 k
+ *                    triangles, 14 ms for 1.8 M, 34 ms for 7 M, 86 ms for 21 M; SAH cost -11 % and 5-13 % more samples
  *                    per second than the LBVH
  *   GLZ_BVH_LBVH     Karras 2012 on the GPU: fastest build (3 ms for 262 k triangles, 33 ms for 21 M)
  *   GLZ_BVH_PLOC     parallel locally-ordered clustering on the GPU (Meister & Bittner 2018): the LBVH's quality here
- *   GLZ_BVH_SAH_HOST the SAH builder's reference implementation on the host cores: the same tree node for node, 2-3 x
+ *   GLZ_BVH_SAH_HOST the SAH builder's reference implementation on the host cores: the same tree node for node, 3-24 x
  *                    slower (tests compare the two) */
 #define GLZ_BVH_LBVH 0
 #define GLZ_BVH_PLOC 1
