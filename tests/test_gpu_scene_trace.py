@@ -284,6 +284,36 @@ def test_gpu_sah_builder_equals_its_host_reference(case):
         assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1].view(np.uint32), out[1][1].view(np.uint32))
 
 
+def test_non_finite_vertices_do_not_break_the_builders():
+    """NaN and infinite vertices (a broken export): every builder must finish, and the triangles that are finite must be hit
+    exactly as with any other builder (triangles with a non-finite vertex can never pass the intersection test)."""
+    from glaze_amd.scene_desc import MESH_DTYPE, VERTEX_DTYPE, SceneDesc
+    rng = np.random.default_rng(3)
+    n = 20000
+    tri = (rng.normal(size=(n, 1, 3)) * 2 + rng.normal(size=(n, 3, 3)) * 0.05).astype(np.float32)
+    tri[::97, 0, 0] = np.nan
+    tri[5::131, 1] = np.inf
+    tri[7::211] = -np.inf
+    verts = np.zeros((n * 3, 8), np.float32)
+    verts[:, :3] = tri.reshape(-1, 3)
+    verts[:, 3:6] = [0, 0, 1]
+    base = cube_scene()
+    desc = SceneDesc(verts.view(VERTEX_DTYPE).reshape(-1), np.arange(n * 3, dtype=np.uint32), np.array([(0, 1, 0, n * 3)], MESH_DTYPE), None,
+                     base.instances, base.materials, base.lights, base.textures, base.camera, base.meta)
+    o = (rng.normal(size=(20000, 3)) * 2).astype(np.float32)
+    d = rng.normal(size=(20000, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    ref = None
+    for b in ("lbvh", "ploc", "sah", "sah_host"):
+        inst = glaze_amd.RayTraceInstance.new()
+        inst.set_bvh_builder(b)
+        t, tri_id, _, _, _ = glaze_amd.RayTraceScene.from_desc(inst, desc).debug_trace_closest(o, d)
+        assert 1000 < np.isfinite(t).sum() < 20000
+        if ref is None:
+            ref = (t, tri_id)
+        assert np.array_equal(t.view(np.uint32), ref[0].view(np.uint32)) and np.array_equal(tri_id, ref[1]), b
+
+
 def test_transform_memory_layout_kat_on_device(instance):
     """geometry/mesh.rs:110-119 (column-major Transform = row-major 3x4 Vulkan transform): world-space leaf of the flattened instance."""
     from test_oracle_kats import LAYOUT_KAT_WORLD, _layout_kat_scene
