@@ -191,7 +191,7 @@ struct TraceTally {
 #define GLZ_REFILL 16
 #endif
 #ifndef GLZ_LEAF_QUORUM
-#define GLZ_LEAF_QUORUM 16   // 4-wide nodes: 8 -> 0.815, 12 -> 0.790, 16 -> 0.781, 24 -> 0.810 ms per k_trace
+#define GLZ_LEAF_QUORUM 16   // 4-wide nodes: 8 -> 0.815, 12 -> 0.790, 16 -> 0.781, 24 -> 0.810 ms per k_trace; with pair leaves 8 / 12 / 16 / 24 / 32 -> 0.650 / 0.606 / 0.589 / 0.583 / 0.598
 #endif
 constexpr int kRefill = GLZ_REFILL;
 constexpr int kLeafQuorum = GLZ_LEAF_QUORUM;
