@@ -650,7 +650,7 @@ __global__ void __launch_bounds__(kSahBlock) k_sah_level(const SahTask* __restri
                                                          uint32_t* idx_a /* read by the level's nodes */, uint32_t* idx_b /* written */,
                                                          SahTask* __restrict__ queue_out, uint32_t* __restrict__ n_out, int n_leaves,
                                                          const float4* __restrict__ leaf_lo, const float4* __restrict__ leaf_hi,
-                                                         int2* __restrict__ children, int* __restrict__ parent) {
+                                                         int2* __restrict__ children, int* __restrict__ parent, int force_halve) {
   if (blockIdx.x >= *n_in) return;
   constexpr int kLocalLeaves = 64;
   SahTask t = queue_in[blockIdx.x];
@@ -672,7 +672,7 @@ __global__ void __launch_bounds__(kSahBlock) k_sah_level(const SahTask* __restri
     const uint32_t cnt = t.e - t.b;
     uint32_t mid = t.b + cnt / 2;
     bool found = false;
-    if (cnt > 2) {
+    if (cnt > 2 && !force_halve) {
       // ---- centroid bounds ----
       float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
       for (uint32_t i = t.b + tid; i < t.e; i += kSahBlock) {
@@ -768,6 +768,7 @@ __global__ void __launch_bounds__(kSahBlock) k_sah_level(const SahTask* __restri
 // combined per node with global atomics on ordered ints (min / max / counts: the result does not depend on the order), the
 // split is picked by one thread per node with the same routine, lefts are counted per chunk, and every chunk scatters
 // its elements behind those of the chunks before it -- the stable partition of the one-block version, hence the same tree.
+constexpr int kSahMaxSplitLevels = 256;   // levels of SAH splits before the rest of the tree is built by halving ranges
 constexpr uint32_t kSahChunk = 4096;
 constexpr uint32_t kSahWideMean = 16384;   // levels whose mean range is at least this long take the several-blocks-per-node path
 constexpr int kSahWideBlock = 1024;
@@ -1313,11 +1314,14 @@ hipError_t build_lbvh(hipStream_t st, const LbvhInputs& in, LbvhOutputs& out) {
       uint32_t *idx_in = sah_idx_a, *idx_out = sah_idx_b;
       SahTask *q_in = sah_queue_a, *q_out = sah_queue_b;
       for (int level = 0, in = 0; active > 0; ++level, in ^= 1) {
-        if (level > 4096) { cleanup(); return hipErrorUnknown; }   // cannot happen: every level at least halves the ranges it cannot split
+        if (level > kSahMaxSplitLevels + 64) { cleanup(); return hipErrorUnknown; }   // cannot happen: halving ends after 32 levels
         // by the mean range of the level: several blocks per node while the ranges are long, then one block per node --
         // many threads for a long range (it is one block's loop), one wave for the wide bottom levels (its barriers cost nothing)
+        // A tree this deep means input that defeats the binning level after level (a geometric progression of scales); the
+        // remaining ranges are halved as they stand so that the depth stays bounded.
+        const int force_halve = level >= kSahMaxSplitLevels ? 1 : 0;
         const uint32_t mean = n / active;
-        if (mean >= kSahWideMean) {
+        if (mean >= kSahWideMean && !force_halve) {
           const uint32_t max_chunks = active + n / kSahChunk + 1;
           const dim3 gc(max_chunks), gn((active + 63) / 64);
           hipLaunchKernelGGL(k_wide_plan, dim3(1), dim3(1024), 0, st, q_in, sah_counts + in, sah_wide, sah_total_chunks);
@@ -1334,7 +1338,7 @@ hipError_t build_lbvh(hipStream_t st, const LbvhInputs& in, LbvhOutputs& out) {
                              sah_counts + (in ^ 1));
         } else {
 #define GLZ_SAH_LAUNCH(B) hipLaunchKernelGGL(k_sah_level<B>, dim3(active), dim3(B), 0, st, q_in, sah_counts + in, idx_in, idx_out, q_out, \
-                                             sah_counts + (in ^ 1), (int)n, node_lo + (n - 1), node_hi + (n - 1), children, parent)
+                                             sah_counts + (in ^ 1), (int)n, node_lo + (n - 1), node_hi + (n - 1), children, parent, force_halve)
           if (mean >= 4096) GLZ_SAH_LAUNCH(1024);
           else if (mean >= 128) GLZ_SAH_LAUNCH(256);
           else GLZ_SAH_LAUNCH(64);
