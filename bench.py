@@ -225,7 +225,8 @@ def main():
                                    % (W, H, args.depth, args.steps, args.steps / args.depth),
                        "width": W, "height": H, "depth": args.depth, "triangles": int(info.n_world_triangles),
                        "sharding": "64x64 tiles round-robin over %d rank(s), %s reduce of the RGBA32F accumulator" % (world, "gloo (rehearsal on one GPU)" if rehearsal else "RCCL"),
-                       "bvh": {"nodes": int(info.bvh_nodes), "depth": int(info.bvh_depth), "build_ms": round(float(info.build_ms), 3)},
+                       "bvh": {"builder": "binned SAH on the GPU, leaves of 1-2 triangles, 4-wide quantised nodes", "nodes": int(info.bvh_nodes),
+                               "depth": int(info.bvh_depth), "sah_cost": round(float(info.bvh_sah_cost), 2), "build_ms": round(float(info.build_ms), 3)},
                        "setup_s": round(setup_s, 3)},
             "roofline": roofline, "cpu_baseline": cpu,
             "mpaths_per_s": round(value / args.depth, 2),
