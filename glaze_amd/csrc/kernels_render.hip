@@ -552,7 +552,7 @@ constexpr uint32_t kSkyLdsFloats = 4096;   // sky marginal tables (3H+1 floats) 
 #endif
 __global__ void __launch_bounds__(kBlock, GLZ_SHADE_WAVES) k_shade(const LaunchArgs A) {
   // The kernel is bound by the memory system's random-access rate (16 extra scattered loads per pixel cost +27 %, 200 extra
-  // VALU instructions nothing; 2, 3 or 4 waves per SIMD take the same time), so the two small tables every texture fetch /
+  // VALU instructions nothing; 1 / 2 / 3 waves per SIMD take 0.76 / 0.45 / 0.36 ms and a fourth needs spills that eat its gain), so the two small tables every texture fetch /
   // sky sample walks are staged in LDS once per block: the sRGB decode LUT (12 lookups per bilinear fetch) and the sky marginal CDF (an 11-step dependent search).
   __shared__ float s_lut[256];
   __shared__ float s_sky[kSkyLdsFloats];
