@@ -343,7 +343,7 @@ bool convert_obj(const std::string& input, const std::string& output, bool gen_m
   for (TextureData& t : textures) {
     glz_texture g = t.info;
     g.pixels = t.level0.data();
-    g.mip_levels = gen_mipmaps ? 32 : 1;   // gen_mipmaps: the full chain (box_mips stops at 1x1)
+    g.mip_levels = gen_mipmaps ? 32 : 1;   // gen_mipmaps: the full chain (catmull_rom_mips stops at 1x1)
     tex_view.push_back(g);
   }
   SerializeInput in;

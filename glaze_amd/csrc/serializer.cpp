@@ -2,6 +2,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cmath>
 #include <cstring>
 
 #include "codec/png_enc.h"
@@ -100,27 +101,67 @@ ChunkBytes encode_cameras(const glz_camera* c, uint64_t n) {   // camera_to_byte
   return xz_chunk(plain);
 }
 
-std::vector<std::vector<uint8_t>> box_mips(const uint8_t* level0, uint32_t w, uint32_t h, int channels, unsigned levels) {
+// Mip chain the way Texture::gen_mipmaps builds it (lib/src/materials/texture.rs:256-277): level k is level k-1 resized to
+// half the size (at least 1) with image::imageops::resize(.., FilterType::CatmullRom).  `image` 0.24 is not vendored in the
+// reference tree; this restates its published resampler (imageops/sample.rs): a vertical pass into a float image, then a
+// horizontal pass; the kernel is the Catmull-Rom cubic (B = 0, C = 1/2) with support 2 stretched by the down-scaling ratio,
+// weights normalised per output sample, result clamped to [0, 255] and rounded to nearest.
+namespace {
+float catmull_rom(float x) {   // bc_cubic_spline(x, 0, 0.5)
+  const float a = std::fabs(x);
+  if (a < 1.0f) return ((9.0f * a - 15.0f) * a * a + 6.0f) / 6.0f;       // 1.5 a^3 - 2.5 a^2 + 1
+  if (a < 2.0f) return (((-3.0f * a + 15.0f) * a - 24.0f) * a + 12.0f) / 6.0f;   // -0.5 a^3 + 2.5 a^2 - 4 a + 2
+  return 0.0f;
+}
+// one axis of the resampler: `n_in` samples with stride `stride_in` -> `n_out` samples, for `lines` independent lines
+void resample_axis(const float* in, size_t line_stride_in, size_t stride_in, uint32_t n_in, float* out, size_t line_stride_out, size_t stride_out,
+                   uint32_t n_out, size_t lines, int channels) {
+  const float ratio = (float)n_in / (float)n_out;
+  const float sratio = ratio < 1.0f ? 1.0f : ratio;
+  const float src_support = 2.0f * sratio;
+  std::vector<float> ws;
+  for (uint32_t o = 0; o < n_out; ++o) {
+    float centre = ((float)o + 0.5f) * ratio;
+    int64_t left = (int64_t)std::floor(centre - src_support);
+    left = std::min<int64_t>(std::max<int64_t>(left, 0), (int64_t)n_in - 1);
+    int64_t right = (int64_t)std::ceil(centre + src_support);
+    right = std::min<int64_t>(std::max<int64_t>(right, left + 1), (int64_t)n_in);
+    centre -= 0.5f;
+    ws.clear();
+    float sum = 0.0f;
+    for (int64_t i = left; i < right; ++i) {
+      const float w = catmull_rom(((float)i - centre) / sratio);
+      ws.push_back(w);
+      sum += w;
+    }
+    for (float& w : ws) w /= sum;
+    for (size_t line = 0; line < lines; ++line) {
+      const float* src = in + line * line_stride_in + (size_t)left * stride_in;
+      float* dst = out + line * line_stride_out + (size_t)o * stride_out;
+      for (int c = 0; c < channels; ++c) {
+        float t = 0.0f;
+        for (size_t k = 0; k < ws.size(); ++k) t += src[k * stride_in + c] * ws[k];
+        dst[c] = t;
+      }
+    }
+  }
+}
+}  // namespace
+
+std::vector<std::vector<uint8_t>> catmull_rom_mips(const uint8_t* level0, uint32_t w, uint32_t h, int channels, unsigned levels) {
   std::vector<std::vector<uint8_t>> out;
   std::vector<uint8_t> prev(level0, level0 + (size_t)w * h * channels);
   uint32_t pw = w, ph = h;
   for (unsigned lvl = 1; lvl < levels && (pw > 1 || ph > 1); ++lvl) {
     const uint32_t nw = std::max(1u, pw >> 1), nh = std::max(1u, ph >> 1);
-    std::vector<uint8_t> cur((size_t)nw * nh * channels);
-    for (uint32_t y = 0; y < nh; ++y) {
-      // source rows / columns covered by this texel (covers the odd remainder on the last one)
-      const uint32_t y0 = (uint32_t)((uint64_t)y * ph / nh), y1 = std::max(y0 + 1, (uint32_t)((uint64_t)(y + 1) * ph / nh));
-      for (uint32_t x = 0; x < nw; ++x) {
-        const uint32_t x0 = (uint32_t)((uint64_t)x * pw / nw), x1 = std::max(x0 + 1, (uint32_t)((uint64_t)(x + 1) * pw / nw));
-        for (int c = 0; c < channels; ++c) {
-          uint32_t sum = 0;
-          for (uint32_t yy = y0; yy < y1; ++yy)
-            for (uint32_t xx = x0; xx < x1; ++xx) sum += prev[((size_t)yy * pw + xx) * channels + c];
-          const uint32_t cnt = (y1 - y0) * (x1 - x0);
-          cur[((size_t)y * nw + x) * channels + c] = (uint8_t)((sum + cnt / 2) / cnt);
-        }
-      }
-    }
+    std::vector<float> src((size_t)pw * ph * channels), tmp((size_t)pw * nh * channels), dst((size_t)nw * nh * channels);
+    for (size_t i = 0; i < src.size(); ++i) src[i] = (float)prev[i];
+    // vertical: every column is a line of ph samples, stride pw * channels
+    resample_axis(src.data(), (size_t)channels, (size_t)pw * channels, ph, tmp.data(), (size_t)channels, (size_t)pw * channels, nh, pw, channels);
+    // horizontal: every row is a line of pw samples, stride channels
+    resample_axis(tmp.data(), (size_t)pw * channels, (size_t)channels, pw, dst.data(), (size_t)nw * channels, (size_t)channels, nw, nh, channels);
+    std::vector<uint8_t> cur(dst.size());
+    for (size_t i = 0; i < dst.size(); ++i) cur[i] = (uint8_t)std::lround(std::min(255.0f, std::max(0.0f, dst[i])));
     out.push_back(cur);
     prev.swap(cur);
     pw = nw;
@@ -146,7 +187,7 @@ ChunkBytes encode_textures(const glz_texture* t, uint64_t n, Error& err) {
     rec.push_back((uint8_t)nl);
     rec.insert(rec.end(), tx.name, tx.name + nl);
     const unsigned want = tx.mip_levels ? tx.mip_levels : 1;
-    const auto mips = box_mips(tx.pixels, tx.width, tx.height, channels, want);
+    const auto mips = catmull_rom_mips(tx.pixels, tx.width, tx.height, channels, want);
     rec.push_back((uint8_t)(1 + mips.size()));
     uint32_t w = tx.width, h = tx.height;
     for (size_t lvl = 0; lvl <= mips.size(); ++lvl) {

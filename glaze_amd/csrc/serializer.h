@@ -41,8 +41,9 @@ bool write_glaze_file(const std::string& path, const std::vector<std::pair<int, 
 // Serializer::serialize()
 bool serialize_scene(const std::string& path, const SerializeInput& in, Error& err);
 
-// Box-filtered mip chain of an 8-bit image (level 0 excluded); stops at 1x1 or after `levels - 1` reductions.
-// (The reference resizes with CatmullRom, texture.rs:226-277; the ray-tracing stages only sample level 0.)
-std::vector<std::vector<uint8_t>> box_mips(const uint8_t* level0, uint32_t w, uint32_t h, int channels, unsigned levels);
+// Mip chain of an 8-bit image the way Texture::gen_mipmaps builds it (texture.rs:256-277): every level is the previous one
+// resized to half the size with the Catmull-Rom filter of image::imageops::resize.  Level 0 excluded; stops at 1x1 or after
+// `levels - 1` reductions.  (The ray-tracing stages only sample level 0.)
+std::vector<std::vector<uint8_t>> catmull_rom_mips(const uint8_t* level0, uint32_t w, uint32_t h, int channels, unsigned levels);
 
 }  // namespace glz

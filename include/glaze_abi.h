@@ -193,7 +193,8 @@ int glz_converted_file(const char* path);         /* parser/mod.rs:259-271: 1 if
  * (lib/src/parser/mod.rs:130-233; ContentV1::serialize / write_chunks, parser/v1.rs:230-295; record encoders :613-1061).
  * Every array may be empty (no chunk is written for it); `meta` NULL = Serializer without with_metadata().
  * Chunks are xz streams (LZMA2, CRC64) with an XXH64 prefix, textures are PNGs: the output is read back by glz_parse and
- * by the reference's parser alike.  glz_texture.mip_levels > 1 asks for that many box-filtered levels below level 0.
+ * by the reference's parser alike.  glz_texture.mip_levels > 1 asks for that many levels in all, each the one before halved with the
+ * Catmull-Rom filter as Texture::gen_mipmaps does (texture.rs:256-277).
  * ---------------------------------------------------------------------------------------- */
 typedef struct glz_serialize_desc {
   const glz_vertex* vertices;         uint64_t n_vertices;

@@ -360,9 +360,22 @@ def test_png_encoder_variants(tmp_path):
     assert [t[3] for t in got] == [1, 1, 1, 4, 5]                                      # 16x16 has 5 levels down to 1x1
     lv = ref[3]["levels"]
     assert [l.shape for l in lv] == [(64, 48), (32, 24), (16, 12), (8, 6)]
-    box = textures[3][1].astype(np.uint32).reshape(32, 2, 24, 2).sum((1, 3))
-    assert np.array_equal(lv[1], ((box + 2) // 4).astype(np.uint8))                    # 2x2 box filter, round to nearest
-    assert all((l == 200).all() for l in ref[4]["levels"])
+    # every level is the previous one halved with the Catmull-Rom filter (Texture::gen_mipmaps, texture.rs:256-277, through
+    # image::imageops::resize); PIL's BICUBIC is the same kernel (a = -0.5) with 8-bit fixed-point coefficients
+    from PIL import Image
+    prev = textures[3][1]
+    for level in lv[1:]:
+        want = np.asarray(Image.fromarray(prev).resize((prev.shape[1] // 2, prev.shape[0] // 2), Image.BICUBIC))
+        assert np.abs(level.astype(int) - want.astype(int)).max() <= 2 and np.abs(level.astype(float) - want).mean() < 0.3
+        prev = level
+    assert all((l == 200).all() for l in ref[4]["levels"])                            # weights are normalised: a flat image stays flat
+    # ringing is clamped, a hard edge overshoots neither way
+    edge = np.zeros((32, 32, 4), np.uint8); edge[:, 16:] = 255
+    path2 = str(tmp_path / "edge.bin")
+    glaze_amd.Serializer(path2).with_textures([textures[0], (abi.TEX_RGBA_SRGB, edge, "edge", 6)]).serialize()
+    lv = both(path2)[1].textures()[1]["levels"]
+    assert [l.shape[:2] for l in lv] == [(32, 32), (16, 16), (8, 8), (4, 4), (2, 2), (1, 1)]
+    assert (lv[1][:, :7] == 0).all() and (lv[1][:, 9:] == 255).all() and 120 <= int(lv[5][0, 0, 0]) <= 135
 
 
 # ---- ParsedScene::update (v1.rs:1986-2140) -------------------------------------------------------------------------
