@@ -57,7 +57,10 @@ struct glz_instance {
   std::unique_ptr<Instance> i;
 };
 struct glz_scene {
-  Scene* s = nullptr;   // owned until handed to a renderer
+  // Shared with the renderer it is handed to (raytracer.rs:109-111 moves the scene into the renderer): the handle stays usable
+  // for the info / debug hooks whatever the renderer does afterwards (destroy, change_scene), and the scene is freed when
+  // the last of the two lets go.  `owned` = not handed to a renderer yet.
+  std::shared_ptr<Scene> s;
   bool owned = true;
 };
 struct glz_renderer {
@@ -253,7 +256,7 @@ glz_scene* glz_scene_create(glz_instance* inst, glz_parsed* parsed) {
   Scene* s = Scene::create(inst->i.get(), std::move(data), e);
   if (!s) { fail(e); return nullptr; }
   glz_scene* h = new glz_scene();
-  h->s = s;
+  h->s.reset(s);
   return h;
   GLZ_GUARD_END(nullptr)
 }
@@ -288,14 +291,13 @@ glz_scene* glz_scene_create_from_desc(glz_instance* inst, const glz_scene_desc* 
   Scene* s = Scene::create(inst->i.get(), std::move(data), e);
   if (!s) { fail(e); return nullptr; }
   glz_scene* h = new glz_scene();
-  h->s = s;
+  h->s.reset(s);
   return h;
   GLZ_GUARD_END(nullptr)
 }
 
 void glz_scene_destroy(glz_scene* h) {
   if (!h) return;
-  if (h->owned) delete h->s;
   delete h;
 }
 int glz_scene_get_info(const glz_scene* h, glz_scene_info* out) {
@@ -315,11 +317,9 @@ glz_renderer* glz_renderer_create(glz_instance* inst, glz_scene* scene, uint32_t
   if (!inst) { fail(GLZ_E_ARG, "instance is null"); return nullptr; }
   if (scene && !scene->owned) { fail(GLZ_E_ARG, "scene already belongs to a renderer"); return nullptr; }
   Error e;
-  Scene* s = scene ? scene->s : nullptr;
   if (scene) scene->owned = false;   // moved into the renderer (raytracer.rs:109-111); the handle stays valid for debug hooks
-  Renderer* r = Renderer::create(inst->i.get(), s, w, h, e);
+  Renderer* r = Renderer::create(inst->i.get(), scene ? scene->s : std::shared_ptr<Scene>(), w, h, e);
   if (!r) {
-    if (scene) scene->s = nullptr;   // Renderer::create released it
     fail(e);
     return nullptr;
   }
@@ -434,7 +434,7 @@ int glz_debug_trace_closest(glz_scene* h, const float* o, const float* d, uint64
   if (!h || !h->s || !o || !d || !t || !tri || !inst || !u || !v) return fail(GLZ_E_ARG, "null argument");
   if (n == 0) return GLZ_OK;
   if (n > 0x7FFFFFFFull) return fail(GLZ_E_ARG, "too many rays");
-  Scene* s = h->s;
+  Scene* s = h->s.get();
   Error e;
   if (!hip_ok(hipSetDevice(s->instance->device), "hipSetDevice", e)) return fail(e);
   hipStream_t st = s->instance->stream;
@@ -462,7 +462,7 @@ int glz_debug_trace_any(glz_scene* h, const float* o, const float* d, const floa
   if (!h || !h->s || !o || !d || !tmax || !out) return fail(GLZ_E_ARG, "null argument");
   if (n == 0) return GLZ_OK;
   if (n > 0x7FFFFFFFull) return fail(GLZ_E_ARG, "too many rays");
-  Scene* s = h->s;
+  Scene* s = h->s.get();
   Error e;
   if (!hip_ok(hipSetDevice(s->instance->device), "hipSetDevice", e)) return fail(e);
   hipStream_t st = s->instance->stream;
@@ -482,7 +482,7 @@ int glz_debug_trace_any(glz_scene* h, const float* o, const float* d, const floa
 int64_t glz_debug_read_derivatives(glz_scene* h, float* out, int64_t cap_tris) {
   GLZ_GUARD_BEGIN
   if (!h || !h->s) return fail(GLZ_E_ARG, "scene is null");
-  Scene* s = h->s;
+  Scene* s = h->s.get();
   uint32_t ntri = 0;
   for (const glz_mesh& m : s->data.meshes) ntri = std::max<uint32_t>(ntri, (m.index_offset + m.index_count) / 3);
   if (out && cap_tris > 0 && ntri > 0) {
@@ -517,7 +517,7 @@ int64_t glz_debug_read_rt_lights(glz_scene* h, void* out, int64_t cap) {
 int64_t glz_debug_read_sky(glz_scene* h, float* out, int64_t cap) {
   GLZ_GUARD_BEGIN
   if (!h || !h->s) return fail(GLZ_E_ARG, "scene is null");
-  Scene* s = h->s;
+  Scene* s = h->s.get();
   std::vector<float> buf(36 + 4 + s->h_sky_marginal.size());
   memcpy(buf.data(), &s->h_sky, 144);
   memcpy(buf.data() + 36, &s->h_sky_header, 16);
@@ -533,7 +533,7 @@ int64_t glz_debug_read_sky(glz_scene* h, float* out, int64_t cap) {
 int64_t glz_debug_read_bvh(glz_scene* h, void* nodes_out, int64_t cap_nodes, void* tris_out, int64_t cap_tris) {
   GLZ_GUARD_BEGIN
   if (!h || !h->s) return fail(GLZ_E_ARG, "scene is null");
-  Scene* s = h->s;
+  Scene* s = h->s.get();
   Error e;
   if (!hip_ok(hipSetDevice(s->instance->device), "hipSetDevice", e)) return fail(e);
   const int64_t nn = s->info.bvh_nodes, nt = (int64_t)s->info.n_world_triangles;

@@ -29,6 +29,8 @@ struct HuffTable {
     for (int l = 1; l <= 16; ++l) {
       valptr[l] = k;
       mincode[l] = code;
+      // Kraft check BEFORE the table is filled: a crafted DHT (e.g. 200 codes of length 2) must not index past lookup[512]
+      if (code + (int)bits[l] > (1 << l)) return false;
       for (int i = 0; i < bits[l]; ++i, ++k, ++code) {
         if (l <= 9) {
           const int shift = 9 - l;
@@ -36,7 +38,6 @@ struct HuffTable {
         }
       }
       maxcode[l] = bits[l] ? code - 1 : -1;
-      if (code > (1 << l)) return false;
       code <<= 1;
     }
     maxcode[17] = 0x7FFFFFFF;
@@ -233,6 +234,9 @@ bool jpeg_decode(const uint8_t* data, size_t size, int want_channels, uint32_t& 
         hmax = std::max(hmax, comps[c].h);
         vmax = std::max(vmax, comps[c].v);
       }
+      // upsample() assumes integer ratios: a 3-in-4 component would copy `width` bytes out of a narrower plane row
+      for (int c = 0; c < nc; ++c)
+        if (hmax % comps[c].h || vmax % comps[c].v) return bad("fractional sampling ratios are not supported");
       have_frame = true;
     } else if (m == 0xC2 || (m >= 0xC5 && m <= 0xCF && m != 0xC8 && m != 0xCC)) {
       return bad("progressive / lossless / arithmetic-coded JPEG is not supported");
@@ -255,6 +259,14 @@ bool jpeg_decode(const uint8_t* data, size_t size, int want_channels, uint32_t& 
       }
       const int mcu_w = 8 * hmax, mcu_h = 8 * vmax;
       const int mcus_x = (int)((width + mcu_w - 1) / mcu_w), mcus_y = (int)((height + mcu_h - 1) / mcu_h);
+      {
+        // every coded block takes at least two bits (a DC code and an EOB): a frame header that promises more blocks than the
+        // entropy-coded data can hold is corrupt and must not size the planes (65535 x 65535 over a few bytes = 12 GB of zeros)
+        uint64_t blocks_per_mcu = 0;
+        for (auto& c : comps) blocks_per_mcu += comps.size() == 1 ? 1u : (uint64_t)c.h * c.v;
+        const uint64_t left = (uint64_t)(size - std::min(size, pos + len));
+        if ((uint64_t)mcus_x * mcus_y * blocks_per_mcu > left * 4u + 64u) return bad("frame size does not match the coded data");
+      }
       for (auto& c : comps) {
         if (comps.size() == 1) { c.h = c.v = 1; }
         c.blocks_w = mcus_x * c.h;

@@ -69,7 +69,11 @@ bool png_decode(const uint8_t* data, size_t size, int want, uint32_t& width, uin
   if (!(depth == 8 || depth == 16) || (ctype == 3 && depth != 8)) { err = "png: unsupported bit depth"; return false; }
   const size_t bpp = channels * depth / 8;          // bytes per complete pixel (filter unit)
   const size_t stride = (size_t)width * bpp;
-  std::vector<uint8_t> raw((stride + 1) * height);
+  // A deflate stream expands at most ~1032x: an IHDR that asks for more than the IDAT can possibly hold is corrupt, and
+  // must not be allowed to allocate (a 100-byte file could otherwise request 34 GB)
+  const uint64_t raw_bytes = ((uint64_t)stride + 1) * height;
+  if (raw_bytes > (uint64_t)idat.size() * 1040u + 1024u) { err = "png: image size does not match the compressed data"; return false; }
+  std::vector<uint8_t> raw((size_t)raw_bytes);
   uLongf raw_len = (uLongf)raw.size();
   int zr = ::uncompress(raw.data(), &raw_len, idat.data(), (uLong)idat.size());
   if (zr != Z_OK || raw_len != raw.size()) { err = "png: inflate failed"; return false; }

@@ -5,6 +5,7 @@
 // Single-shot: the whole compressed chunk is in memory, the whole output is produced at once.
 #include "xz_dec.h"
 
+#include <algorithm>
 #include <cstring>
 
 namespace glz {
@@ -184,7 +185,8 @@ struct Lzma {
 // positions counted from dict_start).
 bool lzma_chunk(Lzma& s, RangeDec& rc, std::vector<uint8_t>& out, size_t dict_start, size_t unpacked) {
   const size_t target = out.size() + unpacked;
-  out.reserve(target);
+  // geometric growth: an exact-size reserve per (<= 2 MiB) chunk would reallocate and copy the whole output once per chunk
+  if (target > out.capacity()) out.reserve(std::max(target, out.capacity() * 2));
   const unsigned pb_mask = (1u << s.pb) - 1, lp_mask = (1u << s.lp) - 1;
   while (out.size() < target) {
     if (rc.overrun) return false;
@@ -375,6 +377,8 @@ bool xz_decompress(const uint8_t* data, size_t size, std::vector<uint8_t>& out, 
       if ((*q & 0x3F) > 40) { err = "xz: bad LZMA2 dictionary size"; return false; }
       p = bh + hsize;
       const size_t out_before = out.size();
+      // the header's uncompressed size (when present and plausible: LZMA2 expands < 2^13 x) sizes the output once
+      if (usize != ~0ull && usize <= (uint64_t)(end - p) * 8192u) out.reserve(out.size() + (size_t)usize);
       const uint8_t* cend = nullptr;
       if (!lzma2_decode(p, end, out, &cend, err)) return false;
       if (csize != ~0ull && (uint64_t)(cend - p) != csize) { err = "xz: compressed size mismatch"; return false; }

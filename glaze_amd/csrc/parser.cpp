@@ -381,7 +381,7 @@ bool Parsed::textures(const std::vector<TextureData>*& out, Error& err) {
       textures_.v.resize(items.size());
       std::vector<Error> errs(items.size());
       // bytes_to_texture (v1.rs:820-882); the reference decodes textures in parallel with rayon (v1.rs:598-601)
-      auto decode_one = [&](size_t i) {
+      auto decode_body = [&](size_t i) {
         const uint8_t* b = items[i].first;
         const size_t n = items[i].second;
         TextureData& t = textures_.v[i];
@@ -413,6 +413,16 @@ bool Parsed::textures(const std::vector<TextureData>*& out, Error& err) {
           idx += ml;
         }
         if (mips == 0) fail(errs[i], GLZ_E_INVALID_DATA, "Corrupted textures: no mip level");
+      };
+      // the workers below run outside the C ABI's exception guard: nothing may escape a thread (std::terminate)
+      auto decode_one = [&](size_t i) {
+        try {
+          decode_body(i);
+        } catch (const std::bad_alloc&) {
+          fail(errs[i], GLZ_E_INVALID_DATA, "Corrupted image: out of memory while decoding");
+        } catch (const std::exception& ex) {
+          fail(errs[i], GLZ_E_INVALID_DATA, std::string("Corrupted image: ") + ex.what());
+        }
       };
       unsigned nthreads = std::min<size_t>(items.size(), std::max(1u, std::thread::hardware_concurrency()));
       if (nthreads <= 1) {

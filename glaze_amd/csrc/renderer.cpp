@@ -23,22 +23,19 @@ inline bool timed_launch(uint64_t i /* 1-based */) {
 }
 }
 
-Renderer* Renderer::create(Instance* inst, Scene* scene, uint32_t w, uint32_t h, Error& err) {
+Renderer* Renderer::create(Instance* inst, std::shared_ptr<Scene> scene, uint32_t w, uint32_t h, Error& err) {
   std::unique_ptr<Renderer> r(new Renderer());
   r->inst_ = inst;
-  if (!hip_ok(hipSetDevice(inst->device), "hipSetDevice", err)) {
-    delete scene;
-    return nullptr;
-  }
+  if (!hip_ok(hipSetDevice(inst->device), "hipSetDevice", err)) return nullptr;
   if (!scene) {
     // RayTraceRenderer::new(.., None, ..) renders an empty scene (raytracer.rs:170-174, NoScene)
     SceneData empty;
     empty.camera = default_camera();
     empty.meta = default_meta();
-    scene = Scene::create(inst, std::move(empty), err);
+    scene.reset(Scene::create(inst, std::move(empty), err));
     if (!scene) return nullptr;
   }
-  r->scene_.reset(scene);
+  r->scene_ = scene;
   if (w == 0 || h == 0) {
     err.code = GLZ_E_ARG;
     err.msg = "resolution must be non-zero";
@@ -370,14 +367,14 @@ bool Renderer::change_resolution(uint32_t w, uint32_t h, Error& err) {
   return update_camera(camera_, err);   // raytracer.rs:297
 }
 
-bool Renderer::change_scene(Scene* scene, Error& err) {
+bool Renderer::change_scene(std::shared_ptr<Scene> scene, Error& err) {
   if (!scene) {
     err.code = GLZ_E_ARG;
     err.msg = "scene is null";
     return false;
   }
   if (!wait_idle(err)) return false;
-  scene_.reset(scene);
+  scene_ = scene;
   exposure_ = scene->data.meta.exposure;
   if (!allocate(err)) return false;
   return update_camera(scene->data.camera, err);   // raytracer.rs:246-247

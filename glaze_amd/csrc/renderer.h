@@ -12,14 +12,14 @@ namespace glz {
 
 class Renderer {
  public:
-  static Renderer* create(Instance* inst, Scene* scene /* owned from here on; may be null */, uint32_t w, uint32_t h, Error& err);
+  static Renderer* create(Instance* inst, std::shared_ptr<Scene> scene /* may be null: empty scene */, uint32_t w, uint32_t h, Error& err);
   ~Renderer();
 
   bool set_integrator(int integrator, Error& err);
   bool set_exposure(float e);
   bool update_camera(const glz_camera& c, Error& err);
   bool change_resolution(uint32_t w, uint32_t h, Error& err);
-  bool change_scene(Scene* scene, Error& err);
+  bool change_scene(std::shared_ptr<Scene> scene, Error& err);
   bool update_materials_and_lights(const glz_material* m, uint32_t nm, const glz_light* l, uint32_t nl, const glz_texture* t, uint32_t nt, Error& err);
   bool refresh_binded_textures(const glz_texture* t, uint32_t nt, Error& err);
   bool wait_idle(Error& err);
@@ -57,7 +57,7 @@ class Renderer {
   bool gather(bool result, float4* dst, Error& err);
 
   Instance* inst_ = nullptr;
-  std::unique_ptr<Scene> scene_;
+  std::shared_ptr<Scene> scene_;   // shared with the glz_scene handle it came from (info / debug hooks stay valid)
   uint32_t w_ = 0, h_ = 0;
   int integrator_ = GLZ_PATH_TRACE;
   uint32_t pt_steps_ = 6;   // PT_STEPS, raytrace_structures.rs:87
