@@ -547,6 +547,29 @@ int64_t glz_debug_read_bvh(glz_scene* h, void* nodes_out, int64_t cap_nodes, voi
   GLZ_GUARD_END(GLZ_E_IO)
 }
 
+int glz_debug_tonemap(glz_instance* inst, const float* rgba32f, uint64_t n, uint8_t* out) {
+  GLZ_GUARD_BEGIN
+  if (!inst || !rgba32f || !out) return fail(GLZ_E_ARG, "null argument");
+  if (n == 0) return GLZ_OK;
+  if (n > 0x7FFFFFFFull) return fail(GLZ_E_ARG, "too many pixels");
+  Error e;
+  if (!hip_ok(hipSetDevice(inst->i->device), "hipSetDevice", e)) return fail(e);
+  hipStream_t st = inst->i->stream;
+  DeviceBuffer<float4> d_in;
+  DeviceBuffer<uchar4> d_out;
+  DeviceBuffer<float> d_thr;
+  float thr[256];
+  host::srgb8_thresholds(thr);
+  if (!hip_ok(d_in.upload(reinterpret_cast<const float4*>(rgba32f), n, st), "upload", e) || !hip_ok(d_thr.upload(thr, 256, st), "upload", e) ||
+      !hip_ok(d_out.alloc(n), "alloc", e))
+    return fail(e);
+  if (!hip_ok(launch_tonemap(st, (uint32_t)n, d_in.ptr, d_thr.ptr, d_out.ptr), "k_tonemap", e)) return fail(e);
+  (void)hipMemcpyAsync(out, d_out.ptr, n * 4, hipMemcpyDeviceToHost, st);
+  if (!hip_ok(hipStreamSynchronize(st), "debug tonemap", e)) return fail(e);
+  return GLZ_OK;
+  GLZ_GUARD_END(GLZ_E_IO)
+}
+
 // ---- host logic without a device ---------------------------------------------------------------
 int glz_host_launch_constants(uint64_t seed, uint32_t launch, uint32_t* seed_out, float offset[2]) {
   GLZ_GUARD_BEGIN
@@ -588,6 +611,12 @@ int glz_host_chain_owner(uint32_t width, uint32_t height, uint32_t rank, uint32_
         owner_out[(size_t)y * width + x] = t % world == rank ? (uint16_t)((t % (world * S)) / world) : (uint16_t)0xFFFF;
       }
   return (int)S;
+}
+
+int glz_host_srgb8_thresholds(float thresholds_out[256]) {
+  if (!thresholds_out) return fail(GLZ_E_ARG, "output is null");
+  host::srgb8_thresholds(thresholds_out);
+  return GLZ_OK;
 }
 
 }  // extern "C"

@@ -248,5 +248,15 @@ class WorkScheduler {
   std::vector<Area> current_, next_;
 };
 
+// Thresholds of the 8-bit sRGB quantiser (the R8G8B8A8_SRGB blit of raytracer.rs:576-584 [ext]): a linear value c encodes to
+// q = #{k in 1..255 : c >= thr[k]}, thr[k] = (float) EOTF((k - 0.5) / 255) -- round(255 * OETF(c)) without evaluating pow()
+// per pixel, so the device and any other implementation of this rule agree on every byte.  thr[0] = 0.
+inline void srgb8_thresholds(float thr[256]) {
+  thr[0] = 0.0f;
+  for (int k = 1; k < 256; ++k) {
+    const double v = ((double)k - 0.5) / 255.0;
+    thr[k] = (float)(v <= 0.04045 ? v / 12.92 : std::pow((v + 0.055) / 1.055, 2.4));
+  }
+}
 }  // namespace host
 }  // namespace glz

@@ -104,7 +104,8 @@ hipError_t launch_shade(hipStream_t st, const LaunchArgs& a);
 // scatter the tile-major cumulative / result images into full-frame row-major RGBA32F buffers
 hipError_t launch_export(hipStream_t st, const TileMap& map, const float4* tiled, float4* frame, bool zero_first);
 // result (out32) -> RGBA8 sRGB, full-frame row-major (the blit of raytracer.rs:576-584)
-hipError_t launch_tonemap(hipStream_t st, uint32_t n_pixels, const float4* result_frame, uchar4* out);
+// thresholds: 256 floats, [k] = smallest linear value that encodes to k (host::srgb8_thresholds); [0] = 0
+hipError_t launch_tonemap(hipStream_t st, uint32_t n_pixels, const float4* result_frame, const float* thresholds, uchar4* out);
 
 // debug / parity hooks
 hipError_t launch_debug_closest(hipStream_t st, const DeviceScene& scene, const float* origins, const float* dirs, uint32_t n, float tmin,

@@ -871,19 +871,31 @@ __global__ void __launch_bounds__(kBlock) k_export(const TileMap map, const floa
   if (px.active) frame[(size_t)px.y * map.width + px.x] = tiled[lid];
 }
 
-// linear -> sRGB OETF, 8 bit, round to nearest (what the R8G8B8A8_SRGB blit does, raytracer.rs:576-584 [ext])
-__device__ __forceinline__ unsigned char srgb8(float c) {
-  if (!(c > 0.0f)) return 0;
-  if (c >= 1.0f) return 255;
-  const float v = c <= 0.0031308f ? 12.92f * c : 1.055f * powf(c, 1.0f / 2.4f) - 0.055f;
-  const int q = (int)(v * 255.0f + 0.5f);
-  return (unsigned char)(q < 0 ? 0 : (q > 255 ? 255 : q));
+// linear -> sRGB OETF, 8 bit, round to nearest (what the R8G8B8A8_SRGB blit does, raytracer.rs:576-584 [ext]).
+// Byte work has to be bit-exact, and pow() is not the same function on any two machines, so the quantiser is stated
+// without it: q = #{k in 1..255 : c >= T_k} with T_k = (float) EOTF((k - 0.5) / 255), the smallest float whose encoded
+// value rounds to k (the OETF is monotonic, so this IS round(255 * OETF(c)) evaluated exactly).  The 255 thresholds are
+// computed once on the host in double precision (Renderer::allocate) and searched here from LDS: 8 compares per channel.
+__device__ __forceinline__ unsigned char srgb8(const float* __restrict__ thr, float c) {
+  if (!(c > 0.0f)) return 0;   // NaN, zero and negatives
+  uint32_t lo = 0, hi = 255;   // invariant: c >= T_lo (T_0 = 0), c < T_(hi+1) (T_256 = +inf)
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const uint32_t mid = (lo + hi + 1u) >> 1;
+    const bool ge = c >= thr[mid];
+    lo = ge ? mid : lo;
+    hi = ge ? hi : mid - 1u;
+  }
+  return (unsigned char)lo;
 }
-__global__ void __launch_bounds__(kBlock) k_tonemap(uint32_t n, const float4* __restrict__ result, uchar4* __restrict__ out) {
+__global__ void __launch_bounds__(kBlock) k_tonemap(uint32_t n, const float4* __restrict__ result, const float* __restrict__ thresholds, uchar4* __restrict__ out) {
+  __shared__ float s_thr[256];
+  s_thr[threadIdx.x] = thresholds[threadIdx.x];
+  __syncthreads();
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   const float4 r = result[i];
-  out[i] = make_uchar4(srgb8(r.x), srgb8(r.y), srgb8(r.z), r.w >= 1.0f ? 255 : 0);
+  out[i] = make_uchar4(srgb8(s_thr, r.x), srgb8(s_thr, r.y), srgb8(s_thr, r.z), r.w >= 1.0f ? 255 : 0);
 }
 // ---------------------------------------------------------------------------------------------
 // debug / parity kernels: arbitrary rays through the same traversal code
@@ -990,8 +1002,9 @@ hipError_t launch_export(hipStream_t st, const TileMap& map, const float4* tiled
   hipLaunchKernelGGL(k_export, grid_for(map.n_local_pixels), dim3(kBlock), 0, st, map, tiled, frame);
   return hipGetLastError();
 }
-hipError_t launch_tonemap(hipStream_t st, uint32_t n, const float4* result_frame, uchar4* out) {
-  hipLaunchKernelGGL(k_tonemap, grid_for(n), dim3(kBlock), 0, st, n, result_frame, out);
+hipError_t launch_tonemap(hipStream_t st, uint32_t n, const float4* result_frame, const float* thresholds, uchar4* out) {
+  static_assert(kBlock == 256, "k_tonemap stages the 256 thresholds with one load per thread");
+  hipLaunchKernelGGL(k_tonemap, grid_for(n), dim3(kBlock), 0, st, n, result_frame, thresholds, out);
   return hipGetLastError();
 }
 hipError_t launch_debug_closest(hipStream_t st, const DeviceScene& scene, const float* o, const float* d, uint32_t n, float tmin, float* t,

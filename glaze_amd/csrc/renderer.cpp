@@ -120,6 +120,12 @@ bool Renderer::allocate(Error& err) {
   }
   if (!hip_ok(frame_tmp_.alloc((size_t)w_ * h_), "alloc frame", err)) return false;
   if (!hip_ok(rgba8_.alloc((size_t)w_ * h_), "alloc rgba8", err)) return false;
+  if (!oetf_thresholds_.ptr) {
+    float thr[256];
+    host::srgb8_thresholds(thr);
+    if (!hip_ok(oetf_thresholds_.upload(thr, 256, chains_[0]->stream), "upload OETF thresholds", err)) return false;
+    if (!hip_ok(hipStreamSynchronize(chains_[0]->stream), "upload OETF thresholds", err)) return false;   // thr[] is on this stack frame
+  }
   if (!hip_ok(counters_.alloc(1), "alloc counters", err)) return false;
   request_new_frame_ = true;
   return true;
@@ -461,7 +467,7 @@ bool Renderer::read_rgba8(uint8_t* out, Error& err) {
   if (!hip_ok(hipSetDevice(inst_->device), "hipSetDevice", err)) return false;
   if (!gather(true, frame_tmp_.ptr, err)) return false;
   hipStream_t st = chains_[0]->stream;
-  if (!hip_ok(launch_tonemap(st, w_ * h_, frame_tmp_.ptr, rgba8_.ptr), "k_tonemap", err)) return false;
+  if (!hip_ok(launch_tonemap(st, w_ * h_, frame_tmp_.ptr, oetf_thresholds_.ptr, rgba8_.ptr), "k_tonemap", err)) return false;
   if (!hip_ok(hipMemcpyAsync(out, rgba8_.ptr, (size_t)w_ * h_ * 4, hipMemcpyDeviceToHost, st), "read rgba8", err)) return false;
   return hip_ok(hipStreamSynchronize(st), "read rgba8", err);
 }
@@ -515,7 +521,7 @@ bool Renderer::export_device(int which, void* dev, Error& err) {
 bool Renderer::tonemap_device(const void* dev_result, uint8_t* out, Error& err) {
   if (!hip_ok(hipSetDevice(inst_->device), "hipSetDevice", err)) return false;
   hipStream_t st = chains_[0]->stream;
-  if (!hip_ok(launch_tonemap(st, w_ * h_, static_cast<const float4*>(dev_result), rgba8_.ptr), "k_tonemap", err)) return false;
+  if (!hip_ok(launch_tonemap(st, w_ * h_, static_cast<const float4*>(dev_result), oetf_thresholds_.ptr, rgba8_.ptr), "k_tonemap", err)) return false;
   if (!hip_ok(hipMemcpyAsync(out, rgba8_.ptr, (size_t)w_ * h_ * 4, hipMemcpyDeviceToHost, st), "read rgba8", err)) return false;
   return hip_ok(hipStreamSynchronize(st), "tonemap_device", err);
 }

@@ -106,6 +106,7 @@ class Renderer {
 
   DeviceBuffer<float4> frame_tmp_;
   DeviceBuffer<uchar4> rgba8_;
+  DeviceBuffer<float> oetf_thresholds_;   // sRGB8 quantiser thresholds (host::srgb8_thresholds), see k_tonemap
   DeviceBuffer<TraceCounters> counters_;
   // stats
   bool counting_ = false;

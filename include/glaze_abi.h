@@ -383,6 +383,9 @@ int64_t glz_debug_read_sky(glz_scene*, float* out, int64_t cap_floats);        /
  * first one's last word says which, and leaf links name the first); see DESIGN.md for the layouts. */
 int64_t glz_debug_read_bvh(glz_scene*, void* nodes_out, int64_t cap_nodes, void* tris_out, int64_t cap_tris);
 
+/* k_tonemap (the out32 -> RGBA8 sRGB blit, raytracer.rs:576-584) on n host pixels of RGBA32F: upload, kernel, read back */
+int glz_debug_tonemap(glz_instance*, const float* rgba32f, uint64_t n_pixels, uint8_t* rgba8_out);
+
 /* ---- host logic, callable without a device (used by the CPU test-suite and by bindings) ------ */
 /* seed + pixel offset of launch `launch` after a restart, for renderer seed `seed`
  * (rng.gen::<u32>() + WorkScheduler::next(), raytracer.rs:486-489, :1168-1206) */
@@ -397,6 +400,9 @@ int glz_host_chain_owner(uint32_t width, uint32_t height, uint32_t rank, uint32_
 /* the host side of GLZ_BVH_SAH on its own (no GPU): binary hierarchy over n >= 2 leaf boxes (box_lo / box_hi: 4 floats per leaf,
  * xyz used).  children_out[2 * i], [2 * i + 1] for inner node i < n - 1: link >= 0 inner node, < 0 ~leaf; parent_out[i] for
  * inner node i (root 0: -1), parent_out[n - 1 + l] for leaf l. */
+/* the 8-bit sRGB quantiser of read_rgba8 / draw (the reference's R8G8B8A8_SRGB blit, raytracer.rs:576-584): c encodes to
+ * #{k in 1..255 : c >= thresholds_out[k]}; thresholds_out[0] = 0 */
+int glz_host_srgb8_thresholds(float thresholds_out[256]);
 int glz_host_build_sah(uint32_t n, const float* box_lo, const float* box_hi, int32_t* children_out, int32_t* parent_out);
 
 #ifdef __cplusplus

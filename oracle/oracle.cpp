@@ -1523,6 +1523,10 @@ struct Renderer {
   bool request_new_frame = true;
   int threads = 1;
   bool count = false;
+  // Optional subset of 64x64-pixel tiles to render (row-major tile ids; empty = the whole frame).  Pixels are independent
+  // (RNG from absolute pixel coordinates, path_trace.rgen:143-147), so a tile rendered alone equals the same tile of a full
+  // render: full-size frames are spot-checked against the product on a sample of tiles in seconds.
+  std::vector<uint32_t> tiles;
   std::atomic<uint64_t> c_closest_nodes{0}, c_closest_tris{0}, c_shadow_nodes{0}, c_shadow_tris{0}, c_hits{0}, c_closest_rays{0}, c_shadow_rays{0};
 };
 
@@ -1733,18 +1737,29 @@ void renderer_launch(Renderer& R) {
   fc.seed = R.rng.next_u32();
   R.sched.take(fc.off);
   int nt = std::max(1, R.threads);
+  // work items: rows of the frame, or (tile, row) pairs when only a subset of tiles is rendered
+  const uint32_t tiles_x = (R.w + 63) / 64;
+  const uint32_t n_items = R.tiles.empty() ? R.h : (uint32_t)R.tiles.size() * 64u;
+  auto run_item = [&](uint32_t item) {
+    if (R.tiles.empty()) {
+      for (uint32_t x = 0; x < R.w; ++x) raygen(R, fc, x, item);
+      return;
+    }
+    const uint32_t t = R.tiles[item / 64u], y = (t / tiles_x) * 64u + item % 64u, x0 = (t % tiles_x) * 64u;
+    if (y >= R.h) return;
+    for (uint32_t x = x0; x < std::min(R.w, x0 + 64u); ++x) raygen(R, fc, x, y);
+  };
   if (nt == 1) {
-    for (uint32_t y = 0; y < R.h; ++y)
-      for (uint32_t x = 0; x < R.w; ++x) raygen(R, fc, x, y);
+    for (uint32_t i = 0; i < n_items; ++i) run_item(i);
   } else {
-    std::atomic<uint32_t> row{0};
+    std::atomic<uint32_t> next{0};
     std::vector<std::thread> pool;
     for (int t = 0; t < nt; ++t)
       pool.emplace_back([&] {
         for (;;) {
-          uint32_t y = row.fetch_add(1);
-          if (y >= R.h) break;
-          for (uint32_t x = 0; x < R.w; ++x) raygen(R, fc, x, y);
+          uint32_t i = next.fetch_add(1);
+          if (i >= n_items) break;
+          run_item(i);
         }
       });
     for (auto& th : pool) th.join();
@@ -1752,13 +1767,27 @@ void renderer_launch(Renderer& R) {
   R.launches++;
 }
 
-// linear -> sRGB 8 bit, what the R8G8B8A8_SRGB blit + export does (raytracer.rs:576-584, memory.rs:269-483) [ext]
+// linear -> sRGB 8 bit, what the R8G8B8A8_SRGB blit + export does (raytracer.rs:576-584, memory.rs:269-483) [ext].
+// Stated as a rule that needs no pow() per pixel so that every implementation agrees on every byte:
+// q = round(255 * OETF(c)) = the number of k in 1..255 whose threshold T_k = (float) EOTF((k - 0.5) / 255) is <= c.
+// This is a plain count over the rule; the product searches an uploaded table instead.
+struct Srgb8Rule {
+  float t[256];
+  Srgb8Rule() {
+    t[0] = 0.0f;
+    for (int k = 1; k <= 255; ++k) {
+      double v = ((double)k - 0.5) / 255.0;
+      t[k] = (float)(v <= 0.04045 ? v / 12.92 : pow((v + 0.055) / 1.055, 2.4));
+    }
+  }
+};
 uint8_t to_srgb8(float c) {
+  static const Srgb8Rule rule;
   if (!(c > 0.0f)) return 0;
-  if (c >= 1.0f) return 255;
-  double v = c <= 0.0031308f ? 12.92 * (double)c : 1.055 * pow((double)c, 1.0 / 2.4) - 0.055;
-  int q = (int)(v * 255.0 + 0.5);
-  return (uint8_t)(q < 0 ? 0 : (q > 255 ? 255 : q));
+  int q = 0;
+  for (int k = 1; k <= 255; ++k)
+    if (c >= rule.t[k]) ++q;
+  return (uint8_t)q;
 }
 
 void scene_finish(Scene& sc, const std::vector<glz_light>& parsed_lights) {
@@ -1939,6 +1968,16 @@ void orc_renderer_draw(void* r, uint64_t spp) {
 }
 void orc_renderer_read_hdr(void* r, float* out) { Renderer* R = (Renderer*)r; if (R->request_new_frame) renderer_reset(*R); memcpy(out, R->cumulative.data(), R->cumulative.size() * 4); }
 void orc_renderer_read_result(void* r, float* out) { Renderer* R = (Renderer*)r; if (R->request_new_frame) renderer_reset(*R); memcpy(out, R->out32.data(), R->out32.size() * 4); }
+uint8_t orc_to_srgb8(float c) { return to_srgb8(c); }
+// restrict rendering to `n` 64x64 tiles (row-major ids over ceil(w/64) x ceil(h/64)); n = 0 = whole frame.  Restarts.
+void orc_renderer_set_tiles(void* r, const uint32_t* tiles, uint32_t n) {
+  Renderer* R = (Renderer*)r;
+  const uint32_t total = ((R->w + 63) / 64) * ((R->h + 63) / 64);
+  R->tiles.clear();
+  for (uint32_t i = 0; i < n; ++i)
+    if (tiles[i] < total) R->tiles.push_back(tiles[i]);
+  R->request_new_frame = true;
+}
 void orc_renderer_read_rgba8(void* r, uint8_t* out) {
   Renderer* R = (Renderer*)r;
   if (R->request_new_frame) renderer_reset(*R);

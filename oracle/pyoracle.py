@@ -46,6 +46,7 @@ def lib():
             "orc_renderer_read_hdr": (None, [_P, _P]), "orc_renderer_read_result": (None, [_P, _P]),
             "orc_renderer_read_rgba8": (None, [_P, _P]), "orc_renderer_read_state": (None, [_P, _P]),
             "orc_renderer_push_constants": (None, [_P, _P]),
+            "orc_renderer_set_tiles": (None, [_P, _P, C.c_uint32]), "orc_to_srgb8": (C.c_uint8, [C.c_float]),
             "orc_launch_constants": (None, [C.c_uint64, C.c_uint32, _P, _P]),
             "orc_renderer_counters": (None, [_P, _P]),
             "orc_spectrum_from_rgb": (None, [C.c_float, C.c_float, C.c_float, C.c_int, _P]),
@@ -177,6 +178,11 @@ class OracleRenderer:
 
     def update_camera(self, cam):
         lib().orc_renderer_update_camera(self.handle, C.byref(cam))
+
+    def set_tiles(self, tiles):
+        """Render only these 64x64 tiles (row-major ids); [] = the whole frame.  Pixels outside stay zero."""
+        t = np.ascontiguousarray(tiles, np.uint32)
+        lib().orc_renderer_set_tiles(self.handle, _ptr(t), t.size)
 
     def steps_per_sample(self):
         return lib().orc_renderer_steps_per_sample(self.handle)

@@ -197,3 +197,49 @@ def test_host_sah_builder_structure_and_determinism():
     nan = c[:1000].copy(); nan[::7] = np.nan                      # degenerate input must still give a tree
     ch, pa = _sah_tree(nan, nan)
     _check_tree(ch, pa, 1000)
+
+
+def test_srgb8_quantiser_rule_host_table_equals_the_oracle_count():
+    """The 8-bit export (raytracer.rs:576-584 blit) is stated as thresholds, not as pow() per pixel: the table behind the C ABI
+    (what k_tonemap searches) and the oracle's count over the rule give the same byte for every float tried, including the
+    thresholds themselves and their neighbours; away from the thresholds the rule is round(255 * OETF(c)) in double precision."""
+    thr = np.zeros(256, np.float32)
+    abi.check(abi.lib().glz_host_srgb8_thresholds(thr.ctypes.data))
+    assert thr[0] == 0.0 and (np.diff(thr) > 0).all() and thr[255] < 1.0
+    L = pyoracle.lib()
+    rng = np.random.default_rng(0)
+    v = np.concatenate([thr, np.nextafter(thr, np.float32(-1)), np.nextafter(thr, np.float32(2)), rng.random(20000, dtype=np.float32),
+                        rng.random(5000, dtype=np.float32) * 0.01, np.array([0, -1, 1, 2, np.inf, 1e-45], np.float32)])
+    got = np.searchsorted(thr[1:], v, side="right")
+    want = np.array([L.orc_to_srgb8(float(c)) for c in v])
+    assert np.array_equal(got, want)
+    assert L.orc_to_srgb8(float("nan")) == 0 and L.orc_to_srgb8(-0.0) == 0 and L.orc_to_srgb8(float("inf")) == 255
+    x = rng.random(20000).astype(np.float32)
+    enc = np.where(x <= 0.0031308, 12.92 * x.astype(np.float64), 1.055 * np.power(x.astype(np.float64), 1 / 2.4) - 0.055) * 255.0
+    clear = np.abs(enc - np.floor(enc) - 0.5) > 1e-4                       # not within rounding noise of a threshold
+    assert np.array_equal(np.searchsorted(thr[1:], x[clear], side="right"), np.floor(enc[clear] + 0.5).astype(int))
+
+
+def test_oracle_tile_subset_equals_the_full_frame():
+    """Pixels are independent (absolute-pixel RNG, path_trace.rgen:143-147): the oracle rendering only some 64x64 tiles gives those
+    tiles of the full render bit for bit and touches nothing else -- what the full-size GPU spot checks rely on."""
+    from glaze_amd.scenes import cube_scene
+    from oracle.pyoracle import OracleRenderer, OracleScene
+    d = cube_scene()
+    w, h, tiles = 200, 136, [0, 3, 5, 11]                                   # 4 x 3 tiles, ragged right and bottom edges
+    full = OracleRenderer(OracleScene(d), w, h)
+    full.set_depth(3)
+    full.step(5)
+    part = OracleRenderer(OracleScene(d), w, h)
+    part.set_depth(3)
+    part.set_tiles(tiles)
+    part.step(5)
+    m = np.zeros((h, w), bool)
+    for t in tiles:
+        m[(t // 4) * 64:(t // 4) * 64 + 64, (t % 4) * 64:(t % 4) * 64 + 64] = True
+    a, b = full.read_hdr(), part.read_hdr()
+    assert np.array_equal(a[m].view(np.uint32), b[m].view(np.uint32)) and not b[~m].any()
+    assert np.array_equal(full.read_rgba8()[m], part.read_rgba8()[m])
+    part.set_tiles([])
+    part.step(5)
+    assert np.array_equal(part.read_hdr().view(np.uint32), a.view(np.uint32))

@@ -66,8 +66,7 @@ def test_cube_lambert_config2(instance):
     exact = assert_parity(r, o, "cube")
     assert exact > 0.999
     assert img.shape == (128, 128, 4) and img[..., 3].min() == 255 and img[..., :3].max() > 10
-    ref8 = o.read_rgba8()
-    assert np.abs(img.astype(int) - ref8.astype(int)).max() <= 1          # 8-bit sRGB export: +-1 LSB (powf on device)
+    assert np.array_equal(img, o.read_rgba8())                            # 8-bit sRGB export: byte work is bit-exact
 
 
 def test_cube_direct_integrator(instance):
@@ -509,3 +508,206 @@ def test_traversal_work_counters_match_the_oracle(instance, mattest_desc):
         assert (s.closest_nodes, s.closest_tris) == (c["closest_nodes"], c["closest_tris"])
         assert (s.shadow_nodes, s.shadow_tris) == (c["shadow_nodes"], c["shadow_tris"])
         assert_parity(r, o, "counting build")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# RGBA8 export (raytracer.rs:576-584 blit + memory.rs:269-483 export): bit-exact
+# ---------------------------------------------------------------------------------------------------------------------
+def test_rgba8_export_is_bit_exact(instance, mattest_desc):
+    """The sRGB8 quantiser is stated as a threshold rule (no pow() per pixel), so the device, the host table behind the C ABI and
+    the oracle's count over the rule agree on every byte: rendered frames, and a frame of adversarial floats pushed through
+    glz_debug_tonemap (values at, just below and just above every threshold, denormals, negatives, NaN, inf)."""
+    from oracle.pyoracle import lib as orc
+    for desc, w, h, depth in ((cube_scene(material_type=abi.MAT_UBER), 160, 96, 4), (mattest_desc, 128, 128, 6)):
+        r, o, img = render_both(instance, desc, w, h, spp=3, depth=depth, seed=5)
+        assert np.array_equal(img, o.read_rgba8())
+        assert np.array_equal(r.read_rgba8(), img)
+    thr = np.zeros(256, np.float32)
+    abi.check(abi.lib().glz_host_srgb8_thresholds(thr.ctypes.data))
+    vals = [thr, np.nextafter(thr, np.float32(-1)), np.nextafter(thr, np.float32(2)),
+            np.array([0.0, -0.0, -1.0, 1.0, 1.5, np.inf, -np.inf, np.nan, 1e-45, 1e-38, 0.0031308, 0.00313081, 0.5, 0.999999], np.float32),
+            np.random.default_rng(3).random(4096, dtype=np.float32), np.random.default_rng(4).random(4096, dtype=np.float32) * 0.01]
+    v = np.concatenate(vals).astype(np.float32)
+    w, h = 64, (v.size + 63) // 64
+    frame = np.zeros((h * w, 4), np.float32)
+    frame[:v.size, 0] = v
+    frame[:v.size, 1] = v[::-1]
+    frame[:v.size, 2] = np.roll(v, 17)
+    frame[:, 3] = 1.0
+    got = np.zeros((h * w, 4), np.uint8)
+    abi.check(abi.lib().glz_debug_tonemap(instance._h, frame.ctypes.data, h * w, got.ctypes.data))
+    L = orc()
+    want = np.array([[L.orc_to_srgb8(float(c)) for c in px[:3]] for px in frame], np.uint8)
+    assert np.array_equal(got[:, :3], want)
+    assert (got[:, 3] == 255).all()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# update_camera (raytracer.rs:300-309) and change_scene (raytracer.rs:234-248) on a live renderer
+# ---------------------------------------------------------------------------------------------------------------------
+def test_update_camera_restarts_and_matches_the_oracle(instance):
+    """update_camera replaces the push constants and requests a new frame: perspective -> orthographic -> another perspective
+    on a live renderer, each compared with an oracle that was given the same camera."""
+    desc = cube_scene(material_type=abi.MAT_UBER)
+    desc.lights.append(make_light(abi.LIGHT_SUN, "sun", direction=(0.2, -0.7, 0.4), intensity=0.5))
+    scene = glaze_amd.RayTraceScene.from_desc(instance, desc)
+    r = glaze_amd.RayTraceRenderer.new(instance, scene, 80, 48)
+    r.set_depth(4)
+    r.set_seed(9)
+    o = OracleRenderer(OracleScene(desc), 80, 48)
+    o.set_depth(4)
+    o.set_seed(9)
+    r.step(5)
+    o.step(5)
+    assert_parity(r, o, "before update_camera")
+    cams = [make_camera(position=(0.2, -0.1, -0.6), target=(0.0, 0.1, 5.0), orthographic=True, scale=0.7, near=1e-3, far=50.0),
+            make_camera(position=(-0.3, 0.3, -0.2), target=(0.6, -0.2, 0.9), up=(0.1, 1.0, 0.0), fovx=1.2, near=1e-2, far=20.0),
+            make_camera(position=(0.0, 0.0, 0.0), target=(0.0, 0.0, 100.0), fovx=np.pi / 2)]
+    for i, cam in enumerate(cams):
+        r.update_camera(cam)
+        o.update_camera(cam)
+        assert np.array_equal(r.push_constants().view(np.uint32), o.push_constants().view(np.uint32))
+        r.step(6)                                                                       # request_new_frame: the count restarts at 0
+        o.step(6)
+        assert r.read_hdr()[..., 3].max() == 6.0
+        assert_parity(r, o, "after update_camera %d" % i)
+    # the scene's own camera is untouched (the renderer keeps its copy, raytracer.rs:300-309)
+    assert tuple(scene.camera().position) == tuple(desc.camera.position)
+    with pytest.raises(abi.GlazeError):
+        bad = make_camera()
+        bad.type = 7
+        r.update_camera(bad)
+    r.step(1)                                                                           # a rejected camera leaves the renderer usable
+
+
+def test_change_scene_on_a_live_renderer(instance, mattest_desc):
+    """change_scene (raytracer.rs:234-248): cube -> mattest -> cube on one renderer.  The new scene's camera and exposure are
+    taken over (:246-247), accumulation restarts, the traversal spill area follows the new BVH; the old scene handle stays
+    valid for the info / debug hooks after the renderer let go of it (shared ownership behind the C ABI)."""
+    cube = cube_scene()
+    s_cube = glaze_amd.RayTraceScene.from_desc(instance, cube)
+    r = glaze_amd.RayTraceRenderer.new(instance, s_cube, 72, 72)
+    r.set_depth(5)
+    r.set_seed(2)
+    r.step(7)
+    s_mat = glaze_amd.RayTraceScene.from_desc(instance, mattest_desc)
+    r.change_scene(s_mat)
+    r.step(10)
+    assert r.read_hdr()[..., 3].max() == 10.0
+    o = OracleRenderer(OracleScene(mattest_desc), 72, 72)
+    o.set_depth(5)
+    o.set_seed(2)
+    o.set_exposure(mattest_desc.meta.exposure)
+    o.step(10)
+    assert_parity(r, o, "after change_scene(mattest)")
+    assert np.array_equal(r.push_constants().view(np.uint32), o.push_constants().view(np.uint32))   # the new scene's camera
+    assert np.array_equal(r.read_rgba8(), o.read_rgba8())                                            # and its exposure
+    # the scene the renderer dropped is still a valid handle
+    info = s_cube.info()
+    assert info.n_world_triangles == 12
+    t, tri, _, _, _ = s_cube.debug_trace_closest([[0, 0, 0]], [[0, 0, 1]])
+    assert np.isfinite(t[0]) and tri[0] < 12
+    with pytest.raises(abi.GlazeError):
+        r.change_scene(s_mat)                                                                         # already owned by a renderer
+    s_cube2 = glaze_amd.RayTraceScene.from_desc(instance, cube)
+    r.change_scene(s_cube2)
+    r.step(4)
+    o2 = OracleRenderer(OracleScene(cube), 72, 72)
+    o2.set_depth(5)
+    o2.set_seed(2)
+    o2.step(4)
+    assert_parity(r, o2, "after change_scene(cube)")
+    del r
+    assert s_mat.info().n_world_triangles == 138480                                                   # outlives the renderer too
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Full-size frames against the oracle on a sample of tiles (BASELINE configs 3, 4, 5 at their real sizes)
+# ---------------------------------------------------------------------------------------------------------------------
+def _sample_tiles(w, h, n_random, seed):
+    """Row-major ids of 64x64 tiles: the four corners (ragged right / bottom edges included), the centre, and n_random more."""
+    tx, ty = (w + 63) // 64, (h + 63) // 64
+    fixed = [0, tx - 1, (ty - 1) * tx, ty * tx - 1, (ty // 2) * tx + tx // 2, (ty // 3) * tx + (2 * tx) // 3]
+    rng = np.random.default_rng(seed)
+    rest = [int(t) for t in rng.permutation(tx * ty) if int(t) not in fixed][:n_random]
+    return sorted(fixed + rest)
+
+
+def _tile_mask(w, h, tiles):
+    tx = (w + 63) // 64
+    m = np.zeros((h, w), bool)
+    for t in tiles:
+        y0, x0 = (t // tx) * 64, (t % tx) * 64
+        m[y0:y0 + 64, x0:x0 + 64] = True
+    return m
+
+
+def _assert_tiles_bit_equal(r, o, w, h, tiles, name):
+    g, c = r.read_hdr(), o.read_hdr()
+    m = _tile_mask(w, h, tiles)
+    assert m.sum() >= 16 * 64 * 32
+    gb, cb = g[m].view(np.uint32), c[m].view(np.uint32)
+    same = (gb == cb) | (np.isnan(g[m]) & np.isnan(c[m]))
+    assert same.all(), "%s: %d of %d sampled pixels differ from the oracle" % (name, int((~same.all(-1)).sum()), int(m.sum()))
+    assert np.array_equal(np.isnan(g[m]), np.isnan(c[m])), name + ": NaN sets differ"
+    gr, cr = r.read_result()[m], o.read_result()[m]
+    assert ((gr.view(np.uint32) == cr.view(np.uint32)) | (np.isnan(gr) & np.isnan(cr))).all(), name + ": result image differs"
+    assert np.array_equal(r.read_rgba8()[m], o.read_rgba8()[m]), name + ": RGBA8 export differs"
+
+
+def test_full_size_mattest_1024_tiles_vs_oracle(instance, mattest_desc):
+    """Config 3: mattest.glaze, 1024 x 1024, depth 8 -- the whole frame on the GPU, 18 of its 256 tiles on the oracle (pixels are
+    independent: absolute-pixel RNG, path_trace.rgen:143-147), bit for bit, NaN sets and the 8-bit export included."""
+    w = h = 1024
+    launches = 17                                                                 # two full paths + the first segment of a third
+    gpu_scene = glaze_amd.RayTraceScene.new(instance, glaze_amd.parse(MATTEST))   # product reader on the GPU side
+    r = glaze_amd.RayTraceRenderer.new(instance, gpu_scene, w, h)
+    r.set_depth(8)
+    r.step(launches)
+    tiles = _sample_tiles(w, h, 12, 1)
+    o = OracleRenderer(OracleScene(mattest_desc), w, h)
+    o.set_depth(8)
+    o.set_exposure(mattest_desc.meta.exposure)
+    o.set_tiles(tiles)
+    o.step(launches)
+    _assert_tiles_bit_equal(r, o, w, h, tiles, "mattest 1024^2")
+
+
+def test_full_size_atrium_1080p_tiles_vs_oracle(instance):
+    """Config 4: Sponza-class atrium, 1920 x 1080 (30 x 17 tiles, the bottom row 56 pixels high), depth 8."""
+    w, h = 1920, 1080
+    launches = 17
+    desc = atrium_scene()
+    r = glaze_amd.RayTraceRenderer.new(instance, glaze_amd.RayTraceScene.from_desc(instance, desc), w, h)
+    r.set_depth(8)
+    r.step(launches)
+    tiles = _sample_tiles(w, h, 12, 2)
+    o = OracleRenderer(OracleScene(desc), w, h)
+    o.set_depth(8)
+    o.set_tiles(tiles)
+    o.step(launches)
+    _assert_tiles_bit_equal(r, o, w, h, tiles, "atrium 1080p")
+
+
+def test_full_size_atrium_4k_depth12_tiles_vs_oracle(instance):
+    """Config 5: 3840 x 2160 (60 x 34 tiles, ragged bottom row), depth 12, rendered as rank 3's share of the 8-way partition
+    plus the whole frame: the sampled tiles that rank 3 owns must match the oracle in both, the others in the whole frame."""
+    w, h = 3840, 2160
+    launches = 14
+    desc = atrium_scene()
+    r = glaze_amd.RayTraceRenderer.new(instance, glaze_amd.RayTraceScene.from_desc(instance, desc), w, h)
+    r.set_depth(12)
+    r.step(launches)
+    tiles = _sample_tiles(w, h, 10, 3)
+    o = OracleRenderer(OracleScene(desc), w, h)
+    o.set_depth(12)
+    o.set_tiles(tiles)
+    o.step(launches)
+    _assert_tiles_bit_equal(r, o, w, h, tiles, "atrium 4K")
+    r.set_partition(3, 8)
+    r.step(launches)
+    mine = [t for t in tiles if t % 8 == 3]
+    part, c = r.read_hdr(), o.read_hdr()
+    m = _tile_mask(w, h, mine)
+    if m.any():
+        assert ((part[m].view(np.uint32) == c[m].view(np.uint32)) | (np.isnan(part[m]) & np.isnan(c[m]))).all()
