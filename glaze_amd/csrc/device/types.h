@@ -115,6 +115,12 @@ struct alignas(16) BvhNode4 {
   uint32_t w[16];
 };
 constexpr int kBvhEmptyChild = 0x7FFFFFFF;
+// Top of the tree, staged in LDS by the tracers ("node packets"): the root, its inner children and their inner children in
+// breadth-first order, at most kBvhTopNodes nodes (1 + 4 + 16).  Inside this table -- and in `cur` of a lane that sits on
+// one of its nodes -- a link to a staged node reads kBvhTopFlag | slot instead of the node index; links that leave the
+// table are the ordinary ones.  Built once per scene (k_top_table), copied into LDS at the start of every tracer block.
+constexpr int kBvhTopNodes = 21;
+constexpr int kBvhTopFlag = 0x40000000;
 struct BvhGrid {
   float lo[3];
   float cell[3];
@@ -150,6 +156,7 @@ struct DeviceScene {
   const uint8_t* tex_pool;
   const float* srgb_lut;           // 256 entries
   const BvhNode4* bvh_nodes;
+  const BvhNode4* bvh_top;         // kBvhTopNodes nodes: the top levels with links into the table flagged (kBvhTopFlag)
   BvhGrid bvh_grid;
   const BvhTri* bvh_tris;
   // per-leaf shading record, 8 x float4 = 128 bytes, in leaf order: VertexPacked x 3 (object space), then

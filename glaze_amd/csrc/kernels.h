@@ -37,13 +37,15 @@ struct LbvhOutputs {
   float bounds_lo[3], bounds_hi[3];
 };
 hipError_t build_lbvh(hipStream_t st, const LbvhInputs& in, LbvhOutputs& out);
+// top-of-tree table for LDS staging (types.h kBvhTopNodes): `top` receives kBvhTopNodes nodes
+hipError_t launch_top_table(hipStream_t st, const BvhNode4* nodes, uint32_t n_nodes, BvhNode4* top);
 // 128-byte per-leaf shading records (see k_shade_records); xf_identity[t] != 0 marks an exact identity transform
 hipError_t launch_shade_records(hipStream_t st, uint32_t n, const BvhTri* tris, const RTInstance* instances, const uint32_t* indices,
                                 const float4* vertices, const float4* derivatives, const uint32_t* xf_identity, float4* out);
 
 // Traversal stack entries each lane keeps in LDS (a near-first 4-wide traversal holds at most three entries per
 // level of the tree; what does not fit spills to a per-lane HBM area).
-constexpr int kTraversalLdsStack = 18;
+constexpr int kTraversalLdsStack = 17;   // 17 levels + the staged top of the tree = 25 920 bytes per block: six blocks per CU (LDS is granted in 1 280-byte granules: 18 levels + the table would take 22 granules and leave room for five)
 
 // ---- rendering ------------------------------------------------------------------------------------
 // Per-pixel wavefront state, indexed by the LOCAL pixel id `lid` (tile-major, one wave = one 8x8 block):

@@ -1173,6 +1173,35 @@ static uint32_t next_pow2(uint32_t v) {
   return p;
 }
 
+// Top-of-tree table (types.h kBvhTopNodes): breadth-first from the root, one thread -- 21 dependent 64-byte reads, once per
+// scene.  An inner child gets the next free slot and its link in the table becomes kBvhTopFlag | slot; leaves, empty
+// slots and inner children beyond the table keep their links.  Unused slots stay zero (never referenced).
+__global__ void k_top_table(const BvhNode4* __restrict__ nodes, uint32_t n_nodes, BvhNode4* __restrict__ top) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  for (int s = 0; s < kBvhTopNodes; ++s)
+    for (int k = 0; k < 16; ++k) top[s].w[k] = 0u;
+  if (n_nodes == 0) return;
+  int source[kBvhTopNodes];
+  int used = 1;
+  source[0] = 0;
+  for (int s = 0; s < used; ++s) {
+    BvhNode4 nd = nodes[source[s]];
+    for (int k = 0; k < 4; ++k) {
+      const int link = (int)nd.w[12 + k];
+      if (link >= 0 && link != kBvhEmptyChild && (uint32_t)link < n_nodes && used < kBvhTopNodes) {
+        source[used] = link;
+        nd.w[12 + k] = (uint32_t)(kBvhTopFlag | used);
+        ++used;
+      }
+    }
+    top[s] = nd;
+  }
+}
+hipError_t launch_top_table(hipStream_t st, const BvhNode4* nodes, uint32_t n_nodes, BvhNode4* top) {
+  hipLaunchKernelGGL(k_top_table, dim3(1), dim3(64), 0, st, nodes, n_nodes, top);
+  return hipGetLastError();
+}
+
 hipError_t launch_shade_records(hipStream_t st, uint32_t n, const BvhTri* tris, const RTInstance* instances, const uint32_t* indices,
                                 const float4* vertices, const float4* derivatives, const uint32_t* xf_identity, float4* out) {
   if (n == 0) return hipSuccess;

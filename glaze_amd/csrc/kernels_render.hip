@@ -126,7 +126,9 @@ struct HitRecord {
 };
 
 // Per-lane traversal stack: the first kLdsStack levels in LDS (column `tid` of a [level][kBlock]
-// array: every lane always hits bank tid % 32, conflict-free whatever the per-lane depth), deeper
+// array, accessed with 4-byte DS instructions, which gfx950 services in two 32-lane halves with bank = (addr / 4) % 32
+// -- the 64-bank mapping only applies to the 8- and 16-byte reads: every lane hits bank tid % 32 of its own half,
+// conflict-free whatever the per-lane depth), deeper
 // levels in a per-lane HBM spill area.  kStolen marks an LDS entry that was handed to an idle lane (work sharing
 // at the tail of trace_wave); pop_live() skips such entries.
 constexpr int kRayDone = 0x7FFFFFFF;   // `cur` of a lane without a node to visit (inner nodes are >= 0, leaves < 0)
@@ -163,8 +165,8 @@ struct TraceTally {
 // [64 * (g * n_waves + w), +64)) and keeps its 64 lanes busy: a lane whose ray has finished takes the next
 // ray of the wave's sequence as soon as kRefill lanes are idle (no atomics: the sequence pointer is wave
 // uniform).  Each round is  [refill] -> [share] -> [inner-node phase] -> [leaf phase] -> [merge] -> [retire]:
-//   * inner-node phase: lanes sitting on an inner node test its two child boxes, descend into the nearer
-//     hit child and push the farther one; lanes that reached a leaf wait.  The phase ends when no lane is on an
+//   * inner-node phase: lanes sitting on an inner node test its four child boxes, descend into the nearest
+//     hit child and push the others farthest first; lanes that reached a leaf wait.  The phase ends when no lane is on an
 //     inner node, or when at least kLeafQuorum lanes are waiting on a leaf.
 //   * leaf phase: every lane on a leaf runs the exact ray/triangle test once, then pops its stack.
 //   * share / merge (only once the wave's sequence is exhausted, i.e. in the tail): an idle lane takes the OLDEST
@@ -193,6 +195,10 @@ struct TraceTally {
 #ifndef GLZ_LEAF_QUORUM
 #define GLZ_LEAF_QUORUM 16   // 4-wide nodes: 8 -> 0.815, 12 -> 0.790, 16 -> 0.781, 24 -> 0.810 ms per k_trace; with pair leaves 8 / 12 / 16 / 24 / 32 -> 0.650 / 0.606 / 0.589 / 0.583 / 0.598
 #endif
+#ifndef GLZ_LDS_TOP
+#define GLZ_LDS_TOP 1   // 1: the top kBvhTopNodes nodes of the tree are fetched from a per-block LDS copy ("LDS-staged node packets"), 0: every node from global memory
+#endif
+constexpr bool kLdsTop = GLZ_LDS_TOP != 0;
 constexpr int kRefill = GLZ_REFILL;
 constexpr int kLeafQuorum = GLZ_LEAF_QUORUM;
 constexpr int kAuxPerWave = 3 * 64 + 4 * 64;   // work sharing (3 x 64) + the four child links of the node a lane is visiting
@@ -203,9 +209,15 @@ __device__ __forceinline__ void sort2(uint32_t& a, uint32_t& b) {
   b = hi;
 }
 
+// The staged nodes are read through a pointer that keeps its LDS address space: with a generic pointer the compiler
+// merges the LDS and the global fetch of a node into ONE flat_load behind a pointer select -- every node of the tree then
+// comes in through the flat path (measured: k_trace 0.586 -> 0.786 ms).
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(3))) u32x4* LdsNodePtr;
+
 template <bool ANY, bool COUNT, class Source, class Sink>
-__device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Sink& sink, int* __restrict__ lds_col, int* aux, uint32_t* __restrict__ spill,
-                                           uint32_t spill_depth, uint32_t total, uint32_t wave, uint32_t n_waves, TraceTally& tally) {
+__device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Sink& sink, int* __restrict__ lds_col, int* aux, LdsNodePtr top_lds,
+                                           uint32_t* __restrict__ spill, uint32_t spill_depth, uint32_t total, uint32_t wave, uint32_t n_waves, TraceTally& tally) {
   constexpr bool SHARE = !COUNT;
   constexpr uint32_t kNone = 0xFFFFFFFFu;
   const BvhNode4* __restrict__ nodes = S.bvh_nodes;
@@ -263,7 +275,7 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
             sel = SlabSel{ig.x < 0.0f ? 0x01000302u : 0x03020100u, ig.y < 0.0f ? 0x01000302u : 0x03020100u, ig.z < 0.0f ? 0x01000302u : 0x03020100u};
             st.sp = 0;
             if (SHARE) aux_sb[lane] = 0;
-            cur = 0;
+            cur = kLdsTop ? kBvhTopFlag : 0;   // the root (slot 0 of the staged table)
             open = true;
           }
         }
@@ -340,29 +352,42 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
       if (at_node) {
         // 64-byte node = 4 x dwordx4: four child boxes in 16-bit grid coordinates (the ray was mapped into grid units at
         // refill) and four links.  Children are entered nearest first; the others are pushed farthest first.
-        const uint4* np = reinterpret_cast<const uint4*>(nodes + cur);
-        const uint4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
+        // Nodes of the top levels come out of the block's LDS copy (their `cur` carries kBvhTopFlag | slot); lanes that read the
+        // same staged node broadcast.
+        u32x4 w0, w1, w2, w3;
+        if (kLdsTop && (cur & kBvhTopFlag)) {
+          LdsNodePtr np = top_lds + 4 * (cur & 0xFFFF);
+          w0 = np[0]; w1 = np[1]; w2 = np[2]; w3 = np[3];
+        } else {
+          const u32x4* np = reinterpret_cast<const u32x4*>(nodes + cur);
+          w0 = np[0]; w1 = np[1]; w2 = np[2]; w3 = np[3];
+        }
         if (COUNT) tally.nodes += 1;
         uint32_t k0 = box_key(w0.x, w0.y, w0.z, w3.x, 0u, sel, ig, cg, tmin, best.t), k1 = box_key(w0.w, w1.x, w1.y, w3.y, 1u, sel, ig, cg, tmin, best.t);
         uint32_t k2 = box_key(w1.z, w1.w, w2.x, w3.z, 2u, sel, ig, cg, tmin, best.t), k3 = box_key(w2.y, w2.z, w2.w, w3.w, 3u, sel, ig, cg, tmin, best.t);
         sort2(k0, k1); sort2(k2, k3); sort2(k0, k2); sort2(k1, k3); sort2(k1, k2);
         // The links go through LDS: picking one of four registers by a per-lane index costs 6 VALU instructions (the
-        // kernel's bottleneck), an LDS read at a computed address 2 (k_trace 0.714 -> 0.691 ms).
-        int* links = aux + 192 + 4 * lane;
-        *reinterpret_cast<uint4*>(links) = w3;
+        // kernel's bottleneck), an LDS read at a computed address 2 (k_trace 0.714 -> 0.691 ms).  The scratch is laid out
+        // [child][lane] so that every access of a wave instruction has bank = lane % 32 (the [lane][child] layout with one
+        // 16-byte store put lanes l, l + 8, l + 16, l + 24 of a half-wave on the same banks: 4.6 M conflict cycles per launch,
+        // 22 % of the LDS-active cycles), and all four sorted links are fetched before the first one is used: the reads
+        // are independent, so one LDS round trip covers them instead of one per push (read -> wait -> write, four times over).
+        int* links = aux + 192 + lane;
+        links[0] = (int)w3.x; links[64] = (int)w3.y; links[128] = (int)w3.z; links[192] = (int)w3.w;
+        const int l0 = links[(k0 & 3u) * 64u], l1 = links[(k1 & 3u) * 64u], l2 = links[(k2 & 3u) * 64u], l3 = links[(k3 & 3u) * 64u];
         if (k0 == 0xFFFFFFFFu) {
           cur = SHARE ? st.pop_live() : (st.sp ? st.pop() : kRayDone);
         } else {
           if (__ballot(st.sp + 3 > kLdsStack) == 0ull) {   // wave-uniform: every lane stays inside the LDS part of its stack (no spill branches)
-            if (k3 != 0xFFFFFFFFu) { st.lds[st.sp * kBlock] = links[k3 & 3u]; ++st.sp; }
-            if (k2 != 0xFFFFFFFFu) { st.lds[st.sp * kBlock] = links[k2 & 3u]; ++st.sp; }
-            if (k1 != 0xFFFFFFFFu) { st.lds[st.sp * kBlock] = links[k1 & 3u]; ++st.sp; }
+            if (k3 != 0xFFFFFFFFu) { st.lds[st.sp * kBlock] = l3; ++st.sp; }
+            if (k2 != 0xFFFFFFFFu) { st.lds[st.sp * kBlock] = l2; ++st.sp; }
+            if (k1 != 0xFFFFFFFFu) { st.lds[st.sp * kBlock] = l1; ++st.sp; }
           } else {
-            if (k3 != 0xFFFFFFFFu) st.push(links[k3 & 3u]);
-            if (k2 != 0xFFFFFFFFu) st.push(links[k2 & 3u]);
-            if (k1 != 0xFFFFFFFFu) st.push(links[k1 & 3u]);
+            if (k3 != 0xFFFFFFFFu) st.push(l3);
+            if (k2 != 0xFFFFFFFFu) st.push(l2);
+            if (k1 != 0xFFFFFFFFu) st.push(l1);
           }
-          cur = links[k0 & 3u];
+          cur = l0;
         }
       }
       if (__popcll(__ballot(cur < 0)) >= kLeafQuorum) break;
@@ -827,17 +852,29 @@ struct ShadowSink {
 // the per-pixel order of `cum += c` is the reference's.
 // Two counter sets: this kernel drains set shade_set ^ 1 and clears set shade_set for the k_shade that follows.
 // ---------------------------------------------------------------------------------------------
+// copies the scene's top-of-tree table (types.h kBvhTopNodes) into the block's LDS; ends with a block barrier
+__device__ __forceinline__ void stage_top(const DeviceScene& S, uint4* s_top) {
+  if (kLdsTop) {
+    const uint4* src = reinterpret_cast<const uint4*>(S.bvh_top);
+    if (threadIdx.x < kBvhTopNodes * 4) s_top[threadIdx.x] = src[threadIdx.x];
+    __syncthreads();
+  }
+}
+
 template <bool COUNT>
 __global__ void __launch_bounds__(kBlock, GLZ_TRACE_WAVES) k_trace(const LaunchArgs A) {
   __shared__ int s_stack[kLdsStack * kBlock];
   __shared__ alignas(16) int s_aux[(kBlock / 64) * kAuxPerWave];
+  __shared__ uint4 s_top[kLdsTop ? kBvhTopNodes * 4 : 1];
+  static_assert(kBvhTopNodes * 4 <= kBlock, "stage_top copies one 16-byte piece per thread");
+  stage_top(A.scene, s_top);
   int* aux = &s_aux[(threadIdx.x >> 6) * kAuxPerWave];
   if (blockIdx.x == 0 && threadIdx.x < kQueueShards) A.st.queue_count[A.shade_set * kQueueSetWords + threadIdx.x * kCounterStride] = 0;
   if (A.do_closest) {
     TraceTally tally;
     ClosestSource src{A, tally};
     ClosestSink sink{A};
-    trace_wave<false, COUNT>(A.scene, src, sink, &s_stack[threadIdx.x], aux, A.st.overflow, A.st.overflow_depth, A.map.n_local_pixels, wave_index(),
+    trace_wave<false, COUNT>(A.scene, src, sink, &s_stack[threadIdx.x], aux, (LdsNodePtr)s_top, A.st.overflow, A.st.overflow_depth, A.map.n_local_pixels, wave_index(),
                              wave_count(), tally);
     if (COUNT) flush_counters(A.counters, false, tally);
   }
@@ -857,7 +894,7 @@ __global__ void __launch_bounds__(kBlock, GLZ_TRACE_WAVES) k_trace(const LaunchA
     const uint32_t n_waves = wave_count();
     const uint32_t closest_groups = A.do_closest ? (A.map.n_local_pixels + 63u) / 64u : 0u;
     const uint32_t wave = (wave_index() + n_waves - closest_groups % n_waves) % n_waves;
-    trace_wave<true, COUNT>(A.scene, src, sink, &s_stack[threadIdx.x], aux, A.st.overflow, A.st.overflow_depth, start[kQueueShards], wave, n_waves, tally);
+    trace_wave<true, COUNT>(A.scene, src, sink, &s_stack[threadIdx.x], aux, (LdsNodePtr)s_top, A.st.overflow, A.st.overflow_depth, start[kQueueShards], wave, n_waves, tally);
     if (COUNT) flush_counters(A.counters, true, tally);
   }
 }
@@ -935,20 +972,24 @@ __global__ void __launch_bounds__(kBlock) k_debug_closest(const DeviceScene S, c
                                                           uint32_t* overflow, uint32_t overflow_depth) {
   __shared__ int s_stack[kLdsStack * kBlock];
   __shared__ alignas(16) int s_aux[(kBlock / 64) * kAuxPerWave];
+  __shared__ uint4 s_top[kLdsTop ? kBvhTopNodes * 4 : 1];
+  stage_top(S, s_top);
   TraceTally tally;
   DebugSource src{o, d, nullptr, tmin};
   DebugClosestSink sink{S, t, tri, inst, u, v};
-  trace_wave<false, false>(S, src, sink, &s_stack[threadIdx.x], &s_aux[(threadIdx.x >> 6) * kAuxPerWave], overflow, overflow_depth, n, wave_index(), wave_count(), tally);
+  trace_wave<false, false>(S, src, sink, &s_stack[threadIdx.x], &s_aux[(threadIdx.x >> 6) * kAuxPerWave], (LdsNodePtr)s_top, overflow, overflow_depth, n, wave_index(), wave_count(), tally);
 }
 __global__ void __launch_bounds__(kBlock) k_debug_any(const DeviceScene S, const float* __restrict__ o, const float* __restrict__ d,
                                                       const float* __restrict__ tmax, uint32_t n, float tmin, uint8_t* out, uint32_t* overflow,
                                                       uint32_t overflow_depth) {
   __shared__ int s_stack[kLdsStack * kBlock];
   __shared__ alignas(16) int s_aux[(kBlock / 64) * kAuxPerWave];
+  __shared__ uint4 s_top[kLdsTop ? kBvhTopNodes * 4 : 1];
+  stage_top(S, s_top);
   TraceTally tally;
   DebugSource src{o, d, tmax, tmin};
   DebugAnySink sink{out};
-  trace_wave<true, false>(S, src, sink, &s_stack[threadIdx.x], &s_aux[(threadIdx.x >> 6) * kAuxPerWave], overflow, overflow_depth, n, wave_index(), wave_count(), tally);
+  trace_wave<true, false>(S, src, sink, &s_stack[threadIdx.x], &s_aux[(threadIdx.x >> 6) * kAuxPerWave], (LdsNodePtr)s_top, overflow, overflow_depth, n, wave_index(), wave_count(), tally);
 }
 
 // ---------------------------------------------------------------------------------------------

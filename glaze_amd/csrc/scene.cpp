@@ -450,6 +450,15 @@ bool Scene::build_bvh(Error& err) {
   const uint32_t stack_bound = 3u * out.depth + 1u;
   stack_overflow_depth = stack_bound > (uint32_t)kTraversalLdsStack ? stack_bound - kTraversalLdsStack + 1 : 1;
   dev.bvh_nodes = d_nodes_.ptr;
+  if (out.n_nodes >= (uint32_t)kBvhTopFlag) {
+    err.code = GLZ_E_UNSUPPORTED;
+    err.msg = "more than 2^30 BVH nodes";
+    return false;
+  }
+  // top levels of the tree for the tracers' LDS staging
+  if (!d_top_.ptr && !hip_ok(d_top_.alloc(kBvhTopNodes), "alloc BVH top table", err)) return false;
+  if (!hip_ok(launch_top_table(st, d_nodes_.ptr, out.n_nodes, d_top_.ptr), "k_top_table", err)) return false;
+  dev.bvh_top = d_top_.ptr;
   dev.bvh_grid = out.grid;
   for (int k = 0; k < 3; ++k) {
     info.bvh_grid_lo[k] = out.grid.lo[k];

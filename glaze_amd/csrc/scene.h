@@ -94,7 +94,7 @@ class Scene {
   DeviceBuffer<TexDesc> d_tex_desc_;
   DeviceBuffer<uint8_t> d_tex_pool_;
   DeviceBuffer<float> d_srgb_lut_, d_sky_marginal_, d_sky_cond_values_, d_sky_cond_cdf_;
-  DeviceBuffer<BvhNode4> d_nodes_;
+  DeviceBuffer<BvhNode4> d_nodes_, d_top_;
   DeviceBuffer<BvhTri> d_tris_;
   DeviceBuffer<float4> d_shade_tris_;
   DeviceBuffer<uint32_t> d_xf_identity_;
