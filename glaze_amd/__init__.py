@@ -439,6 +439,12 @@ class RayTraceRenderer:
         t, nt = _texture_array(textures, keep)
         abi.check(abi.lib().glz_renderer_refresh_binded_textures(self._h, t, nt))
 
+    def set_devices(self, devices):
+        """Render on several GPUs of this process (tiles t % n == i on devices[i], RCCL reduce onto devices[0] at every read-back);
+        devices[0] must be the instance's device.  [d] returns to one device."""
+        arr = (C.c_int * len(devices))(*devices)
+        abi.check(abi.lib().glz_renderer_set_devices(self._h, arr, len(devices)))
+
     def set_chains(self, n):
         """Concurrent launch chains over this rank's tiles (0 = automatic); the image does not depend on it."""
         abi.check(abi.lib().glz_renderer_set_chains(self._h, n))

@@ -13,6 +13,7 @@
 #include "codec/jpeg.h"
 #include "codec/png_enc.h"
 #include <strings.h>
+#include "rccl_dl.h"
 #include "renderer.h"
 #include "scene.h"
 
@@ -401,6 +402,11 @@ int glz_renderer_push_constants(glz_renderer* h, float out[32]) {
   return GLZ_OK;
 }
 int glz_renderer_set_partition(glz_renderer* h, uint32_t rank, uint32_t world) { GLZ_GUARD_BEGIN GLZ_R(h); GLZ_RET(h->r->set_partition(rank, world, e)); GLZ_GUARD_END(GLZ_E_IO) }
+int glz_renderer_set_devices(glz_renderer* h, const int* devices, int n) {
+  GLZ_GUARD_BEGIN GLZ_R(h);
+  GLZ_RET(h->r->set_devices(devices, n, e));
+  GLZ_GUARD_END(GLZ_E_IO)
+}
 int glz_renderer_set_chains(glz_renderer* h, uint32_t n) { GLZ_GUARD_BEGIN GLZ_R(h); GLZ_RET(h->r->set_chains(n, e)); GLZ_GUARD_END(GLZ_E_IO) }
 int glz_renderer_export_device(glz_renderer* h, int which, void* dev) {
   GLZ_GUARD_BEGIN GLZ_R(h);
@@ -566,6 +572,46 @@ int glz_debug_tonemap(glz_instance* inst, const float* rgba32f, uint64_t n, uint
   if (!hip_ok(launch_tonemap(st, (uint32_t)n, d_in.ptr, d_thr.ptr, d_out.ptr), "k_tonemap", e)) return fail(e);
   (void)hipMemcpyAsync(out, d_out.ptr, n * 4, hipMemcpyDeviceToHost, st);
   if (!hip_ok(hipStreamSynchronize(st), "debug tonemap", e)) return fail(e);
+  return GLZ_OK;
+  GLZ_GUARD_END(GLZ_E_IO)
+}
+
+int glz_debug_rccl_selftest(glz_instance* inst, uint64_t n, int* version_out) {
+  GLZ_GUARD_BEGIN
+  if (!inst || n == 0 || n > (1ull << 30)) return fail(GLZ_E_ARG, "bad argument");
+  std::string why;
+  const Rccl* nc = Rccl::get(why);
+  if (!nc) return fail(GLZ_E_DEVICE, why.c_str());
+  Error e;
+  if (!hip_ok(hipSetDevice(inst->i->device), "hipSetDevice", e)) return fail(e);
+  int version = 0;
+  (void)nc->GetVersion(&version);
+  if (version_out) *version_out = version;
+  hipStream_t st = inst->i->stream;
+  std::vector<float> host(n), back(n);
+  uint32_t x = 12345u;
+  for (uint64_t i = 0; i < n; ++i) {   // arbitrary bit patterns that are finite floats
+    x = x * 1664525u + 1013904223u;
+    const uint32_t bits = (x & 0x807FFFFFu) | (((x >> 23) % 200u + 20u) << 23);
+    memcpy(&host[i], &bits, 4);
+  }
+  DeviceBuffer<float> send, recv;
+  if (!hip_ok(send.upload(host.data(), n, st), "upload", e) || !hip_ok(recv.alloc(n), "alloc", e)) return fail(e);
+  if (!hip_ok(hipMemsetAsync(recv.ptr, 0, n * 4, st), "memset", e)) return fail(e);
+  ncclComm_t comm = nullptr;
+  const int dev = inst->i->device;
+  ncclResult_t r = nc->CommInitAll(&comm, 1, &dev);
+  if (r != ncclSuccess) return fail(GLZ_E_DEVICE, (std::string("ncclCommInitAll: ") + nc->GetErrorString(r)).c_str());
+  r = nc->Reduce(send.ptr, recv.ptr, n, ncclFloat, ncclSum, 0, comm, st);
+  bool ok = r == ncclSuccess;
+  std::string msg = ok ? "" : std::string("ncclReduce: ") + nc->GetErrorString(r);
+  if (ok) {
+    ok = hip_ok(hipMemcpyAsync(back.data(), recv.ptr, n * 4, hipMemcpyDeviceToHost, st), "read back", e) && hip_ok(hipStreamSynchronize(st), "ncclReduce", e);
+    if (!ok) msg = e.msg;
+  }
+  (void)nc->CommDestroy(comm);
+  if (!ok) return fail(GLZ_E_DEVICE, msg.c_str());
+  if (memcmp(host.data(), back.data(), n * 4) != 0) return fail(GLZ_E_DEVICE, "ncclReduce on a one-rank communicator changed the data");
   return GLZ_OK;
   GLZ_GUARD_END(GLZ_E_IO)
 }

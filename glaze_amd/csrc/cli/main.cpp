@@ -1,7 +1,9 @@
 // glaze-cli for the HIP render path: same command line as the reference's `glaze-cli`
 // (cli/src/main.rs:24-39: `input output -r/--res WxH -s/--spp N -i/--integrator {direct,pt}`),
 // same messages and exit codes (cli/src/main.rs:41-135), driving the C ABI of libglaze_hip.so.
-// Build-defined extras: --seed, --depth, --device, --hdr-out file.pfm, --report (JSON on stdout).
+// Build-defined extras: --seed, --depth, --device, --devices a,b,c (several GPUs of this process: tiles sharded, RCCL reduce),
+// --hdr-out file.pfm, --report (JSON on stdout).
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -64,6 +66,7 @@ void usage(const char* argv0) {
           "      --seed <N>                seed of the per-launch seed stream [default: 0]\n"
           "      --depth <N>               path depth (the reference's PT_STEPS) [default: 6]\n"
           "      --device <N>              HIP device ordinal [default: first gfx950]\n"
+          "      --devices <A,B,..>        render on several GPUs (64x64 tiles sharded over them, RCCL reduce onto the first)\n"
           "      --hdr-out <FILE.pfm>      also write the float radiance image\n"
           "      --report                  print a JSON timing report on stdout\n",
           argv0);
@@ -77,6 +80,7 @@ int main(int argc, char** argv) {
   uint64_t seed = 0;
   uint32_t depth = 6;
   int device = -1;
+  std::vector<int> devices;
   bool report = false;
   std::vector<std::string> positional;
   for (int i = 1; i < argc; ++i) {
@@ -94,6 +98,19 @@ int main(int argc, char** argv) {
     else if (a == "--seed") seed = strtoull(value("--seed"), nullptr, 10);
     else if (a == "--depth") depth = (uint32_t)strtoul(value("--depth"), nullptr, 10);
     else if (a == "--device") device = atoi(value("--device"));
+    else if (a == "--devices") {
+      const std::string list = value("--devices");
+      size_t pos = 0;
+      while (pos <= list.size()) {
+        const size_t comma = std::min(list.find(',', pos), list.size());
+        char* e = nullptr;
+        const std::string item = list.substr(pos, comma - pos);
+        const long d = strtol(item.c_str(), &e, 10);
+        if (item.empty() || *e || d < 0 || d > 1023) { fprintf(stderr, "error: invalid value '%s' for '--devices' (comma-separated HIP device ordinals)\n", list.c_str()); return 2; }
+        devices.push_back((int)d);
+        pos = comma + 1;
+      }
+    }
     else if (a == "--hdr-out") hdr_out = value("--hdr-out");
     else if (a == "--report") report = true;
     else if (a == "-h" || a == "--help") { usage(argv[0]); return 0; }
@@ -129,6 +146,10 @@ int main(int argc, char** argv) {
   const unsigned long height = strtoul(resolution.substr(xpos + 1).c_str(), &endp, 10);
   if (*endp || height == 0 || height > 65535) { fprintf(stderr, "[ERROR] Failed to parse the requested height\n"); return 1; }
 
+  if (!devices.empty()) {
+    if (device >= 0 && device != devices[0]) { fprintf(stderr, "error: '--device' and the first entry of '--devices' disagree\n"); return 2; }
+    device = devices[0];
+  }
   glz_instance* instance = glz_instance_create(device);
   if (!instance) {
     fprintf(stderr, "[ERROR] Cannot create the HIP instance. Is there an MI355X (gfx950) in this machine? (%s)\n", glz_last_error());
@@ -150,6 +171,10 @@ int main(int argc, char** argv) {
   glz_renderer_set_integrator(renderer, integrator == "direct" ? GLZ_DIRECT : GLZ_PATH_TRACE);
   if (glz_renderer_set_depth(renderer, depth) != GLZ_OK) { fprintf(stderr, "\n[ERROR] %s\n", glz_last_error()); return 1; }
   glz_renderer_set_seed(renderer, seed);
+  if (devices.size() > 1 && glz_renderer_set_devices(renderer, devices.data(), (int)devices.size()) != GLZ_OK) {
+    fprintf(stderr, "\n[ERROR] %s\n", glz_last_error());
+    return 1;
+  }
   const auto t1 = std::chrono::steady_clock::now();
   const double setup_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
   fprintf(stderr, "Done (%.0f ms)\n", setup_ms);
@@ -186,10 +211,10 @@ int main(int argc, char** argv) {
     const uint32_t steps = glz_renderer_steps_per_sample(renderer);
     printf("{\"input\": \"%s\", \"width\": %lu, \"height\": %lu, \"spp\": %zu, \"steps_per_sample\": %u, \"launches\": %llu, "
            "\"triangles\": %llu, \"bvh_nodes\": %u, \"bvh_depth\": %u, \"bvh_build_ms\": %.3f, \"setup_ms\": %.1f, \"render_ms\": %.1f, "
-           "\"kernel_ms\": {\"trace\": %.2f, \"shade\": %.2f, \"shadow_flush\": %.2f}, \"msamples_per_s\": %.2f}\n",
+           "\"kernel_ms\": {\"trace\": %.2f, \"shade\": %.2f, \"shadow_flush\": %.2f}, \"msamples_per_s\": %.2f, \"devices\": %zu}\n",
            input.c_str(), width, height, spp, steps, (unsigned long long)st.launches, (unsigned long long)info.n_world_triangles, info.bvh_nodes,
            info.bvh_depth, info.build_ms, setup_ms, render_ms, st.trace_closest_ms, st.shade_ms, st.trace_shadow_ms,
-           render_ms > 0 ? (double)st.samples / render_ms / 1e3 : 0.0);
+           render_ms > 0 ? (double)st.samples / render_ms / 1e3 : 0.0, devices.empty() ? (size_t)1 : devices.size());
   }
   glz_renderer_destroy(renderer);
   glz_scene_destroy(scene);

@@ -3,9 +3,126 @@
 
 #include <algorithm>
 #include <cmath>
+#include <condition_variable>
+#include <cstdlib>
 #include <cstring>
+#include <exception>
+#include <functional>
+#include <mutex>
+#include <thread>
+
+#include "rccl_dl.h"
 
 namespace glz {
+
+namespace {
+// One host thread per additional GPU: it enqueues that device's launches while the caller's thread enqueues its own (two
+// kernels per launch and device; at 1/8 of a 1080p frame per GPU a launch lasts ~0.17 ms, so eight devices fed from one
+// thread would be bound by the host).  One task at a time: post(), then wait().
+class Worker {
+ public:
+  Worker() : th_([this] { loop(); }) {}
+  ~Worker() { stop(); }
+  void post(std::function<void()> f) {
+    std::lock_guard<std::mutex> l(m_);
+    task_ = std::move(f);
+    has_ = true;
+    done_ = false;
+    cv_.notify_all();
+  }
+  void wait() {
+    std::unique_lock<std::mutex> l(m_);
+    cv_.wait(l, [&] { return done_; });
+  }
+  void stop() {
+    {
+      std::lock_guard<std::mutex> l(m_);
+      if (quit_) return;
+      quit_ = true;
+      cv_.notify_all();
+    }
+    th_.join();
+  }
+
+ private:
+  void loop() {
+    std::unique_lock<std::mutex> l(m_);
+    for (;;) {
+      cv_.wait(l, [&] { return has_ || quit_; });
+      if (!has_) return;
+      std::function<void()> f = std::move(task_);
+      has_ = false;
+      l.unlock();
+      f();
+      l.lock();
+      done_ = true;
+      cv_.notify_all();
+    }
+  }
+  std::mutex m_;
+  std::condition_variable cv_;
+  std::function<void()> task_;
+  bool has_ = false, done_ = true, quit_ = false;
+  std::thread th_;   // last member: the thread starts once everything above exists
+};
+}  // namespace
+
+// Another GPU of this process: its own instance (device + stream), a replica of the scene, a renderer for the tiles
+// t % n == rank, the frame it contributes to the reduce, and the host thread that drives it.
+struct Renderer::Peer {
+  std::unique_ptr<Instance> inst;
+  std::unique_ptr<Renderer> r;
+  DeviceBuffer<float4> frame;
+  Worker worker;
+  ~Peer() {
+    worker.stop();
+    if (inst) (void)hipSetDevice(inst->device);
+    r.reset();
+    frame.release();
+  }
+};
+struct Renderer::Pending {
+  std::vector<Error> errs;
+  std::vector<char> ok;
+};
+
+// f(Peer&, Error&) -> bool on every peer's thread; f is copied into the tasks, whatever it refers to must outlive join_all()
+template <class F>
+void Renderer::post_all(F f, Pending& p) {
+  p.errs.assign(peers_.size(), Error());
+  p.ok.assign(peers_.size(), 1);
+  for (size_t i = 0; i < peers_.size(); ++i) {
+    Peer* peer = peers_[i].get();
+    Error* e = &p.errs[i];
+    char* ok = &p.ok[i];
+    peer->worker.post([=] {
+      try {
+        *ok = f(*peer, *e) ? 1 : 0;
+      } catch (const std::exception& ex) {
+        e->code = GLZ_E_IO;
+        e->msg = ex.what();
+        *ok = 0;
+      }
+    });
+  }
+}
+bool Renderer::join_all(Pending& p, Error& err) {
+  for (auto& peer : peers_) peer->worker.wait();
+  for (size_t i = 0; i < p.ok.size(); ++i)
+    if (!p.ok[i]) {
+      err = p.errs[i];
+      err.msg = "device " + std::to_string(peers_[i]->inst->device) + ": " + err.msg;
+      return false;
+    }
+  return true;
+}
+template <class F>
+bool Renderer::forward(F f, Error& err) {
+  if (peers_.empty()) return true;
+  Pending p;
+  post_all(f, p);
+  return join_all(p, err);
+}
 
 namespace {
 constexpr uint32_t kTile = 64;
@@ -62,7 +179,21 @@ void Renderer::release_chains() {
   chains_.clear();
 }
 
+void Renderer::release_peers() {
+  if (!comms_.empty()) {
+    std::string why;
+    if (const Rccl* nc = Rccl::get(why))
+      for (void* c : comms_)
+        if (c) (void)nc->CommDestroy(static_cast<ncclComm_t>(c));
+    comms_.clear();
+  }
+  peers_.clear();
+  loopback_ = false;
+  if (inst_) (void)hipSetDevice(inst_->device);
+}
+
 Renderer::~Renderer() {
+  release_peers();
   if (inst_) (void)hipSetDevice(inst_->device);
   release_chains();
 }
@@ -327,7 +458,43 @@ bool Renderer::get_stats(glz_render_stats* out, Error& err) {
   out->hits = c.hits;
   out->fresh_paths = c.fresh;
   for (int i = 0; i < 12; ++i) out->phase[i] = c.phase[i];
+  // other GPUs of this process: work counters add up, kernel times overlap (the slowest device is what the job waits for)
+  if (!peers_.empty()) {
+    std::vector<glz_render_stats> ps(peers_.size());
+    glz_render_stats* base = ps.data();
+    Peer* first = peers_[0].get();
+    (void)first;
+    Pending pend;
+    std::vector<Peer*> order;
+    for (auto& p : peers_) order.push_back(p.get());
+    const std::vector<Peer*>* ord = &order;
+    post_all([=](Peer& p, Error& e) {
+      size_t i = 0;
+      while ((*ord)[i] != &p) ++i;
+      return p.r->get_stats(base + i, e);
+    }, pend);
+    if (!join_all(pend, err)) return false;
+    for (const glz_render_stats& q : ps) {
+      out->samples += q.samples;
+      out->trace_closest_ms = std::max(out->trace_closest_ms, q.trace_closest_ms);
+      out->shade_ms = std::max(out->shade_ms, q.shade_ms);
+      out->trace_shadow_ms = std::max(out->trace_shadow_ms, q.trace_shadow_ms);
+      out->closest_rays += q.closest_rays; out->shadow_rays += q.shadow_rays;
+      out->closest_nodes += q.closest_nodes; out->closest_tris += q.closest_tris;
+      out->shadow_nodes += q.shadow_nodes; out->shadow_tris += q.shadow_tris;
+      out->hits += q.hits; out->fresh_paths += q.fresh_paths;
+      for (int i = 0; i < 12; ++i) out->phase[i] += q.phase[i];
+    }
+    out->render_ms = out->trace_closest_ms + out->shade_ms + out->trace_shadow_ms;
+    (void)hipSetDevice(inst_->device);
+  }
   return true;
+}
+
+void Renderer::enable_counters(int flags) {
+  counting_ = (flags & 1) != 0;
+  profile_kernels_ = (flags & 2) != 0;
+  for (auto& p : peers_) p->r->enable_counters(flags);
 }
 
 bool Renderer::set_integrator(int integrator, Error& err) {
@@ -340,11 +507,12 @@ bool Renderer::set_integrator(int integrator, Error& err) {
     integrator_ = integrator;
     request_new_frame_ = true;
   }
-  return true;
+  return forward([=](Peer& p, Error& e) { return p.r->set_integrator(integrator, e); }, err);
 }
 
 bool Renderer::set_exposure(float e) {
   if (e >= 0.0f) exposure_ = e;   // raytracer.rs:186-193: no restart
+  for (auto& p : peers_) p->r->set_exposure(e);
   return true;
 }
 
@@ -357,7 +525,8 @@ bool Renderer::update_camera(const glz_camera& c, Error& err) {
   camera_ = c;
   host::push_constants(camera_, w_, h_, cam_.camera2world, cam_.screen2camera);
   request_new_frame_ = true;
-  return true;
+  const glz_camera cam = c;
+  return forward([=](Peer& p, Error& e) { return p.r->update_camera(cam, e); }, err);
 }
 
 bool Renderer::change_resolution(uint32_t w, uint32_t h, Error& err) {
@@ -370,6 +539,13 @@ bool Renderer::change_resolution(uint32_t w, uint32_t h, Error& err) {
   w_ = w;
   h_ = h;
   if (!allocate(err)) return false;
+  const bool lb = loopback_;
+  if (!forward([=](Peer& p, Error& e) {
+        if (!p.r->change_resolution(w, h, e)) return false;
+        return lb || hip_ok(p.frame.alloc((size_t)w * h), "alloc peer frame", e);
+      }, err))
+    return false;
+  (void)hipSetDevice(inst_->device);
   return update_camera(camera_, err);   // raytracer.rs:297
 }
 
@@ -383,6 +559,15 @@ bool Renderer::change_scene(std::shared_ptr<Scene> scene, Error& err) {
   scene_ = scene;
   exposure_ = scene->data.meta.exposure;
   if (!allocate(err)) return false;
+  // the other GPUs of this process get replicas of the new scene
+  const Scene* src = scene.get();
+  if (!forward([=](Peer& p, Error& e) {
+        SceneData copy = src->data;
+        std::shared_ptr<Scene> replica(Scene::create(p.inst.get(), std::move(copy), e));
+        return replica && p.r->change_scene(replica, e);
+      }, err))
+    return false;
+  (void)hipSetDevice(inst_->device);
   return update_camera(scene->data.camera, err);   // raytracer.rs:246-247
 }
 
@@ -393,46 +578,79 @@ bool Renderer::update_materials_and_lights(const glz_material* m, uint32_t nm, c
   if (!scene_->update_materials_and_lights(m, nm, l, nl, t, nt, err)) return false;
   if (scene_->stack_overflow_depth != od && !allocate(err)) return false;
   request_new_frame_ = true;   // raytracer.rs:325
-  return true;
+  return forward([=](Peer& p, Error& e) { return p.r->update_materials_and_lights(m, nm, l, nl, t, nt, e); }, err);
 }
 
 // raytracer.rs:328-356.  The reference rebuilds descriptors, pipeline and SBT and leaves the accumulation alone; here the
 // kernels read the texture array through the scene struct of every launch, so re-uploading it is all there is to do.
 bool Renderer::refresh_binded_textures(const glz_texture* t, uint32_t nt, Error& err) {
   if (!wait_idle(err)) return false;
-  return scene_->refresh_textures(t, nt, err);
+  if (!scene_->refresh_textures(t, nt, err)) return false;
+  return forward([=](Peer& p, Error& e) { return p.r->refresh_binded_textures(t, nt, e); }, err);
 }
 
 bool Renderer::wait_idle(Error& err) {
-  if (!hip_ok(hipSetDevice(inst_->device), "hipSetDevice", err)) return false;
+  Pending pend;
+  if (!peers_.empty()) post_all([](Peer& p, Error& e) { return p.r->wait_idle(e); }, pend);
+  bool ok = hip_ok(hipSetDevice(inst_->device), "hipSetDevice", err);
   for (auto& c : chains_)
-    if (!flush_shadows(*c, err)) return false;
+    if (ok && !flush_shadows(*c, err)) ok = false;
   for (auto& c : chains_)
-    if (!hip_ok(hipStreamSynchronize(c->stream), "wait_idle", err)) return false;
-  return true;
+    if (ok && !hip_ok(hipStreamSynchronize(c->stream), "wait_idle", err)) ok = false;
+  if (!peers_.empty()) {
+    Error pe;
+    if (!join_all(pend, pe) && ok) {
+      err = pe;
+      ok = false;
+    }
+  }
+  return ok;
 }
 
 bool Renderer::restart() {
   request_new_frame_ = true;
+  for (auto& p : peers_) p->r->restart();
   return true;
 }
 
-bool Renderer::step(uint32_t n, Error& err) {
+bool Renderer::step_local(uint32_t n, Error& err) {
   if (!hip_ok(hipSetDevice(inst_->device), "hipSetDevice", err)) return false;
   for (uint32_t i = 0; i < n; ++i)
     if (!one_launch(err)) return false;
   return true;
 }
 
+// Every device enqueues the same n launches (same seed stream, same jitter sequence) for its own tiles; the peers' host
+// threads work while this thread enqueues the local share.
+bool Renderer::step(uint32_t n, Error& err) {
+  if (peers_.empty()) return step_local(n, err);
+  Pending pend;
+  post_all([=](Peer& p, Error& e) { return p.r->step_local(n, e); }, pend);
+  bool ok = step_local(n, err);
+  Error pe;
+  if (!join_all(pend, pe) && ok) {
+    err = pe;
+    ok = false;
+  }
+  return ok;
+}
+
 // draw (raytracer.rs:615-687)
 bool Renderer::draw(size_t spp, void (*cb)(void*), void* user, uint8_t* rgba8_out, Error& err) {
   if (!hip_ok(hipSetDevice(inst_->device), "hipSetDevice", err)) return false;
-  request_new_frame_ = true;
+  restart();
   const size_t steps = steps_per_sample();
   const size_t substep = spp * steps;
-  for (size_t i = 0; i < substep; ++i) {
-    if (!one_launch(err)) return false;
-    if (cb && i % steps == 0) cb(user);   // raytracer.rs:651-653
+  if (peers_.empty()) {
+    for (size_t i = 0; i < substep; ++i) {
+      if (!one_launch(err)) return false;
+      if (cb && i % steps == 0) cb(user);   // raytracer.rs:651-653
+    }
+  } else {
+    for (size_t sample = 0; sample < spp; ++sample) {   // one batch of launches per sample on every device, then the callback on this thread
+      if (!step((uint32_t)steps, err)) return false;
+      if (cb) cb(user);
+    }
   }
   if (spp == 0 && request_new_frame_ && !reset_buffers(err)) return false;
   if (!wait_idle(err)) return false;
@@ -442,16 +660,61 @@ bool Renderer::draw(size_t spp, void (*cb)(void*), void* user, uint8_t* rgba8_ou
 
 // every chain scatters its tiles into the full-frame buffer `dst` (the first one clears it); all on the first chain's
 // stream after the chains have drained
-bool Renderer::gather(bool result, float4* dst, Error& err) {
+bool Renderer::gather(bool result, float4* dst, Error& err, bool zero_first) {
   if (request_new_frame_ && !reset_buffers(err)) return false;
   if (!wait_idle(err)) return false;
   hipStream_t st = chains_[0]->stream;
-  bool first = true;
+  bool first = zero_first;
   for (auto& c : chains_) {
     if (!hip_ok(launch_export(st, c->map, result ? c->result.ptr : c->cumulative.ptr, dst, first), "k_export", err)) return false;
     first = false;
   }
+  if (!peers_.empty() && !reduce_peers(result, dst, err)) return false;
   return true;
+}
+
+// The frames of the other GPUs meet this device's in `dst`: one ncclReduce(sum, float) of W*H*4 floats per device onto rank 0
+// (the tiles are disjoint and zero elsewhere, so the sum is bit-identical to a one-GPU render), issued for every
+// communicator inside one ncclGroup from this thread.  Loop-back mode (every "device" is this one; tests): RCCL cannot
+// put two ranks on one GPU, and there is nothing to move -- the peers scatter their tiles straight into `dst`.
+bool Renderer::reduce_peers(bool result, float4* dst, Error& err) {
+  hipStream_t st = chains_[0]->stream;
+  if (!hip_ok(hipStreamSynchronize(st), "reduce: local frame", err)) return false;
+  const bool lb = loopback_;
+  if (!forward([=](Peer& p, Error& e) {
+        if (!hip_ok(hipSetDevice(p.inst->device), "hipSetDevice", e)) return false;
+        if (!p.r->gather(result, lb ? dst : p.frame.ptr, e, !lb)) return false;
+        return hip_ok(hipStreamSynchronize(p.inst->stream), "reduce: peer frame", e);
+      }, err))
+    return false;
+  if (!hip_ok(hipSetDevice(inst_->device), "hipSetDevice", err)) return false;
+  if (lb) return true;
+  std::string why;
+  const Rccl* nc = Rccl::get(why);
+  if (!nc || comms_.size() != peers_.size() + 1) {
+    err.code = GLZ_E_DEVICE;
+    err.msg = nc ? "RCCL communicators are missing" : why;
+    return false;
+  }
+  const size_t count = (size_t)w_ * h_ * 4;
+  auto ck = [&](ncclResult_t r, const char* what) {
+    if (r == ncclSuccess) return true;
+    err.code = GLZ_E_DEVICE;
+    err.msg = std::string(what) + ": " + nc->GetErrorString(r);
+    return false;
+  };
+  if (!ck(nc->GroupStart(), "ncclGroupStart")) return false;
+  bool ok = ck(nc->Reduce(dst, dst, count, ncclFloat, ncclSum, 0, static_cast<ncclComm_t>(comms_[0]), st), "ncclReduce");   // in place on the root
+  for (size_t i = 0; ok && i < peers_.size(); ++i)
+    ok = ck(nc->Reduce(peers_[i]->frame.ptr, nullptr, count, ncclFloat, ncclSum, 0, static_cast<ncclComm_t>(comms_[i + 1]), peers_[i]->inst->stream), "ncclReduce");
+  const bool ended = ck(nc->GroupEnd(), "ncclGroupEnd");
+  if (!ok || !ended) return false;
+  for (auto& p : peers_) {
+    if (!hip_ok(hipSetDevice(p->inst->device), "hipSetDevice", err)) return false;
+    if (!hip_ok(hipStreamSynchronize(p->inst->stream), "ncclReduce (peer)", err)) return false;
+  }
+  if (!hip_ok(hipSetDevice(inst_->device), "hipSetDevice", err)) return false;
+  return hip_ok(hipStreamSynchronize(st), "ncclReduce (root)", err);
 }
 
 bool Renderer::read_frame(bool result, float* out, Error& err) {
@@ -475,6 +738,7 @@ bool Renderer::read_rgba8(uint8_t* out, Error& err) {
 bool Renderer::set_seed(uint64_t s) {
   seed_ = s;
   request_new_frame_ = true;
+  for (auto& p : peers_) p->r->set_seed(s);
   return true;
 }
 
@@ -486,19 +750,134 @@ bool Renderer::set_depth(uint32_t d, Error& err) {
   }
   pt_steps_ = d;
   request_new_frame_ = true;
+  for (auto& p : peers_)
+    if (!p->r->set_depth(d, err)) return false;
   return true;
 }
 
 bool Renderer::set_partition(uint32_t rank, uint32_t world, Error& err) {
+  if (!peers_.empty()) {
+    err.code = GLZ_E_ARG;
+    err.msg = "a renderer that spans several devices (set_devices) cannot also be one rank of a process partition";
+    return false;
+  }
+  return set_partition_local(rank, world, err);
+}
+
+bool Renderer::set_partition_local(uint32_t rank, uint32_t world, Error& err) {
   if (world == 0 || rank >= world) {
     err.code = GLZ_E_ARG;
     err.msg = "bad tile partition";
     return false;
   }
-  if (!wait_idle(err)) return false;
+  if (!hip_ok(hipSetDevice(inst_->device), "hipSetDevice", err)) return false;
+  for (auto& c : chains_) {
+    if (!flush_shadows(*c, err)) return false;
+    if (!hip_ok(hipStreamSynchronize(c->stream), "set_partition", err)) return false;
+  }
   rank_ = rank;
   world_ = world;
   return allocate(err);
+}
+
+// what a freshly created peer renderer takes over from this one
+bool Renderer::configure_peer(Renderer& p, Error& err) const {
+  p.integrator_ = integrator_;
+  p.pt_steps_ = pt_steps_;
+  p.seed_ = seed_;
+  p.exposure_ = exposure_;
+  p.camera_ = camera_;
+  p.cam_ = cam_;
+  p.chains_wanted_ = chains_wanted_;
+  p.counting_ = counting_;
+  p.profile_kernels_ = profile_kernels_;
+  p.request_new_frame_ = true;
+  (void)err;
+  return true;
+}
+
+bool Renderer::set_devices(const int* devices, int n, Error& err) {
+  auto bad = [&](const char* m) {
+    err.code = GLZ_E_ARG;
+    err.msg = m;
+    return false;
+  };
+  if (!devices || n < 1 || n > 64) return bad("set_devices: between 1 and 64 devices");
+  if (devices[0] != inst_->device) return bad("set_devices: the first device must be the renderer's own (glz_instance_device)");
+  if (world_ != 1 && peers_.empty()) return bad("set_devices: this renderer is one rank of a process partition (set_partition)");
+  bool all_same = true, any_same = false;
+  for (int i = 0; i < n; ++i) {
+    if (devices[i] != devices[0]) all_same = false;
+    for (int j = 0; j < i; ++j) any_same |= devices[i] == devices[j];
+  }
+  const bool loopback = n > 1 && all_same && getenv("GLAZE_MULTI_LOOPBACK") != nullptr;
+  if (any_same && !loopback) return bad("set_devices: a device is listed twice (GLAZE_MULTI_LOOPBACK=1 allows n copies of ONE device, for tests)");
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess) count = 0;
+  for (int i = 0; i < n; ++i)
+    if (devices[i] < 0 || devices[i] >= count) return bad("set_devices: HIP device ordinal out of range");
+  if (!wait_idle(err)) return false;
+  release_peers();
+  if (n == 1) return set_partition_local(0, 1, err);
+  // RCCL first: without it nothing else needs to be built
+  const Rccl* nc = nullptr;
+  if (!loopback) {
+    std::string why;
+    nc = Rccl::get(why);
+    if (!nc) {
+      err.code = GLZ_E_DEVICE;
+      err.msg = why;
+      return false;
+    }
+  }
+  for (int i = 1; i < n; ++i) peers_.emplace_back(new Peer());
+  loopback_ = loopback;
+  // instance + scene replica (upload, BVH build) + renderer for the tiles t % n == i, on every peer's own thread
+  const Renderer* self = this;
+  const Scene* src = scene_.get();
+  const Instance* my_inst = inst_;
+  const uint32_t w = w_, h = h_, world = (uint32_t)n;
+  std::vector<Peer*> order;
+  for (auto& p : peers_) order.push_back(p.get());
+  const std::vector<Peer*>* ord = &order;
+  const bool built = forward([=](Peer& p, Error& e) {
+    size_t i = 0;
+    while ((*ord)[i] != &p) ++i;
+    p.inst.reset(Instance::create(devices[i + 1], e));
+    if (!p.inst) return false;
+    p.inst->bvh_builder = my_inst->bvh_builder;
+    p.inst->bvh_pair_area_ratio = my_inst->bvh_pair_area_ratio;
+    SceneData copy = src->data;
+    std::shared_ptr<Scene> replica(Scene::create(p.inst.get(), std::move(copy), e));
+    if (!replica) return false;
+    p.r.reset(Renderer::create(p.inst.get(), replica, w, h, e));
+    if (!p.r || !self->configure_peer(*p.r, e)) return false;
+    if (!p.r->set_partition_local((uint32_t)i + 1, world, e)) return false;
+    return loopback || hip_ok(p.frame.alloc((size_t)w * h), "alloc peer frame", e);
+  }, err);
+  if (!built) {
+    release_peers();
+    Error ignored;
+    (void)set_partition_local(0, 1, ignored);
+    return false;
+  }
+  if (!set_partition_local(0, world, err)) return false;
+  if (!loopback) {
+    std::vector<ncclComm_t> comms((size_t)n, nullptr);
+    const ncclResult_t r = nc->CommInitAll(comms.data(), n, devices);
+    if (r != ncclSuccess) {
+      err.code = GLZ_E_DEVICE;
+      err.msg = std::string("ncclCommInitAll: ") + nc->GetErrorString(r);
+      release_peers();
+      Error ignored;
+      (void)set_partition_local(0, 1, ignored);
+      return false;
+    }
+    for (ncclComm_t c : comms) comms_.push_back(c);
+    (void)hipSetDevice(inst_->device);
+  }
+  request_new_frame_ = true;
+  return true;
 }
 
 bool Renderer::set_chains(uint32_t n, Error& err) {
@@ -509,7 +888,10 @@ bool Renderer::set_chains(uint32_t n, Error& err) {
   }
   if (!wait_idle(err)) return false;
   chains_wanted_ = n;
-  return allocate(err);
+  if (!allocate(err)) return false;
+  const bool ok = forward([=](Peer& p, Error& e) { return p.r->set_chains(n, e); }, err);
+  (void)hipSetDevice(inst_->device);
+  return ok;
 }
 
 bool Renderer::export_device(int which, void* dev, Error& err) {

@@ -34,6 +34,12 @@ class Renderer {
   bool set_seed(uint64_t s);
   bool set_depth(uint32_t d, Error& err);
   bool set_partition(uint32_t rank, uint32_t world, Error& err);
+  // Several GPUs inside ONE process: devices[0] must be this renderer's own device; every further entry
+  // gets its own stream, a replica of the scene, a renderer for the tiles t % n == i and a host thread that enqueues its
+  // launches.  Reads sum the zero-padded RGBA32F frames onto devices[0] with one ncclReduce (RCCL over xGMI; one
+  // communicator per device from ncclCommInitAll).  n == 1 returns to a single device.
+  bool set_devices(const int* devices, int n, Error& err);
+  uint32_t device_count() const { return 1u + (uint32_t)peers_.size(); }
   bool set_chains(uint32_t n, Error& err);   // 0 = automatic
   uint32_t chains() const { return (uint32_t)chains_.size(); }
   static uint32_t chains_for(uint32_t w, uint32_t h, uint32_t rank, uint32_t world, uint32_t wanted);
@@ -41,7 +47,7 @@ class Renderer {
   bool tonemap_device(const void* dev_result, uint8_t* out, Error& err);
   bool launch_constants(uint32_t launch, uint32_t* seed, float off[2]);
   void push_constants(float out[32]) const;
-  void enable_counters(int flags) { counting_ = (flags & 1) != 0; profile_kernels_ = (flags & 2) != 0; }
+  void enable_counters(int flags);
   bool get_stats(glz_render_stats* out, Error& err);
 
   Instance* instance() const { return inst_; }
@@ -54,7 +60,7 @@ class Renderer {
   bool allocate(Error& err);
   bool reset_buffers(Error& err);
   bool one_launch(Error& err);
-  bool gather(bool result, float4* dst, Error& err);
+  bool gather(bool result, float4* dst, Error& err, bool zero_first = true);
 
   Instance* inst_ = nullptr;
   std::shared_ptr<Scene> scene_;   // shared with the glz_scene handle it came from (info / debug hooks stay valid)
@@ -103,6 +109,21 @@ class Renderer {
   bool acquire_events(Chain& c, EventSet& ev, Error& err);
   void resolve_events(Chain& c);
   void fill_args(const Chain& c, LaunchArgs& a) const;
+
+  // ---- other GPUs of this process (set_devices) ----
+  struct Peer;
+  struct Pending;
+  std::vector<std::unique_ptr<Peer>> peers_;
+  std::vector<void*> comms_;   // ncclComm_t per device (index 0 = this renderer); empty in loop-back mode
+  bool loopback_ = false;      // all "devices" are this one device (GLAZE_MULTI_LOOPBACK=1, tests on a one-GPU box): no RCCL
+  template <class F> void post_all(F f, Pending& p);
+  bool join_all(Pending& p, Error& err);
+  template <class F> bool forward(F f, Error& err);
+  void release_peers();
+  bool set_partition_local(uint32_t rank, uint32_t world, Error& err);
+  bool configure_peer(Renderer& p, Error& err) const;
+  bool reduce_peers(bool result, float4* dst, Error& err);
+  bool step_local(uint32_t n, Error& err);
 
   DeviceBuffer<float4> frame_tmp_;
   DeviceBuffer<uchar4> rgba8_;

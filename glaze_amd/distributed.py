@@ -26,13 +26,14 @@ def chain_owner(width, height, rank, world, chains=0):
     return n, out
 
 
-def reduce_frame(frame, dst=0, group=None):
+def reduce_frame(frame, dst=0, group=None, force=False):
     """Sum-reduces a full-frame RGBA32F torch tensor (zero outside the caller's tiles) onto `dst`.
 
     With backend "nccl" this is one ncclReduce(sum, float) of W*H*4 floats over xGMI (33 MB at 1080p);
-    with "gloo" (CPU tests) the same call runs on host tensors.
+    with "gloo" (CPU tests) the same call runs on host tensors.  A one-rank group has nothing to exchange and is skipped
+    unless `force` asks for the collective anyway (the GPU test that runs RCCL on a one-GPU box).
     """
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized() and (force or dist.get_world_size(group) > 1):
         dist.reduce(frame, dst=dst, op=dist.ReduceOp.SUM, group=group)
     return frame

@@ -345,6 +345,17 @@ int glz_renderer_set_partition(glz_renderer*, uint32_t rank, uint32_t world);
  * one chain while the rank owns a million pixels, two down to 400 k, three below).  Pixels never interact, so the image does not depend on n; with a small
  * tile share per GPU the chains fill the machine while the longest rays of a launch finish. */
 int glz_renderer_set_chains(glz_renderer*, uint32_t n);
+/* Multi-GPU inside ONE process (what a Rust glaze-cli bound to this library uses for `--devices`; the reference drives exactly one
+ * VkPhysicalDevice, lib/src/vulkan/device.rs:252-321): hip_devices[0] must be the renderer's own device (glz_instance_device);
+ * every further device gets a stream, a replica of the scene (upload + BVH build on that device), a renderer for the 64x64 tiles
+ * t % n == i and a host thread that enqueues its launches.  All setters, step / draw and scene updates apply to every device;
+ * every read-back (read_hdr / read_result / read_rgba8 / draw's image / export_device) first sums the zero-padded RGBA32F
+ * frames onto hip_devices[0] with one ncclReduce(sum, float) per device (one communicator per device from ncclCommInitAll,
+ * RCCL over xGMI).  The tiles are disjoint, so the image is bit-identical to a one-device render.  n = 1 returns to one
+ * device.  Not combinable with glz_renderer_set_partition (one process per GPU).  RCCL is loaded on first use
+ * (librccl.so.1); GLZ_E_DEVICE when it is missing.  With GLAZE_MULTI_LOOPBACK=1 in the environment the list may name ONE
+ * device n times (tests on a one-GPU machine: same sharding, threads and replicas, the tiles meet without RCCL). */
+int glz_renderer_set_devices(glz_renderer*, const int* hip_devices, int n);
 int glz_renderer_export_device(glz_renderer*, int which, void* dev_rgba32f);
 /* Tonemaps a full-frame DEVICE result image (e.g. the reduced one on rank 0) to RGBA8 sRGB host memory. */
 int glz_renderer_tonemap_device(glz_renderer*, const void* dev_result_rgba32f, uint8_t* rgba8_out);
@@ -385,6 +396,11 @@ int64_t glz_debug_read_bvh(glz_scene*, void* nodes_out, int64_t cap_nodes, void*
 
 /* k_tonemap (the out32 -> RGBA8 sRGB blit, raytracer.rs:576-584) on n host pixels of RGBA32F: upload, kernel, read back */
 int glz_debug_tonemap(glz_instance*, const float* rgba32f, uint64_t n_pixels, uint8_t* rgba8_out);
+
+/* First contact with RCCL on this machine: a one-rank communicator on the instance's device (ncclCommInitAll), one
+ * ncclReduce(sum, float) of n_floats values on the instance's stream, result compared bit for bit with the input, communicator
+ * destroyed.  version_out (may be NULL) receives ncclGetVersion(). */
+int glz_debug_rccl_selftest(glz_instance*, uint64_t n_floats, int* version_out);
 
 /* ---- host logic, callable without a device (used by the CPU test-suite and by bindings) ------ */
 /* seed + pixel offset of launch `launch` after a restart, for renderer seed `seed`
