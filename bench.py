@@ -7,7 +7,8 @@
 
 Workload (BASELINE.json configs[3]): the Sponza-class frame, 1920x1080, path tracer, depth 8.  Sponza
 itself is not in the reference repository, so the scene is the deterministic synthetic
-atrium of glaze_amd/scenes.py (262 140 triangles, 25 materials, sun + sky).  Inputs (scene, BVH,
+atrium of glaze_amd/scenes.py (262 140 triangles, 25 materials, sun + sky), written as a `.glaze` V1 file
+(glz_serialize) and loaded the way glaze-cli loads a scene: parse -> RayTraceScene::new.  Inputs (scene, BVH,
 path state) are resident in HBM before the timed region starts.
 
 A "step" is ONE launch of the hot path = one path segment for every pixel of the frame
@@ -16,7 +17,12 @@ same accumulation (draw_frame semantics), K steps = K/depth samples per pixel.
 
 N > 1: the frame's 64x64 tiles are sharded over the ranks (tile t -> rank t % N); after the K steps
 the float HDR accumulator is sum-reduced to rank 0 over RCCL (inside the timed region).  Total work is
-fixed -> "scaling": "strong".
+fixed -> "scaling": "strong".  Rank 0 then checks the reduced frame bit for bit against the frame it renders alone
+(--no-verify skips it).
+
+The timed region is EXACTLY K steps between barrier + synchronize pairs, MAX over ranks.  A region shorter than 0.5 s is
+repeated (five regions in all, the accumulation simply continues) and `value` comes from the MEDIAN region; every
+region's time is listed under "regions_ms".
 """
 import argparse
 import json
@@ -42,7 +48,10 @@ def parse_args():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-launches", type=int, default=16, help="launches of the bounded CPU-baseline sample")
-    ap.add_argument("--verify", action="store_true", help="N > 1: rank 0 re-renders the whole frame alone and compares it bit for bit")
+    ap.add_argument("--verify", dest="verify", action="store_true", default=True,
+                    help="N > 1: rank 0 re-renders the whole frame alone and compares it bit for bit (default)")
+    ap.add_argument("--no-verify", dest="verify", action="store_false")
+    ap.add_argument("--repeats", type=int, default=0, help="timed regions of K steps each (0 = five when a region is shorter than 0.5 s, else one)")
     return ap.parse_args()
 
 
@@ -99,10 +108,19 @@ def main():
         raise SystemExit("no gfx950 device for rank %d: %s" % (rank, glaze_amd.abi.last_error()))
     W, H = args.width, args.height
     desc = atrium_scene()
-    t0 = time.time()
-    scene = glaze_amd.RayTraceScene.from_desc(inst, desc)
+    # the scene goes through the file format end to end: Serializer -> .glaze V1 -> parse -> RayTraceScene::new (cli/src/main.rs:78-91)
+    import tempfile
+    from glaze_amd.scene_desc import save_scene
+    with tempfile.TemporaryDirectory(prefix="glaze_bench_") as tmp:
+        path = os.path.join(tmp, "atrium_rank%d.glaze" % rank)
+        t0 = time.time()
+        save_scene(desc, path)
+        serialize_s = time.time() - t0
+        glaze_bytes = os.path.getsize(path)
+        t0 = time.time()
+        scene = glaze_amd.RayTraceScene.new(inst, glaze_amd.parse(path))
+        setup_s = time.time() - t0
     info = scene.info()
-    setup_s = time.time() - t0
     renderer = glaze_amd.RayTraceRenderer.new(inst, scene, W, H)
     renderer.set_depth(args.depth)
     renderer.set_seed(args.seed)
@@ -136,62 +154,78 @@ def main():
     renderer.stats()            # drains the warmup's kernel events
     s0 = renderer.stats()
 
-    # ---- timed region: exactly K steps ----
-    sync_all()
-    t_start = time.perf_counter()
-    renderer.step(args.steps)
-    if world > 1:
-        reduce_to_rank0()
-    sync_all()
-    elapsed = time.perf_counter() - t_start
-    s1 = renderer.stats()
+    # ---- timed regions: exactly K steps each, barrier + synchronize on both sides, MAX over ranks ----
+    def timed_region():
+        sync_all()
+        t_start = time.perf_counter()
+        renderer.step(args.steps)
+        if world > 1:
+            reduce_to_rank0()
+        sync_all()
+        t = torch.tensor([time.perf_counter() - t_start], dtype=torch.float64, device="cpu" if rehearsal or world == 1 else "cuda")
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
-    t_all = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
-    if world > 1:
-        dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
-    elapsed = float(t_all.item())
-    samples = W * H * args.steps                     # whole frame, all ranks together
+    regions = [timed_region()]
+    # every rank sees the same (max-reduced) first time, so all of them take the same number of regions
+    n_regions = args.repeats if args.repeats > 0 else (5 if regions[0] < 0.5 else 1)
+    while len(regions) < n_regions:
+        regions.append(timed_region())
+    s1 = renderer.stats()
+    elapsed = sorted(regions)[len(regions) // 2]      # median region
+    total_steps = args.steps * len(regions)
+    samples = W * H * args.steps                     # whole frame, all ranks together, per region
     value = samples / elapsed / 1e6
 
-    # per-kernel device time inside the timed region (hipEvents on the instance stream)
-    # (trace_shadow_ms is the stand-alone shadow pass that closes the timed region: one launch's worth, inside `elapsed`)
+    # per-kernel device time inside the timed regions (hipEvents on the instance stream), all regions together
+    # (trace_shadow_ms is the stand-alone shadow pass that closes a region: one launch's worth, inside its time)
     kern_ms = {"k_trace": s1.trace_closest_ms - s0.trace_closest_ms, "k_shade": s1.shade_ms - s0.shade_ms}
 
     out = None
     if rank == 0:
-        # counted per-sample work of the same workload (separate, untimed pass with instrumented kernels)
+        # counted per-sample work of the same workload: a separate, untimed pass with the instrumented kernels over the SAME
+        # launch indices as the timed window (launches [warmup, warmup + K * regions) after a restart -- the mix of path ages,
+        # and with it the work per sample, depends on the launch index), capped at 1024 launches
         renderer.enable_counters(True, True)
         renderer.restart()
-        n_count = max(args.depth * 2, 16)
+        renderer.step(args.warmup)
+        renderer.wait_idle()
+        sa = renderer.stats()
+        n_count = min(total_steps, 1024)
         renderer.step(n_count)
         renderer.wait_idle()
         sc = renderer.stats()
         renderer.enable_counters(False, True)
-        rays = max(1, sc.closest_rays)
+        rays = max(1, sc.closest_rays - sa.closest_rays)
         counted = {
-            "nodes_closest": sc.closest_nodes / rays, "tris_closest": sc.closest_tris / rays,
-            "nodes_shadow": sc.shadow_nodes / rays, "tris_shadow": sc.shadow_tris / rays,
-            "f_hit": sc.hits / rays, "f_shadow": sc.shadow_rays / rays,
-            "f_fresh": sc.fresh_paths / rays,
+            "nodes_closest": (sc.closest_nodes - sa.closest_nodes) / rays, "tris_closest": (sc.closest_tris - sa.closest_tris) / rays,
+            "nodes_shadow": (sc.shadow_nodes - sa.shadow_nodes) / rays, "tris_shadow": (sc.shadow_tris - sa.shadow_tris) / rays,
+            "f_hit": (sc.hits - sa.hits) / rays, "f_shadow": (sc.shadow_rays - sa.shadow_rays) / rays,
+            "f_fresh": (sc.fresh_paths - sa.fresh_paths) / rays,
         }
         bytes_per_sample = algorithmic_bytes(counted)
         dominant = max(kern_ms, key=kern_ms.get)
         owned = W * H / world
-        avg_ms = kern_ms[dominant] / args.steps
+        avg_ms = kern_ms[dominant] / total_steps
         achieved = bytes_per_sample[dominant] * owned / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic = None
+        # HBM traffic is NOT measured in this run (PMC counters need rocprofv3): the number is the per-launch average of the
+        # committed rocprofv3 --pmc passes of this very command (tools/profile_gpu.sh -> profiles/pmc_summary.json)
+        traffic, traffic_source = None, None
         prof = os.path.join(ROOT, "profiles", "pmc_summary.json")
         if os.path.exists(prof) and world == 1:      # the committed PMC passes profiled the N = 1 command
             try:
                 traffic = json.load(open(prof)).get(dominant, {}).get("hbm_bytes_per_launch")
+                traffic_source = "profiles/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `python bench.py`, not this run)"
             except Exception:
                 traffic = None
         roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
-                    "frac": round(achieved / 8000.0, 4), "traffic": traffic,
+                    "frac": round(achieved / 8000.0, 4), "traffic": traffic, "traffic_source": traffic_source,
                     "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_sample": {k: round(v, 1) for k, v in bytes_per_sample.items()},
                     "whole_job_achieved": round(sum(bytes_per_sample.values()) * samples / elapsed / 1e9, 1),
                     "counted_per_sample": {k: round(v, 3) for k, v in counted.items()},
-                    "kernel_ms_per_step": {k: round(v / args.steps, 4) for k, v in kern_ms.items()}}
+                    "counted_over_launches": [args.warmup, args.warmup + n_count],
+                    "kernel_ms_per_step": {k: round(v / total_steps, 4) for k, v in kern_ms.items()}}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             # CPU baseline: the oracle (scalar C++ restatement; the reference has no CPU tracer) on a
@@ -220,34 +254,42 @@ def main():
             "metric": "Msamples/s + achieved HBM GB/s, Sponza 1080p, 1/2/4/8xMI355X",
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
+            "regions_ms": [round(t * 1e3, 3) for t in regions],
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "Sponza-class synthetic atrium (262140 tris) %dx%d, path tracer depth %d, %d steps = %.1f spp"
-                                   % (W, H, args.depth, args.steps, args.steps / args.depth),
+            "config": {"workload": "Sponza-class synthetic atrium (%d tris) as a .glaze V1 file (%d bytes) through parse, %dx%d, path tracer depth %d, %d steps = %.1f spp"
+                                   % (int(info.n_world_triangles), glaze_bytes, W, H, args.depth, args.steps, args.steps / args.depth),
                        "width": W, "height": H, "depth": args.depth, "triangles": int(info.n_world_triangles),
                        "sharding": "64x64 tiles round-robin over %d rank(s), %s reduce of the RGBA32F accumulator" % (world, "gloo (rehearsal on one GPU)" if rehearsal else "RCCL"),
                        "bvh": {"builder": "binned SAH on the GPU, leaves of 1-2 triangles, 4-wide quantised nodes", "nodes": int(info.bvh_nodes),
                                "depth": int(info.bvh_depth), "sah_cost": round(float(info.bvh_sah_cost), 2), "build_ms": round(float(info.build_ms), 3)},
-                       "setup_s": round(setup_s, 3)},
+                       "setup_s": round(setup_s, 3), "serialize_s": round(serialize_s, 3)},
             "roofline": roofline, "cpu_baseline": cpu,
             "mpaths_per_s": round(value / args.depth, 2),
             "grays_per_s": round(value * (1 + counted["f_shadow"]) / 1e3, 3),
         }
+    failure = None
     if world > 1 and args.verify and rank == 0:
-        # the reduced frame against the whole frame rendered by this rank alone, same seed and launch count
-        reduced = frame.cpu().numpy().copy()
-        renderer.set_partition(0, 1)
-        renderer.restart()
-        renderer.step(args.warmup + args.steps)
-        alone = renderer.read_hdr()
-        same = bool(np.array_equal(np.nan_to_num(reduced, nan=-1.0).view(np.uint32), np.nan_to_num(alone, nan=-1.0).view(np.uint32)))
-        out["verify"] = {"bit_identical_to_one_gpu": same, "launches": args.warmup + args.steps}
-        if not same:
-            raise SystemExit("multi-GPU frame differs from the single-GPU frame")
+        # the reduced frame against the whole frame rendered by this rank alone, same seed and launch count; a failure
+        # (or an exception) is only recorded here: every rank must still reach the barrier below, or the others hang in it
+        try:
+            reduced = frame.cpu().numpy().copy()
+            renderer.set_partition(0, 1)
+            renderer.restart()
+            renderer.step(args.warmup + total_steps)
+            alone = renderer.read_hdr()
+            same = bool(np.array_equal(np.nan_to_num(reduced, nan=-1.0).view(np.uint32), np.nan_to_num(alone, nan=-1.0).view(np.uint32)))
+            out["verify"] = {"bit_identical_to_one_gpu": same, "launches": args.warmup + total_steps}
+            if not same:
+                failure = "multi-GPU frame differs from the single-GPU frame"
+        except Exception as ex:     # noqa: BLE001 -- reported after the collective teardown
+            failure = "verify failed: %r" % (ex,)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if out is not None:
         print(json.dumps(out))
+    if failure:
+        raise SystemExit(failure)
 
 
 if __name__ == "__main__":
