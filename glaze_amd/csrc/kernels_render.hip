@@ -587,14 +587,14 @@ __global__ void __launch_bounds__(kBlock, GLZ_SHADE_WAVES) k_shade(const LaunchA
   // sky sample walks are staged in LDS once per block: the sRGB decode LUT (12 lookups per bilinear fetch) and the sky marginal CDF (an 11-step dependent search).
   __shared__ float s_lut[256];
   __shared__ float s_sky[kSkyLdsFloats];
-  __shared__ uint32_t s_bin[64];
+  __shared__ uint32_t s_bin[4 * 64];   // [wave][key] counts, then start offsets
   __shared__ uint16_t s_perm[kBlock];
   const uint32_t n_sky = 3u * (A.scene.sky_header.marginal_cdf_count - 1u) + 1u;
   const bool sky_in_lds = A.scene.sky_header.marginal_cdf_count > 1u && n_sky <= kSkyLdsFloats;
   s_lut[threadIdx.x] = A.scene.srgb_lut[threadIdx.x];
   if (sky_in_lds)
     for (uint32_t i = threadIdx.x; i < n_sky; i += kBlock) s_sky[i] = A.scene.sky_marginal[i];
-  if (threadIdx.x < 64) s_bin[threadIdx.x] = 0;
+  s_bin[threadIdx.x] = 0;
   __syncthreads();
   DeviceScene S = A.scene;
   S.srgb_lut = s_lut;
@@ -625,20 +625,42 @@ __global__ void __launch_bounds__(kBlock, GLZ_SHADE_WAVES) k_shade(const LaunchA
       }
     }
   }
-  const uint32_t rank = atomicAdd(&s_bin[key], 1u);
+  // Counting sort without same-address atomics (256 atomicAdds on a handful of LDS words serialise: SQ_LDS_BANK_CONFLICT was
+  // twice the LDS-active cycles of this kernel): every wave peels off its distinct keys with ballots -- a thread's rank among
+  // the wave's threads with the same key is a popcount -- and leaves one count per (wave, key); 64 threads then turn the
+  // counts into start offsets, key-major, wave-minor.
+  uint32_t rank = 0;
+  {
+    const uint32_t wv = threadIdx.x >> 6, ln = threadIdx.x & 63u;
+    unsigned long long todo = __ballot(true);
+    while (todo != 0ull) {
+      const uint32_t k = (uint32_t)__shfl((int)key, __ffsll((long long)todo) - 1);
+      const unsigned long long m = __ballot(key == k);
+      if (key == k) {
+        rank = (uint32_t)__popcll(m & ((1ull << ln) - 1ull));
+        if (rank == 0u) s_bin[wv * 64u + k] = (uint32_t)__popcll(m);
+      }
+      todo &= ~m;
+    }
+  }
   __syncthreads();
-  if (threadIdx.x < 64) {   // exclusive prefix sum of the 64 bucket sizes
-    const uint32_t cnt = s_bin[threadIdx.x];
+  if (threadIdx.x < 64) {   // exclusive prefix sum over the 64 keys of the per-key totals, then the per-wave starts inside a key
+    const uint32_t c0 = s_bin[threadIdx.x], c1 = s_bin[64 + threadIdx.x], c2 = s_bin[128 + threadIdx.x], c3 = s_bin[192 + threadIdx.x];
+    const uint32_t cnt = (c0 + c1) + (c2 + c3);
     uint32_t incl = cnt;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
       const uint32_t up = __shfl_up(incl, off);
       if ((int)threadIdx.x >= off) incl += up;
     }
-    s_bin[threadIdx.x] = incl - cnt;
+    const uint32_t base = incl - cnt;
+    s_bin[threadIdx.x] = base;
+    s_bin[64 + threadIdx.x] = base + c0;
+    s_bin[128 + threadIdx.x] = base + c0 + c1;
+    s_bin[192 + threadIdx.x] = base + c0 + c1 + c2;
   }
   __syncthreads();
-  s_perm[s_bin[key] + rank] = (uint16_t)threadIdx.x;
+  s_perm[s_bin[(threadIdx.x >> 6) * 64u + key] + rank] = (uint16_t)threadIdx.x;
   __syncthreads();
   const uint32_t lid = blockIdx.x * kBlock + s_perm[threadIdx.x];
 #else

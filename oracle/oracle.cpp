@@ -2028,6 +2028,53 @@ void orc_detmath(int fn, const float* x, const float* y, float* out, uint64_t n)
   }
 }
 uint32_t orc_pcg_hash(uint32_t x) { return pcg_hash(x); }
+// ---- shading routines on their own, for the tests that check this restatement against mathematics (tests/test_oracle_math.py) ----
+// n evaluations of the material's BSDF in the canonical frame (s, t, n) = (x, y, z), so world directions ARE shading-space
+// directions: value (16 bins) and pdf of mat_*_value.rcall for (wo, wi, uv, rand)
+void orc_bsdf_value(void* s, uint32_t material_id, const float* wo3, const float* wi3, const float* uv2, const float* rand1, uint64_t n,
+                    float* value16, float* pdf) {
+  Scene* sc = (Scene*)s;
+  ShadingSpace sh{v3(1, 0, 0), v3(0, 1, 0), v3(0, 0, 1)};
+  for (uint64_t i = 0; i < n; ++i) {
+    BsdfIn in{v3(wo3[3 * i], wo3[3 * i + 1], wo3[3 * i + 2]), v3(wi3[3 * i], wi3[3 * i + 1], wi3[3 * i + 2]), V2{uv2[0], uv2[1]}, sh, material_id};
+    Sp value = sp_uniform(0.0f);
+    pdf[i] = bsdf_value(*sc, in, rand1[i], value);
+    memcpy(value16 + 16 * i, value.w, 64);
+  }
+}
+// n samples of mat_*_sample_value.rcall for (wo, uv, rand3): sampled direction, value (16 bins), pdf
+void orc_bsdf_sample(void* s, uint32_t material_id, const float* wo3, const float* uv2, const float* rand3, uint64_t n, float* wi3, float* value16,
+                     float* pdf) {
+  Scene* sc = (Scene*)s;
+  ShadingSpace sh{v3(1, 0, 0), v3(0, 1, 0), v3(0, 0, 1)};
+  for (uint64_t i = 0; i < n; ++i) {
+    BsdfIn in{v3(wo3[3 * i], wo3[3 * i + 1], wo3[3 * i + 2]), v3(0, 0, 0), V2{uv2[0], uv2[1]}, sh, material_id};
+    Sp value = sp_uniform(0.0f);
+    V3 wi = v3(0, 0, 0);
+    pdf[i] = bsdf_sample(*sc, in, v3(rand3[3 * i], rand3[3 * i + 1], rand3[3 * i + 2]), value, wi);
+    wi3[3 * i] = wi.x; wi3[3 * i + 1] = wi.y; wi3[3 * i + 2] = wi.z;
+    memcpy(value16 + 16 * i, value.w, 64);
+  }
+}
+// n samples of light_*_sample_visible.rcall for RTLight `light_index`: direction, distance, pdf, emission (16 bins)
+void orc_light_sample(void* s, uint32_t light_index, const float* pos3, const float* rand3, uint64_t n, float scene_radius, float* wi3, float* dist,
+                      float* pdf, float* emission16) {
+  Scene* sc = (Scene*)s;
+  for (uint64_t i = 0; i < n; ++i) {
+    SampledLight sam;
+    sam.emission = sp_uniform(0.0f);
+    sam.pdf = 0.0f;
+    sam.wiW = v3(0, 0, 0);
+    sam.distance = 0.0f;
+    light_sample(*sc, light_index, v3(pos3[3 * i], pos3[3 * i + 1], pos3[3 * i + 2]), v3(rand3[3 * i], rand3[3 * i + 1], rand3[3 * i + 2]), scene_radius, sam);
+    wi3[3 * i] = sam.wiW.x; wi3[3 * i + 1] = sam.wiW.y; wi3[3 * i + 2] = sam.wiW.z;
+    dist[i] = sam.distance;
+    pdf[i] = sam.pdf;
+    memcpy(emission16 + 16 * i, sam.emission.w, 64);
+  }
+}
+uint32_t orc_scene_rt_light_count(void* s) { return (uint32_t)((Scene*)s)->rt_lights.size(); }
+
 void orc_rand_stream(uint32_t seed, uint32_t px, uint32_t py, float* out, uint32_t n) {
   uint32_t rng = pcg_hash(fbits((float)seed) ^ pcg_hash(fbits((float)px) ^ pcg_hash(fbits((float)py))));
   for (uint32_t i = 0; i < n; ++i) out[i] = rnd(rng);

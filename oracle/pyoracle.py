@@ -47,6 +47,10 @@ def lib():
             "orc_renderer_read_rgba8": (None, [_P, _P]), "orc_renderer_read_state": (None, [_P, _P]),
             "orc_renderer_push_constants": (None, [_P, _P]),
             "orc_renderer_set_tiles": (None, [_P, _P, C.c_uint32]), "orc_to_srgb8": (C.c_uint8, [C.c_float]),
+            "orc_bsdf_value": (None, [_P, C.c_uint32, _P, _P, _P, _P, C.c_uint64, _P, _P]),
+            "orc_bsdf_sample": (None, [_P, C.c_uint32, _P, _P, _P, C.c_uint64, _P, _P, _P]),
+            "orc_light_sample": (None, [_P, C.c_uint32, _P, _P, C.c_uint64, C.c_float, _P, _P, _P, _P]),
+            "orc_scene_rt_light_count": (C.c_uint32, [_P]),
             "orc_launch_constants": (None, [C.c_uint64, C.c_uint32, _P, _P]),
             "orc_renderer_counters": (None, [_P, _P]),
             "orc_spectrum_from_rgb": (None, [C.c_float, C.c_float, C.c_float, C.c_int, _P]),
@@ -136,6 +140,49 @@ class OracleScene:
         v = np.zeros(n, np.float32)
         lib().orc_trace_closest(self.handle, _ptr(o), _ptr(d), n, tmin, _ptr(t), _ptr(tri), _ptr(inst), _ptr(u), _ptr(v))
         return t, tri, inst, u, v
+
+    # ---- shading routines on their own (tests/test_oracle_math.py); directions are in the canonical shading frame ----
+    def bsdf_value(self, material_id, wo, wi, uv=(0.5, 0.5), rand=None):
+        wo = np.ascontiguousarray(wo, np.float32).reshape(-1, 3)
+        wi = np.ascontiguousarray(wi, np.float32).reshape(-1, 3)
+        n = wo.shape[0]
+        rnd = np.ascontiguousarray(rand if rand is not None else np.zeros(n), np.float32)
+        uvv = np.ascontiguousarray(uv, np.float32)
+        value, pdf = np.zeros((n, 16), np.float32), np.zeros(n, np.float32)
+        lib().orc_bsdf_value(self.handle, material_id, _ptr(wo), _ptr(wi), _ptr(uvv), _ptr(rnd), n, _ptr(value), _ptr(pdf))
+        return value, pdf
+
+    def bsdf_sample(self, material_id, wo, rand3, uv=(0.5, 0.5)):
+        wo = np.ascontiguousarray(wo, np.float32).reshape(-1, 3)
+        r = np.ascontiguousarray(rand3, np.float32).reshape(-1, 3)
+        n = wo.shape[0]
+        uvv = np.ascontiguousarray(uv, np.float32)
+        wi, value, pdf = np.zeros((n, 3), np.float32), np.zeros((n, 16), np.float32), np.zeros(n, np.float32)
+        lib().orc_bsdf_sample(self.handle, material_id, _ptr(wo), _ptr(uvv), _ptr(r), n, _ptr(wi), _ptr(value), _ptr(pdf))
+        return wi, value, pdf
+
+    def light_sample(self, light_index, positions, rand3, scene_radius=1.0):
+        p = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
+        r = np.ascontiguousarray(rand3, np.float32).reshape(-1, 3)
+        n = p.shape[0]
+        wi, dist, pdf, em = np.zeros((n, 3), np.float32), np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros((n, 16), np.float32)
+        lib().orc_light_sample(self.handle, light_index, _ptr(p), _ptr(r), n, scene_radius, _ptr(wi), _ptr(dist), _ptr(pdf), _ptr(em))
+        return wi, dist, pdf, em
+
+    @property
+    def n_rt_lights(self):
+        return lib().orc_scene_rt_light_count(self.handle)
+
+    def sky_cond(self):
+        """(conditional values H x W, conditional cdf H x (W+1)) of the sky distribution"""
+        n = lib().orc_read_sky_cond(self.handle, None, None)
+        hdr = self.sky()
+        h = int(hdr[36:40].view(np.uint32)[0]) - 1
+        w = n // h if h > 0 else 0
+        values, cdf = np.zeros((h, w), np.float32), np.zeros((h, w + 1), np.float32)
+        if n:
+            lib().orc_read_sky_cond(self.handle, _ptr(values), _ptr(cdf))
+        return values, cdf
 
     def trace_any(self, origins, dirs, tmax, tmin=1e-3):
         o = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)
