@@ -164,6 +164,8 @@ struct DeviceScene {
   const float4* shade_tris;
   uint32_t n_world_tris;
   uint32_t n_textures;
+  uint32_t n_materials;            // RTMaterial records
+  uint32_t n_rt_lights;            // RTLight records (area lights expand to one per instance)
   // sky
   RTSky sky;
   SkyHeader sky_header;

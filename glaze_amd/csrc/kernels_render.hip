@@ -576,6 +576,7 @@ __device__ __forceinline__ uint32_t queue_slot(uint32_t* counters, uint32_t n_lo
 // ---------------------------------------------------------------------------------------------
 // k_shade: path_trace.rgen:170-237 minus the two traceRayEXT calls, raytrace_hit.rchit:30-71
 // ---------------------------------------------------------------------------------------------
+constexpr uint32_t kShadeTableBytes = 16384;   // LDS copy of the material / light / texture-descriptor tables (78 materials alone would fill it)
 constexpr uint32_t kSkyLdsFloats = 4096;   // sky marginal tables (3H+1 floats) are staged in LDS when they fit: H <= 1365 rows
 
 #ifndef GLZ_SHADE_WAVES
@@ -587,6 +588,10 @@ __global__ void __launch_bounds__(kBlock, GLZ_SHADE_WAVES) k_shade(const LaunchA
   // sky sample walks are staged in LDS once per block: the sRGB decode LUT (12 lookups per bilinear fetch) and the sky marginal CDF (an 11-step dependent search).
   __shared__ float s_lut[256];
   __shared__ float s_sky[kSkyLdsFloats];
+  // The small scene tables every hit walks through one after the other -- shading record -> RTMaterial -> texture descriptor
+  // -> texels, light pick -> RTLight -- are staged in LDS when they fit: each lookup that stays on chip takes a dependent
+  // memory round trip (1-2 us under load, the kernel's bound) off the hit's critical path.
+  __shared__ uint4 s_tables[kShadeTableBytes / 16];
   __shared__ uint32_t s_bin[4 * 64];   // [wave][key] counts, then start offsets
   __shared__ uint16_t s_perm[kBlock];
   const uint32_t n_sky = 3u * (A.scene.sky_header.marginal_cdf_count - 1u) + 1u;
@@ -595,10 +600,29 @@ __global__ void __launch_bounds__(kBlock, GLZ_SHADE_WAVES) k_shade(const LaunchA
   if (sky_in_lds)
     for (uint32_t i = threadIdx.x; i < n_sky; i += kBlock) s_sky[i] = A.scene.sky_marginal[i];
   s_bin[threadIdx.x] = 0;
+  // [RTMaterial x n_materials | RTLight x n_rt_lights | TexDesc x n_textures] in 16-byte pieces
+  const uint32_t qm = A.scene.n_materials * (uint32_t)(sizeof(RTMaterial) / 16), ql = A.scene.n_rt_lights * (uint32_t)(sizeof(RTLight) / 16),
+                 qt = A.scene.n_textures * (uint32_t)(sizeof(TexDesc) / 16);
+#ifndef GLZ_SHADE_NO_TABLES
+  const bool tables_in_lds = (qm + ql + qt) * 16u <= kShadeTableBytes;   // uniform over the grid
+#else
+  const bool tables_in_lds = false;
+#endif
+  if (tables_in_lds) {
+    const uint4* gm = reinterpret_cast<const uint4*>(A.scene.materials);
+    const uint4* gl = reinterpret_cast<const uint4*>(A.scene.lights);
+    const uint4* gt = reinterpret_cast<const uint4*>(A.scene.tex_desc);
+    for (uint32_t i = threadIdx.x; i < qm + ql + qt; i += kBlock) s_tables[i] = i < qm ? gm[i] : (i < qm + ql ? gl[i - qm] : gt[i - qm - ql]);
+  }
   __syncthreads();
   DeviceScene S = A.scene;
   S.srgb_lut = s_lut;
   if (sky_in_lds) S.sky_marginal = s_sky;
+  if (tables_in_lds) {
+    S.materials = reinterpret_cast<const RTMaterial*>(s_tables);
+    S.lights = reinterpret_cast<const RTLight*>(s_tables + qm);
+    S.tex_desc = reinterpret_cast<const TexDesc*>(s_tables + qm + ql);
+  }
   const FrameData& F = A.frame;
 #ifndef GLZ_SHADE_NO_REGROUP
   // Block-local regrouping: the 256 pixels of the block are bucketed by the code path they are going to take -- miss,

@@ -286,6 +286,7 @@ bool Scene::build_materials(Error& err) {
   if (!hip_ok(d_materials_.upload(h_materials.data(), h_materials.size(), instance->stream), "upload materials", err)) return false;
   if (!hip_ok(hipStreamSynchronize(instance->stream), "materials upload", err)) return false;
   dev.materials = d_materials_.ptr;
+  dev.n_materials = (uint32_t)h_materials.size();
   return true;
 }
 
@@ -353,6 +354,7 @@ bool Scene::build_lights_and_sky(Error& err) {
   }
   if (!hip_ok(d_lights_.upload(h_lights.data(), h_lights.size(), st), "upload lights", err)) return false;
   dev.lights = d_lights_.ptr;
+  dev.n_rt_lights = (uint32_t)h_lights.size();
 
   // sky: Light::default() when the scene has none (scene.rs:2249)
   glz_light dflt{};
