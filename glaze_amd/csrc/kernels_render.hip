@@ -487,6 +487,10 @@ __device__ __forceinline__ void flush_counters(TraceCounters* c, bool shadow, Tr
 }
 
 // persistent launch geometry: every wave of the grid is one independent tracer
+// (XCD-aware numbering -- the blocks with b % 8 == x, which share an L2, taking one contiguous run of groups / pixels each,
+// cdna_hip_programming.md T1 -- measured slower for both kernels: k_trace 0.588 -> 0.621 ms, k_shade 0.348 -> 0.357 ms, a 1/8
+// share 0.162 -> 0.188 ms.  Neighbouring regions differ in cost; dealing them round-robin over the XCDs balances that, and
+// the L2s' hit rates are not what bounds either kernel.)
 __device__ __forceinline__ uint32_t wave_index() { return blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); }
 __device__ __forceinline__ uint32_t wave_count() { return gridDim.x * (kBlock / 64); }
 
