@@ -97,14 +97,19 @@ __device__ __forceinline__ bool ray_is_finite(vec3 o, vec3 d) {
 // the comparisons; the explicit det test keeps the rule the oracle states.
 __device__ __forceinline__ bool ray_triangle(const BvhTri& tr, vec3 o, vec3 d, float tmin, float& t, float& u, float& v) {
   const vec3 e1 = mk3(tr.e1[0], tr.e1[1], tr.e1[2]), e2 = mk3(tr.e2[0], tr.e2[1], tr.e2[2]);
-  const vec3 pvec = cross3(d, e2);
-  const float det = dot3(e1, pvec);
+  // Cross and dot products with explicit fused multiply-adds -- a * b - c * d as fma(a, b, -(c * d)), the dot product as a chain of
+  // two fmas -- exactly as the oracle's ray_tri states them (fmaf is correctly rounded on both sides, so the bits agree):
+  // 14 VALU instructions fewer per test than separate multiplies and adds (k_trace 0.589 -> 0.574 ms), and more accurate.
+  auto crossf = [](vec3 a, vec3 b) { return mk3(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x))); };
+  auto dotf = [](vec3 a, vec3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); };
+  const vec3 pvec = crossf(d, e2);
+  const float det = dotf(e1, pvec);
   const float inv = 1.0f / det;
   const vec3 tvec = o - mk3(tr.v0[0], tr.v0[1], tr.v0[2]);
-  u = dot3(tvec, pvec) * inv;
-  const vec3 qvec = cross3(tvec, e1);
-  v = dot3(d, qvec) * inv;
-  t = dot3(e2, qvec) * inv;
+  u = dotf(tvec, pvec) * inv;
+  const vec3 qvec = crossf(tvec, e1);
+  v = dotf(d, qvec) * inv;
+  t = dotf(e2, qvec) * inv;
   return (det != 0.0f) & (u >= 0.0f) & (u <= 1.0f) & (v >= 0.0f) & (u + v <= 1.0f) & (t > tmin);
 }
 

@@ -765,18 +765,23 @@ void build_accel(Scene& sc) {
 // traceRayEXT ([ext], parity unpinned).  Candidate accepted iff tmin < t < tmax.  No culling
 // (TRIANGLE_FACING_CULL_DISABLE, acceleration.rs:335-345).
 // ------------------------------------------------------------------------------------------
+// The products are stated with explicit fused multiply-adds (fmaf is correctly rounded, so every implementation of this
+// statement gives the same bits): a cross product component a*b - c*d = fma(a, b, -(c*d)), a dot product
+// fma(az, bz, fma(ay, by, ax*bx)).
+inline V3 cross_fma(V3 a, V3 b) { return v3(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x))); }
+inline float dot_fma(V3 a, V3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
 inline bool ray_tri(const Tri& tr, V3 o, V3 d, float tmin, float tmax, float& t, float& u, float& v) {
-  V3 pvec = cross(d, tr.e2);
-  float det = dot(tr.e1, pvec);
+  V3 pvec = cross_fma(d, tr.e2);
+  float det = dot_fma(tr.e1, pvec);
   if (det == 0.0f) return false;
   float inv = 1.0f / det;
   V3 tvec = o - tr.v0;
-  u = dot(tvec, pvec) * inv;
+  u = dot_fma(tvec, pvec) * inv;
   if (!(u >= 0.0f && u <= 1.0f)) return false;
-  V3 qvec = cross(tvec, tr.e1);
-  v = dot(d, qvec) * inv;
+  V3 qvec = cross_fma(tvec, tr.e1);
+  v = dot_fma(d, qvec) * inv;
   if (!(v >= 0.0f && u + v <= 1.0f)) return false;
-  t = dot(tr.e2, qvec) * inv;
+  t = dot_fma(tr.e2, qvec) * inv;
   return t > tmin && t < tmax;
 }
 
