@@ -603,6 +603,9 @@ __global__ void __launch_bounds__(kBlock, GLZ_SHADE_WAVES) k_shade(const LaunchA
   __shared__ uint4 s_tables[kShadeTableBytes / 16];
   __shared__ uint32_t s_bin[4 * 64];   // [wave][key] counts, then start offsets
   __shared__ uint16_t s_perm[kBlock];
+#ifndef GLZ_SHADE_NO_HIT_HANDOVER
+  __shared__ float4 s_hit[kBlock];   // hit records read by the regrouping prologue, handed to the thread that shades the pixel
+#endif
   const uint32_t n_sky = 3u * (A.scene.sky_header.marginal_cdf_count - 1u) + 1u;
   const bool sky_in_lds = A.scene.sky_header.marginal_cdf_count > 1u && n_sky <= kSkyLdsFloats;
   s_lut[threadIdx.x] = A.scene.srgb_lut[threadIdx.x];
@@ -644,7 +647,13 @@ __global__ void __launch_bounds__(kBlock, GLZ_SHADE_WAVES) k_shade(const LaunchA
     const uint32_t lid0 = blockIdx.x * kBlock + threadIdx.x;
     const PixelId px0 = pixel_of(A.map, lid0);
     if (px0.active) {
+#ifndef GLZ_SHADE_NO_HIT_HANDOVER
+      const float4 h0 = A.st.hit[lid0];
+      s_hit[threadIdx.x] = h0;   // the thread at this pixel's sorted slot reads it back after the barriers below: one dependent global load less
+      const uint32_t leaf0 = __float_as_uint(h0.w);
+#else
       const uint32_t leaf0 = __float_as_uint(A.st.hit[lid0].w);
+#endif
       key = 0u;
       if (leaf0 != 0xFFFFFFFFu) {
         const RTMaterial* m0 = &S.materials[__float_as_uint(S.shade_tris[8u * (size_t)leaf0 + 6u].w)];
@@ -701,7 +710,11 @@ __global__ void __launch_bounds__(kBlock, GLZ_SHADE_WAVES) k_shade(const LaunchA
 #endif
   const PixelId px = pixel_of(A.map, lid);
   if (!px.active) return;
+#if !defined(GLZ_SHADE_NO_REGROUP) && !defined(GLZ_SHADE_NO_HIT_HANDOVER)
+  const float4 ro = A.st.ray_o[lid], rd = A.st.ray_d[lid], hr = s_hit[s_perm[threadIdx.x]];
+#else
   const float4 ro = A.st.ray_o[lid], rd = A.st.ray_d[lid], hr = A.st.hit[lid];
+#endif
   const bool fresh = F.direct_only || ro.w == 0.0f;
   float bounce = F.direct_only ? 0.0f : ro.w;
   const vec3 direction = mk3(rd.x, rd.y, rd.z);
