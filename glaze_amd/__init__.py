@@ -372,6 +372,16 @@ class RayTraceScene:
         abi.check(abi.lib().glz_debug_read_sky(self._h, _ptr(out), n))
         return out
 
+    def debug_texture_level(self, texture, level):
+        """HxW[x4] uint8 pixels of one mip level as the device holds it (level 0 = the texture), or None past the last level."""
+        w, h = C.c_uint32(), C.c_uint32()
+        n = abi.check(abi.lib().glz_debug_read_texture_level(self._h, texture, level, None, 0, C.byref(w), C.byref(h)))
+        if n == 0:
+            return None
+        out = np.zeros(n, np.uint8)
+        abi.check(abi.lib().glz_debug_read_texture_level(self._h, texture, level, _ptr(out), n, C.byref(w), C.byref(h)))
+        return out.reshape(h.value, w.value) if n == w.value * h.value else out.reshape(h.value, w.value, 4)
+
     def debug_bvh(self):
         i = self.info()
         nodes = np.zeros((max(1, i.bvh_nodes), 16), np.uint32)
@@ -438,6 +448,10 @@ class RayTraceRenderer:
         keep = []
         t, nt = _texture_array(textures, keep)
         abi.check(abi.lib().glz_renderer_refresh_binded_textures(self._h, t, nt))
+
+    def set_texture_lod(self, mode):
+        """0 = level 0 always (the reference's ray-tracing stages), 1 = ray-cone level of detail over the mip chain.  Restarts."""
+        abi.check(abi.lib().glz_renderer_set_texture_lod(self._h, int(mode)))
 
     def set_devices(self, devices):
         """Render on several GPUs of this process (tiles t % n == i on devices[i], RCCL reduce onto devices[0] at every read-back);

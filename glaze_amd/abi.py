@@ -174,6 +174,9 @@ PROTOTYPES = {
     "glz_host_build_sah": (C.c_int, [C.c_uint32, _P, _P, _P, _P]),
     "glz_host_srgb8_thresholds": (C.c_int, [_P]),
     "glz_debug_tonemap": (C.c_int, [_P, _P, C.c_uint64, _P]),
+    "glz_debug_read_texture_level": (C.c_int64, [_P, C.c_uint32, C.c_uint32, _P, C.c_int64, _P, _P]),
+    "glz_host_mip_level": (C.c_int64, [_P, C.c_uint32, _P, C.c_int64, _P, _P]),
+    "glz_renderer_set_texture_lod": (C.c_int, [_P, C.c_int]),
     "glz_debug_rccl_selftest": (C.c_int, [_P, C.c_uint64, _P]),
     "glz_renderer_set_devices": (C.c_int, [_P, _P, C.c_int]),
     "glz_host_tile_owner": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, _P]),

@@ -13,6 +13,7 @@
 #include "codec/jpeg.h"
 #include "codec/png_enc.h"
 #include <strings.h>
+#include "mipchain.h"
 #include "rccl_dl.h"
 #include "renderer.h"
 #include "scene.h"
@@ -376,6 +377,7 @@ int glz_renderer_read_rgba8(glz_renderer* h, uint8_t* out) {
   GLZ_RET(h->r->read_rgba8(out, e));
   GLZ_GUARD_END(GLZ_E_IO)
 }
+int glz_renderer_set_texture_lod(glz_renderer* h, int mode) { GLZ_GUARD_BEGIN GLZ_R(h); GLZ_RET(h->r->set_texture_lod(mode, e)); GLZ_GUARD_END(GLZ_E_IO) }
 int glz_renderer_set_seed(glz_renderer* h, uint64_t s) { GLZ_GUARD_BEGIN GLZ_R(h); GLZ_RET(h->r->set_seed(s)); GLZ_GUARD_END(GLZ_E_IO) }
 int glz_renderer_set_depth(glz_renderer* h, uint32_t d) { GLZ_GUARD_BEGIN GLZ_R(h); GLZ_RET(h->r->set_depth(d, e)); GLZ_GUARD_END(GLZ_E_IO) }
 int glz_renderer_read_hdr(glz_renderer* h, float* out) {
@@ -553,6 +555,19 @@ int64_t glz_debug_read_bvh(glz_scene* h, void* nodes_out, int64_t cap_nodes, voi
   GLZ_GUARD_END(GLZ_E_IO)
 }
 
+int64_t glz_debug_read_texture_level(glz_scene* h, uint32_t texture, uint32_t level, uint8_t* out, int64_t cap, uint32_t* width, uint32_t* height) {
+  GLZ_GUARD_BEGIN
+  if (!h || !h->s) return fail(GLZ_E_ARG, "scene is null");
+  Error e;
+  std::vector<uint8_t> px;
+  uint32_t w = 0, hh = 0;
+  if (!h->s->read_mip_level(texture, level, px, w, hh, e)) return fail(e);
+  if (width) *width = w;
+  if (height) *height = hh;
+  if (out && cap > 0 && !px.empty()) memcpy(out, px.data(), (size_t)std::min<int64_t>(cap, (int64_t)px.size()));
+  return (int64_t)px.size();
+  GLZ_GUARD_END(GLZ_E_IO)
+}
 int glz_debug_tonemap(glz_instance* inst, const float* rgba32f, uint64_t n, uint8_t* out) {
   GLZ_GUARD_BEGIN
   if (!inst || !rgba32f || !out) return fail(GLZ_E_ARG, "null argument");
@@ -659,6 +674,26 @@ int glz_host_chain_owner(uint32_t width, uint32_t height, uint32_t rank, uint32_
   return (int)S;
 }
 
+int64_t glz_host_mip_level(const glz_texture* t, uint32_t level, uint8_t* out, int64_t cap, uint32_t* width, uint32_t* height) {
+  GLZ_GUARD_BEGIN
+  if (!t || !t->pixels || !t->width || !t->height || t->format < 1 || t->format > 3) return fail(GLZ_E_ARG, "bad texture");
+  std::vector<host::MipLevel> given(1);
+  given[0].width = t->width;
+  given[0].height = t->height;
+  given[0].pixels.assign(t->pixels, t->pixels + (size_t)t->width * t->height * (t->format == GLZ_TEX_GRAY ? 1 : 4));
+  const std::vector<host::MipLevel> chain = host::build_mip_chain(t->format, std::move(given));
+  if (level >= chain.size()) {
+    if (width) *width = 0;
+    if (height) *height = 0;
+    return 0;
+  }
+  const host::MipLevel& m = chain[level];
+  if (width) *width = m.width;
+  if (height) *height = m.height;
+  if (out && cap > 0) memcpy(out, m.pixels.data(), (size_t)std::min<int64_t>(cap, (int64_t)m.pixels.size()));
+  return (int64_t)m.pixels.size();
+  GLZ_GUARD_END(GLZ_E_IO)
+}
 int glz_host_srgb8_thresholds(float thresholds_out[256]) {
   if (!thresholds_out) return fail(GLZ_E_ARG, "output is null");
   host::srgb8_thresholds(thresholds_out);

@@ -100,19 +100,17 @@ GLZ_D uint32_t texel_address(const TexDesc& t, uint32_t format, uint32_t ux, uin
   if (format == GLZ_TEX_GRAY) return t.offset + ((uy >> 3) * tiles_x + (ux >> 4)) * 128u + (uy & 7u) * 16u + (ux & 15u);
   return t.offset + (((uy >> 2) * tiles_x + (ux >> 3)) * 32u + (uy & 3u) * 8u + (ux & 7u)) * 4u;
 }
-GLZ_D uint32_t load_texel(const DeviceScene& S, const TexDesc& t, uint32_t format, uint32_t ux, uint32_t uy) {
+GLZ_D uint32_t load_texel(const uint8_t* __restrict__ pool, const TexDesc& t, uint32_t format, uint32_t ux, uint32_t uy) {
   const uint32_t addr = texel_address(t, format, ux, uy);
-  return format == GLZ_TEX_GRAY ? (uint32_t)S.tex_pool[addr] : *reinterpret_cast<const uint32_t*>(S.tex_pool + addr);
+  return format == GLZ_TEX_GRAY ? (uint32_t)pool[addr] : *reinterpret_cast<const uint32_t*>(pool + addr);
 }
 GLZ_D int wrap_coord(int i, int n) {
   int r = i % n;
   return r < 0 ? r + n : r;
 }
 GLZ_D float lerp_ab(float a, float b, float t) { return a + (b - a) * t; }
-GLZ_D vec4 texture2d(const DeviceScene& S, uint32_t id, float u, float v) {
-  // one dwordx4 for the whole descriptor
-  const uint4 td = reinterpret_cast<const uint4*>(S.tex_desc)[id];
-  const TexDesc t{td.x, td.y, td.z, td.w};
+// bilinear, REPEAT fetch from ONE level: `t` describes it, `pool` holds its texels
+GLZ_D vec4 bilinear_level(const DeviceScene& S, const TexDesc& t, const uint8_t* __restrict__ pool, float u, float v) {
   const uint32_t format = t.format & 0x7Fu;
   float fu = u * (float)t.width - 0.5f, fv = v * (float)t.height - 0.5f;
   float iu = glz_floorf(fu), iv = glz_floorf(fv);
@@ -125,14 +123,14 @@ GLZ_D vec4 texture2d(const DeviceScene& S, uint32_t id, float u, float v) {
     const int x1 = wrap_coord((int)iu + 1, (int)t.width), y1 = wrap_coord((int)iv + 1, (int)t.height);
     if (format != GLZ_TEX_GRAY && x1 == x0 + 1 && (x0 & 7) != 7) {
       // the two texels of a row are neighbours inside one tile row: one 8-byte load per row
-      const uint2 r0 = *reinterpret_cast<const uint2*>(S.tex_pool + texel_address(t, format, (uint32_t)x0, (uint32_t)y0));
-      const uint2 r1 = *reinterpret_cast<const uint2*>(S.tex_pool + texel_address(t, format, (uint32_t)x0, (uint32_t)y1));
+      const uint2 r0 = *reinterpret_cast<const uint2*>(pool + texel_address(t, format, (uint32_t)x0, (uint32_t)y0));
+      const uint2 r1 = *reinterpret_cast<const uint2*>(pool + texel_address(t, format, (uint32_t)x0, (uint32_t)y1));
       ta = r0.x; tb = r0.y; tc = r1.x; tdx = r1.y;
     } else {
-      ta = load_texel(S, t, format, (uint32_t)x0, (uint32_t)y0);
-      tb = load_texel(S, t, format, (uint32_t)x1, (uint32_t)y0);
-      tc = load_texel(S, t, format, (uint32_t)x0, (uint32_t)y1);
-      tdx = load_texel(S, t, format, (uint32_t)x1, (uint32_t)y1);
+      ta = load_texel(pool, t, format, (uint32_t)x0, (uint32_t)y0);
+      tb = load_texel(pool, t, format, (uint32_t)x1, (uint32_t)y0);
+      tc = load_texel(pool, t, format, (uint32_t)x0, (uint32_t)y1);
+      tdx = load_texel(pool, t, format, (uint32_t)x1, (uint32_t)y1);
     }
   }
   const vec4 a = decode_texel(S, format, ta), b = decode_texel(S, format, tb), c = decode_texel(S, format, tc), d = decode_texel(S, format, tdx);
@@ -142,6 +140,54 @@ GLZ_D vec4 texture2d(const DeviceScene& S, uint32_t id, float u, float v) {
   r.z = lerp_ab(lerp_ab(a.z, b.z, ax), lerp_ab(c.z, d.z, ax), ay);
   r.w = lerp_ab(lerp_ab(a.w, b.w, ax), lerp_ab(c.w, d.w, ax), ay);
   return r;
+}
+GLZ_D vec4 texture2d(const DeviceScene& S, uint32_t id, float u, float v) {
+  // one dwordx4 for the whole descriptor
+  const uint4 td = reinterpret_cast<const uint4*>(S.tex_desc)[id];
+  return bilinear_level(S, TexDesc{td.x, td.y, td.z, td.w}, S.tex_pool, u, v);
+}
+// Texture level of detail (build-defined, FrameData::lod_mode; the reference's ray-tracing stages sample level 0).  `lod_base` is
+// the texture-independent part of the ray-cone level, 0.5 log2(uv area / world area * cone width^2 / cos^2); the texture adds
+// 0.5 log2(width * height).  The level is clamped to the chain and the two nearest levels are blended (LINEAR mipmap mode of the
+// reference's sampler, scene.rs:716-749).  kNoLod, no mip chain on the device, or a level <= 0: exactly texture2d().
+constexpr float kNoLod = -1e30f;
+GLZ_D vec4 texture2d_lod(const DeviceScene& S, uint32_t id, float u, float v, float lod_base) {
+  const uint4 td = reinterpret_cast<const uint4*>(S.tex_desc)[id];
+  const TexDesc t0{td.x, td.y, td.z, td.w};
+  uint32_t first = 0, l0 = 0, taps = 1;
+  float frac = 0.0f;
+  if (lod_base > -1e29f && S.tex_mip_base != nullptr && !(t0.format & kTexInline)) {
+    const uint32_t b = S.tex_mip_base[id];
+    const uint32_t levels = b >> 24;
+    first = b & 0xFFFFFFu;
+    float lam = lod_base + 0.5f * glz_log2f((float)t0.width * (float)t0.height);
+    lam = lam > 0.0f ? lam : 0.0f;                                   // NaN -> 0
+    const float top = (float)(levels - 1u);
+    lam = lam < top ? lam : top;
+    const float fl = glz_floorf(lam);
+    l0 = (uint32_t)fl;
+    frac = lam - fl;
+    taps = frac > 0.0f ? 2u : 1u;
+  }
+  vec4 acc{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 1
+  for (uint32_t k = 0; k < taps; ++k) {   // one copy of the fetch code: level l0, then l0 + 1 when the level is fractional
+    const uint32_t level = l0 + k;
+    TexDesc t = t0;
+    const uint8_t* pool = S.tex_pool;
+    if (level != 0u) {
+      const uint4 md = reinterpret_cast<const uint4*>(S.tex_mip_desc)[first + level - 1u];
+      t = TexDesc{md.x, md.y, md.z, md.w};
+      pool = S.tex_mip_pool;
+    }
+    const vec4 r = bilinear_level(S, t, pool, u, v);
+    if (k == 0u) {
+      acc = r;
+    } else {
+      acc.x = lerp_ab(acc.x, r.x, frac); acc.y = lerp_ab(acc.y, r.y, frac); acc.z = lerp_ab(acc.z, r.z, frac); acc.w = lerp_ab(acc.w, r.w, frac);
+    }
+  }
+  return acc;
 }
 GLZ_D vec3 texture_rgb(const DeviceScene& S, uint32_t id, vec2 uv) {
   vec4 t = texture2d(S, id, uv.x, uv.y);
@@ -344,16 +390,16 @@ GLZ_D float oren_nayar(float roughness, vec3 wo, vec3 wi) {
   return kInvPi * (A + B * maxcos * sinalpha * tanbeta);
 }
 
-GLZ_D void fetch_material_textures(const DeviceScene& S, SurfacePoint& P) {
+GLZ_D void fetch_material_textures(const DeviceScene& S, SurfacePoint& P, float lod_base) {
   const uint32_t kind = P.mat.bsdf_index;
   P.tint = mk3(0.0f, 0.0f, 0.0f);
   P.rough_tex = P.metal_tex = 0.0f;
   if (kind == kBsdfLambert || kind == kBsdfUber) {
-    const vec3 tx = texture_rgb(S, P.mat.diffuse, P.uv);
-    P.tint = tx * mk3(P.mat.diffuse_mul[0], P.mat.diffuse_mul[1], P.mat.diffuse_mul[2]);
+    const vec4 tx = texture2d_lod(S, P.mat.diffuse, P.uv.x, P.uv.y, lod_base);
+    P.tint = mk3(tx.x, tx.y, tx.z) * mk3(P.mat.diffuse_mul[0], P.mat.diffuse_mul[1], P.mat.diffuse_mul[2]);
   }
-  if (kind == kBsdfMetal || kind == kBsdfFrosted || kind == kBsdfUber) P.rough_tex = texture_r(S, P.mat.roughness, P.uv);
-  if (kind == kBsdfUber) P.metal_tex = texture_r(S, P.mat.metalness, P.uv);
+  if (kind == kBsdfMetal || kind == kBsdfFrosted || kind == kBsdfUber) P.rough_tex = texture2d_lod(S, P.mat.roughness, P.uv.x, P.uv.y, lod_base).x;
+  if (kind == kBsdfUber) P.metal_tex = texture2d_lod(S, P.mat.metalness, P.uv.x, P.uv.y, lod_base).x;
 }
 GLZ_D vec3 diffuse_tint(const DeviceScene&, const SurfacePoint& P) { return P.tint; }
 

@@ -24,7 +24,12 @@ struct FrameData {
   // build-defined: PT_STEPS and the DIRECT_ONLY compile-time switch as run-time values
   uint32_t pt_steps;
   uint32_t direct_only;
-  uint32_t _pad;
+  // build-defined texture level of detail (the reference's ray-tracing stages sample level 0): 0 = level 0 always,
+  // 1 = ray cones.  The cone of a camera path starts `cone_width0` wide and widens by `cone_spread` per unit of distance.
+  uint32_t lod_mode;
+  float cone_spread;
+  float cone_width0;
+  uint32_t _pad[3];
 };
 
 // raytrace_structures.rs:36-42
@@ -154,6 +159,11 @@ struct DeviceScene {
   const float4* derivatives;       // 3 x float4 per object triangle (normal, dpdu, dpdv)
   const TexDesc* tex_desc;
   const uint8_t* tex_pool;
+  // mip levels 1.. (built on demand, Scene::ensure_mips; null until a renderer asks for texture LOD): one TexDesc per level in
+  // tex_mip_desc, offsets into tex_mip_pool; tex_mip_base[id] = index of the texture's level-1 descriptor | level count << 24
+  const TexDesc* tex_mip_desc;
+  const uint32_t* tex_mip_base;
+  const uint8_t* tex_mip_pool;
   const float* srgb_lut;           // 256 entries
   const BvhNode4* bvh_nodes;
   const BvhNode4* bvh_top;         // kBvhTopNodes nodes: the top levels with links into the table flagged (kBvhTopFlag)

@@ -55,6 +55,7 @@ struct PathState {
   float4* ray_d;     // direction.xyz, last-bounce-specular flag (PTLastVertex.wi)
   float4* imp[4];    // importance spectrum, 4 x vec4    (PTLastVertex.importance)
   float4* hit;       // t, u, v, leaf index (bits)       closest-hit record of the current launch
+  float* cone;       // ray-cone width at the ray origin (texture LOD, FrameData::lod_mode; untouched when it is off)
   // shadow-ray queue, compacted by k_shade (entry q, not pixel lid):
   float4* sh_o;      //   origin.xyz, tmax
   float4* sh_d;      //   direction.xyz, owning pixel lid (bits)

@@ -754,8 +754,31 @@ __global__ void __launch_bounds__(kBlock, GLZ_SHADE_WAVES) k_shade(const LaunchA
   vec3 ng = mk3(dn.x, dn.y, dn.z), dpdu = mk3(du.x, du.y, du.z);   // dpdv is transformed by the reference but never read afterwards
   vec3 ns = (mk3(va0.w, va1.x, va1.y) * b0 + mk3(vb0.w, vb1.x, vb1.y) * b1) + mk3(vc0.w, vc1.x, vc1.y) * b2;
   const MatScalars mat = load_material(&S.materials[material_id]);
+  // ---- texture level of detail by ray cones (build-defined, off by default: the reference's stages sample level 0) ----
+  // The cone of a camera path starts cone_width0 wide and widens by cone_spread per unit of distance along the whole path;
+  // at a hit the footprint on the surface is width / |cos|, and a texture of W x H texels over a triangle with texture-space
+  // area A_uv and world area A_w is minified by sqrt(A_uv W H / A_w) texels per unit length:
+  // level = 0.5 log2(A_uv / A_w * width^2 / cos^2) + 0.5 log2(W H)      (Akenine-Moeller et al., ray cones)
+  float lod_base = kNoLod, cone_w = 0.0f;
+  if (F.lod_mode != 0u) {
+    cone_w = (fresh ? F.cone_width0 : A.st.cone[lid]) + F.cone_spread * hr.x;
+    vec3 e1 = mk3(vb0.x, vb0.y, vb0.z) - mk3(va0.x, va0.y, va0.z), e2 = mk3(vc0.x, vc0.y, vc0.z) - mk3(va0.x, va0.y, va0.z);
+    vec3 n = mk3(dn.x, dn.y, dn.z);
+    if (!(xf_bits >> 31)) {
+      const TransformPair* xf = &S.transforms[xf_bits & 0x7FFFFFFFu];
+      e1 = xform_dir(xf->o2w, e1);
+      e2 = xform_dir(xf->o2w, e2);
+      n = xform_tdir(xf->w2o, n);
+    }
+    const vec3 cr = cross3(e1, e2);
+    const float area2 = sqrtf(dot3(cr, cr));
+    const float uva2 = fabsf((vb1.z - va1.z) * (vc1.w - va1.w) - (vc1.z - va1.z) * (vb1.w - va1.w));
+    const float cosv = fabsf(dot3(n, direction)) / sqrtf(dot3(n, n));
+    const float x = ((uva2 / area2) * (cone_w * cone_w)) / (cosv * cosv);
+    if (x >= 1.17549435e-38f && x <= 3.4e38f) lod_base = 0.5f * glz_log2f(x);
+  }
   if (mat.normal != 0) {
-    const vec4 tx = texture2d(S, mat.normal, uv.x, uv.y);
+    const vec4 tx = texture2d_lod(S, mat.normal, uv.x, uv.y, lod_base);
     Frame old;
     old.s = normalize3(dpdu);
     old.n = ns;
@@ -783,7 +806,7 @@ __global__ void __launch_bounds__(kBlock, GLZ_SHADE_WAVES) k_shade(const LaunchA
   P.uv = uv;
   P.frame = make_frame(dpdu, ns);
   P.mat = mat;
-  fetch_material_textures(S, P);
+  fetch_material_textures(S, P, lod_base);
   float spec_flag;
   if (mat.is_specular == 0) {
     // direct_light(), :84-117
@@ -868,6 +891,7 @@ __global__ void __launch_bounds__(kBlock, GLZ_SHADE_WAVES) k_shade(const LaunchA
     A.st.imp[q][lid] = make_float4(importance.w[4 * q] * (value.w[4 * q] * weight), importance.w[4 * q + 1] * (value.w[4 * q + 1] * weight),
                                    importance.w[4 * q + 2] * (value.w[4 * q + 2] * weight), importance.w[4 * q + 3] * (value.w[4 * q + 3] * weight));
   bounce = bounce < (float)F.pt_steps ? bounce + 1.0f : 0.0f;   // :230-237
+  if (F.lod_mode != 0u) A.st.cone[lid] = cone_w;
   A.st.ray_o[lid] = make_float4(point.x, point.y, point.z, bounce);
   A.st.ray_d[lid] = make_float4(wiW.x, wiW.y, wiW.z, spec_flag);
 }

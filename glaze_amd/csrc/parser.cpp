@@ -400,15 +400,23 @@ bool Parsed::textures(const std::vector<TextureData>*& out, Error& err) {
           size_t ml = rd32(b + idx);
           idx += 4;
           if (idx + ml > n) { fail(errs[i], GLZ_E_INVALID_DATA, "Corrupted textures"); return; }
-          if (lvl == 0) {  // only level 0 is sampled by the ray-tracing stages
+          {  // level 0 is what the reference's ray-tracing stages sample; the other levels feed the opt-in texture LOD
             std::string perr;
             uint32_t w, h;
-            if (!png_decode(b + idx, ml, fmt == GLZ_TEX_GRAY ? 1 : 4, w, h, t.level0, perr)) {
+            std::vector<uint8_t> px;
+            if (!png_decode(b + idx, ml, fmt == GLZ_TEX_GRAY ? 1 : 4, w, h, px, perr)) {
               fail(errs[i], GLZ_E_INVALID_DATA, "Corrupted image: " + perr);
               return;
             }
-            t.info.width = w;
-            t.info.height = h;
+            if (lvl == 0) {
+              t.level0 = std::move(px);
+              t.info.width = w;
+              t.info.height = h;
+            } else {
+              t.more_levels.push_back(std::move(px));
+              t.more_dims.push_back(w);
+              t.more_dims.push_back(h);
+            }
           }
           idx += ml;
         }

@@ -18,6 +18,10 @@ struct Error {
 struct TextureData {
   glz_texture info{};           // info.pixels is patched to level0.data() by the getters
   std::vector<uint8_t> level0;
+  // levels 1.. as stored in the file (`glaze-converter --gen-mipmaps`); used when the chain is complete (materials/texture.rs:196-221),
+  // otherwise the chain is generated at upload (mipchain.h)
+  std::vector<std::vector<uint8_t>> more_levels;
+  std::vector<uint32_t> more_dims;   // width, height per stored level
 };
 
 // Owned, fully decoded scene ("what Box<dyn ParsedScene> yields when every getter is called").

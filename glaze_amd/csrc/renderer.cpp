@@ -242,6 +242,7 @@ bool Renderer::allocate(Error& err) {
                                     &c->cumulative, &c->result};
     for (auto* b : bufs)
       if (!hip_ok(b->alloc((b == &c->sh_o || b == &c->sh_d || b == &c->contrib) ? n_queue : n), "alloc path state", err)) return false;
+    if (!hip_ok(c->cone.alloc(n), "alloc path state", err)) return false;
     c->grid = trace_grid_blocks(m.n_local_pixels, false);
     c->grid_counting = trace_grid_blocks(m.n_local_pixels, true);
     // traversal spill: one slot of `od` entries per lane of the larger of the two persistent grids
@@ -294,6 +295,7 @@ void Renderer::fill_args(const Chain& c, LaunchArgs& a) const {
   a.st.ray_d = c.ray_d.ptr;
   for (int q = 0; q < 4; ++q) a.st.imp[q] = c.imp[q].ptr;
   a.st.hit = c.hit.ptr;
+  a.st.cone = c.cone.ptr;
   a.st.sh_o = c.sh_o.ptr;
   a.st.sh_d = c.sh_d.ptr;
   a.st.contrib = c.contrib.ptr;
@@ -384,6 +386,16 @@ bool Renderer::one_launch(Error& err) {
   fd.camera_persp = camera_.type == GLZ_CAMERA_PERSPECTIVE ? 1u : 0u;
   fd.pt_steps = pt_steps_;
   fd.direct_only = integrator_ == GLZ_DIRECT ? 1u : 0u;
+  fd.lod_mode = (uint32_t)lod_mode_;
+  if (lod_mode_ != 0) {
+    // one pixel of the image plane at unit distance (perspective: the cone's spread) or in world units (orthographic: the
+    // cone's constant width), from the projection's vertical scale: screen2camera[1][1] = -tan(fovy / 2) or -scale
+    const float pixel = 2.0f * fabsf(cam_.screen2camera[5]) / (float)h_;
+    const bool persp = camera_.type == GLZ_CAMERA_PERSPECTIVE;
+    fd.cone_spread = persp ? pixel : 0.0f;
+    fd.cone_width0 = persp ? 0.0f : pixel;
+    if (!scene_->mips_ready() && !scene_->ensure_mips(err)) return false;
+  }
   ++launches_;
   if (fd.lights_no == 0) return true;   // the raygen shader returns before touching anything (path_trace.rgen:137-141)
   for (auto& cp : chains_) {
@@ -735,6 +747,17 @@ bool Renderer::read_rgba8(uint8_t* out, Error& err) {
   return hip_ok(hipStreamSynchronize(st), "read rgba8", err);
 }
 
+bool Renderer::set_texture_lod(int mode, Error& err) {
+  if (mode != 0 && mode != 1) {
+    err.code = GLZ_E_ARG;
+    err.msg = "texture LOD mode must be 0 (level 0) or 1 (ray cones)";
+    return false;
+  }
+  lod_mode_ = mode;
+  request_new_frame_ = true;
+  return forward([=](Peer& p, Error& e) { return p.r->set_texture_lod(mode, e); }, err);
+}
+
 bool Renderer::set_seed(uint64_t s) {
   seed_ = s;
   request_new_frame_ = true;
@@ -783,6 +806,7 @@ bool Renderer::set_partition_local(uint32_t rank, uint32_t world, Error& err) {
 // what a freshly created peer renderer takes over from this one
 bool Renderer::configure_peer(Renderer& p, Error& err) const {
   p.integrator_ = integrator_;
+  p.lod_mode_ = lod_mode_;
   p.pt_steps_ = pt_steps_;
   p.seed_ = seed_;
   p.exposure_ = exposure_;

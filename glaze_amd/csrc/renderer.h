@@ -31,6 +31,7 @@ class Renderer {
   bool read_rgba8(uint8_t* out, Error& err);
   bool read_frame(bool result, float* out, Error& err);
 
+  bool set_texture_lod(int mode, Error& err);   // 0 = level 0 (the reference), 1 = ray cones; restarts
   bool set_seed(uint64_t s);
   bool set_depth(uint32_t d, Error& err);
   bool set_partition(uint32_t rank, uint32_t world, Error& err);
@@ -67,6 +68,7 @@ class Renderer {
   uint32_t w_ = 0, h_ = 0;
   int integrator_ = GLZ_PATH_TRACE;
   uint32_t pt_steps_ = 6;   // PT_STEPS, raytrace_structures.rs:87
+  int lod_mode_ = 0;        // texture level of detail: 0 = level 0 always (what the reference's ray-tracing stages do), 1 = ray cones
   float exposure_ = 1.0f;
   glz_camera camera_{};
   CameraConsts cam_{};
@@ -91,6 +93,7 @@ class Renderer {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     DeviceBuffer<float4> ray_o, ray_d, imp[4], hit, sh_o, sh_d, contrib, cumulative, result;
+    DeviceBuffer<float> cone;
     DeviceBuffer<uint32_t> overflow, queue_count;
     uint32_t grid = 0, grid_counting = 0;   // blocks of k_trace's persistent grid (plain / instrumented kernel)
     // shadow rays queued by the last launch's k_shade and not traced yet (they ride in the next launch's k_trace, or in

@@ -6,8 +6,11 @@
 #include <cmath>
 #include <cstring>
 
+#include <thread>
+
 #include "host_math.h"
 #include "kernels.h"
+#include "mipchain.h"
 
 namespace glz {
 
@@ -250,6 +253,119 @@ bool Scene::upload_textures(Error& err) {
   dev.tex_desc = d_tex_desc_.ptr;
   dev.tex_pool = d_tex_pool_.ptr;
   dev.n_textures = (uint32_t)d.textures.size();
+  // the texels changed: whatever mip levels were built belong to the old ones
+  mips_ready_ = false;
+  dev.tex_mip_desc = nullptr;
+  dev.tex_mip_base = nullptr;
+  dev.tex_mip_pool = nullptr;
+  h_mips_.clear();
+  return true;
+}
+
+// 128-byte tiles: 8 x 4 RGBA texels or 16 x 8 gray texels (upload_textures above), appended to `pool`
+static TexDesc append_tiled(std::vector<uint8_t>& pool, uint32_t format, uint32_t w, uint32_t h, const uint8_t* px) {
+  const bool gray = format == GLZ_TEX_GRAY;
+  const uint32_t tw = gray ? 16u : 8u, th = gray ? 8u : 4u, bpp = gray ? 1u : 4u;
+  const uint32_t tiles_x = (w + tw - 1) / tw, tiles_y = (h + th - 1) / th;
+  pool.resize((pool.size() + 127) & ~size_t(127));
+  const size_t base = pool.size();
+  pool.resize(base + (size_t)tiles_x * tiles_y * 128u, 0);
+  for (uint32_t y = 0; y < h; ++y)
+    for (uint32_t x = 0; x < w; ++x) {
+      const size_t dst = base + ((size_t)(y / th) * tiles_x + x / tw) * 128u + ((size_t)(y % th) * tw + x % tw) * bpp;
+      memcpy(&pool[dst], &px[((size_t)y * w + x) * bpp], bpp);
+    }
+  return TexDesc{(uint32_t)base, w, h, format | (tiles_x << 8)};
+}
+
+bool Scene::ensure_mips(Error& err) {
+  if (mips_ready_) return true;
+  if (!hip_ok(hipSetDevice(instance->device), "hipSetDevice", err)) return false;
+  const size_t nt = data.textures.size();
+  h_mips_.assign(nt, {});
+  std::vector<std::vector<host::MipLevel>> chains(nt);
+  auto build_one = [&](size_t i) {
+    const TextureData& t = data.textures[i];
+    std::vector<host::MipLevel> given(1);
+    given[0].width = t.info.width;
+    given[0].height = t.info.height;
+    given[0].pixels = t.level0;
+    for (size_t l = 0; l < t.more_levels.size(); ++l) {
+      host::MipLevel m;
+      m.width = t.more_dims[2 * l];
+      m.height = t.more_dims[2 * l + 1];
+      m.pixels = t.more_levels[l];
+      given.push_back(std::move(m));
+    }
+    chains[i] = host::build_mip_chain(t.info.format, std::move(given));
+  };
+  const unsigned workers = (unsigned)std::min<size_t>(nt, std::max(1u, std::min(16u, std::thread::hardware_concurrency())));
+  if (workers <= 1) {
+    for (size_t i = 0; i < nt; ++i) build_one(i);
+  } else {
+    std::vector<std::thread> pool;
+    std::vector<std::string> failed(workers);
+    for (unsigned w = 0; w < workers; ++w)
+      pool.emplace_back([&, w] {
+        try {
+          for (size_t i = w; i < nt; i += workers) build_one(i);
+        } catch (const std::exception& ex) {
+          failed[w] = ex.what();
+        }
+      });
+    for (auto& th : pool) th.join();
+    for (auto& f : failed)
+      if (!f.empty()) {
+        err.code = GLZ_E_IO;
+        err.msg = "mip chain: " + f;
+        return false;
+      }
+  }
+  std::vector<uint8_t> pool;
+  std::vector<TexDesc> desc;
+  std::vector<uint32_t> base(nt, 0);
+  for (size_t i = 0; i < nt; ++i) {
+    const uint32_t levels = (uint32_t)chains[i].size();
+    base[i] = (uint32_t)desc.size() | (levels << 24);
+    for (uint32_t l = 1; l < levels; ++l) {
+      const host::MipLevel& m = chains[i][l];
+      desc.push_back(append_tiled(pool, data.textures[i].info.format, m.width, m.height, m.pixels.data()));
+      h_mips_[i].push_back(m.pixels);
+    }
+    if (pool.size() > 0xFFFFFFF0ull || desc.size() >= (1u << 24)) {
+      err.code = GLZ_E_UNSUPPORTED;
+      err.msg = "mip pool larger than 4 GiB";
+      return false;
+    }
+  }
+  hipStream_t st = instance->stream;
+  if (!hip_ok(d_tex_mip_desc_.upload(desc.data(), desc.size(), st), "upload mip descriptors", err)) return false;
+  if (!hip_ok(d_tex_mip_pool_.upload(pool.data(), pool.size(), st), "upload mip pool", err)) return false;
+  if (!hip_ok(d_tex_mip_base_.upload(base.data(), base.size(), st), "upload mip table", err)) return false;
+  if (!hip_ok(hipStreamSynchronize(st), "mip upload", err)) return false;
+  dev.tex_mip_desc = d_tex_mip_desc_.ptr;
+  dev.tex_mip_pool = d_tex_mip_pool_.ptr;
+  dev.tex_mip_base = d_tex_mip_base_.ptr;
+  mips_ready_ = true;
+  return true;
+}
+
+bool Scene::read_mip_level(uint32_t texture, uint32_t level, std::vector<uint8_t>& pixels, uint32_t& w, uint32_t& h, Error& err) {
+  pixels.clear();
+  w = h = 0;
+  if (texture >= data.textures.size()) return true;
+  const TextureData& t = data.textures[texture];
+  if (level == 0) {
+    pixels = t.level0;
+    w = t.info.width;
+    h = t.info.height;
+    return true;
+  }
+  if (!ensure_mips(err)) return false;
+  if (level - 1 >= h_mips_[texture].size()) return true;
+  pixels = h_mips_[texture][level - 1];
+  w = host::mip_dim(t.info.width, level);
+  h = host::mip_dim(t.info.height, level);
   return true;
 }
 

@@ -115,7 +115,8 @@ class SceneDesc:
         mats = (abi.Material * len(self.materials))(*self.materials)
         lights = (abi.Light * max(1, len(self.lights)))(*self.lights)
         texs = (abi.Texture * len(self.textures))()
-        for i, (fmt, px, name) in enumerate(self.textures):
+        for i, t in enumerate(self.textures):     # (format, pixels, name[, mip levels to store when serialised])
+            fmt, px, name = t[0], t[1], t[2]
             px = np.ascontiguousarray(px, np.uint8)
             keep.append(px)
             texs[i].format, texs[i].height, texs[i].width, texs[i].mip_levels = fmt, px.shape[0], px.shape[1], 1

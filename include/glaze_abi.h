@@ -321,6 +321,15 @@ int glz_renderer_read_rgba8(glz_renderer*, uint8_t* rgba8_out); /* blit out32->o
 /* ---- build-defined extensions (no reference counterpart) ---------------- */
 int glz_renderer_set_seed(glz_renderer*, uint64_t seed);    /* replaces Xoshiro128PlusPlus::from_entropy, raytracer.rs:779 */
 int glz_renderer_set_depth(glz_renderer*, uint32_t pt_steps);/* replaces const PT_STEPS = 6, raytrace_structures.rs:87 */
+/* Texture level of detail.  The reference's samplers have LINEAR mip filtering and mip chains (generated by
+ * LINEAR blits at upload when the file brings none, vulkan/scene.rs:1012-1263), but its ray-tracing stages call texture() with
+ * the implicit level, which outside fragment shaders is level 0: GLZ_LOD_BASE (the default) reproduces that bit for bit.
+ * GLZ_LOD_RAY_CONES picks the level per hit from the ray's footprint (cone width carried along the path, triangle texture /
+ * world area ratio, angle of incidence) and blends the two nearest levels; the chain is built on the first launch that needs it.
+ * Restarts accumulation. */
+#define GLZ_LOD_BASE 0
+#define GLZ_LOD_RAY_CONES 1
+int glz_renderer_set_texture_lod(glz_renderer*, int mode);
 /* cumulative image (xyz = sum of rgb radiance, w = launch count; path_trace.rgen:119-133),
  * W*H*4 floats, row-major, to host memory. */
 int glz_renderer_read_hdr(glz_renderer*, float* rgba32f_out);
@@ -394,6 +403,9 @@ int64_t glz_debug_read_sky(glz_scene*, float* out, int64_t cap_floats);        /
  * first one's last word says which, and leaf links name the first); see DESIGN.md for the layouts. */
 int64_t glz_debug_read_bvh(glz_scene*, void* nodes_out, int64_t cap_nodes, void* tris_out, int64_t cap_tris);
 
+/* one level of a scene texture's mip chain as the device holds it (level 0 = the texture; builds the chain if needed): returns the
+ * byte count (0 past the last level), writes up to cap bytes and the level's dimensions */
+int64_t glz_debug_read_texture_level(glz_scene*, uint32_t texture, uint32_t level, uint8_t* out, int64_t cap, uint32_t* width, uint32_t* height);
 /* k_tonemap (the out32 -> RGBA8 sRGB blit, raytracer.rs:576-584) on n host pixels of RGBA32F: upload, kernel, read back */
 int glz_debug_tonemap(glz_instance*, const float* rgba32f, uint64_t n_pixels, uint8_t* rgba8_out);
 
@@ -419,6 +431,9 @@ int glz_host_chain_owner(uint32_t width, uint32_t height, uint32_t rank, uint32_
 /* the 8-bit sRGB quantiser of read_rgba8 / draw (the reference's R8G8B8A8_SRGB blit, raytracer.rs:576-584): c encodes to
  * #{k in 1..255 : c >= thresholds_out[k]}; thresholds_out[0] = 0 */
 int glz_host_srgb8_thresholds(float thresholds_out[256]);
+/* one level of the mip chain the library generates for a texture that brings only level 0 (mipchain.h: LINEAR-blit rule); returns the
+ * byte count of that level (0 past the last), writes up to cap bytes */
+int64_t glz_host_mip_level(const glz_texture* texture, uint32_t level, uint8_t* out, int64_t cap, uint32_t* width, uint32_t* height);
 int glz_host_build_sah(uint32_t n, const float* box_lo, const float* box_hi, int32_t* children_out, int32_t* parent_out);
 
 #ifdef __cplusplus

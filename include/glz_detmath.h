@@ -7,7 +7,7 @@
  * last-bit differences between glibc's libm and the device's ocml.  The reference leaves these to
  * the GLSL built-ins of the Vulkan driver ([ext], SURVEY 8c: parity unpinned).
  *
- * Coefficients: the classic Cephes single-precision minimax polynomials (sinf/cosf/asinf/atanf).
+ * Coefficients: the classic Cephes single-precision minimax polynomials (sinf/cosf/asinf/atanf/logf).
  * Accuracy: <= 2 ulp over the ranges the renderer uses (checked against numpy in tests/).
  */
 #ifndef GLZ_DETMATH_H
@@ -127,6 +127,29 @@ GLZ_HD float glz_atan2f(float y, float x) {
   float a = glz_atan_pos(ay / ax);
   if (x < 0.0f) a = pi - a;
   return y < 0.0f ? -a : a;
+}
+
+/* log2(x) for finite x > 0 (normal numbers): exponent and mantissa split by bit operations, log(1 + t) on
+ * [sqrt(1/2) - 1, sqrt(2) - 1] by the Cephes logf polynomial, scaled by log2(e).  Used for the texture level of detail. */
+GLZ_HD float glz_log2f(float x) {
+  union { float f; unsigned u; } c;
+  c.f = x;
+  int e = (int)((c.u >> 23) & 0xFFu) - 127;
+  c.u = (c.u & 0x007FFFFFu) | 0x3F800000u;
+  float m = c.f;                              /* [1, 2) */
+  if (m > 1.41421356237f) { m = m * 0.5f; e += 1; }
+  float t = m - 1.0f;
+  float z = t * t;
+  float p = 7.0376836292e-2f * t - 1.1514610310e-1f;
+  p = p * t + 1.1676998740e-1f;
+  p = p * t - 1.2420140846e-1f;
+  p = p * t + 1.4249322787e-1f;
+  p = p * t - 1.6668057665e-1f;
+  p = p * t + 2.0000714765e-1f;
+  p = p * t - 2.4999993993e-1f;
+  p = p * t + 3.3333331174e-1f;
+  float y = (p * t) * z - 0.5f * z;
+  return (t + y) * 1.44269504088896340736f + (float)e;
 }
 
 #endif /* GLZ_DETMATH_H */

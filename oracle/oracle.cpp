@@ -404,6 +404,8 @@ static_assert(sizeof(RTLight) == 112, "RTLight layout");
 struct Tex {
   uint32_t format, w, h;
   std::vector<uint8_t> px;
+  // mip levels 1.. (build_mip_chain below), only used by the opt-in texture level of detail
+  std::vector<Tex> mips;
 };
 
 struct Tri {   // world-space triangle for intersection
@@ -471,8 +473,9 @@ inline V4 texel(const Scene& sc, const Tex& t, int x, int y) {
 }
 inline int wrapi(int i, int n) { int r = i % n; return r < 0 ? r + n : r; }
 inline float lerp1(float a, float b, float t) { return a + (b - a) * t; }
-V4 texture_bilinear(const Scene& sc, uint32_t id, float u, float v) {
-  const Tex& t = sc.textures[id];
+V4 texture_bilinear_level(const Scene& sc, const Tex& t, float u, float v);
+V4 texture_bilinear(const Scene& sc, uint32_t id, float u, float v) { return texture_bilinear_level(sc, sc.textures[id], u, v); }
+V4 texture_bilinear_level(const Scene& sc, const Tex& t, float u, float v) {
   float fu = u * (float)t.w - 0.5f, fv = v * (float)t.h - 0.5f;
   float iu = glz_floorf(fu), iv = glz_floorf(fv);
   float ax = fu - iu, ay = fv - iv;
@@ -485,6 +488,75 @@ V4 texture_bilinear(const Scene& sc, uint32_t id, float u, float v) {
   r.z = lerp1(lerp1(a.z, b.z, ax), lerp1(c.z, d.z, ax), ay);
   r.w = lerp1(lerp1(a.w, b.w, ax), lerp1(c.w, d.w, ax), ay);
   return r;
+}
+
+// ------------------------------------------------------------------------------------------
+// Texture level of detail (build-defined and opt-in: the reference's ray-tracing stages sample level 0 [ext]).
+// Mip chain as load_texture_to_gpu builds it when the texture brings none (scene.rs:1012-1263): level l is
+// max(1, w >> l) x max(1, h >> l), 1 + floor(log2(max(w, h))) levels, each from the one before by vkCmdBlitImage(LINEAR) --
+// stated as: destination texel centre (x + 0.5) * (sw / dw) - 0.5 in the source, bilinear blend of the four texels around it
+// with clamp-to-edge, in linear light for the colour channels of sRGB textures, rounded to the nearest code (sRGB codes by
+// the threshold rule of to_srgb8 below).  Double precision, the operations in exactly this order.
+// ------------------------------------------------------------------------------------------
+uint8_t to_srgb8(float c);
+void build_mip_chain(Tex& t) {
+  t.mips.clear();
+  uint32_t levels = 1;
+  for (uint32_t m = std::max(t.w, t.h); m > 1; m >>= 1) ++levels;
+  double eotf[256];
+  for (int i = 0; i < 256; ++i) {
+    double c = i / 255.0;
+    eotf[i] = c <= 0.04045 ? c / 12.92 : pow((c + 0.055) / 1.055, 2.4);
+  }
+  const uint32_t bpp = t.format == GLZ_TEX_GRAY ? 1u : 4u;
+  const Tex* src = &t;
+  t.mips.reserve(levels);
+  for (uint32_t l = 1; l < levels; ++l) {
+    Tex d;
+    d.format = t.format;
+    d.w = std::max(1u, t.w >> l);
+    d.h = std::max(1u, t.h >> l);
+    d.px.assign((size_t)d.w * d.h * bpp, 0);
+    const double rx = (double)src->w / (double)d.w, ry = (double)src->h / (double)d.h;
+    for (uint32_t y = 0; y < d.h; ++y) {
+      double sy = ((double)y + 0.5) * ry - 0.5, fy0 = floor(sy), fy = sy - fy0;
+      long y0 = std::min<long>(std::max<long>((long)fy0, 0), (long)src->h - 1), y1 = std::min<long>(std::max<long>((long)fy0 + 1, 0), (long)src->h - 1);
+      for (uint32_t x = 0; x < d.w; ++x) {
+        double sx = ((double)x + 0.5) * rx - 0.5, fx0 = floor(sx), fx = sx - fx0;
+        long x0 = std::min<long>(std::max<long>((long)fx0, 0), (long)src->w - 1), x1 = std::min<long>(std::max<long>((long)fx0 + 1, 0), (long)src->w - 1);
+        for (uint32_t ch = 0; ch < bpp; ++ch) {
+          bool srgb = t.format == GLZ_TEX_RGBA_SRGB && ch < 3;
+          auto tx = [&](long ax, long ay) { uint8_t v = src->px[((size_t)ay * src->w + (size_t)ax) * bpp + ch]; return srgb ? eotf[v] : (double)v / 255.0; };
+          double a = tx(x0, y0), b = tx(x1, y0), c = tx(x0, y1), e = tx(x1, y1);
+          double v = (a * (1.0 - fx) + b * fx) * (1.0 - fy) + (c * (1.0 - fx) + e * fx) * fy;
+          uint8_t q;
+          if (srgb) q = to_srgb8((float)v);
+          else { int r = (int)(v * 255.0 + 0.5); q = (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r)); }
+          d.px[((size_t)y * d.w + x) * bpp + ch] = q;
+        }
+      }
+    }
+    t.mips.push_back(std::move(d));
+    src = &t.mips.back();
+  }
+}
+// LINEAR mip filtering: the two nearest levels blended (sampler of scene.rs:716-749).  lod_base = the texture-independent part of
+// the ray-cone level (raygen below); NO_LOD or a level <= 0 is texture_bilinear().
+constexpr float NO_LOD = -1e30f;
+V4 texture_lod(const Scene& sc, uint32_t id, float u, float v, float lod_base) {
+  const Tex& t = sc.textures[id];
+  if (!(lod_base > -1e29f) || t.mips.empty()) return texture_bilinear_level(sc, t, u, v);
+  float lam = lod_base + 0.5f * glz_log2f((float)t.w * (float)t.h);
+  lam = lam > 0.0f ? lam : 0.0f;
+  float top = (float)t.mips.size();
+  lam = lam < top ? lam : top;
+  float fl = glz_floorf(lam);
+  uint32_t l0 = (uint32_t)fl;
+  float frac = lam - fl;
+  V4 a = texture_bilinear_level(sc, l0 == 0 ? t : t.mips[l0 - 1], u, v);
+  if (!(frac > 0.0f)) return a;
+  V4 b = texture_bilinear_level(sc, t.mips[l0], u, v);
+  return V4{lerp1(a.x, b.x, frac), lerp1(a.y, b.y, frac), lerp1(a.z, b.z, frac), lerp1(a.w, b.w, frac)};
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1064,9 +1136,9 @@ inline V2 to_anisotropic(float a, float anis) { return V2{a * (1.0f + anis), a *
 // ------------------------------------------------------------------------------------------
 // BSDF callables (mat_*_value.rcall / mat_*_sample_value.rcall)
 // ------------------------------------------------------------------------------------------
-struct BsdfIn { V3 woW, wiW; V2 uv; ShadingSpace sh; uint32_t material_id; };
-inline V3 tex_rgb(const Scene& sc, uint32_t id, V2 uv) { V4 t = texture_bilinear(sc, id, uv.x, uv.y); return v3(t.x, t.y, t.z); }
-inline float tex_r(const Scene& sc, uint32_t id, V2 uv) { return texture_bilinear(sc, id, uv.x, uv.y).x; }
+struct BsdfIn { V3 woW, wiW; V2 uv; ShadingSpace sh; uint32_t material_id; float lod_base = NO_LOD; };
+inline V3 tex_rgb(const Scene& sc, uint32_t id, V2 uv, float lod_base = NO_LOD) { V4 t = texture_lod(sc, id, uv.x, uv.y, lod_base); return v3(t.x, t.y, t.z); }
+inline float tex_r(const Scene& sc, uint32_t id, V2 uv, float lod_base = NO_LOD) { return texture_lod(sc, id, uv.x, uv.y, lod_base).x; }
 
 // Oren-Nayar term shared by mat_uber_value.rcall:56-73 and mat_uber_sample_value.rcall:66-81
 float oren_nayar_term(float roughness, V3 wo, V3 wi) {
@@ -1106,7 +1178,7 @@ float bsdf_value(const Scene& sc, const BsdfIn& in, float rand_sample, Sp& value
     case 4: {   // mat_lambert_value.rcall:23-34
       V3 wo = to_shading_space(in.woW, in.sh), wi = to_shading_space(in.wiW, in.sh);
       float same_hemi = gstep(0.0f, wo.z * wi.z);
-      V3 tx = tex_rgb(sc, mat.diffuse, in.uv);
+      V3 tx = tex_rgb(sc, mat.diffuse, in.uv, in.lod_base);
       V3 dm = v3(mat.diffuse_mul[0], mat.diffuse_mul[1], mat.diffuse_mul[2]);
       value = from_surface_color((tx * dm) * INV_PI);
       return same_hemi * fabsf(wi.z) * INV_PI;
@@ -1119,7 +1191,7 @@ float bsdf_value(const Scene& sc, const BsdfIn& in, float rand_sample, Sp& value
       float costwo = fabsf(wo.z), costwi = fabsf(wi.z);
       if (wo.z * wi.z > 0.0f) {
         Sp F = fresnel_conductor(dot(wi, wh), mat.metal_ior, mat.metal_fresnel);
-        float rough = tex_r(sc, mat.roughness, in.uv);
+        float rough = tex_r(sc, mat.roughness, in.uv, in.lod_base);
         V2 a = to_anisotropic(rough * mat.roughness_mul, mat.anisotropy);
         float d = ggx_d(wh, a);
         float g = ggx_g(wo, wi, a);
@@ -1132,7 +1204,7 @@ float bsdf_value(const Scene& sc, const BsdfIn& in, float rand_sample, Sp& value
     }
     case 12: {  // mat_frosted_value.rcall:19-66
       V3 wo = to_shading_space(in.woW, in.sh), wi = to_shading_space(in.wiW, in.sh);
-      float rough = tex_r(sc, mat.roughness, in.uv);
+      float rough = tex_r(sc, mat.roughness, in.uv, in.lod_base);
       V2 a = to_anisotropic(rough * mat.roughness_mul, mat.anisotropy);
       bool same_hemi = wo.z * wi.z > 0.0f;
       float from_outside = gstep(0.0f, wo.z);
@@ -1163,13 +1235,13 @@ float bsdf_value(const Scene& sc, const BsdfIn& in, float rand_sample, Sp& value
     }
     default: {  // 14: mat_uber_value.rcall:20-77
       V3 wo = to_shading_space(in.woW, in.sh), wi = to_shading_space(in.wiW, in.sh);
-      float rough_tex = tex_r(sc, mat.roughness, in.uv);
+      float rough_tex = tex_r(sc, mat.roughness, in.uv, in.lod_base);
       float roughness = rough_tex * mat.roughness_mul;
       float same_hemi = gstep(0.0f, wo.z * wi.z);
       if (rand_sample < 0.5f) {
         V2 a = to_anisotropic(roughness * mat.roughness_mul, mat.anisotropy);   // Q5: roughness_mul twice
         V3 wh = normalize(wo + wi);
-        float metalness = tex_r(sc, mat.metalness, in.uv) * mat.metalness_mul;
+        float metalness = tex_r(sc, mat.metalness, in.uv, in.lod_base) * mat.metalness_mul;
         float from_outside = gstep(0.0f, wo.z);
         float etai = gmix(mat.ior_dielectric, DEFAULT_IOR, from_outside);
         float etat = gmix(DEFAULT_IOR, mat.ior_dielectric, from_outside);
@@ -1181,7 +1253,7 @@ float bsdf_value(const Scene& sc, const BsdfIn& in, float rand_sample, Sp& value
         value = sp_mul(f, term);
         return checknan(same_hemi * 0.5f * s.pdf);
       } else {
-        V3 tx = tex_rgb(sc, mat.diffuse, in.uv);
+        V3 tx = tex_rgb(sc, mat.diffuse, in.uv, in.lod_base);
         V3 dm = v3(mat.diffuse_mul[0], mat.diffuse_mul[1], mat.diffuse_mul[2]);
         float term = oren_nayar_term(roughness, wo, wi);
         value = from_surface_color((tx * dm) * term);
@@ -1212,7 +1284,7 @@ float bsdf_sample(const Scene& sc, const BsdfIn& in, V3 r, Sp& value, V3& wiW) {
       V3 wi = cosine_sample(r.x, r.y, wo.z);
       float pdf = fabsf(wi.z) * INV_PI;
       wiW = normalize(to_world_space(wi, in.sh));
-      V3 tx = tex_rgb(sc, mat.diffuse, in.uv);
+      V3 tx = tex_rgb(sc, mat.diffuse, in.uv, in.lod_base);
       V3 dm = v3(mat.diffuse_mul[0], mat.diffuse_mul[1], mat.diffuse_mul[2]);
       value = from_surface_color((tx * dm) * INV_PI);
       return pdf;
@@ -1251,7 +1323,7 @@ float bsdf_sample(const Scene& sc, const BsdfIn& in, V3 r, Sp& value, V3& wiW) {
     }
     case 10: {  // mat_metal_sample_value.rcall:21-49
       V3 wo = to_shading_space(in.woW, in.sh);
-      float rough = tex_r(sc, mat.roughness, in.uv);
+      float rough = tex_r(sc, mat.roughness, in.uv, in.lod_base);
       V2 a = to_anisotropic(rough * mat.roughness_mul, mat.anisotropy);
       V3 wh = normalize(ggx_sample_wh(wo, V2{r.x, r.y}, a));
       V3 wi = -normalize(reflect(wo, wh));
@@ -1271,7 +1343,7 @@ float bsdf_sample(const Scene& sc, const BsdfIn& in, V3 r, Sp& value, V3& wiW) {
     }
     case 12: {  // mat_frosted_sample_value.rcall:21-71
       V3 wo = to_shading_space(in.woW, in.sh);
-      float rough = tex_r(sc, mat.roughness, in.uv);
+      float rough = tex_r(sc, mat.roughness, in.uv, in.lod_base);
       V2 a = to_anisotropic(rough * mat.roughness_mul, mat.anisotropy);
       V3 wh = normalize(ggx_sample_wh(wo, V2{r.x, r.y}, a));
       float from_outside = gstep(0.0f, wo.z);
@@ -1305,14 +1377,14 @@ float bsdf_sample(const Scene& sc, const BsdfIn& in, V3 r, Sp& value, V3& wiW) {
     }
     default: {  // 14: mat_uber_sample_value.rcall:21-86
       V3 wo = to_shading_space(in.woW, in.sh);
-      float rough_tex = tex_r(sc, mat.roughness, in.uv);
+      float rough_tex = tex_r(sc, mat.roughness, in.uv, in.lod_base);
       float roughness = rough_tex * mat.roughness_mul;
       V3 wi;
       float pdf_out;
       if (r.z < 0.5f) {
         V2 a = to_anisotropic(roughness * mat.roughness_mul, mat.anisotropy);
         V3 wh = normalize(ggx_sample_wh(wo, V2{r.x, r.y}, a));
-        float metalness = tex_r(sc, mat.metalness, in.uv) * mat.metalness_mul;
+        float metalness = tex_r(sc, mat.metalness, in.uv, in.lod_base) * mat.metalness_mul;
         float from_outside = gstep(0.0f, wo.z);
         float etai = gmix(mat.ior_dielectric, DEFAULT_IOR, from_outside);
         float etat = gmix(DEFAULT_IOR, mat.ior_dielectric, from_outside);
@@ -1326,7 +1398,7 @@ float bsdf_sample(const Scene& sc, const BsdfIn& in, V3 r, Sp& value, V3& wiW) {
         pdf_out = checknan(0.5f * s.pdf);
       } else {
         wi = cosine_sample(r.x, r.y, wo.z);
-        V3 tx = tex_rgb(sc, mat.diffuse, in.uv);
+        V3 tx = tex_rgb(sc, mat.diffuse, in.uv, in.lod_base);
         V3 dm = v3(mat.diffuse_mul[0], mat.diffuse_mul[1], mat.diffuse_mul[2]);
         float term = oren_nayar_term(roughness, wo, wi);
         value = from_surface_color((tx * dm) * term);
@@ -1521,6 +1593,8 @@ struct Renderer {
   glz_camera camera;
   float push[32];
   std::vector<PTLastVertex> last;
+  std::vector<float> cone;   // ray-cone width at the ray origin, per pixel (texture LOD)
+  int lod_mode = 0;          // 0 = level 0 (the reference), 1 = ray cones
   std::vector<float> cumulative, out32;
   Xoshiro128pp rng{0};
   WorkScheduler sched;
@@ -1540,7 +1614,36 @@ struct FrameConsts { uint32_t seed; float off[2]; };
 struct HitData { V3 point, shading_normal, geometric_normal, dpdu, dpdv; V2 uv; uint32_t material_id; float distance; };
 
 // raytrace_hit.rchit:30-71
-void closest_hit_shader(const Scene& sc, const Tri& tr, float t, float u, float v, HitData& hit) {
+// Ray cones (Akenine-Moeller et al.): the cone is `width` wide where the ray meets the triangle; a texture of W x H texels over a
+// triangle with texture-space area A_uv and world area A_w is minified by sqrt(A_uv W H / A_w) texels per unit length and the
+// footprint on the surface is width / |cos|:  level = 0.5 log2(A_uv / A_w * width^2 / cos^2) + 0.5 log2(W H).
+// Edges and the geometric normal are taken to world space when the instance's transform is not the identity (bitwise).
+float ray_cone_lod_base(const Scene& sc, const Tri& tr, V3 direction, float width) {
+  const RTInstance& in = sc.instances[tr.instance];
+  uint32_t triangle_id = in.index_offset / 3 + tr.prim;
+  const uint32_t* ix = &sc.indices[triangle_id * 3];
+  const glz_vertex &a = sc.vertices[ix[0]], &b = sc.vertices[ix[1]], &c = sc.vertices[ix[2]];
+  V3 e1 = v3(b.vv[0], b.vv[1], b.vv[2]) - v3(a.vv[0], a.vv[1], a.vv[2]), e2 = v3(c.vv[0], c.vv[1], c.vv[2]) - v3(a.vv[0], a.vv[1], a.vv[2]);
+  const float* dv = &sc.derivatives[(size_t)triangle_id * 12];
+  V3 n = v3(dv[0], dv[1], dv[2]);
+  static const float ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  const float* M = sc.transforms[in.transform_id].m;
+  if (memcmp(M, ident, 64) != 0) {
+    e1 = mat_dir(M, e1);
+    e2 = mat_dir(M, e2);
+    n = mat_tdir(sc.w2o[in.transform_id].data(), n);
+  }
+  V3 cr = cross(e1, e2);
+  float area2 = sqrtf(dot(cr, cr));
+  float uva2 = fabsf((b.vt[0] - a.vt[0]) * (c.vt[1] - a.vt[1]) - (c.vt[0] - a.vt[0]) * (b.vt[1] - a.vt[1]));
+  float cosv = fabsf(dot(n, direction)) / sqrtf(dot(n, n));
+  float x = ((uva2 / area2) * (width * width)) / (cosv * cosv);
+  if (x >= 1.17549435e-38f && x <= 3.4e38f) return 0.5f * glz_log2f(x);
+  return NO_LOD;
+}
+
+// lod_base: NO_LOD (the reference: level 0) or the ray-cone level without the texture's own size term (ray_cone_lod_base below)
+void closest_hit_shader(const Scene& sc, const Tri& tr, float t, float u, float v, HitData& hit, float lod_base = NO_LOD) {
   const RTInstance& in = sc.instances[tr.instance];
   uint32_t triangle_id = in.index_offset / 3 + tr.prim;
   float b0 = 1.0f - u - v, b1 = u, b2 = v;
@@ -1557,7 +1660,7 @@ void closest_hit_shader(const Scene& sc, const Tri& tr, float t, float u, float 
   hit.material_id = in.material_id;
   const RTMaterial& mat = sc.rt_materials[hit.material_id];
   if (mat.normal != 0) {
-    V4 tx = texture_bilinear(sc, mat.normal, hit.uv.x, hit.uv.y);
+    V4 tx = texture_lod(sc, mat.normal, hit.uv.x, hit.uv.y, lod_base);
     ShadingSpace old;
     old.s = normalize(hit.dpdu);
     old.n = hit.shading_normal;
@@ -1672,12 +1775,22 @@ void raygen(Renderer& R, const FrameConsts& fc, uint32_t px, uint32_t py) {
     return;
   }
   HitData hit;
-  closest_hit_shader(sc, sc.tris[h.tri], h.t, h.u, h.v, hit);
+  float lod_base = NO_LOD, cone_w = 0.0f;
+  if (R.lod_mode != 0) {
+    // one pixel of the image plane at unit distance (perspective: the cone's spread) or in world units (orthographic: its width)
+    const float pixel = 2.0f * fabsf(R.push[16 + 5]) / (float)R.h;
+    const bool persp = R.camera.type == GLZ_CAMERA_PERSPECTIVE;
+    const float spread = persp ? pixel : 0.0f, width0 = persp ? 0.0f : pixel;
+    const bool fresh = direct_only || last.hit[3] == 0.0f;
+    cone_w = (fresh ? width0 : R.cone[path_id]) + spread * h.t;
+    lod_base = ray_cone_lod_base(sc, sc.tris[h.tri], direction, cone_w);
+  }
+  closest_hit_shader(sc, sc.tris[h.tri], h.t, h.u, h.v, hit, lod_base);
   const RTMaterial& material = sc.rt_materials[hit.material_id];
   V3 woW = -direction;
   ShadingSpace matrix = new_shading_space(hit.dpdu, hit.shading_normal);
   BsdfIn bin;
-  bin.woW = woW; bin.uv = hit.uv; bin.sh = matrix; bin.material_id = hit.material_id;
+  bin.woW = woW; bin.uv = hit.uv; bin.sh = matrix; bin.material_id = hit.material_id; bin.lod_base = lod_base;
   if (material.is_specular == 0) {                                       // :183-189, direct_light :84-117
     Sp radiance_light = sp_uniform(0.0f);
     float weight_light = 1.0f;
@@ -1724,10 +1837,12 @@ void raygen(Renderer& R, const FrameConsts& fc, uint32_t px, uint32_t py) {
   last.hit[0] = hit.point.x; last.hit[1] = hit.point.y; last.hit[2] = hit.point.z;
   last.wi[0] = wiW.x; last.wi[1] = wiW.y; last.wi[2] = wiW.z;
   if (last.hit[3] < (float)R.pt_steps) last.hit[3] += 1.0f; else last.hit[3] = 0.0f;   // :230-237
+  if (R.lod_mode != 0) R.cone[path_id] = cone_w;
 }
 
 void renderer_reset(Renderer& R) {
   R.last.assign((size_t)R.w * R.h, PTLastVertex{});
+  R.cone.assign((size_t)R.w * R.h, 0.0f);
   R.cumulative.assign((size_t)R.w * R.h * 4, 0.0f);
   R.out32.assign((size_t)R.w * R.h * 4, 0.0f);
   R.rng = Xoshiro128pp(R.seed);
@@ -1974,6 +2089,28 @@ void orc_renderer_draw(void* r, uint64_t spp) {
 void orc_renderer_read_hdr(void* r, float* out) { Renderer* R = (Renderer*)r; if (R->request_new_frame) renderer_reset(*R); memcpy(out, R->cumulative.data(), R->cumulative.size() * 4); }
 void orc_renderer_read_result(void* r, float* out) { Renderer* R = (Renderer*)r; if (R->request_new_frame) renderer_reset(*R); memcpy(out, R->out32.data(), R->out32.size() * 4); }
 uint8_t orc_to_srgb8(float c) { return to_srgb8(c); }
+// texture level of detail: 0 = level 0 (the reference), 1 = ray cones (the mip chains are built here).  Restarts.
+void orc_renderer_set_texture_lod(void* r, int mode) {
+  Renderer* R = (Renderer*)r;
+  R->lod_mode = mode;
+  if (mode != 0)
+    for (Tex& t : R->scene->textures)
+      if (t.mips.empty() && (t.w > 1 || t.h > 1)) build_mip_chain(t);
+  R->request_new_frame = true;
+}
+// one level of a texture's generated mip chain (level 0 = the texture): returns the byte count, 0 past the last level
+int64_t orc_texture_level(void* s, uint32_t texture, uint32_t level, uint8_t* out, uint32_t* w, uint32_t* h) {
+  Scene* sc = (Scene*)s;
+  if (texture >= sc->textures.size()) return 0;
+  Tex& t = sc->textures[texture];
+  if (level > 0 && t.mips.empty() && (t.w > 1 || t.h > 1)) build_mip_chain(t);
+  if (level > t.mips.size()) return 0;
+  const Tex& l = level == 0 ? t : t.mips[level - 1];
+  if (w) *w = l.w;
+  if (h) *h = l.h;
+  if (out) memcpy(out, l.px.data(), l.px.size());
+  return (int64_t)l.px.size();
+}
 // restrict rendering to `n` 64x64 tiles (row-major ids over ceil(w/64) x ceil(h/64)); n = 0 = whole frame.  Restarts.
 void orc_renderer_set_tiles(void* r, const uint32_t* tiles, uint32_t n) {
   Renderer* R = (Renderer*)r;
@@ -2028,6 +2165,7 @@ void orc_detmath(int fn, const float* x, const float* y, float* out, uint64_t n)
       case 0: out[i] = glz_sinf(x[i]); break;
       case 1: out[i] = glz_cosf(x[i]); break;
       case 2: out[i] = glz_acosf(x[i]); break;
+      case 4: out[i] = glz_log2f(x[i]); break;
       default: out[i] = glz_atan2f(y[i], x[i]); break;
     }
   }

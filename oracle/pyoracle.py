@@ -51,6 +51,8 @@ def lib():
             "orc_bsdf_sample": (None, [_P, C.c_uint32, _P, _P, _P, C.c_uint64, _P, _P, _P]),
             "orc_light_sample": (None, [_P, C.c_uint32, _P, _P, C.c_uint64, C.c_float, _P, _P, _P, _P]),
             "orc_scene_rt_light_count": (C.c_uint32, [_P]),
+            "orc_renderer_set_texture_lod": (None, [_P, C.c_int]),
+            "orc_texture_level": (C.c_int64, [_P, C.c_uint32, C.c_uint32, _P, _P, _P]),
             "orc_launch_constants": (None, [C.c_uint64, C.c_uint32, _P, _P]),
             "orc_renderer_counters": (None, [_P, _P]),
             "orc_spectrum_from_rgb": (None, [C.c_float, C.c_float, C.c_float, C.c_int, _P]),
@@ -173,6 +175,16 @@ class OracleScene:
     def n_rt_lights(self):
         return lib().orc_scene_rt_light_count(self.handle)
 
+    def texture_level(self, texture, level):
+        """pixels of one level of the generated mip chain (level 0 = the texture), or None past the last level"""
+        w, h = C.c_uint32(), C.c_uint32()
+        n = lib().orc_texture_level(self.handle, texture, level, None, C.byref(w), C.byref(h))
+        if n == 0:
+            return None
+        out = np.zeros(n, np.uint8)
+        lib().orc_texture_level(self.handle, texture, level, _ptr(out), C.byref(w), C.byref(h))
+        return out.reshape(h.value, w.value) if n == w.value * h.value else out.reshape(h.value, w.value, 4)
+
     def sky_cond(self):
         """(conditional values H x W, conditional cdf H x (W+1)) of the sky distribution"""
         n = lib().orc_read_sky_cond(self.handle, None, None)
@@ -225,6 +237,9 @@ class OracleRenderer:
 
     def update_camera(self, cam):
         lib().orc_renderer_update_camera(self.handle, C.byref(cam))
+
+    def set_texture_lod(self, mode):
+        lib().orc_renderer_set_texture_lod(self.handle, int(mode))
 
     def set_tiles(self, tiles):
         """Render only these 64x64 tiles (row-major ids); [] = the whole frame.  Pixels outside stay zero."""
@@ -286,5 +301,5 @@ def detmath(fn, x, y=None):
     x = np.ascontiguousarray(x, np.float32)
     y = np.ascontiguousarray(y if y is not None else x, np.float32)
     out = np.zeros_like(x)
-    lib().orc_detmath({"sin": 0, "cos": 1, "acos": 2, "atan2": 3}[fn], _ptr(x), _ptr(y), _ptr(out), x.size)
+    lib().orc_detmath({"sin": 0, "cos": 1, "acos": 2, "atan2": 3, "log2": 4}[fn], _ptr(x), _ptr(y), _ptr(out), x.size)
     return out

@@ -243,3 +243,50 @@ def test_oracle_tile_subset_equals_the_full_frame():
     part.set_tiles([])
     part.step(5)
     assert np.array_equal(part.read_hdr().view(np.uint32), a.view(np.uint32))
+
+
+def _host_mip_chain(fmt, px):
+    tex = abi.Texture()
+    tex.format, tex.width, tex.height, tex.mip_levels = fmt, px.shape[1], px.shape[0], 1
+    keep = np.ascontiguousarray(px)
+    tex.pixels = keep.ctypes.data
+    levels = []
+    for level in range(32):
+        w, h = C.c_uint32(), C.c_uint32()
+        n = abi.check(abi.lib().glz_host_mip_level(C.byref(tex), level, None, 0, C.byref(w), C.byref(h)))
+        if n == 0:
+            break
+        out = np.zeros(n, np.uint8)
+        abi.check(abi.lib().glz_host_mip_level(C.byref(tex), level, out.ctypes.data, n, C.byref(w), C.byref(h)))
+        levels.append(out.reshape(h.value, w.value) if fmt == abi.TEX_GRAY else out.reshape(h.value, w.value, 4))
+    return levels
+
+
+@pytest.mark.parametrize("fmt,shape", [(abi.TEX_RGBA_SRGB, (64, 64)), (abi.TEX_RGBA_NORM, (32, 128)), (abi.TEX_GRAY, (16, 16)),
+                                       (abi.TEX_RGBA_SRGB, (5, 13)), (abi.TEX_GRAY, (1, 7)), (abi.TEX_RGBA_NORM, (3, 1))])
+def test_generated_mip_chain_matches_the_oracle_and_the_blit_rule(fmt, shape):
+    """Textures that bring no mip levels get them the way load_texture_to_gpu generates them (scene.rs:1012-1263): level l from
+    level l - 1 by a LINEAR blit, max(1, w >> l) x max(1, h >> l), 1 + floor(log2(max(w, h))) levels (texture.rs:200-207).  The
+    library's chain (mipchain.h, what Scene::ensure_mips uploads) equals the oracle's restatement byte for byte; for 2:1 steps a
+    texel is the average of 2 x 2 -- in linear light for sRGB colour channels."""
+    from glaze_amd.scenes import cube_scene
+    from oracle.pyoracle import OracleScene
+    rng = np.random.default_rng(shape[0] * 131 + shape[1])
+    px = rng.integers(0, 256, shape if fmt == abi.TEX_GRAY else shape + (4,), dtype=np.uint8)
+    mine = _host_mip_chain(fmt, px)
+    assert len(mine) == 1 + int(np.floor(np.log2(max(shape))))
+    desc = cube_scene()
+    desc.textures.append((fmt, px, "t"))
+    o = OracleScene(desc)
+    tid = len(desc.textures) - 1
+    for l, m in enumerate(mine):
+        assert m.shape[:2] == (max(1, shape[0] >> l), max(1, shape[1] >> l))
+        assert np.array_equal(m, o.texture_level(tid, l)), "level %d" % l
+    assert o.texture_level(tid, len(mine)) is None
+    if shape == (64, 64):                                                   # exact halving: plain 2 x 2 averages
+        lut = np.where(np.arange(256) / 255.0 <= 0.04045, np.arange(256) / 255.0 / 12.92, ((np.arange(256) / 255.0 + 0.055) / 1.055) ** 2.4)
+        lin = lut[px[..., :3]].reshape(32, 2, 32, 2, 3).mean((1, 3))
+        enc = np.where(lin <= 0.0031308, 12.92 * lin, 1.055 * lin ** (1 / 2.4) - 0.055) * 255.0
+        assert np.abs(mine[1][..., :3].astype(np.float64) - enc).max() <= 0.5 + 1e-6          # round to nearest code
+        alpha = px[..., 3].astype(np.float64).reshape(32, 2, 32, 2).mean((1, 3))
+        assert np.abs(mine[1][..., 3] - alpha).max() <= 0.5 + 1e-9
