@@ -288,6 +288,10 @@ class RayTraceInstance:
         """'auto' (default, = 'sah': binned SAH on the GPU), 'lbvh', 'ploc' or 'sah_host' (the SAH builder's host reference) for scenes created afterwards."""
         abi.check(abi.lib().glz_instance_set_bvh_builder(self._h, {"lbvh": 0, "ploc": 1, "sah": 2, "auto": 3, "sah_host": 4}[name]))
 
+    def set_as_levels(self, mode):
+        """'auto' (two levels when instancing multiplies the triangles more than four times), 'flat' or 'two_level' for scenes created afterwards."""
+        abi.check(abi.lib().glz_instance_set_as_levels(self._h, {"auto": 0, "flat": 1, "two_level": 2}[mode]))
+
     def __del__(self):
         if getattr(self, "_h", None):
             abi.lib().glz_instance_destroy(self._h)
@@ -385,9 +389,9 @@ class RayTraceScene:
     def debug_bvh(self):
         i = self.info()
         nodes = np.zeros((max(1, i.bvh_nodes), 16), np.uint32)
-        tris = np.zeros((max(1, i.n_world_triangles), 12), np.float32)
-        abi.check(abi.lib().glz_debug_read_bvh(self._h, _ptr(nodes), i.bvh_nodes, _ptr(tris), i.n_world_triangles))
-        return nodes[:i.bvh_nodes], tris[:i.n_world_triangles]
+        tris = np.zeros((max(1, i.n_as_triangles), 12), np.float32)
+        abi.check(abi.lib().glz_debug_read_bvh(self._h, _ptr(nodes), i.bvh_nodes, _ptr(tris), i.n_as_triangles))
+        return nodes[:i.bvh_nodes], tris[:i.n_as_triangles]
 
     def __del__(self):
         if getattr(self, "_h", None):

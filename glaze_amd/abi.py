@@ -88,7 +88,8 @@ class SceneInfo(C.Structure):
                 ("n_instances", C.c_uint32), ("n_materials", C.c_uint32), ("n_lights", C.c_uint32), ("n_rt_lights", C.c_uint32),
                 ("n_textures", C.c_uint32), ("bvh_nodes", C.c_uint32), ("bvh_depth", C.c_uint32),
                 ("bvh_sah_cost", C.c_float), ("build_ms", C.c_float), ("bounds_min", C.c_float * 3), ("bounds_max", C.c_float * 3),
-                ("bvh_grid_lo", C.c_float * 3), ("bvh_grid_cell", C.c_float * 3)]
+                ("bvh_grid_lo", C.c_float * 3), ("bvh_grid_cell", C.c_float * 3),
+                ("as_levels", C.c_uint32), ("n_as_triangles", C.c_uint32), ("as_bytes", C.c_uint64)]
 
 
 class RenderStats(C.Structure):
@@ -178,6 +179,7 @@ PROTOTYPES = {
     "glz_host_mip_level": (C.c_int64, [_P, C.c_uint32, _P, C.c_int64, _P, _P]),
     "glz_renderer_set_texture_lod": (C.c_int, [_P, C.c_int]),
     "glz_debug_rccl_selftest": (C.c_int, [_P, C.c_uint64, _P]),
+    "glz_instance_set_as_levels": (C.c_int, [_P, C.c_int]),
     "glz_renderer_set_devices": (C.c_int, [_P, _P, C.c_int]),
     "glz_host_tile_owner": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, _P]),
 }

@@ -247,6 +247,12 @@ int glz_instance_set_bvh_builder(glz_instance* h, int builder) {
   return GLZ_OK;
 }
 
+int glz_instance_set_as_levels(glz_instance* h, int mode) {
+  if (!h || mode < GLZ_AS_AUTO || mode > GLZ_AS_TWO_LEVEL) return fail(GLZ_E_INVALID_INPUT, "glz_instance_set_as_levels: bad argument");
+  h->i->as_levels = mode;
+  return GLZ_OK;
+}
+
 // ---- scene -----------------------------------------------------------------------------------
 glz_scene* glz_scene_create(glz_instance* inst, glz_parsed* parsed) {
   GLZ_GUARD_BEGIN
@@ -544,7 +550,7 @@ int64_t glz_debug_read_bvh(glz_scene* h, void* nodes_out, int64_t cap_nodes, voi
   Scene* s = h->s.get();
   Error e;
   if (!hip_ok(hipSetDevice(s->instance->device), "hipSetDevice", e)) return fail(e);
-  const int64_t nn = s->info.bvh_nodes, nt = (int64_t)s->info.n_world_triangles;
+  const int64_t nn = s->info.bvh_nodes, nt = (int64_t)s->info.n_as_triangles;
   if (nodes_out && cap_nodes > 0 && nn > 0 &&
       !hip_ok(hipMemcpy(nodes_out, s->dev.bvh_nodes, (size_t)std::min(cap_nodes, nn) * sizeof(BvhNode4), hipMemcpyDeviceToHost), "read nodes", e))
     return fail(e);

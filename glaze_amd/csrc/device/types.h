@@ -132,6 +132,26 @@ struct BvhGrid {
   float inv_cell[3];
 };
 
+// Two-level structure (instanced scenes; acceleration.rs:319-345: one BLAS per mesh, a TLAS over the instances).  The bottom
+// level is the same 4-wide hierarchy over a mesh's OBJECT-space triangles (nodes, triangles and shading records of all meshes
+// concatenated; links are relative to the mesh's bases), the top level the same hierarchy over the instances' world boxes whose
+// leaves are TlasInstance records in leaf order.  Entering an instance only re-derives the grid-space ray (the object-space
+// ray is used for the box tests alone); the triangle test stays in WORLD space on the triangle transformed exactly as the
+// flattened build transforms it (k_world_tris), so a two-level scene gives bit for bit the hits of its flattened twin.
+struct alignas(16) TlasInstance {
+  float w2o[12];          // rows 0..2 of world -> object (x' = w2o[0..3] . (x, 1), ...): the ray into object space
+  float o2w[16];          // object -> world, column-major as TransformPair::o2w: the triangle into world space
+  BvhGrid grid;           // quantisation grid of the mesh's nodes (object space)
+  float pad_cells;        // slack of the object-space box tests in grid cells (rounding of the transformed ray and triangle)
+  uint32_t node_base;     // first node of the mesh in bvh_nodes
+  uint32_t tri_base;      // first triangle / shading record of the mesh in bvh_tris / shade_tris
+  uint32_t world_base;    // world triangle id of the instance's primitive 0 (tie-break key, as in the flattened build)
+  uint32_t instance;      // RTInstance index
+  uint32_t non_opaque;    // the instance's material has an opacity map (acceleration.rs:136-141)
+  uint32_t _pad[1];
+};
+static_assert(sizeof(TlasInstance) == 176, "TlasInstance is 11 x 16 bytes");
+
 // World-space triangle in BVH leaf order, 48 bytes (36 algorithmic + ids).
 struct alignas(16) BvhTri {
   float v0[3]; uint32_t world_id;   // instance-major id: tie-break key for equal t
@@ -172,6 +192,12 @@ struct DeviceScene {
   // per-leaf shading record, 8 x float4 = 128 bytes, in leaf order: VertexPacked x 3 (object space), then
   // (geometric normal.xyz, material id), (dpdu.xyz, transform id | identity flag in bit 31)
   const float4* shade_tris;
+  // two-level scenes (null / 0 otherwise): TLAS nodes, instance records in TLAS leaf order; bvh_nodes / bvh_tris / shade_tris
+  // then hold the meshes' object-space hierarchies and per-OBJECT-triangle records
+  const BvhNode4* tlas_nodes;
+  const TlasInstance* tlas_instances;
+  const uint32_t* xf_identity;     // per transform: 1 = exactly the identity
+  uint32_t two_level;
   uint32_t n_world_tris;
   uint32_t n_textures;
   uint32_t n_materials;            // RTMaterial records

@@ -21,6 +21,10 @@ struct LbvhInputs {
   uint32_t n_world;
   int builder;                 // kBvhBuilder*
   float pair_area_ratio;       // two triangles share a leaf when area(joint box) <= ratio * (area(a) + area(b)); 0 = never (k_pair_triangles)
+  // Hierarchy over GIVEN boxes instead of triangles (the instance level of a two-level structure): n_world boxes, box i becomes a
+  // one-"triangle" leaf whose BvhTri::world_id is i; vertices / indices / instances are not read.  Device pointers; null = triangles.
+  const float4* given_lo = nullptr;
+  const float4* given_hi = nullptr;
 };
 constexpr int kBvhBuilderLbvh = 0, kBvhBuilderPloc = 1, kBvhBuilderSah = 2, kBvhBuilderAuto = 3, kBvhBuilderSahHost = 4;   // = GLZ_BVH_LBVH / _PLOC / _SAH / _AUTO / _SAH_HOST
 // host side of the SAH builder (bvh_sah.cpp): binary hierarchy over n leaf boxes -> children / parent arrays
@@ -56,6 +60,7 @@ struct PathState {
   float4* imp[4];    // importance spectrum, 4 x vec4    (PTLastVertex.importance)
   float4* hit;       // t, u, v, leaf index (bits)       closest-hit record of the current launch
   float* cone;       // ray-cone width at the ray origin (texture LOD, FrameData::lod_mode; untouched when it is off)
+  uint32_t* hit_inst;// RTInstance of the closest hit (two-level scenes only: a flattened triangle record names its instance)
   // shadow-ray queue, compacted by k_shade (entry q, not pixel lid):
   float4* sh_o;      //   origin.xyz, tmax
   float4* sh_d;      //   direction.xyz, owning pixel lid (bits)

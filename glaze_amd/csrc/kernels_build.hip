@@ -1202,6 +1202,27 @@ hipError_t launch_top_table(hipStream_t st, const BvhNode4* nodes, uint32_t n_no
   return hipGetLastError();
 }
 
+// Leaves from given boxes (LbvhInputs::given_lo / given_hi): the box arrays the rest of the build works on, a placeholder
+// triangle per box that carries its index, and the bounds of the box centres.
+__global__ void __launch_bounds__(256) k_given_boxes(const float4* __restrict__ glo, const float4* __restrict__ ghi, uint32_t n, BvhTri* __restrict__ tris,
+                                                     float4* __restrict__ box_lo, float4* __restrict__ box_hi, int* __restrict__ scene_bounds) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 l = glo[i], h = ghi[i];
+  BvhTri t{};
+  t.world_id = i;
+  t.instance = i;
+  tris[i] = t;
+  box_lo[i] = make_float4(l.x, l.y, l.z, 0.0f);
+  box_hi[i] = make_float4(h.x, h.y, h.z, 0.0f);
+  const float c[3] = {0.5f * (l.x + h.x), 0.5f * (l.y + h.y), 0.5f * (l.z + h.z)};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {   // one atomic pair per box: instance counts are small next to triangle counts
+    atomicMin(&scene_bounds[k], float_to_ordered(c[k]));
+    atomicMax(&scene_bounds[3 + k], float_to_ordered(c[k]));
+  }
+}
+
 hipError_t launch_shade_records(hipStream_t st, uint32_t n, const BvhTri* tris, const RTInstance* instances, const uint32_t* indices,
                                 const float4* vertices, const float4* derivatives, const uint32_t* xf_identity, float4* out) {
   if (n == 0) return hipSuccess;
@@ -1278,11 +1299,15 @@ hipError_t build_lbvh(hipStream_t st, const LbvhInputs& in, LbvhOutputs& out) {
     GLZ_TRY(hipMemcpyAsync(scalars, init, sizeof(init), hipMemcpyHostToDevice, st));
   }
   const dim3 blk(256), grdw((nw + 255) / 256);
-  hipLaunchKernelGGL(k_world_tris, grdw, blk, 0, st, in.vertices, in.indices, in.instances, in.inst_base, in.n_instances, in.transforms,
-                     in.materials, nw, tris_unsorted, lo, hi, scalars);
+  if (in.given_lo && in.given_hi) {
+    hipLaunchKernelGGL(k_given_boxes, grdw, blk, 0, st, in.given_lo, in.given_hi, nw, tris_unsorted, lo, hi, scalars);
+  } else {
+    hipLaunchKernelGGL(k_world_tris, grdw, blk, 0, st, in.vertices, in.indices, in.instances, in.inst_base, in.n_instances, in.transforms,
+                       in.materials, nw, tris_unsorted, lo, hi, scalars);
+  }
   GLZ_TRY(hipGetLastError());
   // leaves: pairs of triangles where they qualify, single triangles otherwise
-  if (in.pair_area_ratio > 0.0f) {
+  if (in.pair_area_ratio > 0.0f && !in.given_lo) {
     for (uint32_t parity = 0; parity < 2; ++parity) {
       hipLaunchKernelGGL(k_pair_triangles, grdw, blk, 0, st, nw, parity, tris_unsorted, in.indices, in.instances, lo, hi, in.pair_area_ratio, role);
       GLZ_TRY(hipGetLastError());

@@ -67,12 +67,14 @@ struct SlabSel { uint32_t x, y, z; };   // v_perm_b32 selectors per axis
 // returns the sort key of the child: entry distance (a positive float, so its bits order like the value) with the child index in
 // the two lowest bits -- nearer first, ties (to 2 ulp) by child index; 0xFFFFFFFF for a missed child or an unused slot
 // (the slab test is symmetric in lo / hi, so an unused slot cannot be excluded through its box: its link says so)
-__device__ __forceinline__ uint32_t box_key(uint32_t wx, uint32_t wy, uint32_t wz, uint32_t link, uint32_t k, SlabSel sel, vec3 ig, vec3 cg,
+// cgn / cgf: the addends of the near and the far plane.  The flattened tracer passes the same vector twice; the two-level tracer
+// widens every box by the instance's slack (cg -+ pad * |ig|) at no extra instruction.
+__device__ __forceinline__ uint32_t box_key(uint32_t wx, uint32_t wy, uint32_t wz, uint32_t link, uint32_t k, SlabSel sel, vec3 ig, vec3 cgn, vec3 cgf,
                                             float tmin, float tmax) {
   const uint32_t px = __builtin_amdgcn_perm(wx, wx, sel.x), py = __builtin_amdgcn_perm(wy, wy, sel.y), pz = __builtin_amdgcn_perm(wz, wz, sel.z);
-  const f32x2 tx = __builtin_elementwise_fma(f32x2{(float)(px & 0xFFFFu), (float)(px >> 16)}, f32x2{ig.x, ig.x}, f32x2{cg.x, cg.x});
-  const f32x2 ty = __builtin_elementwise_fma(f32x2{(float)(py & 0xFFFFu), (float)(py >> 16)}, f32x2{ig.y, ig.y}, f32x2{cg.y, cg.y});
-  const f32x2 tz = __builtin_elementwise_fma(f32x2{(float)(pz & 0xFFFFu), (float)(pz >> 16)}, f32x2{ig.z, ig.z}, f32x2{cg.z, cg.z});
+  const f32x2 tx = __builtin_elementwise_fma(f32x2{(float)(px & 0xFFFFu), (float)(px >> 16)}, f32x2{ig.x, ig.x}, f32x2{cgn.x, cgf.x});
+  const f32x2 ty = __builtin_elementwise_fma(f32x2{(float)(py & 0xFFFFu), (float)(py >> 16)}, f32x2{ig.y, ig.y}, f32x2{cgn.y, cgf.y});
+  const f32x2 tz = __builtin_elementwise_fma(f32x2{(float)(pz & 0xFFFFu), (float)(pz >> 16)}, f32x2{ig.z, ig.z}, f32x2{cgn.z, cgf.z});
   const float t0 = fmaxf(fmaxf(tx.x, ty.x), fmaxf(tz.x, tmin));
   const float t1 = fminf(fminf(tx.y, ty.y), fminf(tz.y, tmax));
   return (t0 <= t1 && link != (uint32_t)kBvhEmptyChild) ? ((__float_as_uint(t0) & 0xFFFFFFFCu) | k) : 0xFFFFFFFFu;
@@ -125,9 +127,22 @@ __device__ __forceinline__ bool alpha_test(const DeviceScene& S, uint32_t leaf, 
   return !(texture_r(S, S.materials[material_id].opacity, vec2{tu, tv}) < 0.5f);
 }
 
+// the same for a two-level scene: the shading record is per OBJECT triangle, the material is the instance's
+__device__ __forceinline__ bool alpha_test_instance(const DeviceScene& S, uint32_t slot, uint32_t instance, float u, float v) {
+  const float4* rec = S.shade_tris + 8u * (size_t)slot;
+  const float4 a = rec[1], b = rec[3], c = rec[5];
+  const uint32_t material_id = S.instances[instance].material_id;
+  const float w = 1.0f - u - v;
+  const float tu = (a.z * w + b.z * u) + c.z * v, tv = (a.w * w + b.w * u) + c.w * v;
+  return !(texture_r(S, S.materials[material_id].opacity, vec2{tu, tv}) < 0.5f);
+}
+
 struct HitRecord {
   float t, u, v;
-  uint32_t leaf;   // index into bvh_tris, 0xFFFFFFFF = miss
+  uint32_t leaf;   // index into bvh_tris / shade_tris, 0xFFFFFFFF = miss
+  // two-level scenes only (a flattened triangle record names its instance itself):
+  uint32_t inst;       // RTInstance of the hit
+  uint32_t world_id;   // world triangle id (instance-major), the tie-break key
 };
 
 // Per-lane traversal stack: the first kLdsStack levels in LDS (column `tid` of a [level][kBlock]
@@ -368,8 +383,8 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
           w0 = np[0]; w1 = np[1]; w2 = np[2]; w3 = np[3];
         }
         if (COUNT) tally.nodes += 1;
-        uint32_t k0 = box_key(w0.x, w0.y, w0.z, w3.x, 0u, sel, ig, cg, tmin, best.t), k1 = box_key(w0.w, w1.x, w1.y, w3.y, 1u, sel, ig, cg, tmin, best.t);
-        uint32_t k2 = box_key(w1.z, w1.w, w2.x, w3.z, 2u, sel, ig, cg, tmin, best.t), k3 = box_key(w2.y, w2.z, w2.w, w3.w, 3u, sel, ig, cg, tmin, best.t);
+        uint32_t k0 = box_key(w0.x, w0.y, w0.z, w3.x, 0u, sel, ig, cg, cg, tmin, best.t), k1 = box_key(w0.w, w1.x, w1.y, w3.y, 1u, sel, ig, cg, cg, tmin, best.t);
+        uint32_t k2 = box_key(w1.z, w1.w, w2.x, w3.z, 2u, sel, ig, cg, cg, tmin, best.t), k3 = box_key(w2.y, w2.z, w2.w, w3.w, 3u, sel, ig, cg, cg, tmin, best.t);
         sort2(k0, k1); sort2(k2, k3); sort2(k0, k2); sort2(k1, k3); sort2(k1, k2);
         // The links go through LDS: picking one of four registers by a per-lane index costs 6 VALU instructions (the
         // kernel's bottleneck), an LDS read at a computed address 2 (k_trace 0.714 -> 0.691 ms).  The scratch is laid out
@@ -460,6 +475,170 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
     // ---- retire ----
     if (open && cur == kRayDone && (!SHARE || aux_out[lane] == 0)) {
       if (COUNT) tally.hits += best.leaf != kNone;
+      sink.store(ray, best);
+      open = false;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Two-level traversal (instanced scenes, DeviceScene::two_level; types.h TlasInstance): the same wave-persistent rounds over a
+// top level whose leaves are instances and, inside an instance, the mesh's object-space hierarchy.
+//   * Entering an instance (a top-level leaf, handled in the leaf phase) pushes an exit marker, takes the ray into object space
+//     ONLY to re-derive the grid-space ray of the mesh's own quantisation grid -- with every box widened by the instance's slack,
+//     folded into the slab test's addends -- and continues at the mesh's root.  Popping the marker re-derives the top-level
+//     grid-space ray from the world ray, which never leaves its registers.
+//   * A mesh leaf transforms its one or two OBJECT triangles to world space with the instance's matrix, operation for
+//     operation what k_world_tris does for the flattened build, and runs the same world-space Moeller-Trumbore test: hits
+//     (t, u, v, tie-break by world triangle id) are bit-identical to the flattened twin of the scene, whatever the hierarchy.
+// Simpler than trace_wave on purpose (no tail work sharing, no counters, no staged top): instanced scenes are about memory --
+// O(meshes + instances) instead of O(instances x triangles) -- and must not put the tuned flattened path at risk.
+// ---------------------------------------------------------------------------------------------
+constexpr int kExitInstance = 0x7FFFFFFD;   // stack marker: the entries below belong to the top level
+
+template <bool ANY, class Source, class Sink>
+__device__ __forceinline__ void trace_wave_tl(const DeviceScene& S, Source& src, Sink& sink, int* __restrict__ lds_col, int* aux, uint32_t* __restrict__ spill,
+                                              uint32_t spill_depth, uint32_t total, uint32_t wave, uint32_t n_waves) {
+  constexpr uint32_t kNone = 0xFFFFFFFFu;
+  const BvhNode4* __restrict__ nodes = S.bvh_nodes;        // top-level nodes first, the meshes' after them (TlasInstance::node_base)
+  const BvhTri* __restrict__ tris = S.bvh_tris;
+  const TlasInstance* __restrict__ instances = S.tlas_instances;
+  const int lane = threadIdx.x & 63;
+  const unsigned long long lanes_below = (1ull << lane) - 1ull;
+  uint32_t seq = 0;
+  const uint32_t first_group = wave, group_stride = n_waves, group_end = (total + 63u) / 64u;
+  bool exhausted = first_group >= group_end;
+  bool open = false;
+  int cur = kRayDone;
+  uint32_t ray = 0, nbase = 0, cur_inst = kNone;
+  vec3 o = mk3(0.0f, 0.0f, 0.0f), d = mk3(0.0f, 0.0f, 1.0f);                                  // the WORLD ray, always
+  vec3 ig = mk3(0.0f, 0.0f, 0.0f), cgn = mk3(0.0f, 0.0f, 0.0f), cgf = mk3(0.0f, 0.0f, 0.0f);    // grid-space ray of the level the lane is in
+  SlabSel sel{0x03020100u, 0x03020100u, 0x03020100u};
+  float tmin = 0.0f, tmax = 0.0f;
+  HitRecord best{0.0f, 0.0f, 0.0f, kNone, 0u, kNone};
+  Stack st{lds_col, spill + ((size_t)(blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 64u + (uint32_t)lane) * spill_depth, 0};
+  // grid-space ray for grid g from a ray (oo, dd) given in that grid's space; boxes widened by `pad` cells
+  auto set_grid_ray = [&](const float* glo, const float* gcell, const float* ginv, vec3 oo, vec3 dd, float pad) {
+    const vec3 og = mk3((oo.x - glo[0]) * ginv[0], (oo.y - glo[1]) * ginv[1], (oo.z - glo[2]) * ginv[2]);
+    ig = mk3(grid_inv_dir(dd.x) * gcell[0], grid_inv_dir(dd.y) * gcell[1], grid_inv_dir(dd.z) * gcell[2]);
+    const vec3 cg = mk3(-(og.x * ig.x), -(og.y * ig.y), -(og.z * ig.z));
+    const vec3 w = mk3(pad * fabsf(ig.x), pad * fabsf(ig.y), pad * fabsf(ig.z));
+    cgn = cg - w;
+    cgf = cg + w;
+    sel = SlabSel{ig.x < 0.0f ? 0x01000302u : 0x03020100u, ig.y < 0.0f ? 0x01000302u : 0x03020100u, ig.z < 0.0f ? 0x01000302u : 0x03020100u};
+  };
+  auto to_top_level = [&]() {
+    cur_inst = kNone;
+    nbase = 0u;
+    set_grid_ray(S.bvh_grid.lo, S.bvh_grid.cell, S.bvh_grid.inv_cell, o, d, 0.0f);
+  };
+  auto pop_next = [&]() -> int {
+    for (;;) {
+      if (st.sp == 0) return kRayDone;
+      const int v = st.pop();
+      if (v != kExitInstance) return v;
+      to_top_level();
+    }
+  };
+  for (;;) {
+    // ---- refill ----
+    const unsigned long long idle = __ballot(!open);
+    const int n_idle = __popcll(idle);
+    if (!exhausted && n_idle >= kRefill) {
+      const uint32_t mine = seq + (uint32_t)__popcll(idle & lanes_below);
+      const uint32_t next_group = first_group + (mine >> 6) * group_stride;
+      const uint32_t next_ray = next_group * 64u + (mine & 63u);
+      if (!open && next_group < group_end && next_ray < total) {
+        if (src.load(next_ray, o, d, tmin, tmax)) {
+          ray = next_ray;
+          best = HitRecord{tmax, 0.0f, 0.0f, kNone, 0u, kNone};
+          if (S.n_world_tris == 0 || !ray_is_finite(o, d)) {
+            sink.store(ray, best);
+          } else {
+            st.sp = 0;
+            to_top_level();
+            cur = 0;
+            open = true;
+          }
+        }
+      }
+      seq += (uint32_t)n_idle;
+      exhausted = first_group + (seq >> 6) * group_stride >= group_end;
+    }
+    if (__ballot(open) == 0ull) {
+      if (exhausted) break;
+      continue;
+    }
+    // ---- inner-node phase (either level) ----
+    for (;;) {
+      const bool at_node = cur >= 0 && cur < kExitInstance;
+      if (__ballot(at_node) == 0ull) break;
+      if (at_node) {
+        const u32x4* np = reinterpret_cast<const u32x4*>(nodes + nbase + (uint32_t)cur);
+        const u32x4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
+        uint32_t k0 = box_key(w0.x, w0.y, w0.z, w3.x, 0u, sel, ig, cgn, cgf, tmin, best.t), k1 = box_key(w0.w, w1.x, w1.y, w3.y, 1u, sel, ig, cgn, cgf, tmin, best.t);
+        uint32_t k2 = box_key(w1.z, w1.w, w2.x, w3.z, 2u, sel, ig, cgn, cgf, tmin, best.t), k3 = box_key(w2.y, w2.z, w2.w, w3.w, 3u, sel, ig, cgn, cgf, tmin, best.t);
+        sort2(k0, k1); sort2(k2, k3); sort2(k0, k2); sort2(k1, k3); sort2(k1, k2);
+        int* links = aux + 192 + lane;
+        links[0] = (int)w3.x; links[64] = (int)w3.y; links[128] = (int)w3.z; links[192] = (int)w3.w;
+        const int l0 = links[(k0 & 3u) * 64u], l1 = links[(k1 & 3u) * 64u], l2 = links[(k2 & 3u) * 64u], l3 = links[(k3 & 3u) * 64u];
+        if (k0 == 0xFFFFFFFFu) {
+          cur = pop_next();
+        } else {
+          if (k3 != 0xFFFFFFFFu) st.push(l3);
+          if (k2 != 0xFFFFFFFFu) st.push(l2);
+          if (k1 != 0xFFFFFFFFu) st.push(l1);
+          cur = l0;
+        }
+      }
+      if (__popcll(__ballot(cur < 0)) >= kLeafQuorum) break;
+    }
+    // ---- leaf phase: an instance to enter (top level) or triangles to test (inside an instance) ----
+    if (cur < 0) {
+      if (cur_inst == kNone) {
+        cur_inst = (uint32_t)~cur;
+        const TlasInstance* ti = instances + cur_inst;
+        const float4* q = reinterpret_cast<const float4*>(ti->w2o);
+        const float4 r0 = q[0], r1 = q[1], r2 = q[2];
+        // object-space ray (a point and a vector through the 3 x 4 matrix): only the box tests see it
+        const vec3 oo = mk3(((r0.x * o.x + r0.y * o.y) + r0.z * o.z) + r0.w, ((r1.x * o.x + r1.y * o.y) + r1.z * o.z) + r1.w, ((r2.x * o.x + r2.y * o.y) + r2.z * o.z) + r2.w);
+        const vec3 dd = mk3((r0.x * d.x + r0.y * d.y) + r0.z * d.z, (r1.x * d.x + r1.y * d.y) + r1.z * d.z, (r2.x * d.x + r2.y * d.y) + r2.z * d.z);
+        st.push(kExitInstance);
+        nbase = ti->node_base;
+        set_grid_ray(ti->grid.lo, ti->grid.cell, ti->grid.inv_cell, oo, dd, ti->pad_cells);
+        cur = 0;   // the mesh's root
+      } else {
+        const TlasInstance* ti = instances + cur_inst;
+        const uint32_t tri_base = ti->tri_base, first = (uint32_t)~cur;
+        bool finished = false;
+        for (uint32_t local = first;; ++local) {
+          const uint32_t slot = tri_base + local;
+          const uint32_t prim_flags = tris[slot].prim_flags;
+          const float4* rec = S.shade_tris + 8u * (size_t)slot;
+          const float4 pa = rec[0], pb = rec[2], pc = rec[4];
+          // world triangle exactly as k_world_tris builds it: three points through o2w, then the two edges
+          const vec3 v0 = xform_point(ti->o2w, mk3(pa.x, pa.y, pa.z)), v1 = xform_point(ti->o2w, mk3(pb.x, pb.y, pb.z)), v2 = xform_point(ti->o2w, mk3(pc.x, pc.y, pc.z));
+          const vec3 e1 = v1 - v0, e2 = v2 - v0;
+          BvhTri tr;
+          tr.v0[0] = v0.x; tr.v0[1] = v0.y; tr.v0[2] = v0.z;
+          tr.e1[0] = e1.x; tr.e1[1] = e1.y; tr.e1[2] = e1.z;
+          tr.e2[0] = e2.x; tr.e2[1] = e2.y; tr.e2[2] = e2.z;
+          float t, u, v;
+          if (ray_triangle(tr, o, d, tmin, t, u, v) && t < tmax) {
+            const uint32_t world_id = ti->world_base + (prim_flags & kTriPrimMask);
+            const bool better = best.leaf == kNone ? true : (t < best.t || (t == best.t && world_id < best.world_id));
+            if (better && (ti->non_opaque == 0u || alpha_test_instance(S, slot, ti->instance, u, v))) {
+              best = HitRecord{t, u, v, slot, ti->instance, world_id};
+              finished = ANY;
+            }
+          }
+          if (local != first || !(prim_flags & kTriHasPartner)) break;
+        }
+        cur = finished ? kRayDone : pop_next();
+      }
+    }
+    // ---- retire ----
+    if (open && cur == kRayDone) {
       sink.store(ray, best);
       open = false;
     }
@@ -656,7 +835,7 @@ __global__ void __launch_bounds__(kBlock, GLZ_SHADE_WAVES) k_shade(const LaunchA
 #endif
       key = 0u;
       if (leaf0 != 0xFFFFFFFFu) {
-        const RTMaterial* m0 = &S.materials[__float_as_uint(S.shade_tris[8u * (size_t)leaf0 + 6u].w)];
+        const RTMaterial* m0 = &S.materials[S.two_level ? S.instances[A.st.hit_inst[lid0]].material_id : __float_as_uint(S.shade_tris[8u * (size_t)leaf0 + 6u].w)];
         uint32_t light = 4u;
         if (m0->is_specular == 0 && F.lights_no != 0u) {
           uint32_t rng0 = pcg(__float_as_uint((float)F.seed) ^ pcg(__float_as_uint((float)px0.x) ^ pcg(__float_as_uint((float)px0.y))));
@@ -747,7 +926,12 @@ __global__ void __launch_bounds__(kBlock, GLZ_SHADE_WAVES) k_shade(const LaunchA
   // ---- closest-hit shader (raytrace_hit.rchit:30-71), inputs from the 128-byte per-leaf shading record ----
   const float4* rec = S.shade_tris + 8u * (size_t)leaf;
   const float4 va0 = rec[0], va1 = rec[1], vb0 = rec[2], vb1 = rec[3], vc0 = rec[4], vc1 = rec[5], dn = rec[6], du = rec[7];
-  const uint32_t material_id = __float_as_uint(dn.w), xf_bits = __float_as_uint(du.w);
+  uint32_t material_id = __float_as_uint(dn.w), xf_bits = __float_as_uint(du.w);
+  if (S.two_level) {   // the record is per OBJECT triangle: material and transform are the instance's
+    const RTInstance in = S.instances[A.st.hit_inst[lid]];
+    material_id = in.material_id;
+    xf_bits = in.transform_id | (S.xf_identity[in.transform_id] ? 0x80000000u : 0u);
+  }
   const float b0 = 1.0f - hr.y - hr.z, b1 = hr.y, b2 = hr.z;
   vec3 point = (mk3(va0.x, va0.y, va0.z) * b0 + mk3(vb0.x, vb0.y, vb0.z) * b1) + mk3(vc0.x, vc0.y, vc0.z) * b2;
   const vec2 uv = vec2{(va1.z * b0 + vb1.z * b1) + vc1.z * b2, (va1.w * b0 + vb1.w * b1) + vc1.w * b2};
@@ -997,6 +1181,40 @@ __global__ void __launch_bounds__(kBlock, GLZ_TRACE_WAVES) k_trace(const LaunchA
   }
 }
 
+// the same kernel for two-level scenes (trace_wave_tl): closest hits additionally record the instance
+struct ClosestSinkTl {
+  const LaunchArgs& A;
+  __device__ __forceinline__ void store(uint32_t lid, const HitRecord& h) {
+    A.st.hit[lid] = make_float4(h.leaf == 0xFFFFFFFFu ? INFINITY : h.t, h.u, h.v, __uint_as_float(h.leaf));
+    A.st.hit_inst[lid] = h.inst;
+  }
+};
+__global__ void __launch_bounds__(kBlock, GLZ_TRACE_WAVES) k_trace_tl(const LaunchArgs A) {
+  __shared__ int s_stack[kLdsStack * kBlock];
+  __shared__ alignas(16) int s_aux[(kBlock / 64) * kAuxPerWave];
+  int* aux = &s_aux[(threadIdx.x >> 6) * kAuxPerWave];
+  if (blockIdx.x == 0 && threadIdx.x < kQueueShards) A.st.queue_count[A.shade_set * kQueueSetWords + threadIdx.x * kCounterStride] = 0;
+  if (A.do_closest) {
+    TraceTally tally;
+    ClosestSource src{A, tally};
+    ClosestSinkTl sink{A};
+    trace_wave_tl<false>(A.scene, src, sink, &s_stack[threadIdx.x], aux, A.st.overflow, A.st.overflow_depth, A.map.n_local_pixels, wave_index(), wave_count());
+  }
+  if (A.do_shadow) {
+    const uint32_t* counts = A.st.queue_count + (A.shade_set ^ 1u) * kQueueSetWords;
+    uint32_t start[kQueueShards + 1];
+    start[0] = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kQueueShards; ++k) start[k + 1] = start[k] + counts[k * kCounterStride];
+    ShadowSource src{A, start, queue_capacity(A.map.n_local_pixels), 0u, make_float4(0.0f, 0.0f, 0.0f, 0.0f)};
+    ShadowSink sink{A, src};
+    const uint32_t n_waves = wave_count();
+    const uint32_t closest_groups = A.do_closest ? (A.map.n_local_pixels + 63u) / 64u : 0u;
+    const uint32_t wave = (wave_index() + n_waves - closest_groups % n_waves) % n_waves;
+    trace_wave_tl<true>(A.scene, src, sink, &s_stack[threadIdx.x], aux, A.st.overflow, A.st.overflow_depth, start[kQueueShards], wave, n_waves);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // image plumbing
 // ---------------------------------------------------------------------------------------------
@@ -1054,8 +1272,8 @@ struct DebugClosestSink {
   __device__ __forceinline__ void store(uint32_t i, const HitRecord& h) {
     const bool hit = h.leaf != 0xFFFFFFFFu;
     t[i] = hit ? h.t : INFINITY;
-    tri[i] = hit ? S.bvh_tris[h.leaf].world_id : 0xFFFFFFFFu;
-    inst[i] = hit ? S.bvh_tris[h.leaf].instance : 0xFFFFFFFFu;
+    tri[i] = hit ? (S.two_level ? h.world_id : S.bvh_tris[h.leaf].world_id) : 0xFFFFFFFFu;
+    inst[i] = hit ? (S.two_level ? h.inst : S.bvh_tris[h.leaf].instance) : 0xFFFFFFFFu;
     u[i] = hit ? h.u : 0.0f;
     v[i] = hit ? h.v : 0.0f;
   }
@@ -1075,7 +1293,8 @@ __global__ void __launch_bounds__(kBlock) k_debug_closest(const DeviceScene S, c
   TraceTally tally;
   DebugSource src{o, d, nullptr, tmin};
   DebugClosestSink sink{S, t, tri, inst, u, v};
-  trace_wave<false, false>(S, src, sink, &s_stack[threadIdx.x], &s_aux[(threadIdx.x >> 6) * kAuxPerWave], (LdsNodePtr)s_top, overflow, overflow_depth, n, wave_index(), wave_count(), tally);
+  if (S.two_level) trace_wave_tl<false>(S, src, sink, &s_stack[threadIdx.x], &s_aux[(threadIdx.x >> 6) * kAuxPerWave], overflow, overflow_depth, n, wave_index(), wave_count());
+  else trace_wave<false, false>(S, src, sink, &s_stack[threadIdx.x], &s_aux[(threadIdx.x >> 6) * kAuxPerWave], (LdsNodePtr)s_top, overflow, overflow_depth, n, wave_index(), wave_count(), tally);
 }
 __global__ void __launch_bounds__(kBlock) k_debug_any(const DeviceScene S, const float* __restrict__ o, const float* __restrict__ d,
                                                       const float* __restrict__ tmax, uint32_t n, float tmin, uint8_t* out, uint32_t* overflow,
@@ -1087,7 +1306,8 @@ __global__ void __launch_bounds__(kBlock) k_debug_any(const DeviceScene S, const
   TraceTally tally;
   DebugSource src{o, d, tmax, tmin};
   DebugAnySink sink{out};
-  trace_wave<true, false>(S, src, sink, &s_stack[threadIdx.x], &s_aux[(threadIdx.x >> 6) * kAuxPerWave], (LdsNodePtr)s_top, overflow, overflow_depth, n, wave_index(), wave_count(), tally);
+  if (S.two_level) trace_wave_tl<true>(S, src, sink, &s_stack[threadIdx.x], &s_aux[(threadIdx.x >> 6) * kAuxPerWave], overflow, overflow_depth, n, wave_index(), wave_count());
+  else trace_wave<true, false>(S, src, sink, &s_stack[threadIdx.x], &s_aux[(threadIdx.x >> 6) * kAuxPerWave], (LdsNodePtr)s_top, overflow, overflow_depth, n, wave_index(), wave_count(), tally);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1117,13 +1337,17 @@ static dim3 persistent_grid(Kernel kernel, uint32_t n_rays) {
 // measured 25-50 % slower for small shares: spread as wide as possible).
 uint32_t trace_grid_blocks(uint32_t n_local_pixels, bool counting) {
   const uint32_t rays = 2u * n_local_pixels;
-  return counting ? persistent_grid(k_trace<true>, rays).x : persistent_grid(k_trace<false>, rays).x;
+  // (the two-level kernel is launched with the plain kernel's grid or fewer blocks: never more lanes than spill slots)
+  const uint32_t tl = persistent_grid(k_trace_tl, rays).x;
+  const uint32_t g = counting ? persistent_grid(k_trace<true>, rays).x : persistent_grid(k_trace<false>, rays).x;
+  return std::min(g, std::max(tl, 1u));
 }
 
 hipError_t launch_trace(hipStream_t st, const LaunchArgs& a, uint32_t blocks) {
   if (a.map.n_local_pixels == 0) return hipSuccess;
   if (blocks == 0 || (uint64_t)blocks * kBlock > 2ull * a.map.n_local_pixels + kBlock) return hipErrorInvalidValue;   // the spill area holds one slot per lane of this bound
-  if (a.counters) hipLaunchKernelGGL(k_trace<true>, dim3(blocks), dim3(kBlock), 0, st, a);
+  if (a.scene.two_level) hipLaunchKernelGGL(k_trace_tl, dim3(blocks), dim3(kBlock), 0, st, a);   // instanced scenes: no work counters
+  else if (a.counters) hipLaunchKernelGGL(k_trace<true>, dim3(blocks), dim3(kBlock), 0, st, a);
   else hipLaunchKernelGGL(k_trace<false>, dim3(blocks), dim3(kBlock), 0, st, a);
   return hipGetLastError();
 }

@@ -243,6 +243,7 @@ bool Renderer::allocate(Error& err) {
     for (auto* b : bufs)
       if (!hip_ok(b->alloc((b == &c->sh_o || b == &c->sh_d || b == &c->contrib) ? n_queue : n), "alloc path state", err)) return false;
     if (!hip_ok(c->cone.alloc(n), "alloc path state", err)) return false;
+    if (!hip_ok(c->hit_inst.alloc(n), "alloc path state", err)) return false;
     c->grid = trace_grid_blocks(m.n_local_pixels, false);
     c->grid_counting = trace_grid_blocks(m.n_local_pixels, true);
     // traversal spill: one slot of `od` entries per lane of the larger of the two persistent grids
@@ -296,6 +297,7 @@ void Renderer::fill_args(const Chain& c, LaunchArgs& a) const {
   for (int q = 0; q < 4; ++q) a.st.imp[q] = c.imp[q].ptr;
   a.st.hit = c.hit.ptr;
   a.st.cone = c.cone.ptr;
+  a.st.hit_inst = c.hit_inst.ptr;
   a.st.sh_o = c.sh_o.ptr;
   a.st.sh_d = c.sh_d.ptr;
   a.st.contrib = c.contrib.ptr;

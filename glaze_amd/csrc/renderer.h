@@ -94,6 +94,7 @@ class Renderer {
     bool own_stream = false;
     DeviceBuffer<float4> ray_o, ray_d, imp[4], hit, sh_o, sh_d, contrib, cumulative, result;
     DeviceBuffer<float> cone;
+    DeviceBuffer<uint32_t> hit_inst;
     DeviceBuffer<uint32_t> overflow, queue_count;
     uint32_t grid = 0, grid_counting = 0;   // blocks of k_trace's persistent grid (plain / instrumented kernel)
     // shadow rays queued by the last launch's k_shade and not traced yet (they ride in the next launch's k_trace, or in

@@ -532,7 +532,274 @@ bool Scene::build_lights_and_sky(Error& err) {
   return true;
 }
 
+// Two-level structure (types.h TlasInstance; acceleration.rs:319-345: a BLAS per mesh, a TLAS over the instances).  The meshes'
+// hierarchies are built by the ordinary builder over ONE pseudo-instance with the identity transform (object space = its "world"),
+// the top level by the same builder over the instances' world boxes (LbvhInputs::given_lo).  Memory is O(meshes + instances).
+bool Scene::build_two_level(Error& err) {
+  hipStream_t st = instance->stream;
+  hipEvent_t e0, e1;
+  if (!hip_ok(hipEventCreate(&e0), "event", err) || !hip_ok(hipEventCreate(&e1), "event", err)) return false;
+  (void)hipEventRecord(e0, st);
+  // ---- unique meshes (index ranges) ----
+  struct MeshAs {
+    uint32_t index_offset, index_count, tri_base, node_base, n_nodes, depth;
+    BvhGrid grid;
+    float lo[3], hi[3];
+    BvhNode4* nodes;
+  };
+  std::vector<MeshAs> meshes;
+  std::vector<uint32_t> mesh_of(h_instances.size());
+  for (size_t i = 0; i < h_instances.size(); ++i) {
+    const RTInstance& in = h_instances[i];
+    size_t m = 0;
+    while (m < meshes.size() && !(meshes[m].index_offset == in.index_offset && meshes[m].index_count == in.index_count)) ++m;
+    if (m == meshes.size()) meshes.push_back(MeshAs{in.index_offset, in.index_count, 0, 0, 0, 0, BvhGrid{}, {0, 0, 0}, {0, 0, 0}, nullptr});
+    mesh_of[i] = (uint32_t)m;
+  }
+  uint64_t total_tris = 0;
+  for (MeshAs& m : meshes) {
+    m.tri_base = (uint32_t)total_tris;
+    total_tris += m.index_count / 3u;
+  }
+  if (total_tris >= 0x3FFFFFFFull) {
+    err.code = GLZ_E_UNSUPPORTED;
+    err.msg = "more than 2^30 mesh triangles";
+    return false;
+  }
+  auto free_nodes = [&]() {
+    for (MeshAs& m : meshes)
+      if (m.nodes) (void)hipFree(m.nodes);
+  };
+  const uint32_t nt = (uint32_t)total_tris;
+  d_nodes_.release();
+  if (!hip_ok(d_tris_.alloc((size_t)nt + 1), "alloc BVH triangles", err)) return false;
+  if (!hip_ok(hipMemsetAsync(d_tris_.ptr + nt, 0, sizeof(BvhTri), st), "clear BVH triangle padding", err)) return false;
+  if (!hip_ok(d_shade_tris_.alloc((size_t)nt * 8), "alloc shading records", err)) return false;
+  // helpers of the per-mesh builds: an identity transform, an opaque material (the opacity flag is per instance here)
+  DeviceBuffer<TransformPair> d_ident;
+  DeviceBuffer<RTMaterial> d_opaque;
+  DeviceBuffer<RTInstance> d_pseudo;
+  DeviceBuffer<uint32_t> d_zero, d_one;
+  {
+    TransformPair ident{};
+    for (int k = 0; k < 4; ++k) ident.o2w[5 * k] = ident.w2o[5 * k] = 1.0f;
+    RTMaterial opaque{};
+    const uint32_t zero = 0u, one = 1u;
+    if (!hip_ok(d_ident.upload(&ident, 1, st), "upload", err) || !hip_ok(d_opaque.upload(&opaque, 1, st), "upload", err) ||
+        !hip_ok(d_zero.upload(&zero, 1, st), "upload", err) || !hip_ok(d_one.upload(&one, 1, st), "upload", err) || !hip_ok(d_pseudo.alloc(1), "alloc", err))
+      return false;
+    if (!hip_ok(hipStreamSynchronize(st), "upload", err)) return false;
+  }
+  uint32_t total_nodes = 0, max_depth = 0;
+  for (MeshAs& m : meshes) {
+    const uint32_t n = m.index_count / 3u;
+    if (n == 0) continue;
+    const RTInstance pseudo{m.index_offset, m.index_count, 0u, 0u};
+    if (!hip_ok(hipMemcpyAsync(d_pseudo.ptr, &pseudo, sizeof(pseudo), hipMemcpyHostToDevice, st), "upload", err) || !hip_ok(hipStreamSynchronize(st), "upload", err)) {
+      free_nodes();
+      return false;
+    }
+    LbvhInputs in{d_vertices_.ptr, d_indices_.ptr, d_pseudo.ptr, d_zero.ptr, 1u, d_ident.ptr, d_opaque.ptr, n, instance->bvh_builder, instance->bvh_pair_area_ratio};
+    LbvhOutputs out{};
+    DeviceBuffer<BvhTri> tris;
+    if (!hip_ok(tris.alloc((size_t)n + 1), "alloc mesh triangles", err)) { free_nodes(); return false; }
+    out.tris = tris.ptr;
+    if (!hip_ok(build_lbvh(st, in, out), "mesh hierarchy", err)) { free_nodes(); return false; }
+    m.nodes = out.nodes;
+    m.n_nodes = out.n_nodes;
+    m.depth = out.depth;
+    m.grid = out.grid;
+    for (int k = 0; k < 3; ++k) { m.lo[k] = out.bounds_lo[k]; m.hi[k] = out.bounds_hi[k]; }
+    total_nodes += out.n_nodes;
+    max_depth = std::max(max_depth, out.depth);
+    // the mesh's triangles and per-object-triangle shading records go to their place in the concatenated arrays
+    if (!hip_ok(hipMemcpyAsync(d_tris_.ptr + m.tri_base, tris.ptr, sizeof(BvhTri) * n, hipMemcpyDeviceToDevice, st), "copy mesh triangles", err) ||
+        !hip_ok(launch_shade_records(st, n, tris.ptr, d_pseudo.ptr, d_indices_.ptr, d_vertices_.ptr, d_derivatives_.ptr, d_one.ptr,
+                                     d_shade_tris_.ptr + 8 * (size_t)m.tri_base), "k_shade_records", err) ||
+        !hip_ok(hipStreamSynchronize(st), "mesh hierarchy", err)) {
+      free_nodes();
+      return false;
+    }
+  }
+  // ---- instance boxes (world AABB of the mesh's root box under the instance's transform, padded) ----
+  const size_t ni = h_instances.size();
+  std::vector<float4> blo(ni), bhi(ni);
+  double wlo[3] = {1e300, 1e300, 1e300}, whi[3] = {-1e300, -1e300, -1e300};
+  for (size_t i = 0; i < ni; ++i) {
+    const MeshAs& m = meshes[mesh_of[i]];
+    const float* M = data.transforms[h_instances[i].transform_id].m;
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (int c = 0; c < 8; ++c) {
+      const double p[3] = {(c & 1) ? m.hi[0] : m.lo[0], (c & 2) ? m.hi[1] : m.lo[1], (c & 4) ? m.hi[2] : m.lo[2]};
+      for (int k = 0; k < 3; ++k) {
+        const double w = (double)M[k] * p[0] + (double)M[4 + k] * p[1] + (double)M[8 + k] * p[2] + (double)M[12 + k];
+        lo[k] = std::min(lo[k], w);
+        hi[k] = std::max(hi[k], w);
+      }
+    }
+    float l[3], h[3];
+    for (int k = 0; k < 3; ++k) {
+      if (!(lo[k] <= hi[k])) lo[k] = hi[k] = 0.0;   // a mesh without triangles / non-finite transform: a point nobody hits
+      const double pad = 1e-5 * std::max({std::fabs(lo[k]), std::fabs(hi[k]), 1e-3}) + 1e-6 * (hi[k] - lo[k]);
+      l[k] = std::nextafterf((float)(lo[k] - pad), -INFINITY);
+      h[k] = std::nextafterf((float)(hi[k] + pad), INFINITY);
+      wlo[k] = std::min(wlo[k], (double)l[k]);
+      whi[k] = std::max(whi[k], (double)h[k]);
+    }
+    blo[i] = make_float4(l[0], l[1], l[2], 0.0f);
+    bhi[i] = make_float4(h[0], h[1], h[2], 0.0f);
+  }
+  DeviceBuffer<float4> d_blo, d_bhi;
+  DeviceBuffer<BvhTri> top_tris;
+  LbvhOutputs top{};
+  if (!hip_ok(d_blo.upload(blo.data(), ni, st), "upload instance boxes", err) || !hip_ok(d_bhi.upload(bhi.data(), ni, st), "upload instance boxes", err) ||
+      !hip_ok(top_tris.alloc(ni + 1), "alloc", err) || !hip_ok(hipStreamSynchronize(st), "upload instance boxes", err)) {
+    free_nodes();
+    return false;
+  }
+  {
+    LbvhInputs in{nullptr, nullptr, nullptr, nullptr, 0u, nullptr, nullptr, (uint32_t)ni, instance->bvh_builder, 0.0f};
+    in.given_lo = d_blo.ptr;
+    in.given_hi = d_bhi.ptr;
+    top.tris = top_tris.ptr;
+    if (!hip_ok(build_lbvh(st, in, top), "instance hierarchy", err)) { free_nodes(); return false; }
+  }
+  // ---- one node array: top level first, then the meshes ----
+  for (MeshAs& m : meshes)
+    if (m.n_nodes == 0) total_nodes += 1;   // a mesh without triangles gets one node without children: entering it finds nothing
+  const uint32_t n_nodes = top.n_nodes + total_nodes;
+  if (n_nodes >= (uint32_t)kBvhTopFlag) {
+    free_nodes();
+    if (top.nodes) (void)hipFree(top.nodes);
+    err.code = GLZ_E_UNSUPPORTED;
+    err.msg = "more than 2^30 BVH nodes";
+    return false;
+  }
+  bool ok = hip_ok(d_nodes_.alloc(n_nodes), "alloc nodes", err);
+  if (ok && top.n_nodes) ok = hip_ok(hipMemcpyAsync(d_nodes_.ptr, top.nodes, sizeof(BvhNode4) * top.n_nodes, hipMemcpyDeviceToDevice, st), "copy nodes", err);
+  uint32_t at = top.n_nodes;
+  for (MeshAs& m : meshes) {
+    m.node_base = at;
+    if (ok && m.n_nodes) ok = hip_ok(hipMemcpyAsync(d_nodes_.ptr + at, m.nodes, sizeof(BvhNode4) * m.n_nodes, hipMemcpyDeviceToDevice, st), "copy nodes", err);
+    if (ok && m.n_nodes == 0) {
+      static BvhNode4 childless;
+      for (int k = 0; k < 4; ++k) {
+        childless.w[3 * k] = childless.w[3 * k + 1] = childless.w[3 * k + 2] = 65535u;
+        childless.w[12 + k] = (uint32_t)kBvhEmptyChild;
+      }
+      ok = hip_ok(hipMemcpyAsync(d_nodes_.ptr + at, &childless, sizeof(BvhNode4), hipMemcpyHostToDevice, st), "copy nodes", err);
+    }
+    at += m.n_nodes ? m.n_nodes : 1u;
+  }
+  // instance records in the top level's leaf order
+  std::vector<BvhTri> order(ni);
+  if (ok) ok = hip_ok(hipMemcpyAsync(order.data(), top_tris.ptr, sizeof(BvhTri) * ni, hipMemcpyDeviceToHost, st), "read instance order", err);
+  if (ok) ok = hip_ok(hipStreamSynchronize(st), "two-level build", err);
+  free_nodes();
+  if (top.nodes) (void)hipFree(top.nodes);
+  if (!ok) return false;
+  const double reach = std::sqrt((whi[0] - wlo[0]) * (whi[0] - wlo[0]) + (whi[1] - wlo[1]) * (whi[1] - wlo[1]) + (whi[2] - wlo[2]) * (whi[2] - wlo[2])) +
+                       std::max({std::fabs(wlo[0]), std::fabs(wlo[1]), std::fabs(wlo[2]), std::fabs(whi[0]), std::fabs(whi[1]), std::fabs(whi[2])});
+  std::vector<TlasInstance> recs(ni);
+  std::vector<TransformPair> xf(data.transforms.size());
+  for (size_t t = 0; t < xf.size(); ++t) {
+    memcpy(xf[t].o2w, data.transforms[t].m, 64);
+    host::Mat4d inv;
+    if (!host::invert(host::Mat4d::from_f32(data.transforms[t].m), inv)) inv = host::Mat4d::identity();
+    inv.to_f32(xf[t].w2o);
+  }
+  for (size_t s = 0; s < ni; ++s) {
+    const uint32_t i = order[s].world_id;   // the box this leaf was built from
+    const RTInstance& in = h_instances[i];
+    const MeshAs& m = meshes[mesh_of[i]];
+    const TransformPair& T = xf[in.transform_id];
+    TlasInstance r{};
+    for (int row = 0; row < 3; ++row)
+      for (int col = 0; col < 4; ++col) r.w2o[4 * row + col] = T.w2o[4 * col + row];   // rows of the column-major inverse
+    memcpy(r.o2w, T.o2w, 64);
+    r.grid = m.grid;
+    // slack of the object-space box tests: rounding of the transformed ray (relative to where in the world it can be) and of
+    // the triangle's world position, taken back to object units and expressed in cells of the mesh's grid; generous (x 32)
+    double wnorm = 0.0, tr = 0.0, objmax = 0.0;
+    for (int row = 0; row < 3; ++row) {
+      wnorm = std::max(wnorm, std::fabs((double)r.w2o[4 * row]) + std::fabs((double)r.w2o[4 * row + 1]) + std::fabs((double)r.w2o[4 * row + 2]));
+      tr = std::max(tr, std::fabs((double)r.w2o[4 * row + 3]));
+      objmax = std::max({objmax, std::fabs((double)m.lo[row]), std::fabs((double)m.hi[row])});
+    }
+    const double eps = 1.1920929e-7;
+    const double delta = 32.0 * eps * (wnorm * reach + tr + objmax);
+    const double cell = std::min({(double)m.grid.cell[0], (double)m.grid.cell[1], (double)m.grid.cell[2]});
+    const double pad = cell > 0.0 ? delta / cell + 1.0 : 1.0;
+    r.pad_cells = (float)std::min(pad, 65536.0);
+    r.node_base = m.node_base;
+    r.tri_base = m.tri_base;
+    r.world_base = inst_base_[i];
+    r.instance = i;
+    r.non_opaque = h_materials[in.material_id].opacity != 0 ? 1u : 0u;
+    recs[s] = r;
+  }
+  if (!hip_ok(d_tlas_instances_.upload(recs.data(), ni, st), "upload instance records", err)) return false;
+  std::vector<uint32_t> ident(data.transforms.size(), 0u);
+  for (size_t i = 0; i < ident.size(); ++i) {
+    static const float id[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    ident[i] = memcmp(data.transforms[i].m, id, 64) == 0 ? 1u : 0u;
+  }
+  if (!hip_ok(d_xf_identity_.upload(ident.data(), ident.size(), st), "upload transform flags", err)) return false;
+  if (!d_top_.ptr && !hip_ok(d_top_.alloc(kBvhTopNodes), "alloc BVH top table", err)) return false;
+  if (!hip_ok(launch_top_table(st, d_nodes_.ptr, top.n_nodes, d_top_.ptr), "k_top_table", err)) return false;   // unused by the two-level tracer, kept valid
+  (void)hipEventRecord(e1, st);
+  if (!hip_ok(hipStreamSynchronize(st), "two-level build", err)) return false;
+  float ms = 0.0f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  info.bvh_nodes = n_nodes;
+  info.bvh_depth = top.depth + max_depth;
+  info.bvh_sah_cost = top.sah;
+  info.build_ms = ms;
+  for (int k = 0; k < 3; ++k) {
+    info.bounds_min[k] = top.bounds_lo[k];
+    info.bounds_max[k] = top.bounds_hi[k];
+    info.bvh_grid_lo[k] = top.grid.lo[k];
+    info.bvh_grid_cell[k] = top.grid.cell[k];
+  }
+  // both levels' entries and one exit marker share the stack
+  const uint32_t stack_bound = 3u * (top.depth + max_depth) + 2u;
+  stack_overflow_depth = stack_bound > (uint32_t)kTraversalLdsStack ? stack_bound - kTraversalLdsStack + 1 : 1;
+  dev.bvh_nodes = d_nodes_.ptr;
+  dev.bvh_top = d_top_.ptr;
+  dev.bvh_grid = top.grid;
+  dev.bvh_tris = d_tris_.ptr;
+  dev.shade_tris = d_shade_tris_.ptr;
+  dev.tlas_nodes = d_nodes_.ptr;
+  dev.tlas_instances = d_tlas_instances_.ptr;
+  dev.xf_identity = d_xf_identity_.ptr;
+  dev.two_level = 1u;
+  dev.n_world_tris = (uint32_t)info.n_world_triangles;
+  info.as_levels = 2;
+  info.n_as_triangles = nt;
+  info.as_bytes = (uint64_t)n_nodes * sizeof(BvhNode4) + (uint64_t)(nt + 1) * sizeof(BvhTri) + (uint64_t)nt * 128u + (uint64_t)ni * sizeof(TlasInstance);
+  return true;
+}
+
 bool Scene::build_bvh(Error& err) {
+  // instanced scenes keep one hierarchy per mesh (acceleration.rs:319-345) instead of one over every instanced triangle
+  {
+    uint64_t unique = 0;
+    std::vector<std::pair<uint32_t, uint32_t>> seen;
+    for (const RTInstance& in : h_instances) {
+      const std::pair<uint32_t, uint32_t> key(in.index_offset, in.index_count);
+      if (std::find(seen.begin(), seen.end(), key) == seen.end()) {
+        seen.push_back(key);
+        unique += in.index_count / 3u;
+      }
+    }
+    const bool wanted = instance->as_levels == 2 || (instance->as_levels == 0 && unique > 0 && info.n_world_triangles > 4 * unique);
+    dev.two_level = 0u;
+    dev.tlas_nodes = nullptr;
+    dev.tlas_instances = nullptr;
+    if (wanted && info.n_world_triangles > 0) return build_two_level(err);
+  }
   hipStream_t st = instance->stream;
   const uint32_t n = (uint32_t)info.n_world_triangles;
   d_nodes_.release();
@@ -596,7 +863,11 @@ bool Scene::build_bvh(Error& err) {
     return false;
   if (!hip_ok(hipStreamSynchronize(st), "shading records", err)) return false;
   dev.shade_tris = d_shade_tris_.ptr;
+  dev.xf_identity = d_xf_identity_.ptr;
   dev.n_world_tris = n;
+  info.as_levels = 1;
+  info.n_as_triangles = n;
+  info.as_bytes = (uint64_t)out.n_nodes * sizeof(BvhNode4) + (uint64_t)(n + 1) * sizeof(BvhTri) + (uint64_t)n * 128u;
   return true;
 }
 

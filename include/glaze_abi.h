@@ -251,6 +251,15 @@ void* glz_instance_stream(const glz_instance*);
 #define GLZ_BVH_AUTO 3
 #define GLZ_BVH_SAH_HOST 4
 int glz_instance_set_bvh_builder(glz_instance*, int builder);
+/* [extension] shape of the acceleration structure of scenes created afterwards.  The reference keeps one BLAS per mesh and a TLAS
+ * over the instances (acceleration.rs:319-345).  GLZ_AS_AUTO (default): two levels when the instances hold more than four
+ * times the triangles of the meshes they share, else ONE hierarchy over world-space triangles (fastest to trace, memory
+ * grows with instances x triangles); GLZ_AS_FLAT / GLZ_AS_TWO_LEVEL force either.  Hits are bit-identical both ways: inside an
+ * instance only the box tests run in object space, the triangle test stays in world space. */
+#define GLZ_AS_AUTO 0
+#define GLZ_AS_FLAT 1
+#define GLZ_AS_TWO_LEVEL 2
+int glz_instance_set_as_levels(glz_instance*, int mode);
 
 /* ------------------------------------------------------------------------------------------
  * RayTraceScene::new(instance, parsed)   (lib/src/vulkan/scene.rs:1414-1556)
@@ -273,6 +282,9 @@ typedef struct glz_scene_info {
   float build_ms;                            /* LBVH build time on the device */
   float bounds_min[3], bounds_max[3];
   float bvh_grid_lo[3], bvh_grid_cell[3];    /* quantisation grid of the BVH node boxes: world = lo + q * cell */
+  uint32_t as_levels;                        /* 1 = one hierarchy over all instanced triangles, 2 = TLAS over per-mesh BLAS */
+  uint32_t n_as_triangles;                   /* triangle records the structure holds (= n_world_triangles when flattened) */
+  uint64_t as_bytes;                         /* device bytes of nodes + triangle records + shading records + instance records */
 } glz_scene_info;
 int glz_scene_get_info(const glz_scene*, glz_scene_info* out);
 int glz_scene_camera(const glz_scene*, glz_camera* out);
