@@ -221,6 +221,12 @@ struct TraceTally {
 constexpr bool kLdsTop = GLZ_LDS_TOP != 0;
 constexpr int kRefill = GLZ_REFILL;
 constexpr int kLeafQuorum = GLZ_LEAF_QUORUM;
+#ifndef GLZ_REFILL_ANY
+#define GLZ_REFILL_ANY GLZ_REFILL
+#endif
+#ifndef GLZ_LEAF_QUORUM_ANY
+#define GLZ_LEAF_QUORUM_ANY GLZ_LEAF_QUORUM
+#endif
 constexpr int kAuxPerWave = 3 * 64 + 4 * 64;   // work sharing (3 x 64) + the four child links of the node a lane is visiting
 
 __device__ __forceinline__ void sort2(uint32_t& a, uint32_t& b) {
@@ -275,7 +281,7 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
     // ---- refill ----
     const unsigned long long idle = __ballot(!(open || helper));
     const int n_idle = __popcll(idle);
-    if (!exhausted && n_idle >= kRefill) {
+    if (!exhausted && n_idle >= (ANY ? GLZ_REFILL_ANY : kRefill)) {
       if (COUNT && lane == 0) { tally.refill_iters += 1; tally.refill_lanes += (unsigned)n_idle; }
       const uint32_t mine = seq + (uint32_t)__popcll(idle & lanes_below);
       const uint32_t next_group = first_group + (mine >> 6) * group_stride;
@@ -413,7 +419,7 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
           cur = l0;
         }
       }
-      if (__popcll(__ballot(cur < 0)) >= kLeafQuorum) break;
+      if (__popcll(__ballot(cur < 0)) >= (ANY ? GLZ_LEAF_QUORUM_ANY : kLeafQuorum)) break;
       // (Leaving for a refill as soon as kRefill finished lanes have piled up, without a leaf phase for the few lanes that wait
       // on a leaf, measured slower: 0.588 -> 0.611 ms, node rounds 41.1 -> 42.1 of 64 lanes.  The idle lanes are not what
       // holds the utilisation down.)
