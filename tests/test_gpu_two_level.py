@@ -190,3 +190,31 @@ def test_two_level_over_real_meshes(instance):
         r.step(8)
         imgs.append(r.read_hdr())
     assert np.array_equal(bits(imgs[0]), bits(imgs[1]))
+
+
+def test_two_level_degenerate_instances(instance):
+    """A zero-scale instance (singular transform: the inverse falls back to the identity), one with NaN in its matrix, one far outside
+    the room, and a scene with ONE instance forced to two levels: same hits as the flattened build, nothing walks off."""
+    desc = instanced_cubes(12, seed=21)
+    t = desc.transforms.copy()
+    t[3] = col_major(np.diag([0.0, 0.0, 0.0, 1.0]))
+    t[4] = col_major(np.diag([0.1, np.nan, 0.1, 1.0]))
+    far = np.eye(4); far[:3, 3] = (1e6, -1e6, 3e5); far[0, 0] = far[1, 1] = far[2, 2] = 1e-3
+    t[5] = col_major(far)
+    desc.transforms = t
+    flat, two = scenes(instance, desc)
+    rng = np.random.default_rng(22)
+    n = 50_000
+    o = rng.uniform(-0.9, 0.9, (n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    a, b = flat.debug_trace_closest(o, d), two.debug_trace_closest(o, d)
+    for x, y in zip(a, b):
+        assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
+    assert not np.isin(a[2], [3, 4]).any()                                          # the degenerate instances are never hit
+    single = cube_scene()
+    flat, two = scenes(instance, single)
+    assert two.info().as_levels == 2 and two.info().n_as_triangles == 12
+    a, b = flat.debug_trace_closest(o, d), two.debug_trace_closest(o, d)
+    for x, y in zip(a, b):
+        assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
