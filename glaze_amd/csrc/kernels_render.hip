@@ -263,6 +263,11 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
   uint32_t first_group = wave, group_stride = n_waves, group_end = (total + 63u) / 64u;
   // (giving each XCD one contiguous eighth of the groups -- rays of one image band per L2 -- measured 5 % slower: the bands
   // differ in cost and the static split loses more to imbalance than the L2 gains)
+  // (Drawing the groups from a counter instead of the stride: the waves of a full-frame launch end between 257 and 406 us of a
+  // 410 us closest-hit phase -- 5 or 6 groups each -- tools/gpu_wave_times.py.  One counter: 577 us, device-scope atomics on one
+  // address are served at ~15 ns each; 32 interleaved counters: the ends move together, 306 - 400 us, but every wave gets slower --
+  // neighbouring groups no longer run on one CU at one time -- 0.572 ms per k_trace either way; whole rounds by the stride and
+  // only the last partial round drawn: 0.601 ms.  A wave's last group runs without refills behind it whoever hands it out.)
   bool exhausted = first_group >= group_end;                // wave-uniform
   // per-lane ray state
   bool open = false;                                        // a ray of this lane's own is in flight and its result has not been stored
@@ -691,6 +696,9 @@ struct ClosestSource {
   const LaunchArgs& A;
   TraceTally& tally;
   // ray generation / resume for local pixel `lid`
+  // (Dealing the rays of a group from 4, 16 or 64 different tiles instead of one row of one tile -- to level the waves of a small
+  // share, whose ends spread from 60 (median) to 105 us -- changes nothing: the spread is not regional, a wave is as slow as the
+  // longest dependent chain among its 64 rays.  Median and end of the phase moved by +3 ... +8 % with the coherence lost.)
   __device__ __forceinline__ bool load(uint32_t lid, vec3& origin, vec3& direction, float& tmin, float& tmax) {
     const PixelId px = pixel_of(A.map, lid);
     if (!px.active) return false;
@@ -1149,12 +1157,20 @@ __device__ __forceinline__ void stage_top(const DeviceScene& S, uint4* s_top) {
   }
 }
 
+#ifdef GLZ_WAVE_TIMES   // tuning builds only (tools/build_variant.sh, tools/gpu_wave_times.py): when each wave of the last k_trace with closest-hit rays started, finished those and ended
+__device__ unsigned long long g_wave_times[3 * 8192];
+#define GLZ_WAVE_STAMP(k) do { if (A.do_closest && (threadIdx.x & 63) == 0 && wave_index() < 8192u) g_wave_times[3 * wave_index() + (k)] = wall_clock64(); } while (0)
+#else
+#define GLZ_WAVE_STAMP(k) do { } while (0)
+#endif
+
 template <bool COUNT>
 __global__ void __launch_bounds__(kBlock, GLZ_TRACE_WAVES) k_trace(const LaunchArgs A) {
   __shared__ int s_stack[kLdsStack * kBlock];
   __shared__ alignas(16) int s_aux[(kBlock / 64) * kAuxPerWave];
   __shared__ uint4 s_top[kLdsTop ? kBvhTopNodes * 4 : 1];
   static_assert(kBvhTopNodes * 4 <= kBlock, "stage_top copies one 16-byte piece per thread");
+  GLZ_WAVE_STAMP(0);
   stage_top(A.scene, s_top);
   int* aux = &s_aux[(threadIdx.x >> 6) * kAuxPerWave];
   if (blockIdx.x == 0 && threadIdx.x < kQueueShards) A.st.queue_count[A.shade_set * kQueueSetWords + threadIdx.x * kCounterStride] = 0;
@@ -1166,6 +1182,7 @@ __global__ void __launch_bounds__(kBlock, GLZ_TRACE_WAVES) k_trace(const LaunchA
                              wave_count(), tally);
     if (COUNT) flush_counters(A.counters, false, tally);
   }
+  GLZ_WAVE_STAMP(1);
   if (A.do_shadow) {
     // prefix sums of the eight shard counts (final: the k_shade that filled them has completed)
     const uint32_t* counts = A.st.queue_count + (A.shade_set ^ 1u) * kQueueSetWords;
@@ -1185,6 +1202,7 @@ __global__ void __launch_bounds__(kBlock, GLZ_TRACE_WAVES) k_trace(const LaunchA
     trace_wave<true, COUNT>(A.scene, src, sink, &s_stack[threadIdx.x], aux, (LdsNodePtr)s_top, A.st.overflow, A.st.overflow_depth, start[kQueueShards], wave, n_waves, tally);
     if (COUNT) flush_counters(A.counters, true, tally);
   }
+  GLZ_WAVE_STAMP(2);
 }
 
 // the same kernel for two-level scenes (trace_wave_tl): closest hits additionally record the instance
@@ -1390,3 +1408,10 @@ hipError_t launch_debug_any(hipStream_t st, const DeviceScene& scene, const floa
 }
 
 }  // namespace glz
+
+#ifdef GLZ_WAVE_TIMES
+extern "C" int glz_debug_wave_times(unsigned long long* out, int n_waves) {
+  if (n_waves > 8192) n_waves = 8192;
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(glz::g_wave_times), sizeof(unsigned long long) * 3 * (size_t)n_waves);
+}
+#endif

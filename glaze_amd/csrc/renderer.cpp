@@ -201,7 +201,9 @@ Renderer::~Renderer() {
 // Number of concurrent chains, from the pixels this rank owns (measured on the atrium, ms per launch of one rank's share of
 // a 1080p frame with 1 / 2 / 3 chains): 2.07 M pixels 1.29 / 1.36 / 1.42, 1.04 M 0.72 / 0.72 / 0.71, 518 k 0.43 / 0.38 / 0.38,
 // 259 k 0.26 / 0.25 / 0.23.  A launch over a million pixels is throughput bound and wants one chain; below that it is bound
-// by the latency of its longest rays and concurrent chains fill the machine.  Four chains were slower again (host enqueue).
+// by the latency of its longest rays and concurrent chains fill the machine.  Four chains are slower again: HIP maps streams
+// onto GPU_MAX_HW_QUEUES (4) hardware queues and the fourth chain shares one (0.154 -> 0.252 ms for a 1/8 share; with 8 queues
+// 0.19 ms, tools/gpu_chain_sweep.py) -- and no number of chains goes below one chain's own step, which lasts as long as its slowest wave.
 uint32_t Renderer::chains_for(uint32_t w, uint32_t h, uint32_t rank, uint32_t world, uint32_t wanted) {
   const uint32_t tiles_x = (w + kTile - 1) / kTile, tiles_y = (h + kTile - 1) / kTile, tiles = tiles_x * tiles_y;
   const uint32_t local_tiles = tiles > rank ? (tiles - rank + world - 1) / world : 0;
