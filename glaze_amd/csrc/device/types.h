@@ -142,7 +142,7 @@ struct alignas(16) TlasInstance {
   float w2o[12];          // rows 0..2 of world -> object (x' = w2o[0..3] . (x, 1), ...): the ray into object space
   float o2w[16];          // object -> world, column-major as TransformPair::o2w: the triangle into world space
   BvhGrid grid;           // quantisation grid of the mesh's nodes (object space)
-  float pad_cells;        // slack of the object-space box tests in grid cells (rounding of the transformed ray and triangle)
+  float slack;            // slack of the object-space box tests in object units (rounding of the transformed ray and triangle); every box is widened by slack / cell + 1 cells per axis
   uint32_t node_base;     // first node of the mesh in bvh_nodes
   uint32_t tri_base;      // first triangle / shading record of the mesh in bvh_tris / shade_tris
   uint32_t world_base;    // world triangle id of the instance's primitive 0 (tie-break key, as in the flattened build)

@@ -106,7 +106,7 @@ struct LaunchArgs {
 constexpr uint32_t kTraceBlock = 256;          // threads per block of the render kernels (4 waves)
 constexpr uint32_t kQueueSetWords = 8 * 32;   // 8 shard counters, 128 bytes apart
 
-uint32_t trace_grid_blocks(uint32_t n_local_pixels, bool counting);   // persistent grid of k_trace (device must be current)
+uint32_t trace_grid_blocks(uint32_t n_local_pixels, bool counting, bool two_level);   // persistent grid of k_trace / k_trace_tl (device must be current)
 hipError_t launch_trace(hipStream_t st, const LaunchArgs& a, uint32_t blocks);
 hipError_t launch_shade(hipStream_t st, const LaunchArgs& a);
 // scatter the tile-major cumulative / result images into full-frame row-major RGBA32F buffers

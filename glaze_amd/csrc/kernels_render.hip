@@ -241,6 +241,12 @@ __device__ __forceinline__ void sort2(uint32_t& a, uint32_t& b) {
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(3))) u32x4* LdsNodePtr;
 
+#ifdef GLZ_WAVE_TIMES
+__device__ unsigned long long g_wave_times[3 * 8192];
+__device__ unsigned int g_wave_stats[8 * 8192];   // closest-hit phase: rounds, node iterations, lanes in them, leaf iterations, lanes in them, rounds with helpers
+__device__ unsigned long long g_tl_stats[8];      // two-level tracer, summed over lanes: rays, top-level node visits, mesh node visits, instances entered, triangle tests, node iterations, leaf iterations
+#endif
+
 template <bool ANY, bool COUNT, class Source, class Sink>
 __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Sink& sink, int* __restrict__ lds_col, int* aux, LdsNodePtr top_lds,
                                            uint32_t* __restrict__ spill, uint32_t spill_depth, uint32_t total, uint32_t wave, uint32_t n_waves, TraceTally& tally) {
@@ -252,8 +258,9 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
   const int lane = threadIdx.x & 63;
   const unsigned long long lanes_below = (1ull << lane) - 1ull;
   int* aux_out = aux;          // [owner lane] helpers currently working for that lane's ray
-  int* aux_pair = aux + 64;    // [k] lane of the k-th donor of this round
+  uint32_t* aux_t = reinterpret_cast<uint32_t*>(aux) + 64;   // [owner lane] bits of the smallest hit distance the ray's owner or any helper has found (tail only)
   int* aux_sb = aux + 128;     // [lane] lowest LDS stack level that may still hold a live entry
+  int* aux_pair = aux + 192;   // [k] lane of the k-th donor of this round; shares its words with the child links, which only live inside a node visit
   if (SHARE) {
     aux_out[lane] = 0;
     aux_sb[lane] = 0;
@@ -282,7 +289,15 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
   uint32_t best_id = kNone;
   // the spill area is indexed by the physical lane slot of the grid (a lane traverses one ray or subtree at a time)
   Stack st{lds_col, spill + ((size_t)(blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 64u + (uint32_t)lane) * spill_depth, 0};
+#ifdef GLZ_WAVE_TIMES
+  unsigned int wt_rounds = 0, wt_node_iters = 0, wt_node_lanes = 0, wt_leaf_iters = 0, wt_leaf_lanes = 0, wt_helper_rounds = 0, wt_wait_rounds = 0;
+#endif
   for (;;) {
+#ifdef GLZ_WAVE_TIMES
+    wt_rounds += 1;
+    wt_helper_rounds += __ballot(helper) != 0ull;
+    wt_wait_rounds += __ballot(open && cur == kRayDone) != 0ull && __ballot(open && cur != kRayDone) == 0ull;   // owners only waiting for helpers
+#endif
     // ---- refill ----
     const unsigned long long idle = __ballot(!(open || helper));
     const int n_idle = __popcll(idle);
@@ -313,6 +328,10 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
       }
       seq += (uint32_t)n_idle;
       exhausted = first_group + (seq >> 6) * group_stride >= group_end;
+      // The tail begins: from here on a ray may be worked on by several lanes, which tell each other the closest distance found so
+      // far through aux_t -- a helper walking a far subtree with the bound it was handed at the start would go through all of
+      // it after the owner has long found something nearer, and the owner cannot retire before its helpers are back.
+      if (SHARE && !ANY && exhausted && open) aux_t[lane] = __float_as_uint(best.t);
     }
     if (__ballot(open || helper) == 0ull) {
       if (exhausted) break;
@@ -380,6 +399,9 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
       const unsigned long long m_node = __ballot(at_node);
       if (m_node == 0ull) break;
       if (COUNT && lane == 0) { tally.node_iters += 1; tally.node_lanes += (unsigned)__popcll(m_node); }
+#ifdef GLZ_WAVE_TIMES
+      wt_node_iters += 1; wt_node_lanes += (unsigned)__popcll(m_node);
+#endif
       if (at_node) {
         // 64-byte node = 4 x dwordx4: four child boxes in 16-bit grid coordinates (the ray was mapped into grid units at
         // refill) and four links.  Children are entered nearest first; the others are pushed farthest first.
@@ -394,8 +416,10 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
           w0 = np[0]; w1 = np[1]; w2 = np[2]; w3 = np[3];
         }
         if (COUNT) tally.nodes += 1;
-        uint32_t k0 = box_key(w0.x, w0.y, w0.z, w3.x, 0u, sel, ig, cg, cg, tmin, best.t), k1 = box_key(w0.w, w1.x, w1.y, w3.y, 1u, sel, ig, cg, cg, tmin, best.t);
-        uint32_t k2 = box_key(w1.z, w1.w, w2.x, w3.z, 2u, sel, ig, cg, cg, tmin, best.t), k3 = box_key(w2.y, w2.z, w2.w, w3.w, 3u, sel, ig, cg, cg, tmin, best.t);
+        float bound = best.t;
+        if (SHARE && !ANY && exhausted) bound = fminf(bound, __uint_as_float(aux_t[helper ? (int)ray : lane]));   // positive floats order like their bits
+        uint32_t k0 = box_key(w0.x, w0.y, w0.z, w3.x, 0u, sel, ig, cg, cg, tmin, bound), k1 = box_key(w0.w, w1.x, w1.y, w3.y, 1u, sel, ig, cg, cg, tmin, bound);
+        uint32_t k2 = box_key(w1.z, w1.w, w2.x, w3.z, 2u, sel, ig, cg, cg, tmin, bound), k3 = box_key(w2.y, w2.z, w2.w, w3.w, 3u, sel, ig, cg, cg, tmin, bound);
         sort2(k0, k1); sort2(k2, k3); sort2(k0, k2); sort2(k1, k3); sort2(k1, k2);
         // The links go through LDS: picking one of four registers by a per-lane index costs 6 VALU instructions (the
         // kernel's bottleneck), an LDS read at a computed address 2 (k_trace 0.714 -> 0.691 ms).  The scratch is laid out
@@ -434,6 +458,9 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
       const unsigned long long m_leaf = __ballot(cur < 0);
       if (lane == 0 && m_leaf) { tally.leaf_iters += 1; tally.leaf_lanes += (unsigned)__popcll(m_leaf); }
     }
+#ifdef GLZ_WAVE_TIMES
+    { const unsigned long long ml = __ballot(cur < 0); if (ml) { wt_leaf_iters += 1; wt_leaf_lanes += (unsigned)__popcll(ml); } }
+#endif
     if (cur < 0) {
       // A leaf is one triangle or two adjacent ones (kTriHasPartner on the first).  The partner is fetched after the
       // first test: six 16-byte loads in flight at once cost 20 more spilled registers (0.64 -> 0.77 ms).
@@ -454,6 +481,7 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
             best = HitRecord{t, u, v, slot};
             best_id = tr.world_id;
             finished = ANY;
+            if (SHARE && !ANY && exhausted) atomicMin(&aux_t[helper ? (int)ray : lane], __float_as_uint(t));
           }
         }
         if (slot != leaf || !(tr.prim_flags & kTriHasPartner)) break;
@@ -490,6 +518,12 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
       open = false;
     }
   }
+#ifdef GLZ_WAVE_TIMES
+  if (!ANY && lane == 0 && wave < 8192u) {
+    unsigned int* o = g_wave_stats + 8 * wave;
+    o[0] = wt_rounds; o[1] = wt_node_iters; o[2] = wt_node_lanes; o[3] = wt_leaf_iters; o[4] = wt_leaf_lanes; o[5] = wt_helper_rounds; o[6] = wt_wait_rounds;
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -528,20 +562,25 @@ __device__ __forceinline__ void trace_wave_tl(const DeviceScene& S, Source& src,
   float tmin = 0.0f, tmax = 0.0f;
   HitRecord best{0.0f, 0.0f, 0.0f, kNone, 0u, kNone};
   Stack st{lds_col, spill + ((size_t)(blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 64u + (uint32_t)lane) * spill_depth, 0};
-  // grid-space ray for grid g from a ray (oo, dd) given in that grid's space; boxes widened by `pad` cells
-  auto set_grid_ray = [&](const float* glo, const float* gcell, const float* ginv, vec3 oo, vec3 dd, float pad) {
+  // grid-space ray for grid g from a ray (oo, dd) given in that grid's space; boxes widened by `slack` (a length in that space)
+  // plus `cells` cells on every side
+  auto set_grid_ray = [&](const float* glo, const float* gcell, const float* ginv, vec3 oo, vec3 dd, float slack, float cells) {
     const vec3 og = mk3((oo.x - glo[0]) * ginv[0], (oo.y - glo[1]) * ginv[1], (oo.z - glo[2]) * ginv[2]);
     ig = mk3(grid_inv_dir(dd.x) * gcell[0], grid_inv_dir(dd.y) * gcell[1], grid_inv_dir(dd.z) * gcell[2]);
     const vec3 cg = mk3(-(og.x * ig.x), -(og.y * ig.y), -(og.z * ig.z));
-    const vec3 w = mk3(pad * fabsf(ig.x), pad * fabsf(ig.y), pad * fabsf(ig.z));
+    const vec3 pad = mk3(fminf(slack * ginv[0] + cells, 65536.0f), fminf(slack * ginv[1] + cells, 65536.0f), fminf(slack * ginv[2] + cells, 65536.0f));
+    const vec3 w = mk3(pad.x * fabsf(ig.x), pad.y * fabsf(ig.y), pad.z * fabsf(ig.z));
     cgn = cg - w;
     cgf = cg + w;
     sel = SlabSel{ig.x < 0.0f ? 0x01000302u : 0x03020100u, ig.y < 0.0f ? 0x01000302u : 0x03020100u, ig.z < 0.0f ? 0x01000302u : 0x03020100u};
   };
+#ifdef GLZ_WAVE_TIMES
+  unsigned long long tl_rays = 0, tl_top = 0, tl_mesh = 0, tl_enter = 0, tl_tris = 0, tl_niter = 0, tl_liter = 0;
+#endif
   auto to_top_level = [&]() {
     cur_inst = kNone;
     nbase = 0u;
-    set_grid_ray(S.bvh_grid.lo, S.bvh_grid.cell, S.bvh_grid.inv_cell, o, d, 0.0f);
+    set_grid_ray(S.bvh_grid.lo, S.bvh_grid.cell, S.bvh_grid.inv_cell, o, d, 0.0f, 0.0f);
   };
   auto pop_next = [&]() -> int {
     for (;;) {
@@ -570,6 +609,9 @@ __device__ __forceinline__ void trace_wave_tl(const DeviceScene& S, Source& src,
             to_top_level();
             cur = 0;
             open = true;
+#ifdef GLZ_WAVE_TIMES
+            tl_rays += 1;
+#endif
           }
         }
       }
@@ -584,6 +626,10 @@ __device__ __forceinline__ void trace_wave_tl(const DeviceScene& S, Source& src,
     for (;;) {
       const bool at_node = cur >= 0 && cur < kExitInstance;
       if (__ballot(at_node) == 0ull) break;
+#ifdef GLZ_WAVE_TIMES
+      if (lane == 0) tl_niter += 1;
+      if (at_node) { if (cur_inst == kNone) tl_top += 1; else tl_mesh += 1; }
+#endif
       if (at_node) {
         const u32x4* np = reinterpret_cast<const u32x4*>(nodes + nbase + (uint32_t)cur);
         const u32x4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
@@ -605,6 +651,10 @@ __device__ __forceinline__ void trace_wave_tl(const DeviceScene& S, Source& src,
       if (__popcll(__ballot(cur < 0)) >= kLeafQuorum) break;
     }
     // ---- leaf phase: an instance to enter (top level) or triangles to test (inside an instance) ----
+#ifdef GLZ_WAVE_TIMES
+    if (lane == 0 && __ballot(cur < 0) != 0ull) tl_liter += 1;
+    if (cur < 0) { if (cur_inst == kNone) tl_enter += 1; else tl_tris += 1; }
+#endif
     if (cur < 0) {
       if (cur_inst == kNone) {
         cur_inst = (uint32_t)~cur;
@@ -616,7 +666,7 @@ __device__ __forceinline__ void trace_wave_tl(const DeviceScene& S, Source& src,
         const vec3 dd = mk3((r0.x * d.x + r0.y * d.y) + r0.z * d.z, (r1.x * d.x + r1.y * d.y) + r1.z * d.z, (r2.x * d.x + r2.y * d.y) + r2.z * d.z);
         st.push(kExitInstance);
         nbase = ti->node_base;
-        set_grid_ray(ti->grid.lo, ti->grid.cell, ti->grid.inv_cell, oo, dd, ti->pad_cells);
+        set_grid_ray(ti->grid.lo, ti->grid.cell, ti->grid.inv_cell, oo, dd, ti->slack, 1.0f);
         cur = 0;   // the mesh's root
       } else {
         const TlasInstance* ti = instances + cur_inst;
@@ -654,6 +704,12 @@ __device__ __forceinline__ void trace_wave_tl(const DeviceScene& S, Source& src,
       open = false;
     }
   }
+#ifdef GLZ_WAVE_TIMES
+  if (!ANY) {
+    atomicAdd(&g_tl_stats[0], tl_rays); atomicAdd(&g_tl_stats[1], tl_top); atomicAdd(&g_tl_stats[2], tl_mesh); atomicAdd(&g_tl_stats[3], tl_enter);
+    atomicAdd(&g_tl_stats[4], tl_tris); atomicAdd(&g_tl_stats[5], tl_niter); atomicAdd(&g_tl_stats[6], tl_liter);
+  }
+#endif
 }
 
 __device__ __forceinline__ void flush_counters(TraceCounters* c, bool shadow, TraceTally t) {
@@ -1158,7 +1214,6 @@ __device__ __forceinline__ void stage_top(const DeviceScene& S, uint4* s_top) {
 }
 
 #ifdef GLZ_WAVE_TIMES   // tuning builds only (tools/build_variant.sh, tools/gpu_wave_times.py): when each wave of the last k_trace with closest-hit rays started, finished those and ended
-__device__ unsigned long long g_wave_times[3 * 8192];
 #define GLZ_WAVE_STAMP(k) do { if (A.do_closest && (threadIdx.x & 63) == 0 && wave_index() < 8192u) g_wave_times[3 * wave_index() + (k)] = wall_clock64(); } while (0)
 #else
 #define GLZ_WAVE_STAMP(k) do { } while (0)
@@ -1213,7 +1268,10 @@ struct ClosestSinkTl {
     A.st.hit_inst[lid] = h.inst;
   }
 };
-__global__ void __launch_bounds__(kBlock, GLZ_TRACE_WAVES) k_trace_tl(const LaunchArgs A) {
+#ifndef GLZ_TRACE_TL_WAVES
+#define GLZ_TRACE_TL_WAVES 4   // the instance entry and the on-the-fly world triangle need 153 VGPRs: at 6 waves per SIMD 201 of them live in scratch (forest x2000, tools/gpu_two_level_timing.py: 4.06 ms per launch), at 4 waves 34 (1.44 ms), at 3 none (1.45 ms)
+#endif
+__global__ void __launch_bounds__(kBlock, GLZ_TRACE_TL_WAVES) k_trace_tl(const LaunchArgs A) {
   __shared__ int s_stack[kLdsStack * kBlock];
   __shared__ alignas(16) int s_aux[(kBlock / 64) * kAuxPerWave];
   int* aux = &s_aux[(threadIdx.x >> 6) * kAuxPerWave];
@@ -1359,12 +1417,10 @@ static dim3 persistent_grid(Kernel kernel, uint32_t n_rays) {
 // answer to every launch_trace; needs the device current).  Up to one closest-hit and one shadow ray per pixel: a small
 // tile share still gets a wave per 64-ray group of either kind (fewer, longer-lived waves -- 2 to 4 groups per wave --
 // measured 25-50 % slower for small shares: spread as wide as possible).
-uint32_t trace_grid_blocks(uint32_t n_local_pixels, bool counting) {
-  const uint32_t rays = 2u * n_local_pixels;
-  // (the two-level kernel is launched with the plain kernel's grid or fewer blocks: never more lanes than spill slots)
-  const uint32_t tl = persistent_grid(k_trace_tl, rays).x;
-  const uint32_t g = counting ? persistent_grid(k_trace<true>, rays).x : persistent_grid(k_trace<false>, rays).x;
-  return std::min(g, std::max(tl, 1u));
+uint32_t trace_grid_blocks(uint32_t n_local_pixels, bool counting, bool two_level) {
+  uint32_t rays = 2u * n_local_pixels;
+  if (two_level) return persistent_grid(k_trace_tl, rays).x;   // compiled for fewer waves per SIMD: its own residency
+  return counting ? persistent_grid(k_trace<true>, rays).x : persistent_grid(k_trace<false>, rays).x;
 }
 
 hipError_t launch_trace(hipStream_t st, const LaunchArgs& a, uint32_t blocks) {
@@ -1413,5 +1469,17 @@ hipError_t launch_debug_any(hipStream_t st, const DeviceScene& scene, const floa
 extern "C" int glz_debug_wave_times(unsigned long long* out, int n_waves) {
   if (n_waves > 8192) n_waves = 8192;
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(glz::g_wave_times), sizeof(unsigned long long) * 3 * (size_t)n_waves);
+}
+extern "C" int glz_debug_tl_stats(unsigned long long* out, int reset) {
+  int e = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(glz::g_tl_stats), sizeof(unsigned long long) * 8);
+  if (reset && e == 0) {
+    const unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    e = (int)hipMemcpyToSymbol(HIP_SYMBOL(glz::g_tl_stats), zero, sizeof(zero));
+  }
+  return e;
+}
+extern "C" int glz_debug_wave_stats(unsigned int* out, int n_waves) {
+  if (n_waves > 8192) n_waves = 8192;
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(glz::g_wave_stats), sizeof(unsigned int) * 8 * (size_t)n_waves);
 }
 #endif

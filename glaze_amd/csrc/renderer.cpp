@@ -246,8 +246,8 @@ bool Renderer::allocate(Error& err) {
       if (!hip_ok(b->alloc((b == &c->sh_o || b == &c->sh_d || b == &c->contrib) ? n_queue : n), "alloc path state", err)) return false;
     if (!hip_ok(c->cone.alloc(n), "alloc path state", err)) return false;
     if (!hip_ok(c->hit_inst.alloc(n), "alloc path state", err)) return false;
-    c->grid = trace_grid_blocks(m.n_local_pixels, false);
-    c->grid_counting = trace_grid_blocks(m.n_local_pixels, true);
+    c->grid = trace_grid_blocks(m.n_local_pixels, false, scene_->dev.two_level != 0);
+    c->grid_counting = trace_grid_blocks(m.n_local_pixels, true, scene_->dev.two_level != 0);
     // traversal spill: one slot of `od` entries per lane of the larger of the two persistent grids
     if (!hip_ok(c->overflow.alloc((size_t)std::max(c->grid, c->grid_counting) * kTraceBlock * od), "alloc traversal spill", err)) return false;
     if (!hip_ok(c->queue_count.alloc(2 * kQueueSetWords), "alloc queue counters", err)) return false;

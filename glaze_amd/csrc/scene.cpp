@@ -719,7 +719,7 @@ bool Scene::build_two_level(Error& err) {
     memcpy(r.o2w, T.o2w, 64);
     r.grid = m.grid;
     // slack of the object-space box tests: rounding of the transformed ray (relative to where in the world it can be) and of
-    // the triangle's world position, taken back to object units and expressed in cells of the mesh's grid; generous (x 32)
+    // the triangle's world position, taken back to object units; generous (x 32)
     double wnorm = 0.0, tr = 0.0, objmax = 0.0;
     for (int row = 0; row < 3; ++row) {
       wnorm = std::max(wnorm, std::fabs((double)r.w2o[4 * row]) + std::fabs((double)r.w2o[4 * row + 1]) + std::fabs((double)r.w2o[4 * row + 2]));
@@ -727,10 +727,9 @@ bool Scene::build_two_level(Error& err) {
       objmax = std::max({objmax, std::fabs((double)m.lo[row]), std::fabs((double)m.hi[row])});
     }
     const double eps = 1.1920929e-7;
-    const double delta = 32.0 * eps * (wnorm * reach + tr + objmax);
-    const double cell = std::min({(double)m.grid.cell[0], (double)m.grid.cell[1], (double)m.grid.cell[2]});
-    const double pad = cell > 0.0 ? delta / cell + 1.0 : 1.0;
-    r.pad_cells = (float)std::min(pad, 65536.0);
+    // (in object units: the tracer turns it into cells of each axis -- a thin mesh has tiny cells across its thin side, and the pad
+    // that side needs, taken for all three, would make every box of the mesh as wide as the mesh)
+    r.slack = (float)(32.0 * eps * (wnorm * reach + tr + objmax));
     r.node_base = m.node_base;
     r.tri_base = m.tri_base;
     r.world_base = inst_base_[i];

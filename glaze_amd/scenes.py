@@ -273,3 +273,34 @@ def atrium_scene(seed=1, detail=0.564, texture_size=512, sky_size=(2048, 1024)):
     radius = float(np.float32(0.5 * np.sqrt(L * L + Wd * Wd + H * H)))
     meta = make_meta(centre=(0, H / 2, 0), radius=radius, exposure=1.0)
     return SceneDesc(vertices, indices, meshes, None, instances, materials, lights, textures, camera, meta)
+
+
+# ------------------------------------------------------------------------------------------------
+# instanced forest of columns
+# ------------------------------------------------------------------------------------------------
+def forest_scene(n, seed=3):
+    """One fluted column (6 144 triangles) instanced n times under random rotations, scales and placements on a flat 40 m ground
+    grid (8 192 triangles): the kind of scene a two-level structure is for (1 + n instances of 2 meshes)."""
+    rng = np.random.default_rng(seed)
+    B = _Builder()
+    B.grid((-20, 0, -20), (0, 0, 40), (40, 0, 0), 64, 64, 1, uv_scale=20.0)
+    B.column((0, 0, 0), 0.25, 3.0, 48, 64, 2)
+    vertices, indices, meshes = B.finish()
+    mats = [np.eye(4)]
+    for i in range(n):
+        a = rng.uniform(0, 2 * np.pi)
+        s = rng.uniform(0.5, 1.5, 3)
+        m = np.eye(4)
+        m[:3, :3] = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]]) @ np.diag(s)
+        m[:3, 3] = (rng.uniform(-19, 19), 0.0, rng.uniform(-19, 19))
+        mats.append(m)
+    transforms = np.stack([np.asarray(m, np.float32).T.reshape(16) for m in mats])
+    instances = np.array([(0, 0)] + [(1, 1 + i) for i in range(n)], INSTANCE_DTYPE)
+    materials = [make_material("default"), make_material("ground", mtype=abi.MAT_LAMBERT, diffuse=1, diffuse_mul=(200, 200, 200)),
+                 make_material("column", mtype=abi.MAT_UBER, diffuse_mul=(220, 210, 190), roughness_mul=0.4)]
+    textures = [(abi.TEX_RGBA_SRGB, np.full((1, 1, 4), 255, np.uint8), "default"), (abi.TEX_RGBA_SRGB, checker_texture(), "checker")]
+    lights = [make_light(abi.LIGHT_SUN, "sun", direction=(-0.35, -0.85, 0.25), intensity=2.5),
+              make_light(abi.LIGHT_OMNI, "omni", position=(0.0, 6.0, 0.0), intensity=40.0)]
+    camera = make_camera(position=(-18, 2.0, -18), target=(10, 1.0, 10), up=(0, 1, 0), fovx=np.float32(np.radians(np.float32(70.0))), near=1e-2, far=200.0)
+    meta = make_meta(centre=(0, 2, 0), radius=30.0, exposure=1.0)
+    return SceneDesc(vertices, indices, meshes, transforms, instances, materials, lights, textures, camera, meta)

@@ -31,6 +31,24 @@ for world in [int(w) for w in os.environ.get("WORLDS", "8,1").split(",")]:
         blk = work[:nb * 4].reshape(nb, 4)
         print("   slowest wave %.1f us; slowest block mean %.1f us (its waves %s); blocks of 8 waves: %.1f us" % (
             work.max(), blk.mean(axis=1).max(), np.round(blk[blk.mean(axis=1).argmax()], 1), work[:(len(work) // 8) * 8].reshape(-1, 8).mean(axis=1).max()), flush=True)
+        st = np.zeros(8 * 8192, dtype=np.uint32)
+        if hasattr(lib, "glz_debug_wave_stats") and lib.glz_debug_wave_stats(st.ctypes.data_as(ctypes.c_void_p), 8192) == 0:
+            st = st.reshape(-1, 8).astype(np.float64)[: len(us)]
+            dur = us[:, 1] - us[:, 0]
+            busy = dur > 5.0
+            order = np.argsort(dur)
+            def row(name, sel):
+                x = st[sel]
+                print("   %-14s %5d waves: %.1f us, rounds %.0f, node iterations %.0f with %.1f lanes, leaf iterations %.0f with %.1f lanes, rounds with helpers %.0f, rounds only waiting for helpers %.0f, us per node iteration %.3f" % (
+                    name, len(x), dur[sel].mean(), x[:, 0].mean(), x[:, 1].mean(), x[:, 2].sum() / max(x[:, 1].sum(), 1), x[:, 3].mean(), x[:, 4].sum() / max(x[:, 3].sum(), 1),
+                    x[:, 5].mean(), x[:, 6].mean(), dur[sel].sum() / max(x[:, 1].sum(), 1)), flush=True)
+            nb = int(busy.sum())
+            ob = order[-nb:]
+            row("all", ob)
+            row("fastest tenth", ob[: nb // 10])
+            row("median tenth", ob[nb // 2 - nb // 20: nb // 2 + nb // 20])
+            row("slowest tenth", ob[-(nb // 10):])
+            row("slowest 1 %", ob[-max(nb // 100, 1):])
         # waves still running as a function of time
         grid = np.linspace(0, end[-1], 11)
         print("   running at", " ".join("%.0fus:%d" % (g, int(((us[:, 0] <= g) & (us[:, 2] > g)).sum())) for g in grid), flush=True)
