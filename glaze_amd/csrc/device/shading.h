@@ -592,11 +592,16 @@ GLZ_D float bsdf_sample(const DeviceScene& S, const SurfacePoint& P, vec3 xi, Sp
 // ---------------------------------------------------------------------------------------------
 // Lights (light_*_sample_visible.rcall)
 // ---------------------------------------------------------------------------------------------
+// The emitted spectrum is not part of the sample: 16 registers that would only wait through the whole BSDF evaluation.  The sample
+// keeps what the spectrum is made from (light_emission below makes it, after the evaluation, with the operations the callables use).
 struct LightSample {
-  Spec emission;
   vec3 wiW;
   float pdf;
   float distance;
+  uint32_t kind;    // RTLight::shader of the light
+  const RTLight* light;
+  float k;          // omni, area: squared distance / intensity
+  vec3 rgb;         // area: the emitter's diffuse_mul; sky: texel * intensity
 };
 
 GLZ_D float sq_dist(vec3 a, vec3 b) {
@@ -629,21 +634,23 @@ GLZ_D float sample_cdf(float xi, int size, Fetch fetch, uint32_t& offset_out) {
 GLZ_D void sample_light(const DeviceScene& S, uint32_t light_index, vec3 p, vec3 xi, float scene_radius, LightSample& out) {
   const RTLight* L = &S.lights[light_index];
   const uint32_t kind = L->shader;
+  out.kind = kind;
+  out.light = L;
+  out.k = 1.0f;
+  out.rgb = mk3(0.0f, 0.0f, 0.0f);
   if (kind == kLightOmni) {   // light_omni_sample_visible.rcall:14-25
     vec3 lp = mk3(L->pos[0], L->pos[1], L->pos[2]);
     out.wiW = normalize3(lp - p);
     float d2 = sq_dist(lp, p);
     out.distance = sqrtf(d2);
     out.pdf = 1.0f;
-    float k = d2 / L->intensity;
-    GLZ_BINS out.emission.w[i] = L->color.w[i] / k;
+    out.k = d2 / L->intensity;
     return;
   }
   if (kind == kLightSun) {   // light_sun_sample_visible.rcall:22-29; dir is not normalised (Q14)
     out.wiW = mk3(-L->dir[0], -L->dir[1], -L->dir[2]);
     out.pdf = 1.0f;
     out.distance = 2.0f * scene_radius + 1.0f;
-    GLZ_BINS out.emission.w[i] = L->color.w[i] * L->intensity;
     return;
   }
   if (kind == kLightArea) {   // light_area_sample_visible.rcall:29-64
@@ -662,8 +669,8 @@ GLZ_D void sample_light(const DeviceScene& S, uint32_t light_index, vec3 p, vec3
     float d2 = sq_dist(rp, p);
     out.distance = sqrtf(d2);
     const RTMaterial* m = &S.materials[in.material_id];
-    Spec e = from_surface_color(mk3(m->diffuse_mul[0], m->diffuse_mul[1], m->diffuse_mul[2]));
-    out.emission = spec_div(e, d2 / L->intensity);
+    out.rgb = mk3(m->diffuse_mul[0], m->diffuse_mul[1], m->diffuse_mul[2]);
+    out.k = d2 / L->intensity;
     out.pdf = (1.0f / (float)ntri) * (1.0f / area);
     return;
   }
@@ -686,10 +693,25 @@ GLZ_D void sample_light(const DeviceScene& S, uint32_t light_index, vec3 p, vec3
     out.pdf = pdf / (2.0f * kPi * kPi * sint);
     out.wiW = normalize3(xform_dir(S.sky.obj2world, mk3(sint * cosp, sint * sinp, cost)));
     out.distance = 2.0f * scene_radius + 1.0f;
-    out.emission = from_illuminant_color(texture_rgb(S, S.sky.tex_id, vec2{u, v}) * S.sky.intensity);
+    out.rgb = texture_rgb(S, S.sky.tex_id, vec2{u, v}) * S.sky.intensity;
   } else {
     out.pdf = 0.0f;
   }
+}
+
+// the spectrum a light sample carries (the `emission` the *_sample_visible callables return)
+GLZ_D Spec light_emission(const LightSample& ls) {
+  Spec e;
+  if (ls.kind == kLightOmni) {
+    GLZ_BINS e.w[i] = ls.light->color.w[i] / ls.k;
+  } else if (ls.kind == kLightSun) {
+    GLZ_BINS e.w[i] = ls.light->color.w[i] * ls.light->intensity;
+  } else if (ls.kind == kLightArea) {
+    e = spec_div(from_surface_color(ls.rgb), ls.k);
+  } else {
+    e = from_illuminant_color(ls.rgb);
+  }
+  return e;
 }
 
 }  // namespace dev

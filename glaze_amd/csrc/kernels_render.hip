@@ -838,11 +838,11 @@ constexpr uint32_t kShadeTableBytes = 16384;   // LDS copy of the material / lig
 constexpr uint32_t kSkyLdsFloats = 4096;   // sky marginal tables (3H+1 floats) are staged in LDS when they fit: H <= 1365 rows
 
 #ifndef GLZ_SHADE_WAVES
-#define GLZ_SHADE_WAVES 3   // 168 VGPRs: no scratch spills (spill traffic is vector-memory traffic too)
+#define GLZ_SHADE_WAVES 4   // 128 VGPRs, 4 of them spilled, since the light's spectrum is made after the BSDF evaluation and the importance is read where it is used (natural demand 152 -> 132): 0.357 -> 0.348 ms; at three waves the same code takes 0.363 ms (the re-reads), the old code at four waves (56 spilled) 0.382 ms
 #endif
 __global__ void __launch_bounds__(kBlock, GLZ_SHADE_WAVES) k_shade(const LaunchArgs A) {
   // The kernel is bound by the memory system's random-access rate (16 extra scattered loads per pixel cost +27 %, 200 extra
-  // VALU instructions nothing; 1 / 2 / 3 waves per SIMD take 0.76 / 0.45 / 0.36 ms and a fourth needs spills that eat its gain), so the two small tables every texture fetch /
+  // VALU instructions nothing; 1 / 2 / 3 / 4 waves per SIMD take 0.76 / 0.45 / 0.36 / 0.35 ms), so the two small tables every texture fetch /
   // sky sample walks are staged in LDS once per block: the sRGB decode LUT (12 lookups per bilinear fetch) and the sky marginal CDF (an 11-step dependent search).
   __shared__ float s_lut[256];
   __shared__ float s_sky[kSkyLdsFloats];
@@ -967,16 +967,23 @@ __global__ void __launch_bounds__(kBlock, GLZ_SHADE_WAVES) k_shade(const LaunchA
   const bool fresh = F.direct_only || ro.w == 0.0f;
   float bounce = F.direct_only ? 0.0f : ro.w;
   const vec3 direction = mk3(rd.x, rd.y, rd.z);
-  Spec importance;
-  if (fresh) {
-    importance = spec_set(1.0f);
-  } else {
+  // The path's importance (16 floats) is read where it is used -- the radiance of the light sample, the roulette, the final product --
+  // instead of once up front: held through texture fetches, light sampling and the two BSDF calls it set the kernel's register peak.
+  // The re-reads hit the lines the first read brought in.
+  auto load_importance = [&]() {
+    asm volatile("" ::: "memory");   // a fresh read every time: merged with an earlier one the values would stay in registers in between
+    Spec imp;
+    if (fresh) {
+      imp = spec_set(1.0f);
+    } else {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float4 v = A.st.imp[q][lid];
-      importance.w[4 * q] = v.x; importance.w[4 * q + 1] = v.y; importance.w[4 * q + 2] = v.z; importance.w[4 * q + 3] = v.w;
+      for (int q = 0; q < 4; ++q) {
+        const float4 v = A.st.imp[q][lid];
+        imp.w[4 * q] = v.x; imp.w[4 * q + 1] = v.y; imp.w[4 * q + 2] = v.z; imp.w[4 * q + 3] = v.w;
+      }
     }
-  }
+    return imp;
+  };
   const uint32_t leaf = __float_as_uint(hr.w);
   if (leaf == 0xFFFFFFFFu) {
     // miss: optional sky radiance, path reset (path_trace.rgen:170-179)
@@ -986,7 +993,7 @@ __global__ void __launch_bounds__(kBlock, GLZ_SHADE_WAVES) k_shade(const LaunchA
       const vec3 w = normalize3(xform_dir(S.sky.world2obj, direction));   // sky_radiance, :75-82
       const float phi = glz_atan2f(w.y, w.x), theta = glz_acosf(w.z);
       const vec3 texel = texture_rgb(S, S.sky.tex_id, vec2{phi * kInv2Pi, theta * kInvPi});
-      c = spec_to_rgb(spec_mul(importance, from_illuminant_color(texel)));
+      c = spec_to_rgb(spec_mul(load_importance(), from_illuminant_color(texel)));
       flags = kFlagUpdate;
     }
     accumulate_pixel(A, lid, c, true, flags != 0, A.frame.exposure);
@@ -1083,10 +1090,12 @@ __global__ void __launch_bounds__(kBlock, GLZ_SHADE_WAVES) k_shade(const LaunchA
         const float w_vis = 1.0f * (fabsf(dot3(ls.wiW, ns)) / ls.pdf);
         const float w_occ = 0.0f * (fabsf(dot3(ls.wiW, ns)) / ls.pdf);
         const float nl = (float)F.lights_no;
+        const Spec emission = light_emission(ls);
+        const Spec importance = load_importance();
         Spec rad;
         float poison = 0.0f;
         GLZ_BINS {
-          const float rl = value.w[i] * ls.emission.w[i];
+          const float rl = value.w[i] * emission.w[i];
           rad.w[i] = ((rl * w_vis) * nl) * importance.w[i];
           poison += ((rl * w_occ) * nl) * importance.w[i];
         }
@@ -1098,6 +1107,7 @@ __global__ void __launch_bounds__(kBlock, GLZ_SHADE_WAVES) k_shade(const LaunchA
     }
     if (!(flags & kFlagShadow)) {
       // no light sample: the reference still adds rgb(0 * lights_no * importance), which is NaN for a non-finite importance
+      const Spec importance = load_importance();
       float probe = 0.0f;
       GLZ_BINS probe += 0.0f * importance.w[i];
       if (probe != probe) c = spec_to_rgb(spec_scale(importance, 0.0f * (float)F.lights_no));
@@ -1119,14 +1129,15 @@ __global__ void __launch_bounds__(kBlock, GLZ_SHADE_WAVES) k_shade(const LaunchA
   }
   if (F.direct_only) return;
   // Russian roulette (:197-210)
+  float rr_scale = 1.0f;   // importance * 1.0f is importance, bit for bit: the paths that skip the roulette multiply by it too
   if (bounce > (float)(F.pt_steps / 2u)) {
-    const float kill = gl_max(0.05f, 1.0f - spec_luminance(importance));
+    const float kill = gl_max(0.05f, 1.0f - spec_luminance(load_importance()));
     if (rand01(rng) < kill) {
       A.st.ray_o[lid] = make_float4(ro.x, ro.y, ro.z, 0.0f);
       A.st.ray_d[lid] = make_float4(rd.x, rd.y, rd.z, spec_flag);
       return;
     }
-    importance = spec_scale(importance, 1.0f / (1.0f - kill));
+    rr_scale = 1.0f / (1.0f - kill);
   }
   vec3 xi;
   xi.x = rand01(rng); xi.y = rand01(rng); xi.z = rand01(rng);
@@ -1140,6 +1151,7 @@ __global__ void __launch_bounds__(kBlock, GLZ_SHADE_WAVES) k_shade(const LaunchA
   }
   float weight = fabsf(dot3(wiW, ns));
   weight /= pdf;
+  const Spec importance = spec_scale(load_importance(), rr_scale);
 #pragma unroll
   for (int q = 0; q < 4; ++q)
     A.st.imp[q][lid] = make_float4(importance.w[4 * q] * (value.w[4 * q] * weight), importance.w[4 * q + 1] * (value.w[4 * q + 1] * weight),
