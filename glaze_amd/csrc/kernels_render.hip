@@ -414,6 +414,8 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
         } else {
           const u32x4* np = reinterpret_cast<const u32x4*>(nodes + cur);
           w0 = np[0]; w1 = np[1]; w2 = np[2]; w3 = np[3];
+          // (A fifth 16-byte load from the node's own line costs 2.4 % of the kernel, 0.580 -> 0.594 ms: a 48-byte node format --
+          // 8-bit boxes relative to a per-node origin -- would buy about that and pay ~12 VALU instructions per visit for it.)
         }
         if (COUNT) tally.nodes += 1;
         float bound = best.t;
