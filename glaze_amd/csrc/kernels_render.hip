@@ -1071,6 +1071,8 @@ __global__ void __launch_bounds__(kBlock, GLZ_SHADE_WAVES) k_shade(const LaunchA
   P.mat = mat;
   fetch_material_textures(S, P, lod_base);
   float spec_flag;
+  float imp_lum = 0.0f;      // luminance of the importance, taken when the light-sampling block reads it: the roulette needs nothing else of it
+  bool have_lum = false;
   if (mat.is_specular == 0) {
     // direct_light(), :84-117
     const uint32_t li = (uint32_t)gl_min(rand01(rng) * (float)F.lights_no, (float)(F.lights_no - 1u));
@@ -1094,6 +1096,8 @@ __global__ void __launch_bounds__(kBlock, GLZ_SHADE_WAVES) k_shade(const LaunchA
         const float nl = (float)F.lights_no;
         const Spec emission = light_emission(ls);
         const Spec importance = load_importance();
+        imp_lum = spec_luminance(importance);
+        have_lum = true;
         Spec rad;
         float poison = 0.0f;
         GLZ_BINS {
@@ -1110,6 +1114,8 @@ __global__ void __launch_bounds__(kBlock, GLZ_SHADE_WAVES) k_shade(const LaunchA
     if (!(flags & kFlagShadow)) {
       // no light sample: the reference still adds rgb(0 * lights_no * importance), which is NaN for a non-finite importance
       const Spec importance = load_importance();
+      imp_lum = spec_luminance(importance);
+      have_lum = true;
       float probe = 0.0f;
       GLZ_BINS probe += 0.0f * importance.w[i];
       if (probe != probe) c = spec_to_rgb(spec_scale(importance, 0.0f * (float)F.lights_no));
@@ -1133,7 +1139,7 @@ __global__ void __launch_bounds__(kBlock, GLZ_SHADE_WAVES) k_shade(const LaunchA
   // Russian roulette (:197-210)
   float rr_scale = 1.0f;   // importance * 1.0f is importance, bit for bit: the paths that skip the roulette multiply by it too
   if (bounce > (float)(F.pt_steps / 2u)) {
-    const float kill = gl_max(0.05f, 1.0f - spec_luminance(load_importance()));
+    const float kill = gl_max(0.05f, 1.0f - (have_lum ? imp_lum : spec_luminance(load_importance())));
     if (rand01(rng) < kill) {
       A.st.ray_o[lid] = make_float4(ro.x, ro.y, ro.z, 0.0f);
       A.st.ray_d[lid] = make_float4(rd.x, rd.y, rd.z, spec_flag);
