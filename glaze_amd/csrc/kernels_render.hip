@@ -184,7 +184,7 @@ struct TraceTally {
 // Wave-persistent traversal.  A wave owns a strided sequence of 64-ray groups (group g of wave w is rays
 // [64 * (g * n_waves + w), +64)) and keeps its 64 lanes busy: a lane whose ray has finished takes the next
 // ray of the wave's sequence as soon as kRefill lanes are idle (no atomics: the sequence pointer is wave
-// uniform).  Each round is  [refill] -> [share] -> [inner-node phase] -> [leaf phase] -> [merge] -> [retire]:
+// uniform).  Each round is  [refill] -> [inner-node phase, a share step before each of its iterations] -> [leaf phase] -> [merge] -> [retire]:
 //   * inner-node phase: lanes sitting on an inner node test its four child boxes, descend into the nearest
 //     hit child and push the others farthest first; lanes that reached a leaf wait.  The phase ends when no lane is on an
 //     inner node, or when at least kLeafQuorum lanes are waiting on a leaf.
@@ -192,7 +192,8 @@ struct TraceTally {
 //   * share / merge (only once the wave's sequence is exhausted, i.e. in the tail): an idle lane takes the OLDEST
 //     pending subtree off the LDS stack of a busy lane (the stacks are LDS columns, so any lane can reach them),
 //     copies that lane's ray through shuffles and traverses the subtree as a helper; its result is merged back into
-//     the owner (smaller t, then smaller world id; any hit for shadow rays), which retires when no helper is left.
+//     the owner (smaller t, then smaller world id; any hit for shadow rays), which retires when no helper is left.  Owner and
+//     helpers prune with the closest distance any of them has found so far (aux_t).
 //     The longest rays then finish in a fraction of their serial time: they set the duration of a launch once a GPU
 //     holds few rays per wave (tile sharding over 8 GPUs: k_trace's floor was 0.17 ms whatever the share of the frame).
 //     Closest-hit and any-hit results do not depend on the visit order, so sharing changes no result; it is compiled
@@ -226,6 +227,9 @@ constexpr int kLeafQuorum = GLZ_LEAF_QUORUM;
 #endif
 #ifndef GLZ_LEAF_QUORUM_ANY
 #define GLZ_LEAF_QUORUM_ANY GLZ_LEAF_QUORUM
+#endif
+#ifndef GLZ_SHARE_REPS
+#define GLZ_SHARE_REPS 1   // hand-overs per donor and node iteration while idle lanes are left: 1 / 2 / 3 -> 0.145 / 0.148 / 0.152 ms per launch of a 1/8 share (each costs its shuffles)
 #endif
 #ifndef GLZ_LEAF_QUORUM_TAIL
 #define GLZ_LEAF_QUORUM_TAIL GLZ_LEAF_QUORUM   // once the wave's sequence is exhausted (a small share of the frame: from the first round on); 4 / 8 / 16 / 24 / 32 -> 0.172 / 0.159 / 0.152 / 0.152 / 0.155 ms per launch of a 1/8 share: the same optimum
@@ -295,6 +299,68 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
 #ifdef GLZ_WAVE_TIMES
   unsigned int wt_rounds = 0, wt_node_iters = 0, wt_node_lanes = 0, wt_leaf_iters = 0, wt_leaf_lanes = 0, wt_helper_rounds = 0, wt_wait_rounds = 0;
 #endif
+  // ---- share: idle lanes adopt the oldest pending subtree of a busy lane (called before every node iteration, see below) ----
+  auto share_step = [&]() {
+  if (SHARE && exhausted)
+  for (int rep = 0; rep < GLZ_SHARE_REPS; ++rep) {
+    bool more = false;
+    const bool busy = open || helper;
+    const unsigned long long idle_m = __ballot(!busy);
+    if (idle_m != 0ull) {
+      if (ANY) {   // helpers of a ray whose hit has been found have nothing left to decide
+        const int owner_found = __shfl((int)(best.leaf != kNone), helper ? (int)ray : lane);
+        if (helper && owner_found) cur = kRayDone;
+      }
+      int sb = 0, lim = 0;
+      if (busy && cur != kRayDone) {
+        sb = aux_sb[lane];
+        if (sb > st.sp) sb = st.sp;
+        lim = st.sp < kLdsStack ? st.sp : kLdsStack;
+        while (sb < lim && st.lds[sb * kBlock] == kStolen) ++sb;
+        aux_sb[lane] = sb;
+      }
+      const bool can_give = busy && cur != kRayDone && sb < lim;
+      const unsigned long long give_m = __ballot(can_give);
+      const int n_give = __popcll(give_m), n_take = __popcll(idle_m);
+      const int n_pairs = n_give < n_take ? n_give : n_take;
+      if (n_pairs > 0) {
+        int give = 0;
+        if (can_give && __popcll(give_m & lanes_below) < n_pairs) {
+          give = st.lds[sb * kBlock];
+          st.lds[sb * kBlock] = kStolen;
+          aux_sb[lane] = sb + 1;
+          aux_pair[__popcll(give_m & lanes_below)] = lane;
+        }
+        const int take_rank = __popcll(idle_m & lanes_below);
+        const bool take = !busy && take_rank < n_pairs;
+        const int donor = take ? aux_pair[take_rank] : lane;   // same-wave LDS: the stores above are complete (in-order)
+        // Every lane runs the shuffles.  Lanes that take nothing read their own lane (donor == lane), so the ray registers
+        // can be assigned unconditionally: no temporaries stay live across the block (register pressure: 72 VGPRs).
+        const int t_node = __shfl(give, donor);
+        const int t_owner = __shfl(helper ? (int)ray : lane, donor);
+        o.x = __shfl(o.x, donor); o.y = __shfl(o.y, donor); o.z = __shfl(o.z, donor);
+        d.x = __shfl(d.x, donor); d.y = __shfl(d.y, donor); d.z = __shfl(d.z, donor);
+        ig.x = __shfl(ig.x, donor); ig.y = __shfl(ig.y, donor); ig.z = __shfl(ig.z, donor);
+        cg.x = __shfl(cg.x, donor); cg.y = __shfl(cg.y, donor); cg.z = __shfl(cg.z, donor);
+        sel = SlabSel{ig.x < 0.0f ? 0x01000302u : 0x03020100u, ig.y < 0.0f ? 0x01000302u : 0x03020100u, ig.z < 0.0f ? 0x01000302u : 0x03020100u};
+        tmin = __shfl(tmin, donor); tmax = __shfl(tmax, donor);
+        best.t = __shfl(best.t, donor); best.u = __shfl(best.u, donor); best.v = __shfl(best.v, donor);
+        best.leaf = (uint32_t)__shfl((int)best.leaf, donor);
+        best_id = (uint32_t)__shfl((int)best_id, donor);
+        if (take) {
+          ray = (uint32_t)t_owner;
+          cur = t_node;
+          st.sp = 0;
+          aux_sb[lane] = 0;
+          helper = true;
+          atomicAdd(&aux_out[t_owner], 1);
+        }
+        more = n_take > n_give;   // idle lanes are left over: the donors may have more to give
+      }
+    }
+    if (!more) break;
+  }
+  };
   for (;;) {
 #ifdef GLZ_WAVE_TIMES
     wt_rounds += 1;
@@ -340,64 +406,12 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
       if (exhausted) break;
       continue;
     }
-    // ---- share: idle lanes adopt the oldest pending subtree of a busy lane ----
-    if (SHARE && exhausted) {
-      const bool busy = open || helper;
-      const unsigned long long idle_m = __ballot(!busy);
-      if (idle_m != 0ull) {
-        if (ANY) {   // helpers of a ray whose hit has been found have nothing left to decide
-          const int owner_found = __shfl((int)(best.leaf != kNone), helper ? (int)ray : lane);
-          if (helper && owner_found) cur = kRayDone;
-        }
-        int sb = 0, lim = 0;
-        if (busy && cur != kRayDone) {
-          sb = aux_sb[lane];
-          if (sb > st.sp) sb = st.sp;
-          lim = st.sp < kLdsStack ? st.sp : kLdsStack;
-          while (sb < lim && st.lds[sb * kBlock] == kStolen) ++sb;
-          aux_sb[lane] = sb;
-        }
-        const bool can_give = busy && cur != kRayDone && sb < lim;
-        const unsigned long long give_m = __ballot(can_give);
-        const int n_give = __popcll(give_m), n_take = __popcll(idle_m);
-        const int n_pairs = n_give < n_take ? n_give : n_take;
-        if (n_pairs > 0) {
-          int give = 0;
-          if (can_give && __popcll(give_m & lanes_below) < n_pairs) {
-            give = st.lds[sb * kBlock];
-            st.lds[sb * kBlock] = kStolen;
-            aux_sb[lane] = sb + 1;
-            aux_pair[__popcll(give_m & lanes_below)] = lane;
-          }
-          const int take_rank = __popcll(idle_m & lanes_below);
-          const bool take = !busy && take_rank < n_pairs;
-          const int donor = take ? aux_pair[take_rank] : lane;   // same-wave LDS: the stores above are complete (in-order)
-          // Every lane runs the shuffles.  Lanes that take nothing read their own lane (donor == lane), so the ray registers
-          // can be assigned unconditionally: no temporaries stay live across the block (register pressure: 72 VGPRs).
-          const int t_node = __shfl(give, donor);
-          const int t_owner = __shfl(helper ? (int)ray : lane, donor);
-          o.x = __shfl(o.x, donor); o.y = __shfl(o.y, donor); o.z = __shfl(o.z, donor);
-          d.x = __shfl(d.x, donor); d.y = __shfl(d.y, donor); d.z = __shfl(d.z, donor);
-          ig.x = __shfl(ig.x, donor); ig.y = __shfl(ig.y, donor); ig.z = __shfl(ig.z, donor);
-          cg.x = __shfl(cg.x, donor); cg.y = __shfl(cg.y, donor); cg.z = __shfl(cg.z, donor);
-          sel = SlabSel{ig.x < 0.0f ? 0x01000302u : 0x03020100u, ig.y < 0.0f ? 0x01000302u : 0x03020100u, ig.z < 0.0f ? 0x01000302u : 0x03020100u};
-          tmin = __shfl(tmin, donor); tmax = __shfl(tmax, donor);
-          best.t = __shfl(best.t, donor); best.u = __shfl(best.u, donor); best.v = __shfl(best.v, donor);
-          best.leaf = (uint32_t)__shfl((int)best.leaf, donor);
-          best_id = (uint32_t)__shfl((int)best_id, donor);
-          if (take) {
-            ray = (uint32_t)t_owner;
-            cur = t_node;
-            st.sp = 0;
-            aux_sb[lane] = 0;
-            helper = true;
-            atomicAdd(&aux_out[t_owner], 1);
-          }
-        }
-      }
-    }
     // ---- inner-node phase ----
     for (;;) {
+      // Idle lanes take over pending subtrees before EVERY node iteration of the tail, not once per round: a round is several
+      // iterations long, and with one hand-over per round the helpers of a long ray multiplied too slowly to matter before it
+      // was over (a 1/8 share: 0.153 -> 0.147 ms per launch; the full frame, where only each wave's last group is a tail: 0.930 -> 0.914).
+      share_step();
       const bool at_node = cur >= 0 && cur < kStolen;
       const unsigned long long m_node = __ballot(at_node);
       if (m_node == 0ull) break;
