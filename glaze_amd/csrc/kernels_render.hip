@@ -248,6 +248,34 @@ __device__ __forceinline__ void sort2(uint32_t& a, uint32_t& b) {
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(3))) u32x4* LdsNodePtr;
 
+// The rays a wave works through, in the order it takes them (all wave-uniform but the position asked for): the 64-ray groups are
+// dealt round-robin, group g to wave g % n_waves.  The rays left over after the whole rounds can be dealt in smaller pieces
+// (GLZ_PIECE_SHIFT < 6) so that every wave gets the same share of them -- a full frame leaves a quarter of the waves with a sixth
+// group and lasts as long as those, and a share with fewer groups than waves fills some waves and leaves the rest empty.  Measured
+// with pieces of 16: the full frame 0.932 -> 0.951 ms per launch, a 1/4 share 0.252 -> 0.343, a 1/8 share 0.148 -> 0.214 (8 and 32
+// likewise).  A wave's iteration costs the same whatever the number of its lanes that work, and the SIMDs are shared: the same rays
+// in more, emptier waves are slower even when there are waves to spare.  So whole groups it is.
+#ifndef GLZ_PIECE_SHIFT
+#define GLZ_PIECE_SHIFT 6
+#endif
+struct RaySequence {
+  static constexpr uint32_t kPieceShift = GLZ_PIECE_SHIFT, kPiece = 1u << GLZ_PIECE_SHIFT;
+  uint32_t wave, n_waves, total;
+  uint32_t own_full;     // rays this wave takes in whole groups
+  uint32_t piece_base;   // first ray that is dealt in pieces
+  __device__ __forceinline__ RaySequence(uint32_t wave_, uint32_t n_waves_, uint32_t total_) : wave(wave_), n_waves(n_waves_), total(total_) {
+    const uint32_t full_rounds = ((total + 63u) >> 6) / n_waves;
+    own_full = full_rounds * 64u;
+    piece_base = full_rounds * n_waves * 64u;
+  }
+  // ray at position `pos` of this wave's sequence; >= total: the sequence has ended (ray_at is monotonic in pos)
+  __device__ __forceinline__ uint32_t ray_at(uint32_t pos) const {
+    if (pos < own_full) return (wave + (pos >> 6) * n_waves) * 64u + (pos & 63u);
+    const uint32_t q = pos - own_full;
+    return piece_base + (wave + (q >> kPieceShift) * n_waves) * kPiece + (q & (kPiece - 1u));
+  }
+};
+
 #ifdef GLZ_WAVE_TIMES
 __device__ unsigned long long g_wave_times[3 * 8192];
 __device__ unsigned int g_wave_stats[8 * 8192];   // closest-hit phase: rounds, node iterations, lanes in them, leaf iterations, lanes in them, rounds with helpers
@@ -273,8 +301,7 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
     aux_sb[lane] = 0;
   }
   uint32_t seq = 0;                                         // wave-uniform: rays of this wave's sequence handed out so far
-  // group sequence of this wave: first_group + i * group_stride while < group_end
-  uint32_t first_group = wave, group_stride = n_waves, group_end = (total + 63u) / 64u;
+  const RaySequence rays(wave, n_waves, total);
   // (giving each XCD one contiguous eighth of the groups -- rays of one image band per L2 -- measured 5 % slower: the bands
   // differ in cost and the static split loses more to imbalance than the L2 gains)
   // (Drawing the groups from a counter instead of the stride: the waves of a full-frame launch end between 257 and 406 us of a
@@ -282,7 +309,7 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
   // address are served at ~15 ns each; 32 interleaved counters: the ends move together, 306 - 400 us, but every wave gets slower --
   // neighbouring groups no longer run on one CU at one time -- 0.572 ms per k_trace either way; whole rounds by the stride and
   // only the last partial round drawn: 0.601 ms.  A wave's last group runs without refills behind it whoever hands it out.)
-  bool exhausted = first_group >= group_end;                // wave-uniform
+  bool exhausted = rays.ray_at(0u) >= total;                // wave-uniform
   // per-lane ray state
   bool open = false;                                        // a ray of this lane's own is in flight and its result has not been stored
   bool helper = false;                                      // this lane traverses a subtree of lane `ray`'s ray (work sharing)
@@ -372,10 +399,8 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
     const int n_idle = __popcll(idle);
     if (!exhausted && n_idle >= (ANY ? GLZ_REFILL_ANY : kRefill)) {
       if (COUNT && lane == 0) { tally.refill_iters += 1; tally.refill_lanes += (unsigned)n_idle; }
-      const uint32_t mine = seq + (uint32_t)__popcll(idle & lanes_below);
-      const uint32_t next_group = first_group + (mine >> 6) * group_stride;
-      const uint32_t next_ray = next_group * 64u + (mine & 63u);
-      if (!open && next_group < group_end && next_ray < total) {
+      const uint32_t next_ray = rays.ray_at(seq + (uint32_t)__popcll(idle & lanes_below));
+      if (!open && next_ray < total) {
         if (src.load(next_ray, o, d, tmin, tmax)) {
           ray = next_ray;
           best = HitRecord{tmax, 0.0f, 0.0f, kNone};
@@ -396,7 +421,7 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
         }
       }
       seq += (uint32_t)n_idle;
-      exhausted = first_group + (seq >> 6) * group_stride >= group_end;
+      exhausted = rays.ray_at(seq) >= total;
       // The tail begins: from here on a ray may be worked on by several lanes, which tell each other the closest distance found so
       // far through aux_t -- a helper walking a far subtree with the bound it was handed at the start would go through all of
       // it after the owner has long found something nearer, and the owner cannot retire before its helpers are back.
@@ -572,8 +597,8 @@ __device__ __forceinline__ void trace_wave_tl(const DeviceScene& S, Source& src,
   const int lane = threadIdx.x & 63;
   const unsigned long long lanes_below = (1ull << lane) - 1ull;
   uint32_t seq = 0;
-  const uint32_t first_group = wave, group_stride = n_waves, group_end = (total + 63u) / 64u;
-  bool exhausted = first_group >= group_end;
+  const RaySequence rays(wave, n_waves, total);
+  bool exhausted = rays.ray_at(0u) >= total;
   bool open = false;
   int cur = kRayDone;
   uint32_t ray = 0, nbase = 0, cur_inst = kNone;
@@ -616,10 +641,8 @@ __device__ __forceinline__ void trace_wave_tl(const DeviceScene& S, Source& src,
     const unsigned long long idle = __ballot(!open);
     const int n_idle = __popcll(idle);
     if (!exhausted && n_idle >= kRefill) {
-      const uint32_t mine = seq + (uint32_t)__popcll(idle & lanes_below);
-      const uint32_t next_group = first_group + (mine >> 6) * group_stride;
-      const uint32_t next_ray = next_group * 64u + (mine & 63u);
-      if (!open && next_group < group_end && next_ray < total) {
+      const uint32_t next_ray = rays.ray_at(seq + (uint32_t)__popcll(idle & lanes_below));
+      if (!open && next_ray < total) {
         if (src.load(next_ray, o, d, tmin, tmax)) {
           ray = next_ray;
           best = HitRecord{tmax, 0.0f, 0.0f, kNone, 0u, kNone};
@@ -637,7 +660,7 @@ __device__ __forceinline__ void trace_wave_tl(const DeviceScene& S, Source& src,
         }
       }
       seq += (uint32_t)n_idle;
-      exhausted = first_group + (seq >> 6) * group_stride >= group_end;
+      exhausted = rays.ray_at(seq) >= total;
     }
     if (__ballot(open) == 0ull) {
       if (exhausted) break;
