@@ -1001,6 +1001,9 @@ __global__ void __launch_bounds__(kBlock, GLZ_SHADE_WAVES) k_shade(const LaunchA
 #else
   const uint32_t lid = blockIdx.x * kBlock + threadIdx.x;
 #endif
+  // (Handing the next k_trace the pixels in this regrouped order -- one more word per pixel -- does nothing for the traversal, 0.588 ->
+  // 0.591 ms; sorted per block by the octant of the new direction, camera rays last, 0.590 -> 0.573 ms, less than the sort and the
+  // indirection cost.)
   const PixelId px = pixel_of(A.map, lid);
   if (!px.active) return;
 #if !defined(GLZ_SHADE_NO_REGROUP) && !defined(GLZ_SHADE_NO_HIT_HANDOVER)
