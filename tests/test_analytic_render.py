@@ -1,0 +1,95 @@
+"""A whole render against a closed form.
+
+HIP == oracle bit for bit says nothing about a misreading both share, and the oracle-against-mathematics tests look at one
+routine at a time.  This one closes the loop at the other end: a scene whose converged image can be written down -- the unit cube
+seen from its centre, grey Lambertian walls, one point light AT the camera, direct lighting -- so that camera rays, intersection,
+shading frame, the light's inverse-square law, the cosine, the division by pi, the jitter average and the accumulation are all
+compared with numpy in float64:
+
+    pixel(u, v) = rgb(albedo / pi * light colour) * intensity / r^3,     r = |(u, v, 1)| / max(|u|, |v|, 1)
+
+(the point on the cube along direction (u, v, 1) lies at distance r, the light is r away from it, and the wall it is on is seen
+and lit under the cosine 1 / r).  The scene is mirror-symmetric in x and y, so the formula does not depend on how the image axes
+are oriented.  Only the spectral step -- an RGB albedo and an RGB light colour to a radiance in RGB -- is taken from the oracle's
+own routines, which have their own tests (test_oracle_math.py: grey stays grey, luminance is the Y row).
+"""
+import numpy as np
+import pytest
+
+import glaze_amd
+from glaze_amd import abi
+from glaze_amd.scene_desc import make_light
+from glaze_amd.scenes import cube_scene
+from oracle import pyoracle
+from oracle.pyoracle import OracleRenderer, OracleScene
+
+CUBE_MAT = 2
+ALBEDO = (150, 150, 150)
+INTENSITY = 0.8
+
+
+def room():
+    desc = cube_scene(material_type=abi.MAT_LAMBERT)
+    m = desc.materials[CUBE_MAT]
+    m.diffuse = 0                      # the 1 x 1 white texture: the walls' colour is diffuse_mul
+    m.diffuse_mul[:3] = ALBEDO
+    desc.lights = [make_light(abi.LIGHT_OMNI, "at the camera", position=(0.0, 0.0, 0.0), intensity=INTENSITY)]
+    return desc
+
+
+def colour_factor(desc):
+    """rgb of (Lambert value of the walls) x (emission of the light at unit distance): the oracle's spectral routines"""
+    o = OracleScene(desc)
+    up = np.array([[0.0, 0.0, 1.0]], np.float32)
+    value, pdf = o.bsdf_value(CUBE_MAT, up, up)                         # albedo spectrum / pi
+    assert pdf[0] > 0
+    _, dist, lpdf, em = o.light_sample(0, np.array([[1.0, 0.0, 0.0]], np.float32), np.zeros((1, 3), np.float32))
+    assert dist[0] == 1.0 and lpdf[0] == 1.0                            # emission at distance 1 = colour x intensity
+    sp = np.ascontiguousarray(value[0] * em[0], np.float32)
+    rgb = np.zeros(3, np.float32)
+    pyoracle.lib().orc_dev_rgb(sp.ctypes.data, rgb.ctypes.data)
+    # the Lambert value is albedo / pi: a grey of 150 / 255 (sRGB-decoded by the material upload) under a white light
+    assert rgb.min() > 0
+    return rgb.astype(np.float64)
+
+
+def closed_form(n, factor, sub=8):
+    """mean over each pixel (sub x sub positions) of factor / r^3 for a square image of n pixels, horizontal field of view 90 degrees"""
+    c = (np.arange(n * sub) + 0.5) / (n * sub) * 2.0 - 1.0              # tan(45 deg) = 1: image plane coordinates at distance 1
+    u, v = np.meshgrid(c, c, indexing="xy")
+    r = np.sqrt(u * u + v * v + 1.0) / np.maximum(np.maximum(np.abs(u), np.abs(v)), 1.0)
+    e = (1.0 / r ** 3).reshape(n, sub, n, sub).mean(axis=(1, 3))
+    return e[..., None] * factor[None, None, :]
+
+
+def check(img, n, factor):
+    assert (img[..., 3] > 0).all()
+    got = img[..., :3].astype(np.float64) / img[..., 3:4]
+    want = closed_form(n, factor)
+    assert np.isfinite(got).all()
+    rel = np.abs(got - want) / want
+    # the jitter sequence visits a handful of positions per pixel, the closed form averages 64: both sample a smooth function
+    assert rel.max() < 0.01 and rel.mean() < 0.004, (rel.max(), rel.mean())
+    # the brightest pixels look straight at a wall (r = 1), the darkest into a corner (r = sqrt 3): a ratio of 3^1.5
+    assert abs(got[..., 1].max() / got[..., 1].min() / 3.0 ** 1.5 - 1.0) < 0.1
+
+
+def test_oracle_render_matches_the_closed_form():
+    desc = room()
+    n = 48
+    o = OracleRenderer(OracleScene(desc), n, n)
+    o.set_integrator(abi.DIRECT)
+    o.set_seed(5)
+    o.step(24)
+    check(o.read_hdr(), n, colour_factor(desc))
+
+
+@pytest.mark.gpu
+def test_hip_render_matches_the_closed_form(instance):
+    desc = room()
+    n = 256
+    r = glaze_amd.RayTraceRenderer.new(instance, glaze_amd.RayTraceScene.from_desc(instance, desc), n, n)
+    r.set_integrator(glaze_amd.Integrator.DIRECT)
+    r.set_seed(5)
+    r.step(32)
+    check(r.read_hdr(), n, colour_factor(desc))
