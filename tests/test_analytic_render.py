@@ -18,7 +18,7 @@ import pytest
 
 import glaze_amd
 from glaze_amd import abi
-from glaze_amd.scene_desc import make_light
+from glaze_amd.scene_desc import INSTANCE_DTYPE, MESH_DTYPE, VERTEX_DTYPE, make_light
 from glaze_amd.scenes import cube_scene
 from oracle import pyoracle
 from oracle.pyoracle import OracleRenderer, OracleScene
@@ -37,13 +37,14 @@ def room():
     return desc
 
 
-def colour_factor(desc):
+def colour_factor(desc, light_pos=(0.0, 0.0, 0.0)):
     """rgb of (Lambert value of the walls) x (emission of the light at unit distance): the oracle's spectral routines"""
     o = OracleScene(desc)
     up = np.array([[0.0, 0.0, 1.0]], np.float32)
     value, pdf = o.bsdf_value(CUBE_MAT, up, up)                         # albedo spectrum / pi
     assert pdf[0] > 0
-    _, dist, lpdf, em = o.light_sample(0, np.array([[1.0, 0.0, 0.0]], np.float32), np.zeros((1, 3), np.float32))
+    at = np.asarray(light_pos, np.float32) + np.array([1.0, 0.0, 0.0], np.float32)
+    _, dist, lpdf, em = o.light_sample(0, at[None, :], np.zeros((1, 3), np.float32))
     assert dist[0] == 1.0 and lpdf[0] == 1.0                            # emission at distance 1 = colour x intensity
     sp = np.ascontiguousarray(value[0] * em[0], np.float32)
     rgb = np.zeros(3, np.float32)
@@ -93,3 +94,86 @@ def test_hip_render_matches_the_closed_form(instance):
     r.set_seed(5)
     r.step(32)
     check(r.read_hdr(), n, colour_factor(desc))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# a hard shadow: a small square between an off-axis light and the far wall
+# ---------------------------------------------------------------------------------------------------------------------
+LIGHT2 = np.array([0.5, 0.0, -0.5])
+OCC_Z, OCC_H = 0.5, 0.1          # the occluder: |x|, |y| <= OCC_H in the plane z = OCC_Z, facing the camera
+
+
+def room_with_occluder():
+    desc = room()
+    desc.lights = [make_light(abi.LIGHT_OMNI, "off axis", position=tuple(LIGHT2), intensity=INTENSITY)]
+    quad = np.zeros(4, VERTEX_DTYPE)
+    for i, (x, y) in enumerate(((-OCC_H, -OCC_H), (OCC_H, -OCC_H), (OCC_H, OCC_H), (-OCC_H, OCC_H))):
+        quad[i] = ((x, y, OCC_Z), (0.0, 0.0, -1.0), (0.5 + x, 0.5 + y))
+    base = len(desc.vertices)
+    desc.vertices = np.concatenate([desc.vertices, quad])
+    first = len(desc.indices)
+    desc.indices = np.concatenate([desc.indices, np.array([0, 1, 2, 0, 2, 3], np.uint32) + base])
+    desc.meshes = np.concatenate([desc.meshes, np.array([(1, CUBE_MAT, first, 6)], MESH_DTYPE)])
+    desc.instances = np.concatenate([desc.instances, np.array([(1, 0)], INSTANCE_DTYPE)])
+    return desc
+
+
+def closed_form_with_occluder(n, factor, flip_x):
+    """per pixel centre: expected value, and a mask of the pixels that are safely inside one region (away from the edges of the
+    occluder and of its shadow, where a pixel mixes two values)"""
+    c = (np.arange(n) + 0.5) / n * 2.0 - 1.0
+    u, v = np.meshgrid(-c if flip_x else c, c, indexing="xy")
+    on_occ = (np.abs(u) * OCC_Z < OCC_H) & (np.abs(v) * OCC_Z < OCC_H)
+    z = np.where(on_occ, OCC_Z, 1.0)
+    p = np.stack([u * z, v * z, z], -1)                                  # the surface point: on the occluder or on the wall z = 1
+    wi = LIGHT2 - p
+    d2 = (wi ** 2).sum(-1)
+    cos = np.abs(wi[..., 2]) / np.sqrt(d2)                               # both surfaces have the normal (0, 0, -1)
+    e = cos / d2
+    # a wall point is shadowed when the segment to the light passes through the square
+    s = (OCC_Z - LIGHT2[2]) / (p[..., 2] - LIGHT2[2])                    # parameter of the plane z = OCC_Z on the segment light -> p
+    q = LIGHT2 + s[..., None] * (p - LIGHT2)
+    shadow = ~on_occ & (np.abs(q[..., 0]) < OCC_H) & (np.abs(q[..., 1]) < OCC_H)
+    e = np.where(shadow, 0.0, e)
+    m = 3.0 / n                                                          # margin: one and a half pixels
+    near_occ_edge = (np.abs(np.abs(u) * OCC_Z - OCC_H) < m) & (np.abs(v) * OCC_Z < OCC_H + m) | (np.abs(np.abs(v) * OCC_Z - OCC_H) < m) & (np.abs(u) * OCC_Z < OCC_H + m)
+    near_shadow_edge = (np.abs(np.abs(q[..., 0]) - OCC_H) < m) & (np.abs(q[..., 1]) < OCC_H + m) | (np.abs(np.abs(q[..., 1]) - OCC_H) < m) & (np.abs(q[..., 0]) < OCC_H + m)
+    safe = ~near_occ_edge & ~(near_shadow_edge & ~on_occ)
+    return e[..., None] * factor[None, None, :], safe, shadow, on_occ
+
+
+def check_shadow(img, n, factor):
+    got = img[..., :3].astype(np.float64) / img[..., 3:4]
+    best = None
+    for flip in (False, True):     # the closed form is stated without knowing which way the image's x axis runs; exactly one way fits
+        want, safe, shadow, on_occ = closed_form_with_occluder(n, factor, flip)
+        lit = safe & ~shadow
+        rel = np.abs(got[lit] - want[lit]) / want[lit]
+        dark = got[safe & shadow]
+        ok = rel.max() < 0.02 and (dark == 0.0).all()
+        if ok:
+            assert best is None, "both orientations fit: the scene is not asymmetric enough"
+            best = (flip, rel.max(), int((safe & shadow).sum()), int((safe & on_occ).sum()))
+    assert best is not None, "neither orientation of the x axis reproduces the closed form"
+    assert best[2] > 0.002 * n * n and best[3] > 0.005 * n * n      # the shadow and the occluder are really in view
+
+
+def test_oracle_shadow_matches_the_closed_form():
+    desc = room_with_occluder()
+    n = 64
+    o = OracleRenderer(OracleScene(desc), n, n)
+    o.set_integrator(abi.DIRECT)
+    o.set_seed(9)
+    o.step(16)
+    check_shadow(o.read_hdr(), n, colour_factor(desc, LIGHT2))
+
+
+@pytest.mark.gpu
+def test_hip_shadow_matches_the_closed_form(instance):
+    desc = room_with_occluder()
+    n = 256
+    r = glaze_amd.RayTraceRenderer.new(instance, glaze_amd.RayTraceScene.from_desc(instance, desc), n, n)
+    r.set_integrator(glaze_amd.Integrator.DIRECT)
+    r.set_seed(9)
+    r.step(24)
+    check_shadow(r.read_hdr(), n, colour_factor(desc, LIGHT2))
