@@ -18,7 +18,7 @@ import pytest
 
 import glaze_amd
 from glaze_amd import abi
-from glaze_amd.scene_desc import INSTANCE_DTYPE, MESH_DTYPE, VERTEX_DTYPE, make_light
+from glaze_amd.scene_desc import INSTANCE_DTYPE, MESH_DTYPE, VERTEX_DTYPE, make_camera, make_light
 from glaze_amd.scenes import cube_scene
 from oracle import pyoracle
 from oracle.pyoracle import OracleRenderer, OracleScene
@@ -118,14 +118,16 @@ def room_with_occluder():
     return desc
 
 
-def closed_form_with_occluder(n, factor, flip_x):
+def closed_form_with_occluder(n, factor, flip_x, ortho=False):
     """per pixel centre: expected value, and a mask of the pixels that are safely inside one region (away from the edges of the
-    occluder and of its shadow, where a pixel mixes two values)"""
+    occluder and of its shadow, where a pixel mixes two values).  ortho: parallel rays from (u, v, 0) instead of rays through
+    (u, v, 1) from the origin."""
     c = (np.arange(n) + 0.5) / n * 2.0 - 1.0
     u, v = np.meshgrid(-c if flip_x else c, c, indexing="xy")
-    on_occ = (np.abs(u) * OCC_Z < OCC_H) & (np.abs(v) * OCC_Z < OCC_H)
+    zs = 1.0 if ortho else OCC_Z                                         # what a pixel coordinate is multiplied by on the plane z = OCC_Z
+    on_occ = (np.abs(u) * zs < OCC_H) & (np.abs(v) * zs < OCC_H)
     z = np.where(on_occ, OCC_Z, 1.0)
-    p = np.stack([u * z, v * z, z], -1)                                  # the surface point: on the occluder or on the wall z = 1
+    p = np.stack([u, v, z], -1) if ortho else np.stack([u * z, v * z, z], -1)   # the surface point: on the occluder or on the wall z = 1
     wi = LIGHT2 - p
     d2 = (wi ** 2).sum(-1)
     cos = np.abs(wi[..., 2]) / np.sqrt(d2)                               # both surfaces have the normal (0, 0, -1)
@@ -136,17 +138,22 @@ def closed_form_with_occluder(n, factor, flip_x):
     shadow = ~on_occ & (np.abs(q[..., 0]) < OCC_H) & (np.abs(q[..., 1]) < OCC_H)
     e = np.where(shadow, 0.0, e)
     m = 3.0 / n                                                          # margin: one and a half pixels
-    near_occ_edge = (np.abs(np.abs(u) * OCC_Z - OCC_H) < m) & (np.abs(v) * OCC_Z < OCC_H + m) | (np.abs(np.abs(v) * OCC_Z - OCC_H) < m) & (np.abs(u) * OCC_Z < OCC_H + m)
+    near_occ_edge = (np.abs(np.abs(u) * zs - OCC_H) < m) & (np.abs(v) * zs < OCC_H + m) | (np.abs(np.abs(v) * zs - OCC_H) < m) & (np.abs(u) * zs < OCC_H + m)
     near_shadow_edge = (np.abs(np.abs(q[..., 0]) - OCC_H) < m) & (np.abs(q[..., 1]) < OCC_H + m) | (np.abs(np.abs(q[..., 1]) - OCC_H) < m) & (np.abs(q[..., 0]) < OCC_H + m)
-    safe = ~near_occ_edge & ~(near_shadow_edge & ~on_occ)
+    # The square is two triangles, and the Moeller-Trumbore test is not watertight: a ray through their shared edge (the diagonal
+    # x = y) can fail `u >= 0` in one and `v >= 0` in the other by a rounding error and go on to the wall.  Parallel rays on a pixel grid
+    # aligned with the square do hit the diagonal exactly, so its neighbourhood is left out -- for the camera rays that see it and for the
+    # shadow rays that cross it.  (Hardware ray tracing, which the reference runs on, guarantees watertightness)
+    near_diagonal = on_occ & (np.abs(p[..., 0] - p[..., 1]) < m) | ~on_occ & (np.abs(q[..., 0] - q[..., 1]) < m) & (np.abs(q[..., 0]) < OCC_H + m)
+    safe = ~near_occ_edge & ~(near_shadow_edge & ~on_occ) & ~near_diagonal
     return e[..., None] * factor[None, None, :], safe, shadow, on_occ
 
 
-def check_shadow(img, n, factor):
+def check_shadow(img, n, factor, ortho=False):
     got = img[..., :3].astype(np.float64) / img[..., 3:4]
     best = None
     for flip in (False, True):     # the closed form is stated without knowing which way the image's x axis runs; exactly one way fits
-        want, safe, shadow, on_occ = closed_form_with_occluder(n, factor, flip)
+        want, safe, shadow, on_occ = closed_form_with_occluder(n, factor, flip, ortho)
         lit = safe & ~shadow
         rel = np.abs(got[lit] - want[lit]) / want[lit]
         dark = got[safe & shadow]
@@ -155,12 +162,13 @@ def check_shadow(img, n, factor):
             assert best is None, "both orientations fit: the scene is not asymmetric enough"
             best = (flip, rel.max(), int((safe & shadow).sum()), int((safe & on_occ).sum()))
     assert best is not None, "neither orientation of the x axis reproduces the closed form"
-    assert best[2] > 0.002 * n * n and best[3] > 0.005 * n * n      # the shadow and the occluder are really in view
+    assert best[2] > 0.001 * n * n and best[3] > 0.001 * n * n      # the shadow and the occluder are really in view
+    return best[0]
 
 
 def test_oracle_shadow_matches_the_closed_form():
     desc = room_with_occluder()
-    n = 64
+    n = 96
     o = OracleRenderer(OracleScene(desc), n, n)
     o.set_integrator(abi.DIRECT)
     o.set_seed(9)
@@ -177,3 +185,47 @@ def test_hip_shadow_matches_the_closed_form(instance):
     r.set_seed(9)
     r.step(24)
     check_shadow(r.read_hdr(), n, colour_factor(desc, LIGHT2))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the orthographic camera
+# ---------------------------------------------------------------------------------------------------------------------
+def ortho_room(scale):
+    desc = room_with_occluder()
+    desc.camera = make_camera(position=(0, 0, 0), target=(0, 0, 100), up=(0, 1, 0), orthographic=True, scale=scale, near=1e-3, far=100.0)
+    return desc
+
+
+def test_oracle_orthographic_render_matches_the_closed_form_whatever_the_scale():
+    """path_trace.rgen:47-56: the orthographic ray starts at camera2world * (ndc, 0, 1) and runs along the view direction, so the image
+    always covers [-1, 1]^2 of the camera plane -- `scale` (geometry/camera.rs: the orthographic projection's half extent) only enters
+    screen2camera, which an orthographic ray never multiplies a pixel coordinate with (Q18).  Kept: the images of two scales are
+    bit-identical, and both are the closed form for parallel rays from (u, v, 0)."""
+    n = 96
+    imgs = []
+    for scale in (0.35, 3.0):
+        desc = ortho_room(scale)
+        o = OracleRenderer(OracleScene(desc), n, n)
+        o.set_integrator(abi.DIRECT)
+        o.set_seed(9)
+        o.step(16)
+        imgs.append(o.read_hdr())
+        flip_ortho = check_shadow(imgs[-1], n, colour_factor(desc, LIGHT2), ortho=True)
+    assert np.array_equal(imgs[0].view(np.uint32), imgs[1].view(np.uint32))
+    # both cameras put world + x on the same side of the image
+    o = OracleRenderer(OracleScene(room_with_occluder()), n, n)
+    o.set_integrator(abi.DIRECT)
+    o.set_seed(9)
+    o.step(16)
+    assert check_shadow(o.read_hdr(), n, colour_factor(room_with_occluder(), LIGHT2)) == flip_ortho
+
+
+@pytest.mark.gpu
+def test_hip_orthographic_render_matches_the_closed_form(instance):
+    desc = ortho_room(0.35)
+    n = 256
+    r = glaze_amd.RayTraceRenderer.new(instance, glaze_amd.RayTraceScene.from_desc(instance, desc), n, n)
+    r.set_integrator(glaze_amd.Integrator.DIRECT)
+    r.set_seed(9)
+    r.step(24)
+    check_shadow(r.read_hdr(), n, colour_factor(desc, LIGHT2), ortho=True)
