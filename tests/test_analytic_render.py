@@ -144,7 +144,10 @@ def closed_form_with_occluder(n, factor, flip_x, ortho=False):
     # x = y) can fail `u >= 0` in one and `v >= 0` in the other by a rounding error and go on to the wall.  Parallel rays on a pixel grid
     # aligned with the square do hit the diagonal exactly, so its neighbourhood is left out -- for the camera rays that see it and for the
     # shadow rays that cross it.  (Hardware ray tracing, which the reference runs on, guarantees watertightness)
-    near_diagonal = on_occ & (np.abs(p[..., 0] - p[..., 1]) < m) | ~on_occ & (np.abs(q[..., 0] - q[..., 1]) < m) & (np.abs(q[..., 0]) < OCC_H + m)
+    # (both diagonals: the scene is symmetric in y, so nothing here knows whether the image's rows run up or down)
+    def diag(a):
+        return np.minimum(np.abs(a[..., 0] - a[..., 1]), np.abs(a[..., 0] + a[..., 1])) < m
+    near_diagonal = on_occ & diag(p) | ~on_occ & diag(q) & (np.abs(q[..., 0]) < OCC_H + m)
     safe = ~near_occ_edge & ~(near_shadow_edge & ~on_occ) & ~near_diagonal
     return e[..., None] * factor[None, None, :], safe, shadow, on_occ
 
@@ -162,7 +165,7 @@ def check_shadow(img, n, factor, ortho=False):
             assert best is None, "both orientations fit: the scene is not asymmetric enough"
             best = (flip, rel.max(), int((safe & shadow).sum()), int((safe & on_occ).sum()))
     assert best is not None, "neither orientation of the x axis reproduces the closed form"
-    assert best[2] > 0.001 * n * n and best[3] > 0.001 * n * n      # the shadow and the occluder are really in view
+    assert best[2] >= max(6, 0.0005 * n * n) and best[3] >= max(6, 0.0005 * n * n)      # the shadow and the occluder are really in view
     return best[0]
 
 
