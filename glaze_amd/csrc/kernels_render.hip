@@ -436,11 +436,19 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
       continue;
     }
     // ---- inner-node phase ----
+#ifdef GLZ_SHARE_ONCE_PER_ROUND
+    bool first_iter = true;
+#endif
     for (;;) {
       // Idle lanes take over pending subtrees before EVERY node iteration of the tail, not once per round: a round is several
       // iterations long, and with one hand-over per round the helpers of a long ray multiplied too slowly to matter before it
       // was over (a 1/8 share: 0.153 -> 0.147 ms per launch; the full frame, where only each wave's last group is a tail: 0.930 -> 0.914).
+#ifndef GLZ_SHARE_ONCE_PER_ROUND
       share_step();
+#else
+      if (first_iter) share_step();
+      first_iter = false;
+#endif
       // (Reading the first word of the triangle as soon as a lane of the tail arrives at a leaf, so that the line is on its way while
       // the others finish their node iterations: slower, 0.146 -> 0.149 ms for a 1/8 share and 0.905 -> 0.924 ms for the full frame.)
       const bool at_node = cur >= 0 && cur < kStolen;
