@@ -1,7 +1,7 @@
 """1/WORLD share of the 1080p atrium frame on one GPU: ms per launch against the number of concurrent launch chains
 (run once per GPU_MAX_HW_QUEUES setting: beyond the hardware queues HIP maps streams onto, chains serialise)."""
 import os, sys, time
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import glaze_amd
 from glaze_amd.scenes import atrium_scene
 inst = glaze_amd.RayTraceInstance.new()
