@@ -27,12 +27,14 @@ struct Rccl {
     static std::once_flag once;
     std::call_once(once, [] {
       void* h = nullptr;
+      std::string why = "librccl.so.1 not found";
       for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
         h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
         if (h) break;
+        if (const char* e = dlerror()) why = e;   // dlerror() hands its message out once
       }
       if (!h) {
-        r.error = std::string("RCCL is not available: ") + (dlerror() ? dlerror() : "librccl.so.1 not found");
+        r.error = "RCCL is not available: " + why;
         return;
       }
       auto sym = [&](const char* n) -> void* {
