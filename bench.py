@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """bench.py -- Msamples/s + achieved HBM GB/s of the render hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]                      (N > 1: ONE process drives the N GPUs)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W                               (one process per GPU)
 
 Workload (BASELINE.json configs[3]): the Sponza-class frame, 1920x1080, path tracer, depth 8.  Sponza
 itself is not in the reference repository, so the scene is the deterministic synthetic
@@ -15,10 +15,16 @@ A "step" is ONE launch of the hot path = one path segment for every pixel of the
 (one vkCmdTraceRaysKHR in the reference, raytracer.rs:553-562): W*H samples.  Steps continue the
 same accumulation (draw_frame semantics), K steps = K/depth samples per pixel.
 
-N > 1: the frame's 64x64 tiles are sharded over the ranks (tile t -> rank t % N); after the K steps
-the float HDR accumulator is sum-reduced to rank 0 over RCCL (inside the timed region).  Total work is
-fixed -> "scaling": "strong".  Rank 0 then checks the reduced frame bit for bit against the frame it renders alone
-(--no-verify skips it).
+N > 1: the frame's 64x64 tiles are sharded over the GPUs (tile t -> GPU t % N); after the K steps the float HDR
+accumulator of every GPU is brought onto GPU 0 over RCCL / xGMI (inside the timed region; its share of the time is also
+printed as `exchange_ms`).  Total work is fixed -> "scaling": "strong".  GPU 0 then checks the assembled frame bit for bit
+against the frame it renders alone (--no-verify skips it).  Two ways to get there, same kernels and same partition:
+  * started plainly (`python bench.py --gpus N`, no WORLD_SIZE in the environment): the product's own in-process path,
+    glz_renderer_set_devices -- what `glaze-cli --devices 0,1,..` runs: one host thread, one scene replica and one RCCL
+    communicator (ncclCommInitAll) per GPU, packed tiles sent to GPU 0 (ncclSend / ncclRecv in one group);
+  * started by torch.distributed.run: one process per GPU, glz_renderer_set_partition(rank, N), and the same packed-tile
+    exchange through torch.distributed's "nccl" backend (= RCCL).
+GLAZE_MULTI_EXCHANGE=reduce switches both to one ncclReduce(sum) of the zero-padded W*H*4 frame.
 
 The timed region is EXACTLY K steps between barrier + synchronize pairs, MAX over ranks.  A region shorter than 0.5 s is
 repeated (five regions in all, the accumulation simply continues) and `value` comes from the MEDIAN region; every
@@ -76,16 +82,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    # n_dev > 1: ONE process spans the GPUs (glz_renderer_set_devices); world > 1: one process per GPU (torch.distributed)
+    n_dev = 1
+    if world == 1 and args.gpus > 1:
+        n_dev = args.gpus
+    elif world != args.gpus:
         args.gpus = world
+    n_gpus = max(world, n_dev)
     import numpy as np
     import torch
     import torch.distributed as dist
 
     import glaze_amd
-    from glaze_amd.distributed import reduce_frame
+    from glaze_amd.distributed import gather_frame, reduce_frame
     from glaze_amd.scenes import atrium_scene
 
     if not torch.cuda.is_available():
@@ -93,11 +102,20 @@ def main():
     # GLAZE_BENCH_REHEARSAL=1: every rank shares GPU 0 and the reduce goes through gloo on host tensors -- lets the N > 1
     # code path (partition, chains, reduce, max-over-ranks timing) be run on a one-GPU box.  Not a measurement.
     rehearsal = os.environ.get("GLAZE_BENCH_REHEARSAL") == "1"
+    # GLAZE_MULTI_LOOPBACK=1 (in-process path only): the N "devices" are all GPU 0 -- same threads, replicas and tile sharding,
+    # the tiles meet without RCCL.  Not a measurement either.
+    loopback = n_dev > 1 and os.environ.get("GLAZE_MULTI_LOOPBACK") is not None
+    exchange = os.environ.get("GLAZE_MULTI_EXCHANGE", "gather")
+    if exchange not in ("gather", "reduce"):
+        raise SystemExit("GLAZE_MULTI_EXCHANGE must be `gather` or `reduce`")
+    if n_dev > 1 and not loopback and torch.cuda.device_count() < n_dev:
+        raise SystemExit("--gpus %d: this machine has %d GPU(s) (GLAZE_MULTI_LOOPBACK=1 rehearses the %d-device path on one)"
+                         % (n_dev, torch.cuda.device_count(), n_dev))
     if rehearsal:
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if rehearsal:
             dist.init_process_group(backend="gloo")
         else:
@@ -124,8 +142,13 @@ def main():
     renderer = glaze_amd.RayTraceRenderer.new(inst, scene, W, H)
     renderer.set_depth(args.depth)
     renderer.set_seed(args.seed)
+    devices_s = None
     if world > 1:
         renderer.set_partition(rank, world)
+    elif n_dev > 1:
+        t0 = time.time()
+        renderer.set_devices([0] * n_dev if loopback else list(range(n_dev)))     # replicas + BVH builds + ncclCommInitAll
+        devices_s = time.time() - t0
     frame = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
 
     def sync_all():
@@ -135,21 +158,26 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def reduce_to_rank0():
-        """export this rank's tiles (zero elsewhere) and sum them onto rank 0: RCCL over xGMI, or gloo in a rehearsal"""
-        renderer.export_device(0, frame.data_ptr())
-        if rehearsal:
+    def exchange_to_gpu0():
+        """every GPU's tiles onto GPU 0 (RCCL over xGMI; gloo on host tensors in a rehearsal)"""
+        if n_dev > 1:
+            renderer.export_device(0, frame.data_ptr())     # set_devices: the library's own exchange, synchronised on return
+        elif rehearsal:
+            renderer.export_device(0, frame.data_ptr())
             host = frame.cpu()
             reduce_frame(host)
             frame.copy_(host)
+        elif exchange == "gather":
+            gather_frame(renderer, frame)
         else:
+            renderer.export_device(0, frame.data_ptr())
             reduce_frame(frame)
 
     # ---- warmup (untimed): same accumulation continues afterwards, like the interactive draw_frame loop
     renderer.restart()
     renderer.step(args.warmup)
-    if world > 1:
-        reduce_to_rank0()
+    if n_gpus > 1:
+        exchange_to_gpu0()      # first use of the communicators / the process group belongs to the warm-up
     sync_all()
     renderer.stats()            # drains the warmup's kernel events
     s0 = renderer.stats()
@@ -159,8 +187,8 @@ def main():
         sync_all()
         t_start = time.perf_counter()
         renderer.step(args.steps)
-        if world > 1:
-            reduce_to_rank0()
+        if n_gpus > 1:
+            exchange_to_gpu0()
         sync_all()
         t = torch.tensor([time.perf_counter() - t_start], dtype=torch.float64, device="cpu" if rehearsal or world == 1 else "cuda")
         if world > 1:
@@ -173,6 +201,20 @@ def main():
     while len(regions) < n_regions:
         regions.append(timed_region())
     s1 = renderer.stats()
+    # the exchange alone (it is INSIDE every timed region above; this is only to show its share): nothing new was rendered,
+    # so it moves the same frame again
+    exchange_ms = None
+    if n_gpus > 1:
+        ex = []
+        for _ in range(3):
+            sync_all()
+            t_start = time.perf_counter()
+            exchange_to_gpu0()
+            sync_all()
+            ex.append((time.perf_counter() - t_start) * 1e3)
+        exchange_ms = sorted(ex)[1]
+    # what GPU 0 holds now is the frame of warmup + K * regions launches, assembled from all GPUs: kept for the check at the end
+    verify_frame = frame.cpu().numpy().copy() if (n_gpus > 1 and args.verify and rank == 0) else None
     elapsed = sorted(regions)[len(regions) // 2]      # median region
     total_steps = args.steps * len(regions)
     samples = W * H * args.steps                     # whole frame, all ranks together, per region
@@ -206,14 +248,14 @@ def main():
         }
         bytes_per_sample = algorithmic_bytes(counted)
         dominant = max(kern_ms, key=kern_ms.get)
-        owned = W * H / world
+        owned = W * H / n_gpus      # per GPU: kernel times are per device (the slowest one when one process spans several)
         avg_ms = kern_ms[dominant] / total_steps
         achieved = bytes_per_sample[dominant] * owned / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         # HBM traffic is NOT measured in this run (PMC counters need rocprofv3): the number is the per-launch average of the
         # committed rocprofv3 --pmc passes of this very command (tools/profile_gpu.sh -> profiles/pmc_summary.json)
         traffic, traffic_source = None, None
         prof = os.path.join(ROOT, "profiles", "pmc_summary.json")
-        if os.path.exists(prof) and world == 1:      # the committed PMC passes profiled the N = 1 command
+        if os.path.exists(prof) and n_gpus == 1:      # the committed PMC passes profiled the N = 1 command
             try:
                 traffic = json.load(open(prof)).get(dominant, {}).get("hbm_bytes_per_launch")
                 traffic_source = "profiles/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `python bench.py`, not this run)"
@@ -227,7 +269,7 @@ def main():
                     "counted_over_launches": [args.warmup, args.warmup + n_count],
                     "kernel_ms_per_step": {k: round(v / total_steps, 4) for k, v in kern_ms.items()}}
         cpu = None
-        if world == 1 and not args.no_cpu_baseline:
+        if n_gpus == 1 and not args.no_cpu_baseline:
             # CPU baseline: the oracle (scalar C++ restatement; the reference has no CPU tracer) on a
             # bounded sample of the SAME workload: same scene/frame/depth/seed, fewer launches.
             from oracle.pyoracle import OracleRenderer, OracleScene
@@ -250,35 +292,58 @@ def main():
             dt1 = time.perf_counter() - tc
             cpu["single_thread"] = {"value": round(W * H / dt1 / 1e6, 3), "unit": "Msamples/s", "cores": 1,
                                     "sample": "1 launch (%.1f s)" % dt1}
+        multi = None
+        how = ""
+        if n_gpus > 1:
+            if n_dev > 1:
+                mode = "one process, glz_renderer_set_devices (a host thread, a scene replica and an RCCL communicator per GPU)"
+                how = "loop-back on ONE GPU, no RCCL (rehearsal)" if loopback else (
+                    "ncclSend/ncclRecv of packed tiles in one group" if exchange == "gather" else "ncclReduce(sum) of the zero-padded frame")
+                rccl = None if loopback else int(glaze_amd.abi.lib().glz_rccl_version())
+                seen = renderer.device_count()
+            else:
+                mode = "one process per GPU (torch.distributed), glz_renderer_set_partition"
+                how = "gloo reduce of host tensors on ONE GPU (rehearsal)" if rehearsal else (
+                    "dist.gather of packed tiles (RCCL send/recv)" if exchange == "gather" else "dist.reduce(sum) of the zero-padded frame (RCCL)")
+                try:
+                    rccl = None if rehearsal else list(torch.cuda.nccl.version())
+                except Exception:       # noqa: BLE001
+                    rccl = None
+                seen = dist.get_world_size()
+            multi = {"mode": mode, "exchange": how, "exchange_ms": round(exchange_ms, 4), "exchange_bytes_to_gpu0": int(W * H * 16 * (n_gpus - 1) / n_gpus) if exchange == "gather" or loopback else W * H * 16,
+                     "rccl_version": rccl, "gpus_seen": seen, "measurement": not (loopback or rehearsal), "set_devices_s": None if devices_s is None else round(devices_s, 3)}
         out = {
             "metric": "Msamples/s + achieved HBM GB/s, Sponza 1080p, 1/2/4/8xMI355X",
-            "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(value, 2), "unit": "Msamples/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
             "regions_ms": [round(t * 1e3, 3) for t in regions],
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "Sponza-class synthetic atrium (%d tris) as a .glaze V1 file (%d bytes) through parse, %dx%d, path tracer depth %d, %d steps = %.1f spp"
                                    % (int(info.n_world_triangles), glaze_bytes, W, H, args.depth, args.steps, args.steps / args.depth),
                        "width": W, "height": H, "depth": args.depth, "triangles": int(info.n_world_triangles),
-                       "sharding": "64x64 tiles round-robin over %d rank(s), %s reduce of the RGBA32F accumulator" % (world, "gloo (rehearsal on one GPU)" if rehearsal else "RCCL"),
+                       "sharding": "64x64 tiles round-robin over %d GPU(s)%s" % (n_gpus, "" if n_gpus == 1 else ", RGBA32F accumulator onto GPU 0: " + how),
                        "bvh": {"builder": "binned SAH on the GPU, leaves of 1-2 triangles, 4-wide quantised nodes", "nodes": int(info.bvh_nodes),
                                "depth": int(info.bvh_depth), "sah_cost": round(float(info.bvh_sah_cost), 2), "build_ms": round(float(info.build_ms), 3)},
                        "setup_s": round(setup_s, 3), "serialize_s": round(serialize_s, 3)},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "multi_gpu": multi,
             "mpaths_per_s": round(value / args.depth, 2),
             "grays_per_s": round(value * (1 + counted["f_shadow"]) / 1e3, 3),
         }
     failure = None
-    if world > 1 and args.verify and rank == 0:
-        # the reduced frame against the whole frame rendered by this rank alone, same seed and launch count; a failure
+    if n_gpus > 1 and args.verify and rank == 0:
+        # the assembled frame against the whole frame rendered by GPU 0 alone, same seed and launch count; a failure
         # (or an exception) is only recorded here: every rank must still reach the barrier below, or the others hang in it
         try:
-            reduced = frame.cpu().numpy().copy()
-            renderer.set_partition(0, 1)
+            launches = args.warmup + total_steps
+            if world == 1:
+                renderer.set_devices([0])       # back to one device (the peers' replicas and communicators are released)
+            else:
+                renderer.set_partition(0, 1)
             renderer.restart()
-            renderer.step(args.warmup + total_steps)
+            renderer.step(launches)
             alone = renderer.read_hdr()
-            same = bool(np.array_equal(np.nan_to_num(reduced, nan=-1.0).view(np.uint32), np.nan_to_num(alone, nan=-1.0).view(np.uint32)))
-            out["verify"] = {"bit_identical_to_one_gpu": same, "launches": args.warmup + total_steps}
+            same = bool(np.array_equal(np.nan_to_num(verify_frame, nan=-1.0).view(np.uint32), np.nan_to_num(alone, nan=-1.0).view(np.uint32)))
+            out["verify"] = {"bit_identical_to_one_gpu": same, "launches": launches, "nonzero_pixels": int((alone[..., 3] > 0).sum())}
             if not same:
                 failure = "multi-GPU frame differs from the single-GPU frame"
         except Exception as ex:     # noqa: BLE001 -- reported after the collective teardown

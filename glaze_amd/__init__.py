@@ -458,10 +458,19 @@ class RayTraceRenderer:
         abi.check(abi.lib().glz_renderer_set_texture_lod(self._h, int(mode)))
 
     def set_devices(self, devices):
-        """Render on several GPUs of this process (tiles t % n == i on devices[i], RCCL reduce onto devices[0] at every read-back);
+        """Render on several GPUs of this process (tiles t % n == i on devices[i], RCCL exchange onto devices[0] at every read-back);
         devices[0] must be the instance's device.  [d] returns to one device."""
         arr = (C.c_int * len(devices))(*devices)
         abi.check(abi.lib().glz_renderer_set_devices(self._h, arr, len(devices)))
+
+    def device_count(self):
+        return int(abi.lib().glz_renderer_device_count(self._h))
+
+    def device_scene_info(self, i):
+        """scene info of the replica device i of set_devices renders (0 = this renderer's own scene)"""
+        info = abi.SceneInfo()
+        abi.check(abi.lib().glz_renderer_device_scene_info(self._h, i, C.byref(info)))
+        return info
 
     def set_chains(self, n):
         """Concurrent launch chains over this rank's tiles (0 = automatic); the image does not depend on it."""
@@ -525,6 +534,18 @@ class RayTraceRenderer:
 
     def export_device(self, which, device_ptr):
         abi.check(abi.lib().glz_renderer_export_device(self._h, which, C.c_void_p(device_ptr)))
+
+    def packed_pixels(self, rank, world):
+        """pixels (of 4 floats) in the packed tiles of partition (rank, world) of this renderer's frame"""
+        return int(abi.lib().glz_renderer_packed_pixels(self._h, rank, world))
+
+    def export_packed(self, which, device_ptr):
+        """this rank's tiles only, tile-major, into a device buffer of packed_pixels(rank, world) x 4 floats"""
+        abi.check(abi.lib().glz_renderer_export_packed(self._h, which, C.c_void_p(device_ptr)))
+
+    def scatter_packed(self, rank, world, packed_ptr, frame_ptr):
+        """rank 0: puts the packed tiles received from `rank` into their place of a full-frame device buffer"""
+        abi.check(abi.lib().glz_renderer_scatter_packed(self._h, rank, world, C.c_void_p(packed_ptr), C.c_void_p(frame_ptr)))
 
     def tonemap_device(self, device_ptr):
         out = np.zeros((self.height, self.width, 4), np.uint8)

@@ -159,6 +159,9 @@ PROTOTYPES = {
     "glz_renderer_set_partition": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
     "glz_renderer_set_chains": (C.c_int, [_P, C.c_uint32]),
     "glz_renderer_export_device": (C.c_int, [_P, C.c_int, _P]),
+    "glz_renderer_packed_pixels": (C.c_uint64, [_P, C.c_uint32, C.c_uint32]),
+    "glz_renderer_export_packed": (C.c_int, [_P, C.c_int, _P]),
+    "glz_renderer_scatter_packed": (C.c_int, [_P, C.c_uint32, C.c_uint32, _P, _P]),
     "glz_renderer_tonemap_device": (C.c_int, [_P, _P, _P]),
     "glz_renderer_enable_counters": (C.c_int, [_P, C.c_int]),
     "glz_renderer_get_stats": (C.c_int, [_P, _P]),
@@ -181,6 +184,9 @@ PROTOTYPES = {
     "glz_debug_rccl_selftest": (C.c_int, [_P, C.c_uint64, _P]),
     "glz_instance_set_as_levels": (C.c_int, [_P, C.c_int]),
     "glz_renderer_set_devices": (C.c_int, [_P, _P, C.c_int]),
+    "glz_renderer_device_count": (C.c_int, [_P]),
+    "glz_renderer_device_scene_info": (C.c_int, [_P, C.c_int, _P]),
+    "glz_rccl_version": (C.c_int, []),
     "glz_host_tile_owner": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, _P]),
 }
 

@@ -422,6 +422,22 @@ int glz_renderer_export_device(glz_renderer* h, int which, void* dev) {
   GLZ_RET(h->r->export_device(which, dev, e));
   GLZ_GUARD_END(GLZ_E_IO)
 }
+uint64_t glz_renderer_packed_pixels(glz_renderer* h, uint32_t rank, uint32_t world) {
+  if (!h) return 0;
+  return (uint64_t)Renderer::packed_count(h->r->width(), h->r->height(), rank, world);
+}
+int glz_renderer_export_packed(glz_renderer* h, int which, void* dev) {
+  GLZ_GUARD_BEGIN GLZ_R(h);
+  if (!dev) return fail(GLZ_E_ARG, "device buffer is null");
+  GLZ_RET(h->r->export_packed(which, dev, e));
+  GLZ_GUARD_END(GLZ_E_IO)
+}
+int glz_renderer_scatter_packed(glz_renderer* h, uint32_t rank, uint32_t world, const void* packed, void* frame) {
+  GLZ_GUARD_BEGIN GLZ_R(h);
+  if (!packed || !frame) return fail(GLZ_E_ARG, "device buffer is null");
+  GLZ_RET(h->r->scatter_packed(rank, world, packed, frame, e));
+  GLZ_GUARD_END(GLZ_E_IO)
+}
 int glz_renderer_tonemap_device(glz_renderer* h, const void* dev, uint8_t* out) {
   GLZ_GUARD_BEGIN GLZ_R(h);
   if (!dev || !out) return fail(GLZ_E_ARG, "null argument");
@@ -594,6 +610,25 @@ int glz_debug_tonemap(glz_instance* inst, const float* rgba32f, uint64_t n, uint
   (void)hipMemcpyAsync(out, d_out.ptr, n * 4, hipMemcpyDeviceToHost, st);
   if (!hip_ok(hipStreamSynchronize(st), "debug tonemap", e)) return fail(e);
   return GLZ_OK;
+  GLZ_GUARD_END(GLZ_E_IO)
+}
+
+int glz_renderer_device_count(glz_renderer* h) { return h ? (int)h->r->device_count() : 0; }
+int glz_renderer_device_scene_info(glz_renderer* h, int i, glz_scene_info* out) {
+  if (!h || !out) return fail(GLZ_E_ARG, "null argument");
+  const Scene* s = h->r->device_scene(i);
+  if (!s) return fail(GLZ_E_ARG, "glz_renderer_device_scene_info: no such device");
+  *out = s->info;
+  return GLZ_OK;
+}
+int glz_rccl_version(void) {
+  GLZ_GUARD_BEGIN
+  std::string why;
+  const Rccl* nc = Rccl::get(why);
+  if (!nc) return fail(GLZ_E_DEVICE, why.c_str());
+  int version = 0;
+  if (nc->GetVersion(&version) != ncclSuccess) return fail(GLZ_E_DEVICE, "ncclGetVersion failed");
+  return version;
   GLZ_GUARD_END(GLZ_E_IO)
 }
 

@@ -111,6 +111,8 @@ hipError_t launch_trace(hipStream_t st, const LaunchArgs& a, uint32_t blocks);
 hipError_t launch_shade(hipStream_t st, const LaunchArgs& a);
 // scatter the tile-major cumulative / result images into full-frame row-major RGBA32F buffers
 hipError_t launch_export(hipStream_t st, const TileMap& map, const float4* tiled, float4* frame, bool zero_first);
+// chain `chain` of `n_chains` -> the rank's packed tile order (local tile j = jl * n_chains + chain), see Renderer::export_packed
+hipError_t launch_pack_tiles(hipStream_t st, uint32_t n_chain_pixels, uint32_t n_chains, uint32_t chain, const float4* tiled, float4* packed);
 // result (out32) -> RGBA8 sRGB, full-frame row-major (the blit of raytracer.rs:576-584)
 // thresholds: 256 floats, [k] = smallest linear value that encodes to k (host::srgb8_thresholds); [0] = 0
 hipError_t launch_tonemap(hipStream_t st, uint32_t n_pixels, const float4* result_frame, const float* thresholds, uchar4* out);

@@ -1383,6 +1383,15 @@ __global__ void __launch_bounds__(kBlock) k_export(const TileMap map, const floa
   if (px.active) frame[(size_t)px.y * map.width + px.x] = tiled[lid];
 }
 
+// chain s of S holds the rank's local tiles j = jl * S + s at chain-local index jl: lay them out in the rank's own tile order
+// (what a rank of a one-process-per-GPU job sends to rank 0, 1 / world of the frame's bytes)
+__global__ void __launch_bounds__(kBlock) k_pack_tiles(uint32_t n_pixels, uint32_t S, uint32_t s, const float4* __restrict__ chain, float4* __restrict__ packed) {
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n_pixels) return;
+  const uint32_t jl = i >> 12, k = i & 4095u;
+  packed[(size_t)(jl * S + s) * 4096u + k] = chain[i];
+}
+
 // linear -> sRGB OETF, 8 bit, round to nearest (what the R8G8B8A8_SRGB blit does, raytracer.rs:576-584 [ext]).
 // Byte work has to be bit-exact, and pow() is not the same function on any two machines, so the quantiser is stated
 // without it: q = #{k in 1..255 : c >= T_k} with T_k = (float) EOTF((k - 0.5) / 255), the smallest float whose encoded
@@ -1520,6 +1529,11 @@ hipError_t launch_export(hipStream_t st, const TileMap& map, const float4* tiled
   }
   if (map.n_local_pixels == 0) return hipSuccess;
   hipLaunchKernelGGL(k_export, grid_for(map.n_local_pixels), dim3(kBlock), 0, st, map, tiled, frame);
+  return hipGetLastError();
+}
+hipError_t launch_pack_tiles(hipStream_t st, uint32_t n_chain_pixels, uint32_t n_chains, uint32_t chain, const float4* tiled, float4* packed) {
+  if (n_chain_pixels == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_pack_tiles, grid_for(n_chain_pixels), dim3(kBlock), 0, st, n_chain_pixels, n_chains, chain, tiled, packed);
   return hipGetLastError();
 }
 hipError_t launch_tonemap(hipStream_t st, uint32_t n, const float4* result_frame, const float* thresholds, uchar4* out) {

@@ -4,6 +4,7 @@
 // library, and a process that already carries an RCCL (PyTorch bundles one under the same soname) shares that copy.
 #pragma once
 #include <dlfcn.h>
+#include <stdlib.h>
 #include <rccl/rccl.h>
 
 #include <mutex>
@@ -15,6 +16,8 @@ struct Rccl {
   decltype(&ncclCommInitAll) CommInitAll = nullptr;
   decltype(&ncclCommDestroy) CommDestroy = nullptr;
   decltype(&ncclReduce) Reduce = nullptr;
+  decltype(&ncclSend) Send = nullptr;
+  decltype(&ncclRecv) Recv = nullptr;
   decltype(&ncclGroupStart) GroupStart = nullptr;
   decltype(&ncclGroupEnd) GroupEnd = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
@@ -28,7 +31,11 @@ struct Rccl {
     std::call_once(once, [] {
       void* h = nullptr;
       std::string why = "librccl.so.1 not found";
-      for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      // GLAZE_RCCL_LIBRARY names the library to load instead (tests/fake_rccl: a recording stand-in that lets the n >= 2 group
+      // construction run on a box with one GPU or none)
+      const char* forced = getenv("GLAZE_RCCL_LIBRARY");
+      for (const char* name : {forced ? forced : "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        if (forced && name != forced) break;
         h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
         if (h) break;
         if (const char* e = dlerror()) why = e;   // dlerror() hands its message out once
@@ -45,6 +52,8 @@ struct Rccl {
       r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(sym("ncclCommInitAll"));
       r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
       r.Reduce = reinterpret_cast<decltype(r.Reduce)>(sym("ncclReduce"));
+      r.Send = reinterpret_cast<decltype(r.Send)>(sym("ncclSend"));
+      r.Recv = reinterpret_cast<decltype(r.Recv)>(sym("ncclRecv"));
       r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
       r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
       r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));

@@ -81,9 +81,19 @@ struct Renderer::Peer {
     frame.release();
   }
 };
+// What the peers' tasks write their outcome into.  The tasks hold pointers into it, so it must not go away while one of them
+// runs: if the poster leaves early (an exception out of its local share of the work), the destructor waits for the workers.
 struct Renderer::Pending {
   std::vector<Error> errs;
   std::vector<char> ok;
+  Renderer* posted_on = nullptr;
+  Pending() = default;
+  Pending(const Pending&) = delete;
+  Pending& operator=(const Pending&) = delete;
+  ~Pending() {
+    if (posted_on)
+      for (auto& peer : posted_on->peers_) peer->worker.wait();
+  }
 };
 
 // f(Peer&, Error&) -> bool on every peer's thread; f is copied into the tasks, whatever it refers to must outlive join_all()
@@ -91,6 +101,7 @@ template <class F>
 void Renderer::post_all(F f, Pending& p) {
   p.errs.assign(peers_.size(), Error());
   p.ok.assign(peers_.size(), 1);
+  p.posted_on = this;
   for (size_t i = 0; i < peers_.size(); ++i) {
     Peer* peer = peers_[i].get();
     Error* e = &p.errs[i];
@@ -102,12 +113,17 @@ void Renderer::post_all(F f, Pending& p) {
         e->code = GLZ_E_IO;
         e->msg = ex.what();
         *ok = 0;
+      } catch (...) {   // nothing may leave a peer's thread: that would be std::terminate
+        e->code = GLZ_E_IO;
+        e->msg = "unknown exception on a device thread";
+        *ok = 0;
       }
     });
   }
 }
 bool Renderer::join_all(Pending& p, Error& err) {
   for (auto& peer : peers_) peer->worker.wait();
+  p.posted_on = nullptr;
   for (size_t i = 0; i < p.ok.size(); ++i)
     if (!p.ok[i]) {
       err = p.errs[i];
@@ -555,10 +571,10 @@ bool Renderer::change_resolution(uint32_t w, uint32_t h, Error& err) {
   w_ = w;
   h_ = h;
   if (!allocate(err)) return false;
-  const bool lb = loopback_;
+  const bool want_frame = !loopback_ && exchange_ == kExchangeReduce;
   if (!forward([=](Peer& p, Error& e) {
         if (!p.r->change_resolution(w, h, e)) return false;
-        return lb || hip_ok(p.frame.alloc((size_t)w * h), "alloc peer frame", e);
+        return !want_frame || hip_ok(p.frame.alloc((size_t)w * h), "alloc peer frame", e);
       }, err))
     return false;
   (void)hipSetDevice(inst_->device);
@@ -575,9 +591,12 @@ bool Renderer::change_scene(std::shared_ptr<Scene> scene, Error& err) {
   scene_ = scene;
   exposure_ = scene->data.meta.exposure;
   if (!allocate(err)) return false;
-  // the other GPUs of this process get replicas of the new scene
+  // the other GPUs of this process get replicas of the new scene, in the shape (flattened / two levels) this device built
   const Scene* src = scene.get();
+  const Instance* src_inst = scene->instance ? scene->instance : inst_;
   if (!forward([=](Peer& p, Error& e) {
+        p.inst->copy_build_options(*src_inst);
+        if (src->info.as_levels) p.inst->as_levels = (int)src->info.as_levels;
         SceneData copy = src->data;
         std::shared_ptr<Scene> replica(Scene::create(p.inst.get(), std::move(copy), e));
         return replica && p.r->change_scene(replica, e);
@@ -677,8 +696,7 @@ bool Renderer::draw(size_t spp, void (*cb)(void*), void* user, uint8_t* rgba8_ou
 // every chain scatters its tiles into the full-frame buffer `dst` (the first one clears it); all on the first chain's
 // stream after the chains have drained
 bool Renderer::gather(bool result, float4* dst, Error& err, bool zero_first) {
-  if (request_new_frame_ && !reset_buffers(err)) return false;
-  if (!wait_idle(err)) return false;
+  if (!settle(err)) return false;
   hipStream_t st = chains_[0]->stream;
   bool first = zero_first;
   for (auto& c : chains_) {
@@ -689,18 +707,41 @@ bool Renderer::gather(bool result, float4* dst, Error& err, bool zero_first) {
   return true;
 }
 
-// The frames of the other GPUs meet this device's in `dst`: one ncclReduce(sum, float) of W*H*4 floats per device onto rank 0
-// (the tiles are disjoint and zero elsewhere, so the sum is bit-identical to a one-GPU render), issued for every
-// communicator inside one ncclGroup from this thread.  Loop-back mode (every "device" is this one; tests): RCCL cannot
-// put two ranks on one GPU, and there is nothing to move -- the peers scatter their tiles straight into `dst`.
+// The tiles of the other GPUs meet this device's in `dst` (RCCL over xGMI; one communicator per device, every call of one
+// exchange inside ONE ncclGroup issued from this thread).  Two shapes:
+//  * gather (default): every peer chain SENDS its packed tile-major buffer (its share of the frame, 1/n of the bytes) straight to
+//    device 0, which receives into a staging area and scatters with k_export.  xGMI is point to point: the n - 1 transfers use
+//    n - 1 different links at the same time, each carrying 1/n of the frame (4 MB of a 1080p frame at n = 8).
+//  * reduce (GLAZE_MULTI_EXCHANGE=reduce): one ncclReduce(sum, float) of the zero-padded W*H*4 frame per device, in place on the
+//    root -- what SURVEY 8(e) names first; a ring moves the whole frame over every link (33 MB at 1080p).
+// The tiles are disjoint, so both give the image of a one-GPU render bit for bit.  Loop-back mode (every "device" is this one;
+// tests): RCCL cannot put two ranks on one GPU, and there is nothing to move -- the peers scatter their tiles straight into `dst`.
 bool Renderer::reduce_peers(bool result, float4* dst, Error& err) {
   hipStream_t st = chains_[0]->stream;
-  if (!hip_ok(hipStreamSynchronize(st), "reduce: local frame", err)) return false;
+  if (!hip_ok(hipStreamSynchronize(st), "exchange: local frame", err)) return false;
   const bool lb = loopback_;
+  const bool packed = !lb && exchange_ == kExchangeGather;
   if (!forward([=](Peer& p, Error& e) {
         if (!hip_ok(hipSetDevice(p.inst->device), "hipSetDevice", e)) return false;
+        if (packed) {
+          // the chains' own tile-major buffers are what travels: one chain is sent from where it lies, several are laid end
+          // to end first so that every peer issues exactly ONE send (copies and send are ordered by the peer's stream)
+          if (!p.r->settle(e)) return false;
+          auto& ch = p.r->chains_;
+          if (ch.size() < 2) return true;
+          size_t total = 0, off = 0;
+          for (auto& c : ch) total += c->map.n_local_pixels;
+          if (p.frame.count < total && !hip_ok(p.frame.alloc(total), "alloc peer staging", e)) return false;
+          for (auto& c : ch) {
+            const size_t n = c->map.n_local_pixels;
+            if (n && !hip_ok(hipMemcpyAsync(p.frame.ptr + off, result ? c->result.ptr : c->cumulative.ptr, sizeof(float4) * n, hipMemcpyDeviceToDevice, p.inst->stream), "pack tiles", e))
+              return false;
+            off += n;
+          }
+          return true;
+        }
         if (!p.r->gather(result, lb ? dst : p.frame.ptr, e, !lb)) return false;
-        return hip_ok(hipStreamSynchronize(p.inst->stream), "reduce: peer frame", e);
+        return hip_ok(hipStreamSynchronize(p.inst->stream), "exchange: peer frame", e);
       }, err))
     return false;
   if (!hip_ok(hipSetDevice(inst_->device), "hipSetDevice", err)) return false;
@@ -712,25 +753,68 @@ bool Renderer::reduce_peers(bool result, float4* dst, Error& err) {
     err.msg = nc ? "RCCL communicators are missing" : why;
     return false;
   }
-  const size_t count = (size_t)w_ * h_ * 4;
   auto ck = [&](ncclResult_t r, const char* what) {
     if (r == ncclSuccess) return true;
-    err.code = GLZ_E_DEVICE;
-    err.msg = std::string(what) + ": " + nc->GetErrorString(r);
+    if (err.code == 0 || err.msg.empty()) {
+      err.code = GLZ_E_DEVICE;
+      err.msg = std::string(what) + ": " + nc->GetErrorString(r);
+    }
     return false;
   };
-  if (!ck(nc->GroupStart(), "ncclGroupStart")) return false;
-  bool ok = ck(nc->Reduce(dst, dst, count, ncclFloat, ncclSum, 0, static_cast<ncclComm_t>(comms_[0]), st), "ncclReduce");   // in place on the root
-  for (size_t i = 0; ok && i < peers_.size(); ++i)
-    ok = ck(nc->Reduce(peers_[i]->frame.ptr, nullptr, count, ncclFloat, ncclSum, 0, static_cast<ncclComm_t>(comms_[i + 1]), peers_[i]->inst->stream), "ncclReduce");
-  const bool ended = ck(nc->GroupEnd(), "ncclGroupEnd");
-  if (!ok || !ended) return false;
+  bool ok = true;
+  if (packed) {
+    size_t total = 0;
+    for (auto& p : peers_)
+      for (auto& c : p->r->chains_) total += c->map.n_local_pixels;
+    if (recv_stage_.count < total && !hip_ok(recv_stage_.alloc(total), "alloc exchange staging", err)) return false;
+    if (!ck(nc->GroupStart(), "ncclGroupStart")) return false;
+    size_t off = 0;
+    for (size_t i = 0; ok && i < peers_.size(); ++i) {
+      auto& ch = peers_[i]->r->chains_;
+      size_t n = 0;
+      for (auto& c : ch) n += c->map.n_local_pixels;
+      if (!n) continue;
+      const float4* src = ch.size() > 1 ? peers_[i]->frame.ptr : (result ? ch[0]->result.ptr : ch[0]->cumulative.ptr);
+      ok = ck(nc->Send(src, n * 4, ncclFloat, 0, static_cast<ncclComm_t>(comms_[i + 1]), peers_[i]->inst->stream), "ncclSend") &&
+           ck(nc->Recv(recv_stage_.ptr + off, n * 4, ncclFloat, (int)i + 1, static_cast<ncclComm_t>(comms_[0]), st), "ncclRecv");
+      off += n;
+    }
+    const bool ended = ck(nc->GroupEnd(), "ncclGroupEnd");   // always closed, also after a failed call inside it
+    if (!ok || !ended) return false;
+    off = 0;
+    for (auto& p : peers_)
+      for (auto& c : p->r->chains_) {
+        if (!hip_ok(launch_export(st, c->map, recv_stage_.ptr + off, dst, false), "k_export (received tiles)", err)) return false;
+        off += c->map.n_local_pixels;
+      }
+  } else {
+    const size_t count = (size_t)w_ * h_ * 4;
+    if (!ck(nc->GroupStart(), "ncclGroupStart")) return false;
+    ok = ck(nc->Reduce(dst, dst, count, ncclFloat, ncclSum, 0, static_cast<ncclComm_t>(comms_[0]), st), "ncclReduce");   // in place on the root
+    for (size_t i = 0; ok && i < peers_.size(); ++i)
+      ok = ck(nc->Reduce(peers_[i]->frame.ptr, nullptr, count, ncclFloat, ncclSum, 0, static_cast<ncclComm_t>(comms_[i + 1]), peers_[i]->inst->stream), "ncclReduce");
+    const bool ended = ck(nc->GroupEnd(), "ncclGroupEnd");
+    if (!ok || !ended) return false;
+  }
+  // the peers' streams first (their buffers are free again), the root's last: everything has arrived when it is idle
   for (auto& p : peers_) {
-    if (!hip_ok(hipSetDevice(p->inst->device), "hipSetDevice", err)) return false;
-    if (!hip_ok(hipStreamSynchronize(p->inst->stream), "ncclReduce (peer)", err)) return false;
+    if (!hip_ok(hipSetDevice(p->inst->device), "hipSetDevice", err)) {
+      (void)hipSetDevice(inst_->device);
+      return false;
+    }
+    if (!hip_ok(hipStreamSynchronize(p->inst->stream), "exchange (peer)", err)) {
+      (void)hipSetDevice(inst_->device);
+      return false;
+    }
   }
   if (!hip_ok(hipSetDevice(inst_->device), "hipSetDevice", err)) return false;
-  return hip_ok(hipStreamSynchronize(st), "ncclReduce (root)", err);
+  return hip_ok(hipStreamSynchronize(st), "exchange (root)", err);
+}
+
+// everything this renderer has enqueued is done and its images are final (what gather() establishes before it scatters)
+bool Renderer::settle(Error& err) {
+  if (request_new_frame_ && !reset_buffers(err)) return false;
+  return wait_idle(err);
 }
 
 bool Renderer::read_frame(bool result, float* out, Error& err) {
@@ -838,18 +922,25 @@ bool Renderer::set_devices(const int* devices, int n, Error& err) {
     if (devices[i] != devices[0]) all_same = false;
     for (int j = 0; j < i; ++j) any_same |= devices[i] == devices[j];
   }
-  const bool loopback = n > 1 && all_same && getenv("GLAZE_MULTI_LOOPBACK") != nullptr;
-  if (any_same && !loopback) return bad("set_devices: a device is listed twice (GLAZE_MULTI_LOOPBACK=1 allows n copies of ONE device, for tests)");
+  // GLAZE_MULTI_LOOPBACK: the list may name ONE device n times (tests on a one-GPU box).  Any value but `rccl`: the tiles meet
+  // without RCCL (which cannot put two ranks on one GPU).  `rccl`: the exchange still goes through the RCCL entry points -- for
+  // a stand-in library named by GLAZE_RCCL_LIBRARY (tests/fake_rccl), so that the n >= 2 group construction itself runs.
+  const char* lbenv = getenv("GLAZE_MULTI_LOOPBACK");
+  const bool dup_ok = n > 1 && all_same && lbenv != nullptr;
+  const bool loopback = dup_ok && strcmp(lbenv, "rccl") != 0;
+  if (any_same && !dup_ok) return bad("set_devices: a device is listed twice (GLAZE_MULTI_LOOPBACK=1 allows n copies of ONE device, for tests)");
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess) count = 0;
   for (int i = 0; i < n; ++i)
     if (devices[i] < 0 || devices[i] >= count) return bad("set_devices: HIP device ordinal out of range");
-  if (!wait_idle(err)) return false;
-  release_peers();
-  if (n == 1) return set_partition_local(0, 1, err);
-  // RCCL first: without it nothing else needs to be built
+  int exchange = kExchangeGather;
+  if (const char* x = getenv("GLAZE_MULTI_EXCHANGE")) {
+    if (!strcmp(x, "reduce")) exchange = kExchangeReduce;
+    else if (strcmp(x, "gather")) return bad("GLAZE_MULTI_EXCHANGE must be `gather` or `reduce`");
+  }
+  // RCCL first: without it nothing is touched (a renderer that already spans devices keeps them)
   const Rccl* nc = nullptr;
-  if (!loopback) {
+  if (n > 1 && !loopback) {
     std::string why;
     nc = Rccl::get(why);
     if (!nc) {
@@ -858,13 +949,26 @@ bool Renderer::set_devices(const int* devices, int n, Error& err) {
       return false;
     }
   }
+  if (!wait_idle(err)) return false;
+  release_peers();
+  // from here on every failure leaves ONE device rendering the whole frame
+  auto fail = [&]() {
+    release_peers();
+    Error ignored;
+    (void)set_partition_local(0, 1, ignored);
+    request_new_frame_ = true;
+    return false;
+  };
+  if (n == 1) return set_partition_local(0, 1, err) ? true : fail();
   for (int i = 1; i < n; ++i) peers_.emplace_back(new Peer());
   loopback_ = loopback;
+  exchange_ = exchange;
   // instance + scene replica (upload, BVH build) + renderer for the tiles t % n == i, on every peer's own thread
   const Renderer* self = this;
   const Scene* src = scene_.get();
-  const Instance* my_inst = inst_;
+  const Instance* src_inst = scene_->instance ? scene_->instance : inst_;
   const uint32_t w = w_, h = h_, world = (uint32_t)n;
+  const bool want_frame = !loopback && exchange == kExchangeReduce;
   std::vector<Peer*> order;
   for (auto& p : peers_) order.push_back(p.get());
   const std::vector<Peer*>* ord = &order;
@@ -873,39 +977,39 @@ bool Renderer::set_devices(const int* devices, int n, Error& err) {
     while ((*ord)[i] != &p) ++i;
     p.inst.reset(Instance::create(devices[i + 1], e));
     if (!p.inst) return false;
-    p.inst->bvh_builder = my_inst->bvh_builder;
-    p.inst->bvh_pair_area_ratio = my_inst->bvh_pair_area_ratio;
+    // the replica takes the shape the root's scene HAS (builder, pair leaves, flattened or two levels), not what the
+    // environment of this thread would choose
+    p.inst->copy_build_options(*src_inst);
+    if (src->info.as_levels) p.inst->as_levels = (int)src->info.as_levels;
     SceneData copy = src->data;
     std::shared_ptr<Scene> replica(Scene::create(p.inst.get(), std::move(copy), e));
     if (!replica) return false;
     p.r.reset(Renderer::create(p.inst.get(), replica, w, h, e));
     if (!p.r || !self->configure_peer(*p.r, e)) return false;
     if (!p.r->set_partition_local((uint32_t)i + 1, world, e)) return false;
-    return loopback || hip_ok(p.frame.alloc((size_t)w * h), "alloc peer frame", e);
+    return !want_frame || hip_ok(p.frame.alloc((size_t)w * h), "alloc peer frame", e);
   }, err);
-  if (!built) {
-    release_peers();
-    Error ignored;
-    (void)set_partition_local(0, 1, ignored);
-    return false;
-  }
-  if (!set_partition_local(0, world, err)) return false;
+  if (!built) return fail();
+  if (!set_partition_local(0, world, err)) return fail();
   if (!loopback) {
     std::vector<ncclComm_t> comms((size_t)n, nullptr);
     const ncclResult_t r = nc->CommInitAll(comms.data(), n, devices);
+    (void)hipSetDevice(inst_->device);
     if (r != ncclSuccess) {
       err.code = GLZ_E_DEVICE;
       err.msg = std::string("ncclCommInitAll: ") + nc->GetErrorString(r);
-      release_peers();
-      Error ignored;
-      (void)set_partition_local(0, 1, ignored);
-      return false;
+      return fail();
     }
     for (ncclComm_t c : comms) comms_.push_back(c);
-    (void)hipSetDevice(inst_->device);
   }
   request_new_frame_ = true;
   return true;
+}
+
+const Scene* Renderer::device_scene(int i) const {
+  if (i == 0) return scene_.get();
+  if (i < 0 || (size_t)i > peers_.size() || !peers_[(size_t)i - 1]->r) return nullptr;
+  return peers_[(size_t)i - 1]->r->scene_.get();
 }
 
 bool Renderer::set_chains(uint32_t n, Error& err) {
@@ -926,6 +1030,51 @@ bool Renderer::export_device(int which, void* dev, Error& err) {
   if (!hip_ok(hipSetDevice(inst_->device), "hipSetDevice", err)) return false;
   if (!gather(which != 0, static_cast<float4*>(dev), err)) return false;
   return hip_ok(hipStreamSynchronize(chains_[0]->stream), "export_device", err);
+}
+
+// One process per GPU: what a rank hands to the exchange instead of a zero-padded frame -- its tiles only, tile-major, in the
+// order of its partition (local tile j = global tile rank + j * world), packed_count() float4s.
+size_t Renderer::packed_count(uint32_t w, uint32_t h, uint32_t rank, uint32_t world) {
+  if (world == 0 || rank >= world) return 0;
+  const uint32_t tiles = ((w + kTile - 1) / kTile) * ((h + kTile - 1) / kTile);
+  return tiles > rank ? (size_t)((tiles - rank + world - 1) / world) * kTile * kTile : 0;
+}
+bool Renderer::export_packed(int which, void* dev, Error& err) {
+  if (!peers_.empty()) {
+    err.code = GLZ_E_ARG;
+    err.msg = "export_packed is for one rank of a process partition (a renderer that spans devices exchanges by itself)";
+    return false;
+  }
+  if (!hip_ok(hipSetDevice(inst_->device), "hipSetDevice", err)) return false;
+  if (!settle(err)) return false;
+  hipStream_t st = chains_[0]->stream;
+  const uint32_t S = (uint32_t)chains_.size();
+  for (uint32_t s = 0; s < S; ++s) {
+    Chain& c = *chains_[s];
+    if (!hip_ok(launch_pack_tiles(st, c.map.n_local_pixels, S, s, which ? c.result.ptr : c.cumulative.ptr, static_cast<float4*>(dev)), "k_pack_tiles", err)) return false;
+  }
+  return hip_ok(hipStreamSynchronize(st), "export_packed", err);
+}
+// rank 0 of such a job: the packed tiles of partition (rank, world) go to their place in a full frame (nothing else is touched)
+bool Renderer::scatter_packed(uint32_t rank, uint32_t world, const void* dev_packed, void* dev_frame, Error& err) {
+  if (world == 0 || rank >= world) {
+    err.code = GLZ_E_ARG;
+    err.msg = "bad tile partition";
+    return false;
+  }
+  if (!hip_ok(hipSetDevice(inst_->device), "hipSetDevice", err)) return false;
+  TileMap m{};
+  m.width = w_;
+  m.height = h_;
+  m.tiles_x = (w_ + kTile - 1) / kTile;
+  m.tiles_y = (h_ + kTile - 1) / kTile;
+  m.rank = rank;
+  m.world = world;
+  m.n_local_pixels = (uint32_t)packed_count(w_, h_, rank, world);
+  m.n_local_tiles = m.n_local_pixels / (kTile * kTile);
+  hipStream_t st = chains_[0]->stream;
+  if (!hip_ok(launch_export(st, m, static_cast<const float4*>(dev_packed), static_cast<float4*>(dev_frame), false), "k_export (packed tiles)", err)) return false;
+  return hip_ok(hipStreamSynchronize(st), "scatter_packed", err);
 }
 
 bool Renderer::tonemap_device(const void* dev_result, uint8_t* out, Error& err) {

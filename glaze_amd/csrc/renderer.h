@@ -41,10 +41,14 @@ class Renderer {
   // communicator per device from ncclCommInitAll).  n == 1 returns to a single device.
   bool set_devices(const int* devices, int n, Error& err);
   uint32_t device_count() const { return 1u + (uint32_t)peers_.size(); }
+  const Scene* device_scene(int i) const;    // the scene (replica) device i of set_devices renders; null when out of range
   bool set_chains(uint32_t n, Error& err);   // 0 = automatic
   uint32_t chains() const { return (uint32_t)chains_.size(); }
   static uint32_t chains_for(uint32_t w, uint32_t h, uint32_t rank, uint32_t world, uint32_t wanted);
   bool export_device(int which, void* dev_rgba32f, Error& err);
+  static size_t packed_count(uint32_t w, uint32_t h, uint32_t rank, uint32_t world);   // float4s of a rank's packed tiles
+  bool export_packed(int which, void* dev_packed, Error& err);
+  bool scatter_packed(uint32_t rank, uint32_t world, const void* dev_packed, void* dev_frame, Error& err);
   bool tonemap_device(const void* dev_result, uint8_t* out, Error& err);
   bool launch_constants(uint32_t launch, uint32_t* seed, float off[2]);
   void push_constants(float out[32]) const;
@@ -120,6 +124,10 @@ class Renderer {
   std::vector<std::unique_ptr<Peer>> peers_;
   std::vector<void*> comms_;   // ncclComm_t per device (index 0 = this renderer); empty in loop-back mode
   bool loopback_ = false;      // all "devices" are this one device (GLAZE_MULTI_LOOPBACK=1, tests on a one-GPU box): no RCCL
+  enum { kExchangeGather = 0, kExchangeReduce = 1 };
+  int exchange_ = kExchangeGather;      // how the peers' tiles reach device 0 (reduce_peers); GLAZE_MULTI_EXCHANGE at set_devices
+  DeviceBuffer<float4> recv_stage_;     // device 0: the packed tiles received from the peers (gather shape)
+  bool settle(Error& err);
   template <class F> void post_all(F f, Pending& p);
   bool join_all(Pending& p, Error& err);
   template <class F> bool forward(F f, Error& err);

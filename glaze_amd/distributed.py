@@ -37,3 +37,29 @@ def reduce_frame(frame, dst=0, group=None, force=False):
     if dist.is_available() and dist.is_initialized() and (force or dist.get_world_size(group) > 1):
         dist.reduce(frame, dst=dst, op=dist.ReduceOp.SUM, group=group)
     return frame
+
+
+def gather_frame(renderer, frame, which=0, dst=0, group=None):
+    """The packed-tile exchange of a one-process-per-GPU job: every rank hands over its own tiles only (1 / world of the
+    frame's bytes: ncclSend / ncclRecv pairs inside one group = `dist.gather` on the "nccl" backend, each pair on its own
+    xGMI link) and `dst` puts them into `frame` (a full-frame RGBA32F CUDA tensor); the other ranks' `frame` is untouched.
+
+    `renderer` must have its partition set to (rank, world) of the group.  Bit-identical to `reduce_frame` of the
+    zero-padded frames.
+    """
+    import torch
+    import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    n_max = renderer.packed_pixels(0, world)      # rank 0 owns the most tiles; everybody sends that many (gather wants equal sizes)
+    packed = torch.zeros((n_max, 4), dtype=torch.float32, device=frame.device)
+    renderer.export_packed(which, packed.data_ptr())
+    parts = [torch.empty_like(packed) for _ in range(world)] if rank == dst else None
+    dist.gather(packed, parts, dst=dst, group=group)
+    if rank == dst:
+        if frame.is_cuda:
+            torch.cuda.synchronize(frame.device)      # the scatter below runs on the renderer's own stream
+        renderer.export_device(which, frame.data_ptr())
+        for r in range(world):
+            if r != dst:
+                renderer.scatter_packed(r, world, parts[r].data_ptr(), frame.data_ptr())
+    return frame

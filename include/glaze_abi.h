@@ -354,15 +354,23 @@ int glz_renderer_launch_constants(glz_renderer*, uint32_t launch, uint32_t* seed
 int glz_renderer_push_constants(glz_renderer*, float out32[32]);
 
 /* Multi-GPU (one process per GPU): this renderer owns the 64x64-pixel tiles t with
- * t % world == rank; other pixels stay zero.  The reduce of the HDR accumulator itself is done
- * by the caller (RCCL through torch.distributed or rccl directly) on the device buffer below. */
+ * t % world == rank; other pixels stay zero.  The exchange of the HDR accumulator itself is done
+ * by the caller (RCCL through torch.distributed or rccl directly) on the device buffers below. */
 int glz_renderer_set_partition(glz_renderer*, uint32_t rank, uint32_t world);
 /* Scatters the owned tiles of the cumulative image (which = 0) or of the result image `out32`
  * (which = 1) into a caller-provided DEVICE buffer of W*H*4 floats, zero elsewhere, on the instance
  * stream (synchronised before returning): the operand of ncclReduce(sum).  Tiles are disjoint, so
  * the sum over ranks is bit-identical to a single-GPU render. */
+int glz_renderer_export_device(glz_renderer*, int which, void* dev_rgba32f);
+/* The same exchange with 1 / world of the bytes: a rank's tiles ONLY, tile-major (64x64 pixels of 4 floats per tile, local
+ * tile j = global tile rank + j * world), glz_renderer_packed_pixels(r, rank, world) pixels -- the operand of an ncclSend /
+ * gather to rank 0, which puts every received buffer in its place of a full frame with glz_renderer_scatter_packed (nothing
+ * but those tiles is written; rank 0's own tiles come from glz_renderer_export_device).  Device pointers; synchronised
+ * before returning. */
+uint64_t glz_renderer_packed_pixels(glz_renderer*, uint32_t rank, uint32_t world);
+int glz_renderer_export_packed(glz_renderer*, int which, void* dev_packed_rgba32f);
+int glz_renderer_scatter_packed(glz_renderer*, uint32_t rank, uint32_t world, const void* dev_packed_rgba32f, void* dev_frame_rgba32f);
 /* Concurrent chains: the tiles of this process advance as `n` independent launch sequences on `n` HIP streams (0 = automatic:
-
  * one chain while the rank owns a million pixels, two down to 400 k, three below).  Pixels never interact, so the image does not depend on n; with a small
  * tile share per GPU the chains fill the machine while the longest rays of a launch finish. */
 int glz_renderer_set_chains(glz_renderer*, uint32_t n);
@@ -370,14 +378,18 @@ int glz_renderer_set_chains(glz_renderer*, uint32_t n);
  * VkPhysicalDevice, lib/src/vulkan/device.rs:252-321): hip_devices[0] must be the renderer's own device (glz_instance_device);
  * every further device gets a stream, a replica of the scene (upload + BVH build on that device), a renderer for the 64x64 tiles
  * t % n == i and a host thread that enqueues its launches.  All setters, step / draw and scene updates apply to every device;
- * every read-back (read_hdr / read_result / read_rgba8 / draw's image / export_device) first sums the zero-padded RGBA32F
- * frames onto hip_devices[0] with one ncclReduce(sum, float) per device (one communicator per device from ncclCommInitAll,
- * RCCL over xGMI).  The tiles are disjoint, so the image is bit-identical to a one-device render.  n = 1 returns to one
- * device.  Not combinable with glz_renderer_set_partition (one process per GPU).  RCCL is loaded on first use
+ * every read-back (read_hdr / read_result / read_rgba8 / draw's image / export_device) first brings the other devices' tiles
+ * onto hip_devices[0] over RCCL / xGMI (one communicator per device from ncclCommInitAll, all calls of one exchange in one
+ * ncclGroup): by default every device ncclSends its packed tiles (1 / n of the frame) and device 0 ncclRecvs and scatters
+ * them; with GLAZE_MULTI_EXCHANGE=reduce in the environment at this call, one ncclReduce(sum, float) of the zero-padded
+ * RGBA32F frame per device.  The tiles are disjoint, so the image is bit-identical to a one-device render.  n = 1 returns to one
+ * device; after a failure the renderer is a one-device renderer again.  Not combinable with glz_renderer_set_partition (one process per GPU).  RCCL is loaded on first use
  * (librccl.so.1); GLZ_E_DEVICE when it is missing.  With GLAZE_MULTI_LOOPBACK=1 in the environment the list may name ONE
  * device n times (tests on a one-GPU machine: same sharding, threads and replicas, the tiles meet without RCCL). */
 int glz_renderer_set_devices(glz_renderer*, const int* hip_devices, int n);
-int glz_renderer_export_device(glz_renderer*, int which, void* dev_rgba32f);
+int glz_renderer_device_count(glz_renderer*);   /* devices this renderer spans (1 unless set_devices succeeded with more) */
+int glz_renderer_device_scene_info(glz_renderer*, int i, glz_scene_info* out);   /* the scene replica device i renders (0 = the renderer's own) */
+int glz_rccl_version(void);                     /* ncclGetVersion() of the RCCL this library loads (> 0), or a negative status */
 /* Tonemaps a full-frame DEVICE result image (e.g. the reduced one on rank 0) to RGBA8 sRGB host memory. */
 int glz_renderer_tonemap_device(glz_renderer*, const void* dev_result_rgba32f, uint8_t* rgba8_out);
 

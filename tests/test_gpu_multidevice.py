@@ -225,3 +225,225 @@ def test_torch_nccl_backend_world_size_one():
     assert p.returncode == 0, p.stderr[-3000:]
     out = json.loads(p.stdout.strip().splitlines()[-1])
     assert out == {"same": True, "same_after_more_steps": True, "t": 1.5, "backend": "nccl"}
+
+
+def test_replicas_take_the_shape_of_the_root_scene(instance, loopback):
+    """A shape forced on the root (two levels for memory, or flattened) is what every peer builds, whatever AUTO would pick."""
+    desc = desc_from_oracle_parse(MATTEST)
+    for mode, want in (("two_level", 2), ("flat", 1)):
+        instance.set_as_levels(mode)
+        try:
+            scene = glaze_amd.RayTraceScene.from_desc(instance, desc)
+        finally:
+            instance.set_as_levels("auto")                     # the peers must not depend on the option still being set
+        assert scene.info().as_levels == want
+        r = glaze_amd.RayTraceRenderer.new(instance, scene, 136, 72)
+        r.set_devices([instance.device] * 3)
+        assert [r.device_scene_info(i).as_levels for i in range(3)] == [want] * 3
+        with pytest.raises(abi.GlazeError):
+            r.device_scene_info(3)
+        # ... also after change_scene to a scene of the other shape
+        instance.set_as_levels("flat" if want == 2 else "two_level")
+        try:
+            other = glaze_amd.RayTraceScene.from_desc(instance, desc)
+        finally:
+            instance.set_as_levels("auto")
+        r.change_scene(other)
+        assert [r.device_scene_info(i).as_levels for i in range(3)] == [3 - want] * 3
+
+
+def test_packed_tiles_export_and_scatter(instance):
+    """The 1/world-sized exchange of a one-process-per-GPU job: every rank exports its tiles only, rank 0 scatters them; equals
+    the sum of the zero-padded frames (three sequential partitions on the one GPU, with one and with several chains)."""
+    import torch
+    desc = cube_scene(material_type=abi.MAT_UBER)
+    w, h, world = 200, 136, 3
+    one = glaze_amd.RayTraceRenderer.new(instance, glaze_amd.RayTraceScene.from_desc(instance, desc), w, h)
+    one.set_depth(3)
+    one.step(5)
+    want = one.read_hdr()
+    for chains in (1, 2):
+        frame = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+        for rank in range(world):
+            r = glaze_amd.RayTraceRenderer.new(instance, glaze_amd.RayTraceScene.from_desc(instance, desc), w, h)
+            r.set_depth(3)
+            r.set_partition(rank, world)
+            r.set_chains(chains)
+            r.step(5)
+            n = r.packed_pixels(rank, world)
+            assert n == len(range(rank, 4 * 3, world)) * 4096
+            if rank == 0:
+                r.export_device(0, frame.data_ptr())
+            else:
+                packed = torch.full((r.packed_pixels(0, world), 4), -7.0, dtype=torch.float32, device="cuda")   # padded to rank 0's size
+                r.export_packed(0, packed.data_ptr())
+                assert float(packed[n:].max().item()) == -7.0 if n < packed.shape[0] else True                 # nothing past its own tiles
+                one.scatter_packed(rank, world, packed.data_ptr(), frame.data_ptr())
+        assert np.array_equal(bits(frame.cpu().numpy()), bits(want)), chains
+    with pytest.raises(abi.GlazeError):
+        one.scatter_packed(3, 3, frame.data_ptr(), frame.data_ptr())
+
+
+FAKE_RCCL = r'''
+import os, sys, json
+import numpy as np
+sys.path.insert(0, os.environ["GLAZE_ROOT"])
+import glaze_amd
+from glaze_amd import abi
+from glaze_amd.scenes import cube_scene
+n = int(os.environ["GLAZE_TEST_N"])
+inst = glaze_amd.RayTraceInstance.new(0)
+w, h = 520, 200                                     # 9 x 4 = 36 tiles: every one of 8 devices owns some, ragged edges
+desc = cube_scene(material_type=abi.MAT_UBER)
+def fresh():
+    r = glaze_amd.RayTraceRenderer.new(inst, glaze_amd.RayTraceScene.from_desc(inst, desc), w, h)
+    r.set_depth(3); r.set_seed(9)
+    return r
+one = fresh()
+one.step(7)
+want_hdr, want_res = one.read_hdr(), one.read_result()
+out = {"version": int(abi.lib().glz_rccl_version())}
+r = fresh()
+try:
+    r.set_devices([0] * n)
+    out["set_devices"] = "ok"
+except abi.GlazeError as e:
+    out["set_devices"] = str(e)
+out["devices"] = r.device_count()
+chains = int(os.environ.get("GLAZE_TEST_CHAINS", "0"))
+if chains:
+    r.set_chains(chains)
+r.step(7)
+def read(fn, want):
+    try:
+        return bool(np.array_equal(np.nan_to_num(fn(), nan=-1).view(np.uint32), np.nan_to_num(want, nan=-1).view(np.uint32)))
+    except abi.GlazeError as e:
+        return str(e)
+out["hdr"] = read(r.read_hdr, want_hdr)
+out["hdr_again"] = read(r.read_hdr, want_hdr)       # after a failed exchange the next one works: nothing is left half done
+out["result"] = read(r.read_result, want_res)
+r.step(2); one.step(2)                              # rendering continues after an exchange
+out["hdr_after_more"] = read(r.read_hdr, one.read_hdr())
+del r
+import gc; gc.collect()
+print(json.dumps(out))
+'''
+
+
+def run_fake(tmp_path, n, exchange="gather", fail=None, chains=0):
+    lib = os.path.join(ROOT, "tests", "fake_rccl", "libfake_rccl.so")
+    if not os.path.exists(lib):
+        pytest.skip("tests/fake_rccl/libfake_rccl.so is not built (__graft_entry__.build())")
+    log = str(tmp_path / ("rccl_%s_%d_%s_%d.log" % (exchange, n, fail or "ok", chains)).replace(":", "_"))
+    env = dict(os.environ, GLAZE_ROOT=ROOT, GLAZE_RCCL_LIBRARY=lib, GLAZE_MULTI_LOOPBACK="rccl", GLAZE_MULTI_EXCHANGE=exchange,
+               GLAZE_FAKE_RCCL_LOG=log, GLAZE_TEST_N=str(n), GLAZE_TEST_CHAINS=str(chains))
+    if fail:
+        env["GLAZE_FAKE_RCCL_FAIL"] = fail
+    p = subprocess.run([sys.executable, "-c", FAKE_RCCL], capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    calls = [json.loads(l) for l in open(log)] if os.path.exists(log) else []
+    return json.loads(p.stdout.strip().splitlines()[-1]), calls
+
+
+def exchanges_of(calls):
+    """the calls between each outermost ncclGroupStart and its ncclGroupEnd"""
+    groups, cur = [], None
+    for c in calls:
+        if c["fn"] == "ncclGroupStart":
+            cur = []
+        elif c["fn"] == "ncclGroupEnd":
+            groups.append((cur, c["result"]))
+            cur = None
+        elif cur is not None:
+            cur.append(c)
+        else:
+            assert c["fn"] in ("ncclCommInitAll", "ncclCommDestroy"), "a transfer outside a group: %r" % (c,)
+    assert cur is None, "a group was left open"
+    return groups
+
+
+@pytest.mark.parametrize("n,chains", [(2, 0), (8, 0), (3, 2)])
+def test_group_construction_packed_gather(tmp_path, n, chains):
+    """The n >= 2 exchange against the recording stand-in for librccl (tests/fake_rccl): n "ranks" on the one GPU, real
+    communicator / group / stream semantics.  Default shape: every peer SENDS its packed tiles once, device 0 receives."""
+    out, calls = run_fake(tmp_path, n, chains=chains)
+    assert out == {"version": 99999, "set_devices": "ok", "devices": n, "hdr": True, "hdr_again": True, "result": True, "hdr_after_more": True}
+    init = [c for c in calls if c["fn"] == "ncclCommInitAll"]
+    assert len(init) == 1 and init[0]["count"] == n
+    groups = exchanges_of(calls)
+    assert len(groups) == 4 and all(res == 0 for _, res in groups)                               # four read-backs, four groups
+    for ops, _ in groups:
+        sends = [c for c in ops if c["fn"] == "ncclSend"]
+        recvs = [c for c in ops if c["fn"] == "ncclRecv"]
+        assert len(sends) == len(recvs) == n - 1 and len(ops) == 2 * (n - 1)
+        assert sorted(c["rank"] for c in sends) == list(range(1, n)) and all(c["peer"] == 0 for c in sends)     # one send per peer, to device 0
+        assert all(c["rank"] == 0 for c in recvs) and sorted(c["peer"] for c in recvs) == list(range(1, n))
+        assert len({c["stream"] for c in sends}) == n - 1 and len({c["stream"] for c in recvs}) == 1            # each peer's own stream; the root's
+        assert not ({c["stream"] for c in sends} & {c["stream"] for c in recvs})
+        by_peer = {c["rank"]: c["count"] for c in sends}
+        assert all(by_peer[c["peer"]] == c["count"] for c in recvs)
+        assert sum(by_peer.values()) == sum(len(range(i, 36, n)) for i in range(1, n)) * 4096 * 4                # 1/n-sized: the peers' tiles only
+        spans = sorted((c["recv"], c["count"] * 4) for c in recvs)
+        assert all(a + b <= c for (a, b), (c, _) in zip(spans, spans[1:]))                                       # disjoint staging areas
+    destroyed = [c for c in calls if c["fn"] == "ncclCommDestroy"]
+    assert len(destroyed) == n and all(c["result"] == 0 for c in destroyed) and sorted(c["rank"] for c in destroyed) == list(range(n))
+    assert calls.index(destroyed[0]) > max(i for i, c in enumerate(calls) if c["fn"] == "ncclGroupEnd")         # after the last exchange
+
+
+def test_group_construction_reduce(tmp_path):
+    """GLAZE_MULTI_EXCHANGE=reduce: one ncclReduce(sum) per device in one group, in place on the root, no receive buffer on the peers."""
+    n = 8
+    out, calls = run_fake(tmp_path, n, exchange="reduce")
+    assert out == {"version": 99999, "set_devices": "ok", "devices": n, "hdr": True, "hdr_again": True, "result": True, "hdr_after_more": True}
+    groups = exchanges_of(calls)
+    assert len(groups) == 4
+    for ops, res in groups:
+        assert res == 0 and [c["fn"] for c in ops] == ["ncclReduce"] * n
+        assert sorted(c["rank"] for c in ops) == list(range(n)) and all(c["peer"] == 0 for c in ops)            # root 0
+        assert all(c["count"] == 520 * 200 * 4 for c in ops)
+        root = [c for c in ops if c["rank"] == 0][0]
+        assert root["send"] == root["recv"] != 0                                                                 # in place on the root
+        assert all(c["recv"] == 0 and c["send"] not in (0, root["send"]) for c in ops if c["rank"] != 0)
+        assert len({c["stream"] for c in ops}) == n and len({c["send"] for c in ops}) == n
+    assert len([c for c in calls if c["fn"] == "ncclCommDestroy"]) == n
+
+
+@pytest.mark.parametrize("exchange,fail", [("gather", "ncclCommInitAll:1"), ("gather", "ncclSend:3"), ("gather", "ncclRecv:1"),
+                                           ("gather", "ncclGroupEnd:1"), ("gather", "ncclGroupStart:1"), ("reduce", "ncclReduce:2")])
+def test_rccl_failures_leave_a_usable_renderer(tmp_path, exchange, fail):
+    """An RCCL call that fails: the error reaches the caller, an opened group is always closed, the communicators are destroyed
+    exactly once, and the renderer keeps working (one device after a failed set_devices; the next exchange after a failed one)."""
+    n = 4
+    out, calls = run_fake(tmp_path, n, exchange=exchange, fail=fail)
+    groups = exchanges_of(calls)                                                                                 # asserts no group is left open
+    created = sum(c["count"] for c in calls if c["fn"] == "ncclCommInitAll" and c["result"] == 0)
+    destroyed = [c for c in calls if c["fn"] == "ncclCommDestroy"]
+    assert len(destroyed) == created and all(c["result"] == 0 for c in destroyed)
+    if fail.startswith("ncclCommInitAll"):
+        assert "ncclCommInitAll" in out["set_devices"] and out["devices"] == 1 and created == 0
+        assert out["hdr"] is True and out["result"] is True and out["hdr_after_more"] is True                    # one device renders the whole frame
+        assert groups == []
+    else:
+        assert out["set_devices"] == "ok" and out["devices"] == n
+        assert isinstance(out["hdr"], str) and fail.split(":")[0] in out["hdr"]                                  # the first exchange reports the failure
+        assert out["hdr_again"] is True and out["result"] is True and out["hdr_after_more"] is True
+
+
+BENCH_LOOPBACK_ENV = {"GLAZE_MULTI_LOOPBACK": "1"}
+
+
+def test_bench_in_process_multi_gpu(tmp_path):
+    """`python bench.py --gpus N` without a launcher: the in-process set_devices path (loop-back on the one GPU), verified bit for bit;
+    a plain --gpus 2 on a one-GPU box fails with a clear message instead of hanging."""
+    import torch
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "4", "--warmup", "2", "--width", "640", "--height", "360", "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run(cmd, capture_output=True, text=True, env=dict(env, **BENCH_LOOPBACK_ENV), timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json.loads(p.stdout.strip().splitlines()[-1])
+    assert out["n_gpus"] == 8 and out["multi_gpu"]["gpus_seen"] == 8 and out["multi_gpu"]["measurement"] is False
+    assert out["verify"]["bit_identical_to_one_gpu"] is True and out["verify"]["launches"] == 2 + 4 * len(out["regions_ms"])
+    assert out["multi_gpu"]["exchange_ms"] > 0 and out["value"] > 0
+    if torch.cuda.device_count() < 2:
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"], capture_output=True, text=True, env=env, timeout=600)
+        assert p.returncode != 0 and "this machine has 1 GPU" in p.stderr
