@@ -152,11 +152,12 @@ struct alignas(16) TlasInstance {
 };
 static_assert(sizeof(TlasInstance) == 176, "TlasInstance is 11 x 16 bytes");
 
-// World-space triangle in BVH leaf order, 48 bytes (36 algorithmic + ids).
+// World-space triangle in BVH leaf order, 48 bytes (36 algorithmic + ids).  The three VERTICES, not a vertex and two edges:
+// the watertight test (ray_triangle) needs the floats two triangles share to be the same floats in both records.
 struct alignas(16) BvhTri {
   float v0[3]; uint32_t world_id;   // instance-major id: tie-break key for equal t
-  float e1[3]; uint32_t instance;
-  float e2[3]; uint32_t prim_flags; // kTriNonOpaque | kTriHasPartner | primitive in instance
+  float v1[3]; uint32_t instance;
+  float v2[3]; uint32_t prim_flags; // kTriNonOpaque | kTriHasPartner | primitive in instance
 };
 static_assert(sizeof(BvhTri) == 48, "BvhTri is 48 bytes");
 

@@ -82,11 +82,10 @@ __global__ void __launch_bounds__(256) k_world_tris(const float4* __restrict__ v
       const float4 p = vertices[2 * ix[k]];
       v[k] = xform_point(M, mk3(p.x, p.y, p.z));
     }
-    const vec3 e1 = v[1] - v[0], e2 = v[2] - v[0];
     BvhTri t;
     t.v0[0] = v[0].x; t.v0[1] = v[0].y; t.v0[2] = v[0].z; t.world_id = w;
-    t.e1[0] = e1.x; t.e1[1] = e1.y; t.e1[2] = e1.z; t.instance = inst;
-    t.e2[0] = e2.x; t.e2[1] = e2.y; t.e2[2] = e2.z;
+    t.v1[0] = v[1].x; t.v1[1] = v[1].y; t.v1[2] = v[1].z; t.instance = inst;
+    t.v2[0] = v[2].x; t.v2[1] = v[2].y; t.v2[2] = v[2].z;
     t.prim_flags = prim | (materials[in.material_id].opacity != 0 ? kTriNonOpaque : 0u);   // acceleration.rs:136-141
     tris[w] = t;
     const float* A = &v[0].x; const float* B = &v[1].x; const float* C = &v[2].x;

@@ -97,26 +97,55 @@ __device__ __forceinline__ bool ray_is_finite(vec3 o, vec3 d) {
   return s - s == 0.0f;
 }
 
-// Straight-line on purpose: with ~10 of 64 lanes in a leaf round an early exit is almost never taken by all of them,
-// and without branches the three 16-byte loads of the triangle are issued together (the compiler otherwise sinks the
-// v0 load behind the det test: a second memory round trip).  A zero determinant gives inf / NaN barycentrics that fail
-// the comparisons; the explicit det test keeps the rule the oracle states.
-__device__ __forceinline__ bool ray_triangle(const BvhTri& tr, vec3 o, vec3 d, float tmin, float& t, float& u, float& v) {
-  const vec3 e1 = mk3(tr.e1[0], tr.e1[1], tr.e1[2]), e2 = mk3(tr.e2[0], tr.e2[1], tr.e2[2]);
-  // Cross and dot products with explicit fused multiply-adds -- a * b - c * d as fma(a, b, -(c * d)), the dot product as a chain of
-  // two fmas -- exactly as the oracle's ray_tri states them (fmaf is correctly rounded on both sides, so the bits agree):
-  // 14 VALU instructions fewer per test than separate multiplies and adds (k_trace 0.589 -> 0.574 ms), and more accurate.
-  auto crossf = [](vec3 a, vec3 b) { return mk3(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x))); };
-  auto dotf = [](vec3 a, vec3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); };
-  const vec3 pvec = crossf(d, e2);
-  const float det = dotf(e1, pvec);
+// The watertight ray / triangle test, statement for statement the oracle's ray_tri (oracle.cpp; the reference's hits come from
+// traceRayEXT on the driver's acceleration structure, path_trace.rgen:169 / acceleration.rs:319-345, which the Vulkan
+// specification requires to be watertight): Woop, Benthin, Wald 2013 with the exact tie-break in single precision.
+//   per ray    kz = axis of the largest |d|, shear Sz = 1 / d[kz], Sx = d[kx] Sz, Sy = d[ky] Sz        (ray_shear; once per leaf round,
+//              from d alone -- nothing is kept per ray, the traversal has no register to spare)
+//   per vertex A = P - o, image (A[kx] - Sx A[kz], A[ky] - Sy A[kz], Sz A[kz]): the same 2-D point in every triangle that uses P
+//   per edge   U = Cx By - Cy Bx from two separately rounded products: its sign is exact unless the rounded products are equal, and
+//              then the difference of their rounding errors (one fma each) is.  Exact orientation predicates on consistent points
+//              cannot leave a gap at a shared edge or vertex.  -ffp-contract=off keeps the products unfused.
+// Straight-line: with ~10 of 64 lanes in a leaf round an early exit is almost never taken by all of them, and without branches
+// the three 16-byte loads of the triangle are issued together; only the tie-break is a (wave-uniform) branch, taken when some
+// lane's ray meets an edge exactly -- axis-aligned geometry under an orthographic camera, otherwise hardly ever.
+struct RayShear {
+  bool z_is_x, z_is_y;   // kz == 0, kz == 1 (else 2): wave masks in SGPRs
+  float sx, sy, sz;
+};
+__device__ __forceinline__ RayShear ray_shear(vec3 d) {
+  const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+  RayShear r;
+  r.z_is_x = (ax >= ay) & (ax >= az);
+  r.z_is_y = !r.z_is_x & (ay >= az);
+  // (kx, ky, kz) = (1, 2, 0), (2, 0, 1) or (0, 1, 2)
+  const float dz = r.z_is_x ? d.x : (r.z_is_y ? d.y : d.z), dx = r.z_is_x ? d.y : (r.z_is_y ? d.z : d.x), dy = r.z_is_x ? d.z : (r.z_is_y ? d.x : d.y);
+  r.sz = 1.0f / dz;
+  r.sx = dx * r.sz;
+  r.sy = dy * r.sz;
+  return r;
+}
+__device__ __forceinline__ vec3 shear_vertex(const RayShear& r, const float* p, vec3 o) {
+  const vec3 a = mk3(p[0], p[1], p[2]) - o;
+  const float az = r.z_is_x ? a.x : (r.z_is_y ? a.y : a.z), ax = r.z_is_x ? a.y : (r.z_is_y ? a.z : a.x), ay = r.z_is_x ? a.z : (r.z_is_y ? a.x : a.y);
+  return mk3(fmaf(-r.sx, az, ax), fmaf(-r.sy, az, ay), r.sz * az);
+}
+__device__ __forceinline__ bool ray_triangle(const RayShear& rs, const BvhTri& tr, vec3 o, float tmin, float& t, float& u, float& v) {
+  const vec3 A = shear_vertex(rs, tr.v0, o), B = shear_vertex(rs, tr.v1, o), C = shear_vertex(rs, tr.v2, o);
+  const float pu = C.x * B.y, qu = C.y * B.x, pv = A.x * C.y, qv = A.y * C.x, pw = B.x * A.y, qw = B.y * A.x;
+  float U = pu - qu, V = pv - qv, W = pw - qw;
+  if (__builtin_expect(__any((U == 0.0f) | (V == 0.0f) | (W == 0.0f)), 0)) {   // edge_fn's second branch, for the lanes that need it
+    if (U == 0.0f) U = fmaf(C.x, B.y, -pu) - fmaf(C.y, B.x, -qu);
+    if (V == 0.0f) V = fmaf(A.x, C.y, -pv) - fmaf(A.y, C.x, -qv);
+    if (W == 0.0f) W = fmaf(B.x, A.y, -pw) - fmaf(B.y, A.x, -qw);
+  }
+  const float lo = fminf(fminf(U, V), W), hi = fmaxf(fmaxf(U, V), W);   // two opposite signs <=> lo < 0 < hi (a NaN fails the distance test)
+  const float det = (U + V) + W;
   const float inv = 1.0f / det;
-  const vec3 tvec = o - mk3(tr.v0[0], tr.v0[1], tr.v0[2]);
-  u = dotf(tvec, pvec) * inv;
-  const vec3 qvec = crossf(tvec, e1);
-  v = dotf(d, qvec) * inv;
-  t = dotf(e2, qvec) * inv;
-  return (det != 0.0f) & (u >= 0.0f) & (u <= 1.0f) & (v >= 0.0f) & (u + v <= 1.0f) & (t > tmin);
+  u = V * inv;
+  v = W * inv;
+  t = fmaf(W, C.z, fmaf(V, B.z, U * A.z)) * inv;
+  return !((lo < 0.0f) & (hi > 0.0f)) & (det != 0.0f) & (t > tmin);
 }
 
 // raytrace_hit.rahit:24-39 -- candidates on non-opaque geometry are dropped when opacity.r < 0.5
@@ -524,16 +553,17 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
       // first test: six 16-byte loads in flight at once cost 20 more spilled registers (0.64 -> 0.77 ms).
       const uint32_t leaf = (uint32_t)~cur;
       bool finished = false;
+      const RayShear rs = ray_shear(d);
       for (uint32_t slot = leaf;; ++slot) {   // one copy of the test (inlined twice it spilt 15 more registers)
         const float4* tp = reinterpret_cast<const float4*>(tris + slot);
         const float4 a = tp[0], b = tp[1], c = tp[2];
         if (COUNT) tally.tris += 1;
         BvhTri tr;
         tr.v0[0] = a.x; tr.v0[1] = a.y; tr.v0[2] = a.z; tr.world_id = __float_as_uint(a.w);
-        tr.e1[0] = b.x; tr.e1[1] = b.y; tr.e1[2] = b.z; tr.instance = __float_as_uint(b.w);
-        tr.e2[0] = c.x; tr.e2[1] = c.y; tr.e2[2] = c.z; tr.prim_flags = __float_as_uint(c.w);
+        tr.v1[0] = b.x; tr.v1[1] = b.y; tr.v1[2] = b.z; tr.instance = __float_as_uint(b.w);
+        tr.v2[0] = c.x; tr.v2[1] = c.y; tr.v2[2] = c.z; tr.prim_flags = __float_as_uint(c.w);
         float t, u, v;
-        if (ray_triangle(tr, o, d, tmin, t, u, v) && t < tmax) {
+        if (ray_triangle(rs, tr, o, tmin, t, u, v) && t < tmax) {
           const bool better = best.leaf == kNone ? true : (t < best.t || (t == best.t && tr.world_id < best_id));
           if (better && (!(tr.prim_flags & kTriNonOpaque) || alpha_test(S, slot, u, v))) {
             best = HitRecord{t, u, v, slot};
@@ -728,20 +758,20 @@ __device__ __forceinline__ void trace_wave_tl(const DeviceScene& S, Source& src,
         const TlasInstance* ti = instances + cur_inst;
         const uint32_t tri_base = ti->tri_base, first = (uint32_t)~cur;
         bool finished = false;
+        const RayShear rs = ray_shear(d);
         for (uint32_t local = first;; ++local) {
           const uint32_t slot = tri_base + local;
           const uint32_t prim_flags = tris[slot].prim_flags;
           const float4* rec = S.shade_tris + 8u * (size_t)slot;
           const float4 pa = rec[0], pb = rec[2], pc = rec[4];
-          // world triangle exactly as k_world_tris builds it: three points through o2w, then the two edges
+          // world triangle exactly as k_world_tris builds it: three points through o2w
           const vec3 v0 = xform_point(ti->o2w, mk3(pa.x, pa.y, pa.z)), v1 = xform_point(ti->o2w, mk3(pb.x, pb.y, pb.z)), v2 = xform_point(ti->o2w, mk3(pc.x, pc.y, pc.z));
-          const vec3 e1 = v1 - v0, e2 = v2 - v0;
           BvhTri tr;
           tr.v0[0] = v0.x; tr.v0[1] = v0.y; tr.v0[2] = v0.z;
-          tr.e1[0] = e1.x; tr.e1[1] = e1.y; tr.e1[2] = e1.z;
-          tr.e2[0] = e2.x; tr.e2[1] = e2.y; tr.e2[2] = e2.z;
+          tr.v1[0] = v1.x; tr.v1[1] = v1.y; tr.v1[2] = v1.z;
+          tr.v2[0] = v2.x; tr.v2[1] = v2.y; tr.v2[2] = v2.z;
           float t, u, v;
-          if (ray_triangle(tr, o, d, tmin, t, u, v) && t < tmax) {
+          if (ray_triangle(rs, tr, o, tmin, t, u, v) && t < tmax) {
             const uint32_t world_id = ti->world_base + (prim_flags & kTriPrimMask);
             const bool better = best.leaf == kNone ? true : (t < best.t || (t == best.t && world_id < best.world_id));
             if (better && (ti->non_opaque == 0u || alpha_test_instance(S, slot, ti->instance, u, v))) {

@@ -409,7 +409,7 @@ struct Tex {
 };
 
 struct Tri {   // world-space triangle for intersection
-  V3 v0, e1, e2;
+  V3 v0, v1, v2;
   uint32_t world_id, instance, prim;
   bool non_opaque;
 };
@@ -764,7 +764,7 @@ void build_accel(Scene& sc) {
         v[k] = mat_point(M, v3(vt.vv[0], vt.vv[1], vt.vv[2]));
       }
       Tri t;
-      t.v0 = v[0]; t.e1 = v[1] - v[0]; t.e2 = v[2] - v[0];
+      t.v0 = v[0]; t.v1 = v[1]; t.v2 = v[2];
       t.world_id = world_id; t.instance = (uint32_t)i; t.prim = p; t.non_opaque = non_opaque;
       sc.tris.push_back(t);
     }
@@ -774,12 +774,12 @@ void build_accel(Scene& sc) {
   if (n == 0) return;
   std::vector<float> lo(n * 3), hi(n * 3), ce(n * 3);
   auto bounds_of = [&](const Tri& t, float* l, float* h) {
-    V3 a = t.v0, b = t.v0 + t.e1, c = t.v0 + t.e2;
+    V3 a = t.v0, b = t.v1, c = t.v2;
     const float* A = &a.x; const float* B = &b.x; const float* C = &c.x;
     for (int k = 0; k < 3; ++k) {
       l[k] = fminf(A[k], fminf(B[k], C[k]));
       h[k] = fmaxf(A[k], fmaxf(B[k], C[k]));
-      // conservative padding: M-T may accept points a few ulps outside the exact bounds
+      // conservative padding: the ray / triangle test may accept points a few ulps outside the exact bounds
       float pad = 1e-5f * fmaxf(fmaxf(fabsf(l[k]), fabsf(h[k])), 1e-3f);
       l[k] -= pad; h[k] += pad;
     }
@@ -833,28 +833,71 @@ void build_accel(Scene& sc) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Ray / triangle (Moeller-Trumbore) -- the build's definition of what the Vulkan driver does for
-// traceRayEXT ([ext], parity unpinned).  Candidate accepted iff tmin < t < tmax.  No culling
-// (TRIANGLE_FACING_CULL_DISABLE, acceleration.rs:335-345).
+// Ray / triangle -- the build's definition of what the Vulkan driver does for traceRayEXT ([ext], parity unpinned;
+// path_trace.rgen:169, :106-109 on the acceleration structure of acceleration.rs:319-345).  Candidate accepted iff
+// tmin < t < tmax.  No culling (TRIANGLE_FACING_CULL_DISABLE, acceleration.rs:335-345).
+//
+// WATERTIGHT, as the Vulkan specification requires of the driver's intersector: a ray cannot pass between triangles that share
+// an edge or a vertex.  The rule is the one of Woop, Benthin, Wald, "Watertight Ray/Triangle Intersection" (JCGT 2013), with
+// the exact tie-break done in single precision:
+//   * per RAY: the axis kz of the direction's largest component and the shear that takes d to (0, 0, 1):
+//     Sz = 1 / d[kz], Sx = d[kx] * Sz, Sy = d[ky] * Sz  (kx, ky the next two axes; no winding swap -- nothing is culled);
+//   * per VERTEX P: A = P - o, then its image (A[kx] - Sx A[kz], A[ky] - Sy A[kz], Sz A[kz]).  The image is a function of the
+//     ray and of the vertex's floats only, so every triangle that uses the vertex sees the SAME 2-D point (the records hold
+//     the vertices themselves for that reason, not a vertex and two edges);
+//   * per EDGE: the 2-D edge function  U = Cx By - Cy Bx  (V, W alike) from two separately rounded products.  Rounding is
+//     monotonic, so the sign of fl(Cx By) - fl(Cy Bx) is the sign of the exact value unless the two rounded products are
+//     equal; then the exact value is the difference of the two rounding errors, each of which one fma delivers exactly
+//     (fma(a, b, -fl(a b)) = a b - fl(a b)).  Every sign is therefore the EXACT orientation of the origin against two fixed 2-D
+//     points, and exact predicates on consistent points cannot disagree: across a shared edge one triangle sees e, the other
+//     -e; around a shared vertex the fan's spokes cannot all lie on one side of the origin unless the origin is outside the fan.
+//     (A product that underflows loses this exactness; scenes are not built out of 1e-20-sized coordinates.)
+//   * inside iff no two of U, V, W have opposite signs; zero counts as inside for BOTH neighbours, the tie on t then goes to
+//     the smaller world id.  det = U + V + W;  u = V / det, v = W / det (weights of v1, v2);  t = (U Az + V Bz + W Cz) / det.
+// Moeller-Trumbore, which north_star names and rounds 1-2 ran, evaluates u, v and 1 - u - v by three differently rounded
+// expressions per triangle and leaks (found by tests/test_analytic_render.py: the parallel rays of an orthographic camera
+// through a square's diagonal); scalar triple products d . (P x Q) made antisymmetric by unfused cross products close the
+// edges but not the vertices (5 % of the rays aimed at the vertices of a closed mesh got out: tests/test_watertight.py).
 // ------------------------------------------------------------------------------------------
-// The products are stated with explicit fused multiply-adds (fmaf is correctly rounded, so every implementation of this
-// statement gives the same bits): a cross product component a*b - c*d = fma(a, b, -(c*d)), a dot product
-// fma(az, bz, fma(ay, by, ax*bx)).
-inline V3 cross_fma(V3 a, V3 b) { return v3(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x))); }
+// Fused operations are stated explicitly (fmaf is correctly rounded, so every implementation of this statement gives the same
+// bits); everything else is one rounding per operation (-ffp-contract=off).
 inline float dot_fma(V3 a, V3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+struct RayShear { int kx, ky, kz; float sx, sy, sz; };
+inline RayShear ray_shear(V3 d) {
+  const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+  RayShear r;
+  r.kz = (ax >= ay && ax >= az) ? 0 : (ay >= az ? 1 : 2);
+  r.kx = (r.kz + 1) % 3;
+  r.ky = (r.kz + 2) % 3;
+  const float* c = &d.x;
+  r.sz = 1.0f / c[r.kz];
+  r.sx = c[r.kx] * r.sz;
+  r.sy = c[r.ky] * r.sz;
+  return r;
+}
+inline V3 shear_vertex(const RayShear& r, V3 p, V3 o) {
+  const V3 a = p - o;
+  const float* c = &a.x;
+  return v3(fmaf(-r.sx, c[r.kz], c[r.kx]), fmaf(-r.sy, c[r.kz], c[r.ky]), r.sz * c[r.kz]);
+}
+// a*b - c*d with the exact sign: the difference of the rounded products, or of their rounding errors when those are equal
+inline float edge_fn(float a, float b, float c, float d) {
+  const float p = a * b, q = c * d;
+  const float e = p - q;
+  return e != 0.0f ? e : fmaf(a, b, -p) - fmaf(c, d, -q);
+}
 inline bool ray_tri(const Tri& tr, V3 o, V3 d, float tmin, float tmax, float& t, float& u, float& v) {
-  V3 pvec = cross_fma(d, tr.e2);
-  float det = dot_fma(tr.e1, pvec);
-  if (det == 0.0f) return false;
-  float inv = 1.0f / det;
-  V3 tvec = o - tr.v0;
-  u = dot_fma(tvec, pvec) * inv;
-  if (!(u >= 0.0f && u <= 1.0f)) return false;
-  V3 qvec = cross_fma(tvec, tr.e1);
-  v = dot_fma(d, qvec) * inv;
-  if (!(v >= 0.0f && u + v <= 1.0f)) return false;
-  t = dot_fma(tr.e2, qvec) * inv;
-  return t > tmin && t < tmax;
+  const RayShear rs = ray_shear(d);
+  const V3 A = shear_vertex(rs, tr.v0, o), B = shear_vertex(rs, tr.v1, o), C = shear_vertex(rs, tr.v2, o);
+  const float U = edge_fn(C.x, B.y, C.y, B.x), V = edge_fn(A.x, C.y, A.y, C.x), W = edge_fn(B.x, A.y, B.y, A.x);
+  if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) return false;
+  const float det = (U + V) + W;
+  if (det == 0.0f) return false;   // the ray lies in the triangle's plane, or the triangle has no area in this projection
+  const float inv = 1.0f / det;
+  u = V * inv;
+  v = W * inv;
+  t = fmaf(W, C.z, fmaf(V, B.z, U * A.z)) * inv;
+  return t > tmin && t < tmax;      // a NaN anywhere above ends here
 }
 
 // raytrace_hit.rahit:24-39: ignore the candidate when the opacity texture's red channel < 0.5
@@ -949,7 +992,7 @@ bool trace_any(const Scene& sc, V3 o, V3 d, float tmin, float tmax) {
 // rule of the HIP tracer, so the instrumented kernels' counters must equal these counts.
 inline uint32_t fbits(float f);
 struct ExtNode { uint32_t w[16]; };   // BvhNode4
-struct ExtTri { float v0[3]; uint32_t world_id; float e1[3]; uint32_t instance; float e2[3]; uint32_t prim_flags; };
+struct ExtTri { float v0[3]; uint32_t world_id; float v1[3]; uint32_t instance; float v2[3]; uint32_t prim_flags; };
 inline float box_entry_q(float lox, float loy, float loz, float hix, float hiy, float hiz, V3 ig, V3 cg, float tmin, float tmax) {
   // plane distances as one correctly rounded fma each (kernels_render.hip box_entry: v_pk_fma_f32)
   const float ax = fmaf(lox, ig.x, cg.x), bx = fmaf(hix, ig.x, cg.x);
@@ -1001,7 +1044,7 @@ void ext_trace(const Scene& sc, V3 o, V3 d, float tmin, float tmax, bool any, Co
       for (uint32_t s = first; s < first + count; ++s) {
         const ExtTri& et = tris[s];
         c.tris++;
-        Tri tr; tr.v0 = v3(et.v0[0], et.v0[1], et.v0[2]); tr.e1 = v3(et.e1[0], et.e1[1], et.e1[2]); tr.e2 = v3(et.e2[0], et.e2[1], et.e2[2]);
+        Tri tr; tr.v0 = v3(et.v0[0], et.v0[1], et.v0[2]); tr.v1 = v3(et.v1[0], et.v1[1], et.v1[2]); tr.v2 = v3(et.v2[0], et.v2[1], et.v2[2]);
         tr.instance = et.instance; tr.prim = et.prim_flags & 0x3FFFFFFFu; tr.non_opaque = (et.prim_flags >> 31) != 0;
         float t, u, v;
         if (ray_tri(tr, o, d, tmin, INF, t, u, v) && t < tmax) {

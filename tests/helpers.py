@@ -57,3 +57,40 @@ def rel_err(a, b):
     b = b.astype(np.float64)
     floor = max(1e-12, 1e-3 * float(np.abs(b).mean()))
     return np.abs(a - b) / np.maximum(np.abs(b), floor)
+
+
+class DeviceArray:
+    """A float32 array in device memory for tests that hand device pointers through the C ABI, allocated with the HIP runtime
+    libglaze_hip.so itself is linked to (a test process must not load torch next to it: torch brings its own copy of the runtime,
+    and two of them in one process end in a double free at exit)."""
+    _hip = None
+
+    def __init__(self, shape, fill=0.0):
+        import ctypes as C
+        if DeviceArray._hip is None:
+            abi.lib()                                                    # makes sure the runtime is the library's
+            DeviceArray._hip = C.CDLL("libamdhip64.so.7")
+        self.shape = tuple(shape)
+        self.nbytes = int(np.prod(self.shape)) * 4
+        p = C.c_void_p()
+        assert DeviceArray._hip.hipMalloc(C.byref(p), C.c_size_t(self.nbytes)) == 0
+        self.ptr = p.value
+        self.upload(np.full(self.shape, fill, np.float32))
+
+    def upload(self, a):
+        import ctypes as C
+        a = np.ascontiguousarray(a, np.float32)
+        assert a.nbytes == self.nbytes
+        assert DeviceArray._hip.hipMemcpy(C.c_void_p(self.ptr), a.ctypes.data_as(C.c_void_p), C.c_size_t(self.nbytes), 1) == 0
+
+    def numpy(self):
+        import ctypes as C
+        out = np.empty(self.shape, np.float32)
+        assert DeviceArray._hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr), C.c_size_t(self.nbytes), 2) == 0
+        return out
+
+    def __del__(self):
+        import ctypes as C
+        if getattr(self, "ptr", None) and DeviceArray._hip is not None:
+            DeviceArray._hip.hipFree(C.c_void_p(self.ptr))
+            self.ptr = None

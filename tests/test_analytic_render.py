@@ -140,15 +140,10 @@ def closed_form_with_occluder(n, factor, flip_x, ortho=False):
     m = 3.0 / n                                                          # margin: one and a half pixels
     near_occ_edge = (np.abs(np.abs(u) * zs - OCC_H) < m) & (np.abs(v) * zs < OCC_H + m) | (np.abs(np.abs(v) * zs - OCC_H) < m) & (np.abs(u) * zs < OCC_H + m)
     near_shadow_edge = (np.abs(np.abs(q[..., 0]) - OCC_H) < m) & (np.abs(q[..., 1]) < OCC_H + m) | (np.abs(np.abs(q[..., 1]) - OCC_H) < m) & (np.abs(q[..., 0]) < OCC_H + m)
-    # The square is two triangles, and the Moeller-Trumbore test is not watertight: a ray through their shared edge (the diagonal
-    # x = y) can fail `u >= 0` in one and `v >= 0` in the other by a rounding error and go on to the wall.  Parallel rays on a pixel grid
-    # aligned with the square do hit the diagonal exactly, so its neighbourhood is left out -- for the camera rays that see it and for the
-    # shadow rays that cross it.  (Hardware ray tracing, which the reference runs on, guarantees watertightness)
-    # (both diagonals: the scene is symmetric in y, so nothing here knows whether the image's rows run up or down)
-    def diag(a):
-        return np.minimum(np.abs(a[..., 0] - a[..., 1]), np.abs(a[..., 0] + a[..., 1])) < m
-    near_diagonal = on_occ & diag(p) | ~on_occ & diag(q) & (np.abs(q[..., 0]) < OCC_H + m)
-    safe = ~near_occ_edge & ~(near_shadow_edge & ~on_occ) & ~near_diagonal
+    # The square is two triangles and parallel rays on a pixel grid aligned with it meet their shared edge (the diagonal x = y)
+    # exactly: the intersector is watertight (oracle.cpp ray_tri), so the diagonal is NOT left out -- neither for the camera rays
+    # that see it nor for the shadow rays that cross it.  (Rounds 1-2 ran Moeller-Trumbore and had to mask it.)
+    safe = ~near_occ_edge & ~(near_shadow_edge & ~on_occ)
     return e[..., None] * factor[None, None, :], safe, shadow, on_occ
 
 
