@@ -463,6 +463,14 @@ class RayTraceRenderer:
         arr = (C.c_int * len(devices))(*devices)
         abi.check(abi.lib().glz_renderer_set_devices(self._h, arr, len(devices)))
 
+    def set_launch_mode(self, mode):
+        """'auto' (by the pixels this device owns), 'two_kernels' (k_trace + k_shade per launch) or 'path' (the per-wave launch loop, k_path);
+        the image does not depend on it"""
+        abi.check(abi.lib().glz_renderer_set_launch_mode(self._h, {"auto": 0, "two_kernels": 1, "path": 2}[mode]))
+
+    def launch_mode(self):
+        return {1: "two_kernels", 2: "path"}[int(abi.lib().glz_renderer_launch_mode(self._h))]
+
     def device_count(self):
         return int(abi.lib().glz_renderer_device_count(self._h))
 

@@ -184,6 +184,8 @@ PROTOTYPES = {
     "glz_debug_rccl_selftest": (C.c_int, [_P, C.c_uint64, _P]),
     "glz_instance_set_as_levels": (C.c_int, [_P, C.c_int]),
     "glz_renderer_set_devices": (C.c_int, [_P, _P, C.c_int]),
+    "glz_renderer_set_launch_mode": (C.c_int, [_P, C.c_int]),
+    "glz_renderer_launch_mode": (C.c_int, [_P]),
     "glz_renderer_device_count": (C.c_int, [_P]),
     "glz_renderer_device_scene_info": (C.c_int, [_P, C.c_int, _P]),
     "glz_rccl_version": (C.c_int, []),

@@ -415,6 +415,8 @@ int glz_renderer_set_devices(glz_renderer* h, const int* devices, int n) {
   GLZ_RET(h->r->set_devices(devices, n, e));
   GLZ_GUARD_END(GLZ_E_IO)
 }
+int glz_renderer_set_launch_mode(glz_renderer* h, int mode) { GLZ_GUARD_BEGIN GLZ_R(h); GLZ_RET(h->r->set_launch_mode(mode, e)); GLZ_GUARD_END(GLZ_E_IO) }
+int glz_renderer_launch_mode(glz_renderer* h) { return h ? (h->r->path_mode() ? GLZ_LAUNCH_PATH : GLZ_LAUNCH_TWO_KERNELS) : 0; }
 int glz_renderer_set_chains(glz_renderer* h, uint32_t n) { GLZ_GUARD_BEGIN GLZ_R(h); GLZ_RET(h->r->set_chains(n, e)); GLZ_GUARD_END(GLZ_E_IO) }
 int glz_renderer_export_device(glz_renderer* h, int which, void* dev) {
   GLZ_GUARD_BEGIN GLZ_R(h);

@@ -103,12 +103,25 @@ struct LaunchArgs {
   uint32_t shade_set;        // which of the two shadow-queue counter sets this launch's k_shade fills (the other one is drained)
   float shadow_exposure;     // exposure of the launch that queued the shadow rays (update_result uses it)
 };
+// The launches one k_path call runs (kernels_render.hip): what differs between launches, by value in the kernel arguments
+constexpr uint32_t kPathMaxLaunches = 16;
+struct PathBatch {
+  uint32_t n;                              // launches in this call
+  uint32_t tables_in_lds;                  // filled by launch_path
+  uint32_t seed[kPathMaxLaunches];         // FrameData::seed of each
+  float offset[kPathMaxLaunches][2];       // FrameData::pixel_offset
+  float exposure[kPathMaxLaunches];        // FrameData::exposure
+};
 constexpr uint32_t kTraceBlock = 256;          // threads per block of the render kernels (4 waves)
 constexpr uint32_t kQueueSetWords = 8 * 32;   // 8 shard counters, 128 bytes apart
 
 uint32_t trace_grid_blocks(uint32_t n_local_pixels, bool counting, bool two_level);   // persistent grid of k_trace / k_trace_tl (device must be current)
 hipError_t launch_trace(hipStream_t st, const LaunchArgs& a, uint32_t blocks);
 hipError_t launch_shade(hipStream_t st, const LaunchArgs& a);
+// the per-wave launch loop of a small tile share: `batch.n` launches for every pixel in ONE kernel (a.frame holds what the launches
+// share; flattened scenes, no work counters); blocks from path_grid_blocks (device must be current)
+uint32_t path_grid_blocks(uint32_t n_local_pixels, const DeviceScene& scene);
+hipError_t launch_path(hipStream_t st, const LaunchArgs& a, const PathBatch& batch, uint32_t blocks);
 // scatter the tile-major cumulative / result images into full-frame row-major RGBA32F buffers
 hipError_t launch_export(hipStream_t st, const TileMap& map, const float4* tiled, float4* frame, bool zero_first);
 // chain `chain` of `n_chains` -> the rank's packed tile order (local tile j = jl * n_chains + chain), see Renderer::export_packed

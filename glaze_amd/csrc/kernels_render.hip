@@ -836,23 +836,26 @@ __device__ __forceinline__ uint32_t wave_count() { return gridDim.x * (kBlock / 
 // ---------------------------------------------------------------------------------------------
 struct ClosestSource {
   const LaunchArgs& A;
+  const FrameData& F;   // the launch's constants (k_trace: A.frame; k_path: one entry of its batch)
   TraceTally& tally;
+  uint32_t base;        // ray i is local pixel base + i (k_trace: 0; k_path: the first pixel of the wave's group)
   // ray generation / resume for local pixel `lid`
   // (Dealing the rays of a group from 4, 16 or 64 different tiles instead of one row of one tile -- to level the waves of a small
   // share, whose ends spread from 60 (median) to 105 us -- changes nothing: the spread is not regional, a wave is as slow as the
   // longest dependent chain among its 64 rays.  Median and end of the phase moved by +3 ... +8 % with the coherence lost.)
-  __device__ __forceinline__ bool load(uint32_t lid, vec3& origin, vec3& direction, float& tmin, float& tmax) {
+  __device__ __forceinline__ bool load(uint32_t i, vec3& origin, vec3& direction, float& tmin, float& tmax) {
+    const uint32_t lid = base + i;
     const PixelId px = pixel_of(A.map, lid);
     if (!px.active) return false;
     const float4 ro = A.st.ray_o[lid], rd = A.st.ray_d[lid];
-    if (A.frame.direct_only || ro.w == 0.0f) {
+    if (F.direct_only || ro.w == 0.0f) {
       tally.fresh += 1;
       // new path: camera ray through the jittered pixel (ray_origin / ray_dir, path_trace.rgen:47-73)
-      const float pxf = (float)px.x + A.frame.pixel_offset[0], pyf = (float)px.y + A.frame.pixel_offset[1];
-      const float ndcx = -1.0f + 2.0f * (pxf / A.frame.scene_size[0]), ndcy = -1.0f + 2.0f * (pyf / A.frame.scene_size[1]);
+      const float pxf = (float)px.x + F.pixel_offset[0], pyf = (float)px.y + F.pixel_offset[1];
+      const float ndcx = -1.0f + 2.0f * (pxf / F.scene_size[0]), ndcy = -1.0f + 2.0f * (pyf / F.scene_size[1]);
       const float* c2w = A.cam.camera2world;
       const float* s2c = A.cam.screen2camera;
-      const float ortho = gl_step(0.5f, A.frame.camera_persp ? 0.0f : 1.0f), persp = gl_step(0.5f, A.frame.camera_persp ? 1.0f : 0.0f);
+      const float ortho = gl_step(0.5f, F.camera_persp ? 0.0f : 1.0f), persp = gl_step(0.5f, F.camera_persp ? 1.0f : 0.0f);
       const float ox = ndcx * ortho, oy = ndcy * ortho;
       origin = mk3((c2w[0] * ox + c2w[4] * oy) + c2w[12], (c2w[1] * ox + c2w[5] * oy) + c2w[13], (c2w[2] * ox + c2w[6] * oy) + c2w[14]);
       const float fx = ndcx * persp, fy = ndcy * persp;
@@ -915,6 +918,222 @@ __device__ __forceinline__ uint32_t queue_slot(uint32_t* counters, uint32_t n_lo
     slot = shard * queue_capacity(n_local_pixels) + base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
   }
   return slot;
+}
+
+// ---------------------------------------------------------------------------------------------
+// One pixel of path_trace.rgen:170-237 minus the two traceRayEXT calls, with raytrace_hit.rchit:30-71 in front: what k_shade
+// runs for the pixel at its sorted slot and what k_path (the per-wave launch loop of a small tile share) runs for each of a
+// wave's 64 pixels.  `hr` is the closest-hit record of this launch, `queue.slot(push)` hands out the shadow-queue entry (all
+// lanes that get this far call it together).
+// ---------------------------------------------------------------------------------------------
+struct SharedQueue {   // k_shade: the rank's sharded queue in HBM, drained by the next k_trace
+  const LaunchArgs& A;
+  __device__ __forceinline__ uint32_t slot(bool push) { return queue_slot(A.st.queue_count + A.shade_set * kQueueSetWords, A.map.n_local_pixels, push); }
+};
+template <class Queue>
+__device__ __forceinline__ void shade_pixel(const LaunchArgs& A, const DeviceScene& S, const FrameData& F, uint32_t lid, PixelId px, float4 ro, float4 rd, float4 hr, Queue& queue) {
+  const bool fresh = F.direct_only || ro.w == 0.0f;
+  float bounce = F.direct_only ? 0.0f : ro.w;
+  const vec3 direction = mk3(rd.x, rd.y, rd.z);
+  // The path's importance (16 floats) is read where it is used -- the radiance of the light sample, the roulette, the final product --
+  // instead of once up front: held through texture fetches, light sampling and the two BSDF calls it set the kernel's register peak.
+  // The re-reads hit the lines the first read brought in.
+  auto load_importance = [&]() {
+    asm volatile("" ::: "memory");   // a fresh read every time: merged with an earlier one the values would stay in registers in between
+    Spec imp;
+    if (fresh) {
+      imp = spec_set(1.0f);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 v = A.st.imp[q][lid];
+        imp.w[4 * q] = v.x; imp.w[4 * q + 1] = v.y; imp.w[4 * q + 2] = v.z; imp.w[4 * q + 3] = v.w;
+      }
+    }
+    return imp;
+  };
+  const uint32_t leaf = __float_as_uint(hr.w);
+  if (leaf == 0xFFFFFFFFu) {
+    // miss: optional sky radiance, path reset (path_trace.rgen:170-179)
+    uint32_t flags = 0;
+    vec3 c = mk3(0.0f, 0.0f, 0.0f);
+    if ((bounce == 0.0f || rd.w == 1.0f) && S.sky.tex_id > 0) {
+      const vec3 w = normalize3(xform_dir(S.sky.world2obj, direction));   // sky_radiance, :75-82
+      const float phi = glz_atan2f(w.y, w.x), theta = glz_acosf(w.z);
+      const vec3 texel = texture_rgb(S, S.sky.tex_id, vec2{phi * kInv2Pi, theta * kInvPi});
+      c = spec_to_rgb(spec_mul(load_importance(), from_illuminant_color(texel)));
+      flags = kFlagUpdate;
+    }
+    accumulate_pixel(A, lid, c, true, flags != 0, F.exposure);
+    if (!F.direct_only) A.st.ray_o[lid] = make_float4(ro.x, ro.y, ro.z, 0.0f);   // RESET_PATH
+    return;
+  }
+  // ---- closest-hit shader (raytrace_hit.rchit:30-71), inputs from the 128-byte per-leaf shading record ----
+  const float4* rec = S.shade_tris + 8u * (size_t)leaf;
+  const float4 va0 = rec[0], va1 = rec[1], vb0 = rec[2], vb1 = rec[3], vc0 = rec[4], vc1 = rec[5], dn = rec[6], du = rec[7];
+  uint32_t material_id = __float_as_uint(dn.w), xf_bits = __float_as_uint(du.w);
+  if (S.two_level) {   // the record is per OBJECT triangle: material and transform are the instance's
+    const RTInstance in = S.instances[A.st.hit_inst[lid]];
+    material_id = in.material_id;
+    xf_bits = in.transform_id | (S.xf_identity[in.transform_id] ? 0x80000000u : 0u);
+  }
+  const float b0 = 1.0f - hr.y - hr.z, b1 = hr.y, b2 = hr.z;
+  vec3 point = (mk3(va0.x, va0.y, va0.z) * b0 + mk3(vb0.x, vb0.y, vb0.z) * b1) + mk3(vc0.x, vc0.y, vc0.z) * b2;
+  const vec2 uv = vec2{(va1.z * b0 + vb1.z * b1) + vc1.z * b2, (va1.w * b0 + vb1.w * b1) + vc1.w * b2};
+  vec3 ng = mk3(dn.x, dn.y, dn.z), dpdu = mk3(du.x, du.y, du.z);   // dpdv is transformed by the reference but never read afterwards
+  vec3 ns = (mk3(va0.w, va1.x, va1.y) * b0 + mk3(vb0.w, vb1.x, vb1.y) * b1) + mk3(vc0.w, vc1.x, vc1.y) * b2;
+  const MatScalars mat = load_material(&S.materials[material_id]);
+  // ---- texture level of detail by ray cones (build-defined, off by default: the reference's stages sample level 0) ----
+  // The cone of a camera path starts cone_width0 wide and widens by cone_spread per unit of distance along the whole path;
+  // at a hit the footprint on the surface is width / |cos|, and a texture of W x H texels over a triangle with texture-space
+  // area A_uv and world area A_w is minified by sqrt(A_uv W H / A_w) texels per unit length:
+  // level = 0.5 log2(A_uv / A_w * width^2 / cos^2) + 0.5 log2(W H)      (Akenine-Moeller et al., ray cones)
+  float lod_base = kNoLod, cone_w = 0.0f;
+  if (F.lod_mode != 0u) {
+    cone_w = (fresh ? F.cone_width0 : A.st.cone[lid]) + F.cone_spread * hr.x;
+    vec3 e1 = mk3(vb0.x, vb0.y, vb0.z) - mk3(va0.x, va0.y, va0.z), e2 = mk3(vc0.x, vc0.y, vc0.z) - mk3(va0.x, va0.y, va0.z);
+    vec3 n = mk3(dn.x, dn.y, dn.z);
+    if (!(xf_bits >> 31)) {
+      const TransformPair* xf = &S.transforms[xf_bits & 0x7FFFFFFFu];
+      e1 = xform_dir(xf->o2w, e1);
+      e2 = xform_dir(xf->o2w, e2);
+      n = xform_tdir(xf->w2o, n);
+    }
+    const vec3 cr = cross3(e1, e2);
+    const float area2 = sqrtf(dot3(cr, cr));
+    const float uva2 = fabsf((vb1.z - va1.z) * (vc1.w - va1.w) - (vc1.z - va1.z) * (vb1.w - va1.w));
+    const float cosv = fabsf(dot3(n, direction)) / sqrtf(dot3(n, n));
+    const float x = ((uva2 / area2) * (cone_w * cone_w)) / (cosv * cosv);
+    if (x >= 1.17549435e-38f && x <= 3.4e38f) lod_base = 0.5f * glz_log2f(x);
+  }
+  if (mat.normal != 0) {
+    const vec4 tx = texture2d_lod(S, mat.normal, uv.x, uv.y, lod_base);
+    Frame old;
+    old.s = normalize3(dpdu);
+    old.n = ns;
+    old.t = normalize3(cross3(old.n, old.s));
+    ns = normalize3(to_world(mk3(tx.x * 2.0f - 1.0f, tx.y * 2.0f - 1.0f, tx.z * 2.0f - 1.0f), old));
+    ns = ns * gl_sign(dot3(ng, ns));
+  }
+  if (!(xf_bits >> 31)) {
+    // object -> world.  Skipped for an exact identity transform: m*x with m = I reproduces x bit for bit
+    // (x*1 + y*0 + z*0 + 0 for finite coordinates), so the result is unchanged and ~25 scalar loads are saved.
+    const float4* xq = reinterpret_cast<const float4*>(&S.transforms[xf_bits & 0x7FFFFFFFu]);
+    const float4 m0 = xq[0], m1 = xq[1], m2 = xq[2], m3 = xq[3], w0 = xq[4], w1 = xq[5], w2 = xq[6];
+    const float o2w[16] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w, m2.x, m2.y, m2.z, m2.w, m3.x, m3.y, m3.z, m3.w};
+    const float w2o[12] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
+    point = xform_point(o2w, point);
+    dpdu = xform_point(o2w, dpdu);   // transformed as a point, w = 1 (Q8)
+    ng = xform_tdir(w2o, ng);
+    ns = xform_tdir(w2o, ns);
+  }
+  (void)ng;
+  // ---- raygen continues (path_trace.rgen:180-237) ----
+  uint32_t rng = pcg(__float_as_uint((float)F.seed) ^ pcg(__float_as_uint((float)px.x) ^ pcg(__float_as_uint((float)px.y))));   // :143, Q11
+  SurfacePoint P;
+  P.woW = -direction;
+  P.uv = uv;
+  P.frame = make_frame(dpdu, ns);
+  P.mat = mat;
+  fetch_material_textures(S, P, lod_base);
+  float spec_flag;
+  float imp_lum = 0.0f;      // luminance of the importance, taken when the light-sampling block reads it: the roulette needs nothing else of it
+  bool have_lum = false;
+  if (mat.is_specular == 0) {
+    // direct_light(), :84-117
+    const uint32_t li = (uint32_t)gl_min(rand01(rng) * (float)F.lights_no, (float)(F.lights_no - 1u));
+    vec3 xi;
+    xi.x = rand01(rng); xi.y = rand01(rng); xi.z = rand01(rng);
+    LightSample ls;
+    ls.pdf = 0.0f;
+    sample_light(S, li, point, xi, F.scene_radius, ls);
+    vec3 c = mk3(0.0f, 0.0f, 0.0f);
+    uint32_t flags = kFlagUpdate;
+    vec3 sh_dir = mk3(0.0f, 0.0f, 0.0f);
+    float sh_tmax = 0.0f;
+    if (ls.pdf > 0.0f) {
+      const float xi_b = rand01(rng);
+      Spec value = spec_set(0.0f);
+      const float bpdf = bsdf_eval(S, P, ls.wiW, xi_b, value);
+      if (bpdf > 0.0f) {
+        // weight_light = (1 or 0) * |cos| / pdf; radiance = value*emission*weight*lights_no*importance
+        const float w_vis = 1.0f * (fabsf(dot3(ls.wiW, ns)) / ls.pdf);
+        const float w_occ = 0.0f * (fabsf(dot3(ls.wiW, ns)) / ls.pdf);
+        const float nl = (float)F.lights_no;
+        const Spec emission = light_emission(ls);
+        const Spec importance = load_importance();
+        imp_lum = spec_luminance(importance);
+        have_lum = true;
+        Spec rad;
+        float poison = 0.0f;
+        GLZ_BINS {
+          const float rl = value.w[i] * emission.w[i];
+          rad.w[i] = ((rl * w_vis) * nl) * importance.w[i];
+          poison += ((rl * w_occ) * nl) * importance.w[i];
+        }
+        c = spec_to_rgb(rad);
+        flags |= kFlagShadow | (poison == poison ? 0u : kFlagPoison);
+        sh_dir = ls.wiW;
+        sh_tmax = ls.distance - 1e-3f;
+      }
+    }
+    if (!(flags & kFlagShadow)) {
+      // no light sample: the reference still adds rgb(0 * lights_no * importance), which is NaN for a non-finite importance
+      const Spec importance = load_importance();
+      imp_lum = spec_luminance(importance);
+      have_lum = true;
+      float probe = 0.0f;
+      GLZ_BINS probe += 0.0f * importance.w[i];
+      if (probe != probe) c = spec_to_rgb(spec_scale(importance, 0.0f * (float)F.lights_no));
+    }
+    // shadow-ray queue (consumed by the next launch's k_trace); pixels without a shadow ray are accumulated right here
+    const bool push = (flags & kFlagShadow) != 0;
+    const uint32_t slot = queue.slot(push);
+    if (push) {
+      A.st.sh_o[slot] = make_float4(point.x, point.y, point.z, sh_tmax);
+      A.st.sh_d[slot] = make_float4(sh_dir.x, sh_dir.y, sh_dir.z, __uint_as_float(lid));
+      A.st.contrib[slot] = make_float4(c.x, c.y, c.z, __uint_as_float(flags));
+    } else {
+      accumulate_pixel(A, lid, c, true, true, F.exposure);
+    }
+    spec_flag = 0.0f;
+  } else {
+    accumulate_pixel(A, lid, mk3(0.0f, 0.0f, 0.0f), false, false, F.exposure);
+    spec_flag = 1.0f;
+  }
+  if (F.direct_only) return;
+  // Russian roulette (:197-210)
+  float rr_scale = 1.0f;   // importance * 1.0f is importance, bit for bit: the paths that skip the roulette multiply by it too
+  if (bounce > (float)(F.pt_steps / 2u)) {
+    const float kill = gl_max(0.05f, 1.0f - (have_lum ? imp_lum : spec_luminance(load_importance())));
+    if (rand01(rng) < kill) {
+      A.st.ray_o[lid] = make_float4(ro.x, ro.y, ro.z, 0.0f);
+      A.st.ray_d[lid] = make_float4(rd.x, rd.y, rd.z, spec_flag);
+      return;
+    }
+    rr_scale = 1.0f / (1.0f - kill);
+  }
+  vec3 xi;
+  xi.x = rand01(rng); xi.y = rand01(rng); xi.z = rand01(rng);
+  Spec value = spec_set(0.0f);
+  vec3 wiW = mk3(0.0f, 0.0f, 0.0f);
+  const float pdf = bsdf_sample(S, P, xi, value, wiW);   // :212-218
+  if (pdf == 0.0f) {
+    A.st.ray_o[lid] = make_float4(ro.x, ro.y, ro.z, 0.0f);
+    A.st.ray_d[lid] = make_float4(rd.x, rd.y, rd.z, spec_flag);
+    return;
+  }
+  float weight = fabsf(dot3(wiW, ns));
+  weight /= pdf;
+  const Spec importance = spec_scale(load_importance(), rr_scale);
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    A.st.imp[q][lid] = make_float4(importance.w[4 * q] * (value.w[4 * q] * weight), importance.w[4 * q + 1] * (value.w[4 * q + 1] * weight),
+                                   importance.w[4 * q + 2] * (value.w[4 * q + 2] * weight), importance.w[4 * q + 3] * (value.w[4 * q + 3] * weight));
+  bounce = bounce < (float)F.pt_steps ? bounce + 1.0f : 0.0f;   // :230-237
+  if (F.lod_mode != 0u) A.st.cone[lid] = cone_w;
+  A.st.ray_o[lid] = make_float4(point.x, point.y, point.z, bounce);
+  A.st.ray_d[lid] = make_float4(wiW.x, wiW.y, wiW.z, spec_flag);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1053,208 +1272,8 @@ __global__ void __launch_bounds__(kBlock, GLZ_SHADE_WAVES) k_shade(const LaunchA
 #else
   const float4 ro = A.st.ray_o[lid], rd = A.st.ray_d[lid], hr = A.st.hit[lid];
 #endif
-  const bool fresh = F.direct_only || ro.w == 0.0f;
-  float bounce = F.direct_only ? 0.0f : ro.w;
-  const vec3 direction = mk3(rd.x, rd.y, rd.z);
-  // The path's importance (16 floats) is read where it is used -- the radiance of the light sample, the roulette, the final product --
-  // instead of once up front: held through texture fetches, light sampling and the two BSDF calls it set the kernel's register peak.
-  // The re-reads hit the lines the first read brought in.
-  auto load_importance = [&]() {
-    asm volatile("" ::: "memory");   // a fresh read every time: merged with an earlier one the values would stay in registers in between
-    Spec imp;
-    if (fresh) {
-      imp = spec_set(1.0f);
-    } else {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float4 v = A.st.imp[q][lid];
-        imp.w[4 * q] = v.x; imp.w[4 * q + 1] = v.y; imp.w[4 * q + 2] = v.z; imp.w[4 * q + 3] = v.w;
-      }
-    }
-    return imp;
-  };
-  const uint32_t leaf = __float_as_uint(hr.w);
-  if (leaf == 0xFFFFFFFFu) {
-    // miss: optional sky radiance, path reset (path_trace.rgen:170-179)
-    uint32_t flags = 0;
-    vec3 c = mk3(0.0f, 0.0f, 0.0f);
-    if ((bounce == 0.0f || rd.w == 1.0f) && S.sky.tex_id > 0) {
-      const vec3 w = normalize3(xform_dir(S.sky.world2obj, direction));   // sky_radiance, :75-82
-      const float phi = glz_atan2f(w.y, w.x), theta = glz_acosf(w.z);
-      const vec3 texel = texture_rgb(S, S.sky.tex_id, vec2{phi * kInv2Pi, theta * kInvPi});
-      c = spec_to_rgb(spec_mul(load_importance(), from_illuminant_color(texel)));
-      flags = kFlagUpdate;
-    }
-    accumulate_pixel(A, lid, c, true, flags != 0, A.frame.exposure);
-    if (!F.direct_only) A.st.ray_o[lid] = make_float4(ro.x, ro.y, ro.z, 0.0f);   // RESET_PATH
-    return;
-  }
-  // ---- closest-hit shader (raytrace_hit.rchit:30-71), inputs from the 128-byte per-leaf shading record ----
-  const float4* rec = S.shade_tris + 8u * (size_t)leaf;
-  const float4 va0 = rec[0], va1 = rec[1], vb0 = rec[2], vb1 = rec[3], vc0 = rec[4], vc1 = rec[5], dn = rec[6], du = rec[7];
-  uint32_t material_id = __float_as_uint(dn.w), xf_bits = __float_as_uint(du.w);
-  if (S.two_level) {   // the record is per OBJECT triangle: material and transform are the instance's
-    const RTInstance in = S.instances[A.st.hit_inst[lid]];
-    material_id = in.material_id;
-    xf_bits = in.transform_id | (S.xf_identity[in.transform_id] ? 0x80000000u : 0u);
-  }
-  const float b0 = 1.0f - hr.y - hr.z, b1 = hr.y, b2 = hr.z;
-  vec3 point = (mk3(va0.x, va0.y, va0.z) * b0 + mk3(vb0.x, vb0.y, vb0.z) * b1) + mk3(vc0.x, vc0.y, vc0.z) * b2;
-  const vec2 uv = vec2{(va1.z * b0 + vb1.z * b1) + vc1.z * b2, (va1.w * b0 + vb1.w * b1) + vc1.w * b2};
-  vec3 ng = mk3(dn.x, dn.y, dn.z), dpdu = mk3(du.x, du.y, du.z);   // dpdv is transformed by the reference but never read afterwards
-  vec3 ns = (mk3(va0.w, va1.x, va1.y) * b0 + mk3(vb0.w, vb1.x, vb1.y) * b1) + mk3(vc0.w, vc1.x, vc1.y) * b2;
-  const MatScalars mat = load_material(&S.materials[material_id]);
-  // ---- texture level of detail by ray cones (build-defined, off by default: the reference's stages sample level 0) ----
-  // The cone of a camera path starts cone_width0 wide and widens by cone_spread per unit of distance along the whole path;
-  // at a hit the footprint on the surface is width / |cos|, and a texture of W x H texels over a triangle with texture-space
-  // area A_uv and world area A_w is minified by sqrt(A_uv W H / A_w) texels per unit length:
-  // level = 0.5 log2(A_uv / A_w * width^2 / cos^2) + 0.5 log2(W H)      (Akenine-Moeller et al., ray cones)
-  float lod_base = kNoLod, cone_w = 0.0f;
-  if (F.lod_mode != 0u) {
-    cone_w = (fresh ? F.cone_width0 : A.st.cone[lid]) + F.cone_spread * hr.x;
-    vec3 e1 = mk3(vb0.x, vb0.y, vb0.z) - mk3(va0.x, va0.y, va0.z), e2 = mk3(vc0.x, vc0.y, vc0.z) - mk3(va0.x, va0.y, va0.z);
-    vec3 n = mk3(dn.x, dn.y, dn.z);
-    if (!(xf_bits >> 31)) {
-      const TransformPair* xf = &S.transforms[xf_bits & 0x7FFFFFFFu];
-      e1 = xform_dir(xf->o2w, e1);
-      e2 = xform_dir(xf->o2w, e2);
-      n = xform_tdir(xf->w2o, n);
-    }
-    const vec3 cr = cross3(e1, e2);
-    const float area2 = sqrtf(dot3(cr, cr));
-    const float uva2 = fabsf((vb1.z - va1.z) * (vc1.w - va1.w) - (vc1.z - va1.z) * (vb1.w - va1.w));
-    const float cosv = fabsf(dot3(n, direction)) / sqrtf(dot3(n, n));
-    const float x = ((uva2 / area2) * (cone_w * cone_w)) / (cosv * cosv);
-    if (x >= 1.17549435e-38f && x <= 3.4e38f) lod_base = 0.5f * glz_log2f(x);
-  }
-  if (mat.normal != 0) {
-    const vec4 tx = texture2d_lod(S, mat.normal, uv.x, uv.y, lod_base);
-    Frame old;
-    old.s = normalize3(dpdu);
-    old.n = ns;
-    old.t = normalize3(cross3(old.n, old.s));
-    ns = normalize3(to_world(mk3(tx.x * 2.0f - 1.0f, tx.y * 2.0f - 1.0f, tx.z * 2.0f - 1.0f), old));
-    ns = ns * gl_sign(dot3(ng, ns));
-  }
-  if (!(xf_bits >> 31)) {
-    // object -> world.  Skipped for an exact identity transform: m*x with m = I reproduces x bit for bit
-    // (x*1 + y*0 + z*0 + 0 for finite coordinates), so the result is unchanged and ~25 scalar loads are saved.
-    const float4* xq = reinterpret_cast<const float4*>(&S.transforms[xf_bits & 0x7FFFFFFFu]);
-    const float4 m0 = xq[0], m1 = xq[1], m2 = xq[2], m3 = xq[3], w0 = xq[4], w1 = xq[5], w2 = xq[6];
-    const float o2w[16] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w, m2.x, m2.y, m2.z, m2.w, m3.x, m3.y, m3.z, m3.w};
-    const float w2o[12] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
-    point = xform_point(o2w, point);
-    dpdu = xform_point(o2w, dpdu);   // transformed as a point, w = 1 (Q8)
-    ng = xform_tdir(w2o, ng);
-    ns = xform_tdir(w2o, ns);
-  }
-  (void)ng;
-  // ---- raygen continues (path_trace.rgen:180-237) ----
-  uint32_t rng = pcg(__float_as_uint((float)F.seed) ^ pcg(__float_as_uint((float)px.x) ^ pcg(__float_as_uint((float)px.y))));   // :143, Q11
-  SurfacePoint P;
-  P.woW = -direction;
-  P.uv = uv;
-  P.frame = make_frame(dpdu, ns);
-  P.mat = mat;
-  fetch_material_textures(S, P, lod_base);
-  float spec_flag;
-  float imp_lum = 0.0f;      // luminance of the importance, taken when the light-sampling block reads it: the roulette needs nothing else of it
-  bool have_lum = false;
-  if (mat.is_specular == 0) {
-    // direct_light(), :84-117
-    const uint32_t li = (uint32_t)gl_min(rand01(rng) * (float)F.lights_no, (float)(F.lights_no - 1u));
-    vec3 xi;
-    xi.x = rand01(rng); xi.y = rand01(rng); xi.z = rand01(rng);
-    LightSample ls;
-    ls.pdf = 0.0f;
-    sample_light(S, li, point, xi, F.scene_radius, ls);
-    vec3 c = mk3(0.0f, 0.0f, 0.0f);
-    uint32_t flags = kFlagUpdate;
-    vec3 sh_dir = mk3(0.0f, 0.0f, 0.0f);
-    float sh_tmax = 0.0f;
-    if (ls.pdf > 0.0f) {
-      const float xi_b = rand01(rng);
-      Spec value = spec_set(0.0f);
-      const float bpdf = bsdf_eval(S, P, ls.wiW, xi_b, value);
-      if (bpdf > 0.0f) {
-        // weight_light = (1 or 0) * |cos| / pdf; radiance = value*emission*weight*lights_no*importance
-        const float w_vis = 1.0f * (fabsf(dot3(ls.wiW, ns)) / ls.pdf);
-        const float w_occ = 0.0f * (fabsf(dot3(ls.wiW, ns)) / ls.pdf);
-        const float nl = (float)F.lights_no;
-        const Spec emission = light_emission(ls);
-        const Spec importance = load_importance();
-        imp_lum = spec_luminance(importance);
-        have_lum = true;
-        Spec rad;
-        float poison = 0.0f;
-        GLZ_BINS {
-          const float rl = value.w[i] * emission.w[i];
-          rad.w[i] = ((rl * w_vis) * nl) * importance.w[i];
-          poison += ((rl * w_occ) * nl) * importance.w[i];
-        }
-        c = spec_to_rgb(rad);
-        flags |= kFlagShadow | (poison == poison ? 0u : kFlagPoison);
-        sh_dir = ls.wiW;
-        sh_tmax = ls.distance - 1e-3f;
-      }
-    }
-    if (!(flags & kFlagShadow)) {
-      // no light sample: the reference still adds rgb(0 * lights_no * importance), which is NaN for a non-finite importance
-      const Spec importance = load_importance();
-      imp_lum = spec_luminance(importance);
-      have_lum = true;
-      float probe = 0.0f;
-      GLZ_BINS probe += 0.0f * importance.w[i];
-      if (probe != probe) c = spec_to_rgb(spec_scale(importance, 0.0f * (float)F.lights_no));
-    }
-    // shadow-ray queue (consumed by the next launch's k_trace); pixels without a shadow ray are accumulated right here
-    const bool push = (flags & kFlagShadow) != 0;
-    const uint32_t slot = queue_slot(A.st.queue_count + A.shade_set * kQueueSetWords, A.map.n_local_pixels, push);
-    if (push) {
-      A.st.sh_o[slot] = make_float4(point.x, point.y, point.z, sh_tmax);
-      A.st.sh_d[slot] = make_float4(sh_dir.x, sh_dir.y, sh_dir.z, __uint_as_float(lid));
-      A.st.contrib[slot] = make_float4(c.x, c.y, c.z, __uint_as_float(flags));
-    } else {
-      accumulate_pixel(A, lid, c, true, true, A.frame.exposure);
-    }
-    spec_flag = 0.0f;
-  } else {
-    accumulate_pixel(A, lid, mk3(0.0f, 0.0f, 0.0f), false, false, A.frame.exposure);
-    spec_flag = 1.0f;
-  }
-  if (F.direct_only) return;
-  // Russian roulette (:197-210)
-  float rr_scale = 1.0f;   // importance * 1.0f is importance, bit for bit: the paths that skip the roulette multiply by it too
-  if (bounce > (float)(F.pt_steps / 2u)) {
-    const float kill = gl_max(0.05f, 1.0f - (have_lum ? imp_lum : spec_luminance(load_importance())));
-    if (rand01(rng) < kill) {
-      A.st.ray_o[lid] = make_float4(ro.x, ro.y, ro.z, 0.0f);
-      A.st.ray_d[lid] = make_float4(rd.x, rd.y, rd.z, spec_flag);
-      return;
-    }
-    rr_scale = 1.0f / (1.0f - kill);
-  }
-  vec3 xi;
-  xi.x = rand01(rng); xi.y = rand01(rng); xi.z = rand01(rng);
-  Spec value = spec_set(0.0f);
-  vec3 wiW = mk3(0.0f, 0.0f, 0.0f);
-  const float pdf = bsdf_sample(S, P, xi, value, wiW);   // :212-218
-  if (pdf == 0.0f) {
-    A.st.ray_o[lid] = make_float4(ro.x, ro.y, ro.z, 0.0f);
-    A.st.ray_d[lid] = make_float4(rd.x, rd.y, rd.z, spec_flag);
-    return;
-  }
-  float weight = fabsf(dot3(wiW, ns));
-  weight /= pdf;
-  const Spec importance = spec_scale(load_importance(), rr_scale);
-#pragma unroll
-  for (int q = 0; q < 4; ++q)
-    A.st.imp[q][lid] = make_float4(importance.w[4 * q] * (value.w[4 * q] * weight), importance.w[4 * q + 1] * (value.w[4 * q + 1] * weight),
-                                   importance.w[4 * q + 2] * (value.w[4 * q + 2] * weight), importance.w[4 * q + 3] * (value.w[4 * q + 3] * weight));
-  bounce = bounce < (float)F.pt_steps ? bounce + 1.0f : 0.0f;   // :230-237
-  if (F.lod_mode != 0u) A.st.cone[lid] = cone_w;
-  A.st.ray_o[lid] = make_float4(point.x, point.y, point.z, bounce);
-  A.st.ray_d[lid] = make_float4(wiW.x, wiW.y, wiW.z, spec_flag);
+  SharedQueue queue{A};
+  shade_pixel(A, S, F, lid, px, ro, rd, hr, queue);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1338,7 +1357,7 @@ __global__ void __launch_bounds__(kBlock, GLZ_TRACE_WAVES) k_trace(const LaunchA
   if (blockIdx.x == 0 && threadIdx.x < kQueueShards) A.st.queue_count[A.shade_set * kQueueSetWords + threadIdx.x * kCounterStride] = 0;
   if (A.do_closest) {
     TraceTally tally;
-    ClosestSource src{A, tally};
+    ClosestSource src{A, A.frame, tally, 0u};
     ClosestSink sink{A};
     trace_wave<false, COUNT>(A.scene, src, sink, &s_stack[threadIdx.x], aux, (LdsNodePtr)s_top, A.st.overflow, A.st.overflow_depth, A.map.n_local_pixels, wave_index(),
                              wave_count(), tally);
@@ -1385,7 +1404,7 @@ __global__ void __launch_bounds__(kBlock, GLZ_TRACE_TL_WAVES) k_trace_tl(const L
   if (blockIdx.x == 0 && threadIdx.x < kQueueShards) A.st.queue_count[A.shade_set * kQueueSetWords + threadIdx.x * kCounterStride] = 0;
   if (A.do_closest) {
     TraceTally tally;
-    ClosestSource src{A, tally};
+    ClosestSource src{A, A.frame, tally, 0u};
     ClosestSinkTl sink{A};
     trace_wave_tl<false>(A.scene, src, sink, &s_stack[threadIdx.x], aux, A.st.overflow, A.st.overflow_depth, A.map.n_local_pixels, wave_index(), wave_count());
   }
@@ -1401,6 +1420,145 @@ __global__ void __launch_bounds__(kBlock, GLZ_TRACE_TL_WAVES) k_trace_tl(const L
     const uint32_t closest_groups = A.do_closest ? (A.map.n_local_pixels + 63u) / 64u : 0u;
     const uint32_t wave = (wave_index() + n_waves - closest_groups % n_waves) % n_waves;
     trace_wave_tl<true>(A.scene, src, sink, &s_stack[threadIdx.x], aux, A.st.overflow, A.st.overflow_depth, start[kQueueShards], wave, n_waves);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_path: the launch loop of a SMALL tile share (a 1080p frame over 8 GPUs: 259 k pixels per device) inside one persistent kernel.
+// With so few pixels the chip holds one 64-pixel group per resident wave and the two-kernel launch lasts as long as its slowest
+// wave -- the median wave of a 1/8 share is done after 60-67 us, the last one after 99-118 us (tools/gpu_wave_times.py), and every launch
+// pays that maximum again, twice (k_trace, k_shade).  Pixels are independent (path_trace.rgen:143-168: state, RNG and accumulator are
+// per pixel), so nothing forces a wave to wait for the others: here every wave carries ITS 64 pixels through
+//     closest hits of launch L -> shadow rays queued by launch L-1 (+ update_count / update_result) -> shade of launch L
+// for all launches of the batch, with no grid-wide boundary in between.  A step then costs the slowest wave's SUM over the launches
+// instead of the sum over launches of the slowest wave.  Per pixel the operations and their order are those of k_trace / k_shade
+// (same sources, same shade_pixel, shadow rays of a launch resolved before the next launch's shading), so the image is bit-identical
+// -- tests/test_gpu_render.py compares the two modes and the oracle.
+// A wave's closest-hit records stay in LDS, its shadow queue is its own 64 entries of the queue arrays (no atomics, no shards), and
+// the batch ends with the shadow rays of its last launch, so nothing is pending when the kernel ends.  The kernel runs at k_shade's
+// 128 registers, four waves per SIMD -- the objection to a fused kernel at full-frame size, where throughput counts; here every wave of
+// the share is resident anyway.  The sky's marginal table stays in global memory (with it in LDS only three blocks fit a CU).
+// ---------------------------------------------------------------------------------------------
+struct GroupHitSink {   // closest-hit record of ray i of the group -> the wave's LDS slots
+  float4* hit;
+  __device__ __forceinline__ void store(uint32_t i, const HitRecord& h) {
+    hit[i] = make_float4(h.leaf == 0xFFFFFFFFu ? INFINITY : h.t, h.u, h.v, __uint_as_float(h.leaf));
+  }
+};
+struct GroupQueue {     // shade_pixel's shadow-queue policy: entry k of the wave's own 64 (the lanes that push, in lane order)
+  uint32_t base;
+  bool pushed;
+  __device__ __forceinline__ uint32_t slot(bool push) {
+    const unsigned long long m = __ballot(push);
+    pushed = push;
+    return base + (uint32_t)__popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull));
+  }
+};
+struct GroupShadowSource {
+  const LaunchArgs& A;
+  uint32_t base;
+  uint32_t lid;            // per-lane: owning pixel and contribution of the ray in flight
+  float4 contrib;
+  __device__ __forceinline__ bool load(uint32_t i, vec3& o, vec3& d, float& tmin, float& tmax) {
+    const uint32_t q = base + i;
+    const float4 so = A.st.sh_o[q], sd = A.st.sh_d[q];
+    contrib = A.st.contrib[q];
+    lid = __float_as_uint(sd.w);
+    o = mk3(so.x, so.y, so.z);
+    d = mk3(sd.x, sd.y, sd.z);
+    tmin = 0.001f;
+    tmax = so.w;
+    return true;
+  }
+};
+struct GroupShadowSink {
+  const LaunchArgs& A;
+  GroupShadowSource& src;
+  float exposure;          // of the launch that queued the rays
+  __device__ __forceinline__ void store(uint32_t, const HitRecord& h) {
+    const bool occluded = h.leaf != 0xFFFFFFFFu;
+    const uint32_t flags = __float_as_uint(src.contrib.w);
+    vec3 c = mk3(src.contrib.x, src.contrib.y, src.contrib.z);
+    bool add = !occluded;
+    if (occluded && (flags & kFlagPoison)) {
+      const float nan = __uint_as_float(0x7FC00000u);
+      c = mk3(nan, nan, nan);
+      add = true;
+    }
+    accumulate_pixel(A, src.lid, c, add, true, exposure);
+  }
+};
+
+#ifndef GLZ_PATH_WAVES
+#define GLZ_PATH_WAVES 4
+#endif
+__global__ void __launch_bounds__(kBlock, GLZ_PATH_WAVES) k_path(const LaunchArgs A, const PathBatch B) {
+  __shared__ int s_stack[kLdsStack * kBlock];
+  __shared__ alignas(16) int s_aux[(kBlock / 64) * kAuxPerWave];
+  __shared__ uint4 s_top[kLdsTop ? kBvhTopNodes * 4 : 1];
+  __shared__ float s_lut[256];
+  __shared__ float4 s_hit[kBlock];
+  extern __shared__ uint4 s_dyn[];   // [RTMaterial x n_materials | RTLight x n_rt_lights | TexDesc x n_textures] when B.tables_in_lds
+  stage_top(A.scene, s_top);
+  s_lut[threadIdx.x] = A.scene.srgb_lut[threadIdx.x];
+  const uint32_t qm = A.scene.n_materials * (uint32_t)(sizeof(RTMaterial) / 16), ql = A.scene.n_rt_lights * (uint32_t)(sizeof(RTLight) / 16),
+                 qt = A.scene.n_textures * (uint32_t)(sizeof(TexDesc) / 16);
+  if (B.tables_in_lds) {
+    const uint4* gm = reinterpret_cast<const uint4*>(A.scene.materials);
+    const uint4* gl = reinterpret_cast<const uint4*>(A.scene.lights);
+    const uint4* gt = reinterpret_cast<const uint4*>(A.scene.tex_desc);
+    for (uint32_t i = threadIdx.x; i < qm + ql + qt; i += kBlock) s_dyn[i] = i < qm ? gm[i] : (i < qm + ql ? gl[i - qm] : gt[i - qm - ql]);
+  }
+  __syncthreads();   // the only block-wide barrier: from here on the four waves of the block never wait for each other
+  DeviceScene S = A.scene;
+  S.srgb_lut = s_lut;
+  if (B.tables_in_lds) {
+    S.materials = reinterpret_cast<const RTMaterial*>(s_dyn);
+    S.lights = reinterpret_cast<const RTLight*>(s_dyn + qm);
+    S.tex_desc = reinterpret_cast<const TexDesc*>(s_dyn + qm + ql);
+  }
+  int* aux = &s_aux[(threadIdx.x >> 6) * kAuxPerWave];
+  float4* hit = &s_hit[threadIdx.x & ~63u];
+  const uint32_t lane = threadIdx.x & 63u;
+  FrameData F = A.frame;
+  TraceTally tally;
+  const uint32_t n_groups = (A.map.n_local_pixels + 63u) / 64u;
+  for (uint32_t g = wave_index(); g < n_groups; g += wave_count()) {
+    const uint32_t lid0 = g * 64u;
+    uint32_t n_shadow = 0;      // wave-uniform: shadow rays the group's last shading queued
+    float queued_exposure = 0.0f;
+    for (uint32_t L = 0;; ++L) {
+      if (n_shadow != 0u && L == B.n) {
+        // the batch ends with the shadow rays of its last launch (nothing of the next launch depends on them)
+      } else if (L >= B.n) {
+        break;
+      }
+      if (L < B.n) {
+        F.seed = B.seed[L];
+        F.pixel_offset[0] = B.offset[L][0];
+        F.pixel_offset[1] = B.offset[L][1];
+        F.exposure = B.exposure[L];
+        ClosestSource src{A, F, tally, lid0};
+        GroupHitSink sink{hit};
+        trace_wave<false, false>(A.scene, src, sink, &s_stack[threadIdx.x], aux, (LdsNodePtr)s_top, A.st.overflow, A.st.overflow_depth, 64u, 0u, 1u, tally);
+      }
+      if (n_shadow != 0u) {
+        GroupShadowSource src{A, lid0, 0u, make_float4(0.0f, 0.0f, 0.0f, 0.0f)};
+        GroupShadowSink sink{A, src, queued_exposure};
+        trace_wave<true, false>(A.scene, src, sink, &s_stack[threadIdx.x], aux, (LdsNodePtr)s_top, A.st.overflow, A.st.overflow_depth, n_shadow, 0u, 1u, tally);
+        n_shadow = 0u;
+      }
+      if (L >= B.n) break;
+      const uint32_t lid = lid0 + lane;
+      const PixelId px = pixel_of(A.map, lid);
+      GroupQueue queue{lid0, false};
+      if (px.active) {
+        const float4 ro = A.st.ray_o[lid], rd = A.st.ray_d[lid];
+        shade_pixel(A, S, F, lid, px, ro, rd, hit[lane], queue);
+      }
+      n_shadow = (uint32_t)__popcll(__ballot(queue.pushed));
+      queued_exposure = F.exposure;
+    }
   }
 }
 
@@ -1545,6 +1703,32 @@ hipError_t launch_trace(hipStream_t st, const LaunchArgs& a, uint32_t blocks) {
   if (a.scene.two_level) hipLaunchKernelGGL(k_trace_tl, dim3(blocks), dim3(kBlock), 0, st, a);   // instanced scenes: no work counters
   else if (a.counters) hipLaunchKernelGGL(k_trace<true>, dim3(blocks), dim3(kBlock), 0, st, a);
   else hipLaunchKernelGGL(k_trace<false>, dim3(blocks), dim3(kBlock), 0, st, a);
+  return hipGetLastError();
+}
+// dynamic LDS of k_path: the scene's material / light / texture-descriptor tables when they fit kShadeTableBytes, else nothing
+static uint32_t path_table_bytes(const DeviceScene& sc) {
+  const uint32_t bytes = sc.n_materials * (uint32_t)sizeof(RTMaterial) + sc.n_rt_lights * (uint32_t)sizeof(RTLight) + sc.n_textures * (uint32_t)sizeof(TexDesc);
+  return bytes <= kShadeTableBytes ? bytes : 0u;
+}
+uint32_t path_grid_blocks(uint32_t n_local_pixels, const DeviceScene& sc) {
+  int dev = 0, cus = 256, per_cu = 4;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+  }
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_path, kBlock, path_table_bytes(sc)) != hipSuccess || per_cu < 1) per_cu = 2;
+  per_cu = std::min(per_cu, 8);
+  const uint32_t groups = (n_local_pixels + 63u) / 64u, blocks = (groups + kBlock / 64 - 1) / (kBlock / 64);
+  return std::max<uint32_t>(1u, std::min<uint32_t>(blocks, (uint32_t)cus * (uint32_t)per_cu));
+}
+hipError_t launch_path(hipStream_t st, const LaunchArgs& a, const PathBatch& batch, uint32_t blocks) {
+  static_assert(sizeof(LaunchArgs) + sizeof(PathBatch) <= 4096, "kernel arguments of k_path");
+  if (a.map.n_local_pixels == 0 || batch.n == 0) return hipSuccess;
+  if (blocks == 0 || batch.n > kPathMaxLaunches || a.scene.two_level || a.counters) return hipErrorInvalidValue;
+  PathBatch b = batch;
+  const uint32_t dyn = path_table_bytes(a.scene);
+  b.tables_in_lds = dyn != 0u ? 1u : 0u;
+  hipLaunchKernelGGL(k_path, dim3(blocks), dim3(kBlock), dyn, st, a, b);
   return hipGetLastError();
 }
 hipError_t launch_shade(hipStream_t st, const LaunchArgs& a) {

@@ -229,10 +229,23 @@ uint32_t Renderer::chains_for(uint32_t w, uint32_t h, uint32_t rank, uint32_t wo
   if (want > local_tiles) want = local_tiles;
   return want ? want : 1u;
 }
-uint32_t Renderer::pick_chains() const { return chains_for(w_, h_, rank_, world_, chains_wanted_); }
+uint32_t Renderer::pick_chains() const { return path_mode_ ? 1u : chains_for(w_, h_, rank_, world_, chains_wanted_); }
+
+// Below this many owned pixels a device runs its launches as k_path batches (0 = automatic launch mode).  Measured on the atrium
+// (tools/gpu_partition_timing.py, one MI355X rendering rank 0's share): see DESIGN.md section 6.
+#ifndef GLZ_PATH_PIXELS
+#define GLZ_PATH_PIXELS 400000u
+#endif
 
 bool Renderer::allocate(Error& err) {
   release_chains();
+  {
+    const uint32_t tiles_x = (w_ + kTile - 1) / kTile, tiles_y = (h_ + kTile - 1) / kTile, tiles = tiles_x * tiles_y;
+    const uint64_t pixels = (uint64_t)(tiles > rank_ ? (tiles - rank_ + world_ - 1) / world_ : 0) * kTile * kTile;
+    const char* px = getenv("GLAZE_PATH_PIXELS");
+    const uint64_t limit = px ? (uint64_t)atoll(px) : (uint64_t)GLZ_PATH_PIXELS;
+    path_mode_ = scene_->dev.two_level == 0 && (launch_mode_ == 2 || (launch_mode_ == 0 && pixels > 0 && pixels < limit));
+  }
   const uint32_t S = pick_chains();
   const uint32_t od = scene_->stack_overflow_depth;
   for (uint32_t s = 0; s < S; ++s) {
@@ -264,8 +277,9 @@ bool Renderer::allocate(Error& err) {
     if (!hip_ok(c->hit_inst.alloc(n), "alloc path state", err)) return false;
     c->grid = trace_grid_blocks(m.n_local_pixels, false, scene_->dev.two_level != 0);
     c->grid_counting = trace_grid_blocks(m.n_local_pixels, true, scene_->dev.two_level != 0);
-    // traversal spill: one slot of `od` entries per lane of the larger of the two persistent grids
-    if (!hip_ok(c->overflow.alloc((size_t)std::max(c->grid, c->grid_counting) * kTraceBlock * od), "alloc traversal spill", err)) return false;
+    c->grid_path = path_mode_ ? path_grid_blocks(m.n_local_pixels, scene_->dev) : 0u;
+    // traversal spill: one slot of `od` entries per lane of the largest of the persistent grids
+    if (!hip_ok(c->overflow.alloc((size_t)std::max(std::max(c->grid, c->grid_counting), c->grid_path) * kTraceBlock * od), "alloc traversal spill", err)) return false;
     if (!hip_ok(c->queue_count.alloc(2 * kQueueSetWords), "alloc queue counters", err)) return false;
     chains_.push_back(std::move(c));
   }
@@ -295,7 +309,7 @@ bool Renderer::reset_buffers(Error& err) {
       if (bytes && !hip_ok(hipMemsetAsync(b->ptr, 0, bytes, c.stream), "clear path state", err)) return false;
     if (!hip_ok(hipMemsetAsync(c.queue_count.ptr, 0, sizeof(uint32_t) * 2 * kQueueSetWords, c.stream), "clear queue counters", err)) return false;
     c.shadow_pending = false;   // queued shadow rays of the abandoned frame are dropped with it
-    c.trace_ms = c.shade_ms = c.flush_ms = 0;
+    c.trace_ms = c.shade_ms = c.flush_ms = c.path_ms = 0;
     for (auto& s : c.pending_events) c.free_events.push_back(s);
     c.pending_events.clear();
   }
@@ -336,8 +350,10 @@ void Renderer::resolve_events(Chain& c) {
   for (auto& s : c.pending_events) {
     float a = 0, b = 0;
     (void)hipEventElapsedTime(&a, s.e[0], s.e[1]);
-    if (s.flush) {
+    if (s.kind == 1) {
       c.flush_ms += a;
+    } else if (s.kind == 2) {
+      c.path_ms += a;
     } else {
       (void)hipEventElapsedTime(&b, s.e[1], s.e[2]);
       const double weight = (double)kEventStride;
@@ -353,7 +369,7 @@ bool Renderer::acquire_events(Chain& c, EventSet& ev, Error& err) {
   if (c.free_events.empty()) {
     if (c.pending_events.size() >= 64) {
       // resolve and recycle the pending sets (without the flush get_stats would do)
-      if (!hip_ok(hipEventSynchronize(c.pending_events.back().e[c.pending_events.back().flush ? 1 : 2]), "hipEventSynchronize", err)) return false;
+      if (!hip_ok(hipEventSynchronize(c.pending_events.back().e[c.pending_events.back().kind ? 1 : 2]), "hipEventSynchronize", err)) return false;
       resolve_events(c);
     }
     if (c.free_events.empty()) {
@@ -378,7 +394,7 @@ bool Renderer::flush_shadows(Chain& c, Error& err) {
   EventSet ev{};
   if (profile_kernels_) {
     if (!acquire_events(c, ev, err)) return false;
-    ev.flush = true;
+    ev.kind = 1;
     (void)hipEventRecord(ev.e[0], c.stream);
   }
   if (!hip_ok(launch_trace(c.stream, a, counting_ ? c.grid_counting : c.grid), "k_trace (shadow pass)", err)) return false;
@@ -390,16 +406,11 @@ bool Renderer::flush_shadows(Chain& c, Error& err) {
   return true;
 }
 
-// draw_frame (raytracer.rs:369-613): one path segment per pixel
-bool Renderer::one_launch(Error& err) {
-  if (request_new_frame_ && !reset_buffers(err)) return false;
-  FrameData fd;
+// what all launches of a frame share in RTFrameData (raytracer.rs:369-613); seed, pixel offset and exposure are per launch
+bool Renderer::launch_constants_common(FrameData& fd, Error& err) {
   memset(&fd, 0, sizeof(fd));
-  fd.seed = rng_.next();                  // rng.gen::<u32>(), raytracer.rs:487
   fd.lights_no = scene_->lights_no;
-  sched_.next(fd.pixel_offset);           // WorkScheduler::next(), :489
   fd.scene_radius = scene_->data.meta.scene_radius;
-  fd.exposure = exposure_;
   fd.scene_size[0] = (float)w_;
   fd.scene_size[1] = (float)h_;
   for (int k = 0; k < 3; ++k) fd.scene_centre[k] = scene_->data.meta.scene_centre[k];
@@ -416,6 +427,17 @@ bool Renderer::one_launch(Error& err) {
     fd.cone_width0 = persp ? 0.0f : pixel;
     if (!scene_->mips_ready() && !scene_->ensure_mips(err)) return false;
   }
+  return true;
+}
+
+// draw_frame (raytracer.rs:369-613): one path segment per pixel
+bool Renderer::one_launch(Error& err) {
+  if (request_new_frame_ && !reset_buffers(err)) return false;
+  FrameData fd;
+  if (!launch_constants_common(fd, err)) return false;
+  fd.seed = rng_.next();                  // rng.gen::<u32>(), raytracer.rs:487
+  sched_.next(fd.pixel_offset);           // WorkScheduler::next(), :489
+  fd.exposure = exposure_;
   ++launches_;
   if (fd.lights_no == 0) return true;   // the raygen shader returns before touching anything (path_trace.rgen:137-141)
   for (auto& cp : chains_) {
@@ -430,7 +452,7 @@ bool Renderer::one_launch(Error& err) {
     EventSet ev{};
     if (timed) {
       if (!acquire_events(c, ev, err)) return false;
-      ev.flush = false;
+      ev.kind = 0;
       (void)hipEventRecord(ev.e[0], st);
     }
     if (!hip_ok(launch_trace(st, a, counting_ ? c.grid_counting : c.grid), "k_trace", err)) return false;
@@ -447,19 +469,83 @@ bool Renderer::one_launch(Error& err) {
   return true;
 }
 
+// n <= kPathMaxLaunches launches of draw_frame in ONE kernel (k_path): the same per-launch constants, in the same order
+bool Renderer::path_batch(uint32_t n, Error& err) {
+  if (request_new_frame_ && !reset_buffers(err)) return false;
+  FrameData fd;
+  if (!launch_constants_common(fd, err)) return false;
+  PathBatch b;
+  memset(&b, 0, sizeof(b));
+  b.n = n;
+  for (uint32_t i = 0; i < n; ++i) {
+    b.seed[i] = rng_.next();
+    sched_.next(b.offset[i]);
+    b.exposure[i] = exposure_;
+  }
+  launches_ += n;
+  if (fd.lights_no == 0) return true;   // the raygen shader returns before touching anything (path_trace.rgen:137-141)
+  Chain& c = *chains_[0];
+  if (!flush_shadows(c, err)) return false;   // left by launches that ran as two kernels (work counters had been on)
+  LaunchArgs a;
+  fill_args(c, a);
+  a.frame = fd;
+  a.counters = nullptr;
+  EventSet ev{};
+  if (profile_kernels_) {
+    if (!acquire_events(c, ev, err)) return false;
+    ev.kind = 2;
+    (void)hipEventRecord(ev.e[0], c.stream);
+  }
+  if (!hip_ok(launch_path(c.stream, a, b, c.grid_path), "k_path", err)) return false;
+  if (profile_kernels_) {
+    (void)hipEventRecord(ev.e[1], c.stream);
+    c.pending_events.push_back(ev);
+  }
+  return true;   // nothing is pending: the kernel ends with the shadow rays of its last launch
+}
+
+bool Renderer::run_launches(uint32_t n, Error& err) {
+  while (n != 0) {
+    if (use_path()) {
+      const uint32_t m = std::min(n, kPathMaxLaunches);
+      if (!path_batch(m, err)) return false;
+      n -= m;
+    } else {
+      if (!one_launch(err)) return false;
+      --n;
+    }
+  }
+  return true;
+}
+
+bool Renderer::set_launch_mode(int mode, Error& err) {
+  if (mode < 0 || mode > 2) {
+    err.code = GLZ_E_ARG;
+    err.msg = "launch mode must be 0 (automatic), 1 (two kernels per launch) or 2 (per-wave launch loop)";
+    return false;
+  }
+  if (!wait_idle(err)) return false;
+  launch_mode_ = mode;
+  if (!allocate(err)) return false;
+  const bool ok = forward([=](Peer& p, Error& e) { return p.r->set_launch_mode(mode, e); }, err);
+  (void)hipSetDevice(inst_->device);
+  return ok;
+}
+
 bool Renderer::get_stats(glz_render_stats* out, Error& err) {
   if (!hip_ok(hipSetDevice(inst_->device), "hipSetDevice", err)) return false;
-  double trace_ms = 0, shade_ms = 0, flush_ms = 0;
+  double trace_ms = 0, shade_ms = 0, flush_ms = 0, path_ms = 0;
   for (auto& cp : chains_) {
     Chain& c = *cp;
     if (!flush_shadows(c, err)) return false;   // the counters and timings of the last launch's shadow rays belong to it
     if (!c.pending_events.empty()) {
-      if (!hip_ok(hipEventSynchronize(c.pending_events.back().e[c.pending_events.back().flush ? 1 : 2]), "hipEventSynchronize", err)) return false;
+      if (!hip_ok(hipEventSynchronize(c.pending_events.back().e[c.pending_events.back().kind ? 1 : 2]), "hipEventSynchronize", err)) return false;
       resolve_events(c);
     }
     trace_ms += c.trace_ms;
     shade_ms += c.shade_ms;
     flush_ms += c.flush_ms;
+    path_ms += c.path_ms;
   }
   // concurrent chains overlap in time: the mean over chains is the time the rank spent in S concurrent instances of a kernel
   const double inv = chains_.empty() ? 0.0 : 1.0 / (double)chains_.size();
@@ -476,7 +562,8 @@ bool Renderer::get_stats(glz_render_stats* out, Error& err) {
   out->trace_closest_ms = trace_ms * inv;
   out->shade_ms = shade_ms * inv;
   out->trace_shadow_ms = flush_ms * inv;
-  out->render_ms = out->trace_closest_ms + out->shade_ms + out->trace_shadow_ms;
+  out->other_ms = path_ms * inv;   // k_path: the per-wave launch loop of a small tile share (all three phases in one kernel)
+  out->render_ms = out->trace_closest_ms + out->shade_ms + out->trace_shadow_ms + out->other_ms;
   for (auto& c : chains_)
     if (!hip_ok(hipStreamSynchronize(c->stream), "read counters", err)) return false;
   TraceCounters c{};
@@ -511,13 +598,14 @@ bool Renderer::get_stats(glz_render_stats* out, Error& err) {
       out->trace_closest_ms = std::max(out->trace_closest_ms, q.trace_closest_ms);
       out->shade_ms = std::max(out->shade_ms, q.shade_ms);
       out->trace_shadow_ms = std::max(out->trace_shadow_ms, q.trace_shadow_ms);
+      out->other_ms = std::max(out->other_ms, q.other_ms);
       out->closest_rays += q.closest_rays; out->shadow_rays += q.shadow_rays;
       out->closest_nodes += q.closest_nodes; out->closest_tris += q.closest_tris;
       out->shadow_nodes += q.shadow_nodes; out->shadow_tris += q.shadow_tris;
       out->hits += q.hits; out->fresh_paths += q.fresh_paths;
       for (int i = 0; i < 12; ++i) out->phase[i] += q.phase[i];
     }
-    out->render_ms = out->trace_closest_ms + out->shade_ms + out->trace_shadow_ms;
+    out->render_ms = out->trace_closest_ms + out->shade_ms + out->trace_shadow_ms + out->other_ms;
     (void)hipSetDevice(inst_->device);
   }
   return true;
@@ -650,9 +738,7 @@ bool Renderer::restart() {
 
 bool Renderer::step_local(uint32_t n, Error& err) {
   if (!hip_ok(hipSetDevice(inst_->device), "hipSetDevice", err)) return false;
-  for (uint32_t i = 0; i < n; ++i)
-    if (!one_launch(err)) return false;
-  return true;
+  return run_launches(n, err);
 }
 
 // Every device enqueues the same n launches (same seed stream, same jitter sequence) for its own tiles; the peers' host
@@ -676,10 +762,11 @@ bool Renderer::draw(size_t spp, void (*cb)(void*), void* user, uint8_t* rgba8_ou
   restart();
   const size_t steps = steps_per_sample();
   const size_t substep = spp * steps;
+  (void)substep;
   if (peers_.empty()) {
-    for (size_t i = 0; i < substep; ++i) {
-      if (!one_launch(err)) return false;
-      if (cb && i % steps == 0) cb(user);   // raytracer.rs:651-653
+    for (size_t sample = 0; sample < spp; ++sample) {
+      if (!run_launches((uint32_t)steps, err)) return false;
+      if (cb) cb(user);   // once per sample, on the caller's thread (raytracer.rs:651-653)
     }
   } else {
     for (size_t sample = 0; sample < spp; ++sample) {   // one batch of launches per sample on every device, then the callback on this thread
@@ -901,6 +988,7 @@ bool Renderer::configure_peer(Renderer& p, Error& err) const {
   p.camera_ = camera_;
   p.cam_ = cam_;
   p.chains_wanted_ = chains_wanted_;
+  p.launch_mode_ = launch_mode_;
   p.counting_ = counting_;
   p.profile_kernels_ = profile_kernels_;
   p.request_new_frame_ = true;

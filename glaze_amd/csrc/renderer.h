@@ -43,6 +43,11 @@ class Renderer {
   uint32_t device_count() const { return 1u + (uint32_t)peers_.size(); }
   const Scene* device_scene(int i) const;    // the scene (replica) device i of set_devices renders; null when out of range
   bool set_chains(uint32_t n, Error& err);   // 0 = automatic
+  // How a launch reaches the device: 1 = two kernels per launch (k_trace, k_shade: throughput, the full frame), 2 = the per-wave
+  // launch loop k_path (one kernel per batch of launches: latency, a small tile share per GPU), 0 = by the pixels this device
+  // owns.  Images do not depend on it.
+  bool set_launch_mode(int mode, Error& err);
+  bool path_mode() const { return path_mode_; }
   uint32_t chains() const { return (uint32_t)chains_.size(); }
   static uint32_t chains_for(uint32_t w, uint32_t h, uint32_t rank, uint32_t world, uint32_t wanted);
   bool export_device(int which, void* dev_rgba32f, Error& err);
@@ -65,6 +70,10 @@ class Renderer {
   bool allocate(Error& err);
   bool reset_buffers(Error& err);
   bool one_launch(Error& err);
+  bool launch_constants_common(FrameData& fd, Error& err);
+  bool path_batch(uint32_t n, Error& err);
+  bool run_launches(uint32_t n, Error& err);
+  bool use_path() const { return path_mode_ && !counting_ && chains_.size() == 1 && chains_[0]->grid_path != 0; }
   bool gather(bool result, float4* dst, Error& err, bool zero_first = true);
 
   Instance* inst_ = nullptr;
@@ -82,6 +91,8 @@ class Renderer {
   bool request_new_frame_ = true;
   uint32_t rank_ = 0, world_ = 1;   // tile partition of this process (glz_renderer_set_partition)
   uint32_t chains_wanted_ = 0;      // 0 = automatic (pick_chains)
+  int launch_mode_ = getenv("GLAZE_LAUNCH_MODE") ? atoi(getenv("GLAZE_LAUNCH_MODE")) : 0;   // set_launch_mode
+  bool path_mode_ = false;          // decided in allocate(): this device's launches run as k_path batches
 
   // One chain = one independent sequence of launches over a subset of this rank's tiles, on its own HIP stream.
   // Pixels never interact, so the tiles of a rank can advance as several concurrent chains: chain s of S renders the
@@ -90,7 +101,7 @@ class Renderer {
   // scaling of the 1080p frame over 8 GPUs).  Results are bit-identical for every S.
   struct EventSet {
     hipEvent_t e[4];
-    bool flush;   // e[0]..e[1] around a stand-alone shadow pass instead of e[0]..e[2] around k_trace, k_shade
+    int kind;   // 0: e[0]..e[2] around k_trace, k_shade; 1: e[0]..e[1] around a stand-alone shadow pass; 2: e[0]..e[1] around k_path
   };
   struct Chain {
     TileMap map{};
@@ -101,6 +112,7 @@ class Renderer {
     DeviceBuffer<uint32_t> hit_inst;
     DeviceBuffer<uint32_t> overflow, queue_count;
     uint32_t grid = 0, grid_counting = 0;   // blocks of k_trace's persistent grid (plain / instrumented kernel)
+    uint32_t grid_path = 0;                 // blocks of k_path's grid (0: this chain never runs it)
     // shadow rays queued by the last launch's k_shade and not traced yet (they ride in the next launch's k_trace, or in
     // a stand-alone pass as soon as anything looks at the images: flush_shadows)
     bool shadow_pending = false;
@@ -108,7 +120,7 @@ class Renderer {
     float pending_exposure = 1.0f;
     std::vector<EventSet> pending_events;   // per-launch kernel boundaries, resolved lazily in get_stats
     std::vector<EventSet> free_events;
-    double trace_ms = 0, shade_ms = 0, flush_ms = 0;
+    double trace_ms = 0, shade_ms = 0, flush_ms = 0, path_ms = 0;
   };
   std::vector<std::unique_ptr<Chain>> chains_;
   uint32_t pick_chains() const;

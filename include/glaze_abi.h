@@ -374,6 +374,17 @@ int glz_renderer_scatter_packed(glz_renderer*, uint32_t rank, uint32_t world, co
  * one chain while the rank owns a million pixels, two down to 400 k, three below).  Pixels never interact, so the image does not depend on n; with a small
  * tile share per GPU the chains fill the machine while the longest rays of a launch finish. */
 int glz_renderer_set_chains(glz_renderer*, uint32_t n);
+/* How a launch (one path segment per pixel, draw_frame) reaches the device.  GLZ_LAUNCH_TWO_KERNELS: k_trace + k_shade per launch over
+ * all pixels -- throughput, the full frame.  GLZ_LAUNCH_PATH: every wave carries its 64 pixels through the launches of a batch
+ * (closest hits -> shadow rays of the launch before -> shading) inside one persistent kernel, no grid-wide boundary between launches
+ * -- latency, a small tile share per GPU (a 1080p frame over 8 GPUs); flattened scenes, and only while the work counters are off.
+ * GLZ_LAUNCH_AUTO (default): by the pixels this device owns.  The image does not depend on the mode.  glz_renderer_launch_mode
+ * returns the mode in force (never AUTO). */
+#define GLZ_LAUNCH_AUTO 0
+#define GLZ_LAUNCH_TWO_KERNELS 1
+#define GLZ_LAUNCH_PATH 2
+int glz_renderer_set_launch_mode(glz_renderer*, int mode);
+int glz_renderer_launch_mode(glz_renderer*);
 /* Multi-GPU inside ONE process (what a Rust glaze-cli bound to this library uses for `--devices`; the reference drives exactly one
  * VkPhysicalDevice, lib/src/vulkan/device.rs:252-321): hip_devices[0] must be the renderer's own device (glz_instance_device);
  * every further device gets a stream, a replica of the scene (upload + BVH build on that device), a renderer for the 64x64 tiles
@@ -398,7 +409,7 @@ typedef struct glz_render_stats {
   uint64_t launches;        /* launches since the last restart */
   uint64_t samples;         /* owned pixels x launches */
   double   render_ms;       /* device time of those launches (hipEvent, instance stream) */
-  double   trace_closest_ms, shade_ms, trace_shadow_ms, other_ms; /* per-kernel-class device time */
+  double   trace_closest_ms, shade_ms, trace_shadow_ms, other_ms; /* per-kernel-class device time: k_trace, k_shade, stand-alone shadow passes, k_path (GLZ_LAUNCH_PATH) */
   uint64_t closest_rays, shadow_rays;
   /* traversal work counters (only filled when counting is enabled, slows rendering down) */
   uint64_t closest_nodes, closest_tris, shadow_nodes, shadow_tris, hits;

@@ -24,6 +24,10 @@ from helpers import desc_from_oracle_parse, rel_err
 
 pytestmark = pytest.mark.gpu
 
+
+def bits(a):
+    return np.nan_to_num(a, nan=-1.0).view(np.uint32)
+
 REL_TOL = 1e-4
 
 
@@ -711,3 +715,87 @@ def test_full_size_atrium_4k_depth12_tiles_vs_oracle(instance):
     m = _tile_mask(w, h, mine)
     if m.any():
         assert ((part[m].view(np.uint32) == c[m].view(np.uint32)) | (np.isnan(part[m]) & np.isnan(c[m]))).all()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# launch modes: two kernels per launch (throughput) and the per-wave launch loop k_path (a small tile share per GPU)
+# ---------------------------------------------------------------------------------------------------------------------
+def _mode_pair(instance, desc, w, h, depth, seed=7, **kw):
+    out = []
+    for mode in ("two_kernels", "path"):
+        r = glaze_amd.RayTraceRenderer.new(instance, glaze_amd.RayTraceScene.from_desc(instance, desc), w, h)
+        r.set_launch_mode(mode)
+        assert r.launch_mode() == mode
+        r.set_depth(depth)
+        r.set_seed(seed)
+        out.append(r)
+    return out
+
+
+@pytest.mark.parametrize("mtype", [abi.MAT_LAMBERT, abi.MAT_GLASS, abi.MAT_METAL, abi.MAT_UBER])
+def test_path_mode_equals_two_kernels_and_the_oracle(instance, mtype):
+    """k_path runs every wave's 64 pixels through the launches of a batch with no grid-wide boundary; per pixel the operations and
+    their order are those of k_trace / k_shade: cumulative image, result image and RGBA8 bit for bit, for every BSDF family."""
+    desc = cube_scene(material_type=mtype)
+    w, h, depth = 136, 72, 5                                                                   # ragged tiles
+    two, path = _mode_pair(instance, desc, w, h, depth)
+    o = OracleRenderer(OracleScene(desc), w, h)
+    o.set_depth(depth)
+    o.set_seed(7)
+    for k in (1, 4, 17, 35):                                                                   # batches of 1, 4, 16 + 1, 16 + 16 + 3 launches
+        two.step(k); path.step(k); o.step(k)
+        a, b = two.read_hdr(), path.read_hdr()
+        assert np.array_equal(bits(a), bits(b)), k
+        assert np.array_equal(bits(two.read_result()), bits(path.read_result())), k
+        assert np.array_equal(bits(b), bits(o.read_hdr())), k
+    assert np.array_equal(two.read_rgba8(), path.read_rgba8())
+    assert path.stats().launches == two.stats().launches == 57
+    assert path.stats().other_ms > 0 and path.stats().trace_closest_ms == 0                    # it really was k_path
+    assert two.stats().other_ms == 0 and two.stats().trace_closest_ms > 0
+
+
+def test_path_mode_mattest_partition_exposure_and_counters(instance):
+    """mattest (sky light, glass, metal) on a tile partition; exposure changed between batches; the work counters switched on in
+    the middle (launches then run as two kernels) and off again; draw() with its per-sample callback."""
+    desc = desc_from_oracle_parse(MATTEST)
+    w, h, depth = 200, 136, 6
+    two, path = _mode_pair(instance, desc, w, h, depth, seed=3)
+    for r in (two, path):
+        r.set_partition(1, 3)
+    assert path.launch_mode() == "path"
+    two.step(7); path.step(7)
+    for r in (two, path):
+        r.set_exposure(0.4)
+    two.step(9); path.step(9)
+    path.enable_counters(True, True)
+    two.step(5); path.step(5)
+    path.wait_idle()
+    assert path.stats().closest_rays > 0                                                       # counted: these five ran as k_trace / k_shade
+    path.enable_counters(False, True)
+    two.step(20); path.step(20)
+    assert np.array_equal(bits(two.read_hdr()), bits(path.read_hdr()))
+    assert np.array_equal(bits(two.read_result()), bits(path.read_result()))
+    ticks = []
+    img = path.draw(3, callback=lambda: ticks.append(1))
+    assert len(ticks) == 3 and np.array_equal(img, two.draw(3))
+    # DIRECT integrator: one launch per sample
+    for r in (two, path):
+        r.set_integrator(glaze_amd.Integrator.DIRECT)
+        r.step(6)
+    assert np.array_equal(bits(two.read_hdr()), bits(path.read_hdr()))
+
+
+def test_auto_launch_mode_goes_by_the_pixels_a_device_owns(instance):
+    desc = cube_scene()
+    r = glaze_amd.RayTraceRenderer.new(instance, glaze_amd.RayTraceScene.from_desc(instance, desc), 1920, 1080)
+    assert r.launch_mode() == "two_kernels"
+    r.set_partition(0, 8)
+    assert r.launch_mode() == "path"
+    r.set_partition(0, 2)
+    assert r.launch_mode() == "two_kernels"
+    r.set_launch_mode("path")
+    assert r.launch_mode() == "path"
+    r.set_launch_mode("auto")
+    r.set_partition(0, 1)
+    r.change_resolution(320, 200)
+    assert r.launch_mode() == "path"

@@ -116,7 +116,7 @@ def test_bvh_structure(builder, mattest_by_builder):
     v0 = tris[:, 0:3].astype(np.float64)
     t = ~links[leaf]
     for slot, sel in ((t, np.ones(t.size, bool)), (np.minimum(t + 1, n - 1), partner[t])):   # the leaf's first triangle, then its partner
-        for v in (v0, v0 + tris[:, 4:7], v0 + tris[:, 8:11]):
+        for v in (v0, tris[:, 4:7].astype(np.float64), tris[:, 8:11].astype(np.float64)):      # the records hold the three vertices
             q = (v[slot[sel]] - glo) / cell
             assert (lo[leaf][sel] <= q + 1e-6).all() and (hi[leaf][sel] >= q - 1e-6).all()
     assert 2 <= info.bvh_depth <= 48
@@ -321,7 +321,7 @@ def test_transform_memory_layout_kat_on_device(instance):
     _, tris = gpu.debug_bvh()
     w = LAYOUT_KAT_WORLD
     assert tris.shape[0] == 1
-    assert np.array_equal(tris[0, 0:3], w[0]) and np.array_equal(tris[0, 4:7], w[1] - w[0]) and np.array_equal(tris[0, 8:11], w[2] - w[0])
+    assert np.array_equal(tris[0, 0:3], w[0]) and np.array_equal(tris[0, 4:7], w[1]) and np.array_equal(tris[0, 8:11], w[2])
 
 
 def test_oracle_bvh_against_brute_force(mattest):

@@ -1,26 +1,37 @@
-"""Per-launch cost of one rank's share of the 1080p frame at world sizes 1/2/4/8, measured on ONE GPU (rank 0's tiles).
-Predicts the strong-scaling efficiency of bench.py --gpus N before the 8-GPU run: speed-up(N) ~ t(1) / t(N)."""
-import sys, time
+"""Per-launch cost of one rank's share of the 1080p frame at world sizes 1..16, measured on ONE GPU (rank 0's tiles), for both
+launch modes (two kernels per launch / the per-wave launch loop k_path).  Predicts the strong scaling of bench.py --gpus N before
+the 8-GPU run: speed-up(N) ~ t(1) / t(N), against the best mode at world 1.
+
+    python tools/gpu_partition_timing.py [two_kernels|path|auto ...]        env: CHAINS=<n> NOPROFILE=1 STEPS=<n>
+"""
+import os
+import sys
+import time
 sys.path.insert(0, ".")
 import glaze_amd
 from glaze_amd.scenes import atrium_scene
 inst = glaze_amd.RayTraceInstance.new()
 scene = glaze_amd.RayTraceScene.from_desc(inst, atrium_scene())
-base = None
-import os
 chains = int(os.environ.get('CHAINS', '0'))
-for world in (1, 2, 3, 4, 6, 8, 16):
-    r = glaze_amd.RayTraceRenderer.new(inst, scene, 1920, 1080) if world == 1 else r
-    r.set_depth(8)
-    r.set_partition(0, world)
-    r.set_chains(chains)
-    if os.environ.get('NOPROFILE'):
-        r.enable_counters(False, False)
-    r.restart(); r.step(16); r.wait_idle(); r.stats()
-    s0 = r.stats(); n = 128
-    t = time.time(); r.step(n); r.wait_idle(); dt = (time.time() - t) / n * 1e3
-    s = r.stats()
-    k = [(s.trace_closest_ms - s0.trace_closest_ms) / n, (s.shade_ms - s0.shade_ms) / n, (s.trace_shadow_ms - s0.trace_shadow_ms) / n]
-    base = base or dt
-    print("world %d: %.3f ms/launch wall (kernels %.3f + %.3f + %.3f = %.3f) -> predicted speed-up %.2fx, efficiency %.0f%%" % (
-        world, dt, k[0], k[1], k[2], sum(k), base / dt, 100 * base / dt / world))
+n = int(os.environ.get('STEPS', '128'))
+modes = sys.argv[1:] or ["two_kernels", "path", "auto"]
+r = glaze_amd.RayTraceRenderer.new(inst, scene, 1920, 1080)
+r.set_depth(8)
+base = None
+for mode in modes:
+    for world in (1, 2, 3, 4, 6, 8, 16):
+        if mode == "path" and world == 1 and os.environ.get("SKIP_PATH_1", "1") == "1":
+            continue            # the full frame through k_path: 8 groups per wave one after the other, of no interest
+        r.set_partition(0, world)
+        r.set_launch_mode(mode)
+        r.set_chains(chains)
+        if os.environ.get('NOPROFILE'):
+            r.enable_counters(False, False)
+        r.restart(); r.step(16); r.wait_idle(); r.stats()
+        s0 = r.stats()
+        t = time.time(); r.step(n); r.wait_idle(); dt = (time.time() - t) / n * 1e3
+        s = r.stats()
+        k = [(s.trace_closest_ms - s0.trace_closest_ms) / n, (s.shade_ms - s0.shade_ms) / n, (s.trace_shadow_ms - s0.trace_shadow_ms) / n, (s.other_ms - s0.other_ms) / n]
+        base = base or dt
+        print("%-11s world %2d (%s): %.4f ms/launch wall (k_trace %.3f + k_shade %.3f + shadow pass %.3f + k_path %.3f = %.3f) -> speed-up %.2fx, efficiency %.0f%%" % (
+            mode, world, r.launch_mode(), dt, k[0], k[1], k[2], k[3], sum(k), base / dt, 100 * base / dt / world), flush=True)
