@@ -1,0 +1,1217 @@
+// Device code shared by the render kernels (kernels_render.hip: k_trace, k_shade, k_trace_tl; kernels_path.hip: k_path): pixel
+// mapping, the slab and the watertight triangle test, the wave-persistent tracers, ray sources / sinks, and shade_pixel.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdlib>
+
+#include "device/math.h"
+#include "device/shading.h"
+#include "device/types.h"
+#include "kernels.h"
+
+namespace glz {
+using namespace dev;
+
+constexpr int kBlock = (int)kTraceBlock;   // 4 waves
+constexpr int kLdsStack = kTraversalLdsStack;   // stack entries kept in LDS per lane (18 KB per block -> 8 blocks per CU); deeper levels spill to HBM
+constexpr uint32_t kQueueShards = 8;     // shadow-ray sub-queues (see queue_slot)
+constexpr uint32_t kCounterStride = 32;  // uint32 words between shard counters (128 bytes)
+constexpr uint32_t kFlagUpdate = 1u;    // update_result() is called for this pixel in this launch
+constexpr uint32_t kFlagShadow = 2u;    // the contribution is gated by a shadow ray
+constexpr uint32_t kFlagPoison = 4u;    // 0 * (|cos|/pdf) * radiance is NaN: an occluded sample still poisons the pixel
+
+// ---------------------------------------------------------------------------------------------
+// pixel <-> thread mapping
+// ---------------------------------------------------------------------------------------------
+struct PixelId {
+  uint32_t x, y;
+  bool active;
+};
+__device__ __forceinline__ PixelId pixel_of(const TileMap& m, uint32_t lid) {
+  const uint32_t lane = lid & 63u, sub = (lid >> 6) & 63u, ltile = lid >> 12;
+  const uint32_t gtile = ltile * m.world + m.rank;
+  const uint32_t tx = gtile % m.tiles_x, ty = gtile / m.tiles_x;
+  PixelId p;
+  p.x = tx * 64u + (sub & 7u) * 8u + (lane & 7u);
+  p.y = ty * 64u + (sub >> 3) * 8u + (lane >> 3);
+  p.active = lid < m.n_local_pixels && p.x < m.width && p.y < m.height;
+  return p;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Ray / box and ray / triangle.  The triangle test is Moeller-Trumbore with the candidate accepted
+// iff tmin < t < tmax, no face culling (acceleration.rs:335-345); it stands in for the driver's
+// intersector ([ext]).  Ties on t are broken by the smaller world triangle id so that the result
+// does not depend on traversal order.
+// ---------------------------------------------------------------------------------------------
+// Slab test on a quantised box.  It only prunes: boxes are padded by 1/16 cell when they are quantised, which covers the
+// rounding of the plane distances (< 0.01 cell), so it never rejects a box whose triangle the exact Moeller-Trumbore test
+// below accepts.  The ray is mapped into grid units once (ig = cell / d, cg = -(origin_grid * ig)); a node word holds
+// lo | hi << 16 of one axis, and a per-ray byte permutation (sel: identity for ig >= 0, halves swapped for ig < 0) moves the
+// plane the ray meets first into the low half -- no min / max per axis.  Both plane distances of an axis then come from one
+// packed v_pk_fma_f32.  The tracers are VALU-issue bound, so instructions per node visit are what counts.  ig is kept
+// finite (grid_inv_dir), so no plane distance is ever NaN: a ray parallel to a slab gets +-1e30-scale distances whose signs
+// still say on which side of each plane the origin lies.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+struct SlabSel { uint32_t x, y, z; };   // v_perm_b32 selectors per axis
+// (Tried: 15-bit coordinates that a byte permute turns into floats directly -- 0x47000000 | q << 8 is 32768 + q -- with the 32768 folded
+// into the addend: two permutes per axis instead of one permute and two conversions, 12 VALU instructions fewer per node visit.  It
+// needs six selectors instead of three, and with three more live registers the compiler spills inside the node loop at the 80 this
+// kernel has: 0.58 -> 1.34 ms.  Same node and triangle counts, same images.)
+// returns the sort key of the child: entry distance (a positive float, so its bits order like the value) with the child index in
+// the two lowest bits -- nearer first, ties (to 2 ulp) by child index; 0xFFFFFFFF for a missed child or an unused slot
+// (the slab test is symmetric in lo / hi, so an unused slot cannot be excluded through its box: its link says so)
+// cgn / cgf: the addends of the near and the far plane.  The flattened tracer passes the same vector twice; the two-level tracer
+// widens every box by the instance's slack (cg -+ pad * |ig|) at no extra instruction.
+__device__ __forceinline__ uint32_t box_key(uint32_t wx, uint32_t wy, uint32_t wz, uint32_t link, uint32_t k, SlabSel sel, vec3 ig, vec3 cgn, vec3 cgf,
+                                            float tmin, float tmax) {
+  const uint32_t px = __builtin_amdgcn_perm(wx, wx, sel.x), py = __builtin_amdgcn_perm(wy, wy, sel.y), pz = __builtin_amdgcn_perm(wz, wz, sel.z);
+  const f32x2 tx = __builtin_elementwise_fma(f32x2{(float)(px & 0xFFFFu), (float)(px >> 16)}, f32x2{ig.x, ig.x}, f32x2{cgn.x, cgf.x});
+  const f32x2 ty = __builtin_elementwise_fma(f32x2{(float)(py & 0xFFFFu), (float)(py >> 16)}, f32x2{ig.y, ig.y}, f32x2{cgn.y, cgf.y});
+  const f32x2 tz = __builtin_elementwise_fma(f32x2{(float)(pz & 0xFFFFu), (float)(pz >> 16)}, f32x2{ig.z, ig.z}, f32x2{cgn.z, cgf.z});
+  const float t0 = fmaxf(fmaxf(tx.x, ty.x), fmaxf(tz.x, tmin));
+  const float t1 = fminf(fminf(tx.y, ty.y), fminf(tz.y, tmax));
+  return (t0 <= t1 && link != (uint32_t)kBvhEmptyChild) ? ((__float_as_uint(t0) & 0xFFFFFFFCu) | k) : 0xFFFFFFFFu;
+}
+
+// 1 / d clamped to +-1e30: zero (or denormal) direction components must not produce inf - inf in the fma above --
+// a ray with a NaN plane distance on every axis would pass every box test and walk the whole tree.
+__device__ __forceinline__ float grid_inv_dir(float d) {
+  const float i = 1.0f / d;
+  return fabsf(i) <= 1e30f ? i : copysignf(1e30f, i);
+}
+// rays with a NaN / infinite origin or direction cannot be accepted by ray_triangle (every comparison fails): they
+// are reported as misses without traversal
+__device__ __forceinline__ bool ray_is_finite(vec3 o, vec3 d) {
+  const float s = ((o.x + o.y) + o.z) + ((d.x + d.y) + d.z);
+  return s - s == 0.0f;
+}
+
+// The watertight ray / triangle test, statement for statement the oracle's ray_tri (oracle.cpp; the reference's hits come from
+// traceRayEXT on the driver's acceleration structure, path_trace.rgen:169 / acceleration.rs:319-345, which the Vulkan
+// specification requires to be watertight): Woop, Benthin, Wald 2013 with the exact tie-break in single precision.
+//   per ray    kz = axis of the largest |d|, shear Sz = 1 / d[kz], Sx = d[kx] Sz, Sy = d[ky] Sz        (ray_shear; once per leaf round,
+//              from d alone -- nothing is kept per ray, the traversal has no register to spare)
+//   per vertex A = P - o, image (A[kx] - Sx A[kz], A[ky] - Sy A[kz], Sz A[kz]): the same 2-D point in every triangle that uses P
+//   per edge   U = Cx By - Cy Bx from two separately rounded products: its sign is exact unless the rounded products are equal, and
+//              then the difference of their rounding errors (one fma each) is.  Exact orientation predicates on consistent points
+//              cannot leave a gap at a shared edge or vertex.  -ffp-contract=off keeps the products unfused.
+// Straight-line: with ~10 of 64 lanes in a leaf round an early exit is almost never taken by all of them, and without branches
+// the three 16-byte loads of the triangle are issued together; only the tie-break is a (wave-uniform) branch, taken when some
+// lane's ray meets an edge exactly -- axis-aligned geometry under an orthographic camera, otherwise hardly ever.
+struct RayShear {
+  bool z_is_x, z_is_y;   // kz == 0, kz == 1 (else 2): wave masks in SGPRs
+  float sx, sy, sz;
+};
+__device__ __forceinline__ RayShear ray_shear(vec3 d) {
+  const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+  RayShear r;
+  r.z_is_x = (ax >= ay) & (ax >= az);
+  r.z_is_y = !r.z_is_x & (ay >= az);
+  // (kx, ky, kz) = (1, 2, 0), (2, 0, 1) or (0, 1, 2)
+  const float dz = r.z_is_x ? d.x : (r.z_is_y ? d.y : d.z), dx = r.z_is_x ? d.y : (r.z_is_y ? d.z : d.x), dy = r.z_is_x ? d.z : (r.z_is_y ? d.x : d.y);
+  r.sz = 1.0f / dz;
+  r.sx = dx * r.sz;
+  r.sy = dy * r.sz;
+  return r;
+}
+__device__ __forceinline__ vec3 shear_vertex(const RayShear& r, const float* p, vec3 o) {
+  const vec3 a = mk3(p[0], p[1], p[2]) - o;
+  const float az = r.z_is_x ? a.x : (r.z_is_y ? a.y : a.z), ax = r.z_is_x ? a.y : (r.z_is_y ? a.z : a.x), ay = r.z_is_x ? a.z : (r.z_is_y ? a.x : a.y);
+  return mk3(fmaf(-r.sx, az, ax), fmaf(-r.sy, az, ay), r.sz * az);
+}
+__device__ __forceinline__ bool ray_triangle(const RayShear& rs, const BvhTri& tr, vec3 o, float tmin, float& t, float& u, float& v) {
+  const vec3 A = shear_vertex(rs, tr.v0, o), B = shear_vertex(rs, tr.v1, o), C = shear_vertex(rs, tr.v2, o);
+  const float pu = C.x * B.y, qu = C.y * B.x, pv = A.x * C.y, qv = A.y * C.x, pw = B.x * A.y, qw = B.y * A.x;
+  float U = pu - qu, V = pv - qv, W = pw - qw;
+  if (__builtin_expect(__any((U == 0.0f) | (V == 0.0f) | (W == 0.0f)), 0)) {   // edge_fn's second branch, for the lanes that need it
+    if (U == 0.0f) U = fmaf(C.x, B.y, -pu) - fmaf(C.y, B.x, -qu);
+    if (V == 0.0f) V = fmaf(A.x, C.y, -pv) - fmaf(A.y, C.x, -qv);
+    if (W == 0.0f) W = fmaf(B.x, A.y, -pw) - fmaf(B.y, A.x, -qw);
+  }
+  const float lo = fminf(fminf(U, V), W), hi = fmaxf(fmaxf(U, V), W);   // two opposite signs <=> lo < 0 < hi (a NaN fails the distance test)
+  const float det = (U + V) + W;
+  const float inv = 1.0f / det;
+  u = V * inv;
+  v = W * inv;
+  t = fmaf(W, C.z, fmaf(V, B.z, U * A.z)) * inv;
+  return !((lo < 0.0f) & (hi > 0.0f)) & (det != 0.0f) & (t > tmin);
+}
+
+// raytrace_hit.rahit:24-39 -- candidates on non-opaque geometry are dropped when opacity.r < 0.5
+__device__ __forceinline__ bool alpha_test(const DeviceScene& S, uint32_t leaf, float u, float v) {
+  // uv of the three vertices and the material id come from the leaf's 128-byte shading record (the same values the
+  // reference's any-hit shader reads through instance -> indices -> vertices)
+  const float4* rec = S.shade_tris + 8u * (size_t)leaf;
+  const float4 a = rec[1], b = rec[3], c = rec[5];
+  const uint32_t material_id = __float_as_uint(rec[6].w);
+  const float w = 1.0f - u - v;
+  const float tu = (a.z * w + b.z * u) + c.z * v, tv = (a.w * w + b.w * u) + c.w * v;
+  return !(texture_r(S, S.materials[material_id].opacity, vec2{tu, tv}) < 0.5f);
+}
+
+// the same for a two-level scene: the shading record is per OBJECT triangle, the material is the instance's
+__device__ __forceinline__ bool alpha_test_instance(const DeviceScene& S, uint32_t slot, uint32_t instance, float u, float v) {
+  const float4* rec = S.shade_tris + 8u * (size_t)slot;
+  const float4 a = rec[1], b = rec[3], c = rec[5];
+  const uint32_t material_id = S.instances[instance].material_id;
+  const float w = 1.0f - u - v;
+  const float tu = (a.z * w + b.z * u) + c.z * v, tv = (a.w * w + b.w * u) + c.w * v;
+  return !(texture_r(S, S.materials[material_id].opacity, vec2{tu, tv}) < 0.5f);
+}
+
+struct HitRecord {
+  float t, u, v;
+  uint32_t leaf;   // index into bvh_tris / shade_tris, 0xFFFFFFFF = miss
+  // two-level scenes only (a flattened triangle record names its instance itself):
+  uint32_t inst;       // RTInstance of the hit
+  uint32_t world_id;   // world triangle id (instance-major), the tie-break key
+};
+
+// Per-lane traversal stack: the first kLdsStack levels in LDS (column `tid` of a [level][kBlock]
+// array, accessed with 4-byte DS instructions, which gfx950 services in two 32-lane halves with bank = (addr / 4) % 32
+// -- the 64-bank mapping only applies to the 8- and 16-byte reads: every lane hits bank tid % 32 of its own half,
+// conflict-free whatever the per-lane depth), deeper
+// levels in a per-lane HBM spill area.  kStolen marks an LDS entry that was handed to an idle lane (work sharing
+// at the tail of trace_wave); pop_live() skips such entries.
+constexpr int kRayDone = 0x7FFFFFFF;   // `cur` of a lane without a node to visit (inner nodes are >= 0, leaves < 0)
+constexpr int kStolen = 0x7FFFFFFE;
+struct Stack {
+  int* lds;             // &s_stack[threadIdx.x]
+  uint32_t* spill;      // overflow words of this lane
+  int sp;
+  __device__ __forceinline__ void push(int v) {
+    if (sp < kLdsStack) lds[sp * kBlock] = v; else spill[sp - kLdsStack] = (uint32_t)v;
+    ++sp;
+  }
+  __device__ __forceinline__ int pop() {
+    --sp;
+    return sp < kLdsStack ? lds[sp * kBlock] : (int)spill[sp - kLdsStack];
+  }
+  __device__ __forceinline__ int pop_live() {
+    while (sp > 0) {
+      const int v = pop();
+      if (v != kStolen) return v;
+    }
+    return kRayDone;
+  }
+};
+
+struct TraceTally {
+  unsigned long long rays = 0, nodes = 0, tris = 0, hits = 0, fresh = 0;
+  // phase occupancy (instrumented build only): rounds executed and lanes doing useful work in them, counted on lane 0
+  unsigned long long node_iters = 0, node_lanes = 0, leaf_iters = 0, leaf_lanes = 0, refill_iters = 0, refill_lanes = 0;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Wave-persistent traversal.  A wave owns a strided sequence of 64-ray groups (group g of wave w is rays
+// [64 * (g * n_waves + w), +64)) and keeps its 64 lanes busy: a lane whose ray has finished takes the next
+// ray of the wave's sequence as soon as kRefill lanes are idle (no atomics: the sequence pointer is wave
+// uniform).  Each round is  [refill] -> [inner-node phase, a share step before each of its iterations] -> [leaf phase] -> [merge] -> [retire]:
+//   * inner-node phase: lanes sitting on an inner node test its four child boxes, descend into the nearest
+//     hit child and push the others farthest first; lanes that reached a leaf wait.  The phase ends when no lane is on an
+//     inner node, or when at least kLeafQuorum lanes are waiting on a leaf.
+//   * leaf phase: every lane on a leaf runs the exact ray/triangle test once, then pops its stack.
+//   * share / merge (only once the wave's sequence is exhausted, i.e. in the tail): an idle lane takes the OLDEST
+//     pending subtree off the LDS stack of a busy lane (the stacks are LDS columns, so any lane can reach them),
+//     copies that lane's ray through shuffles and traverses the subtree as a helper; its result is merged back into
+//     the owner (smaller t, then smaller world id; any hit for shadow rays), which retires when no helper is left.  Owner and
+//     helpers prune with the closest distance any of them has found so far (aux_t).
+//     The longest rays then finish in a fraction of their serial time: they set the duration of a launch once a GPU
+//     holds few rays per wave (tile sharding over 8 GPUs: k_trace's floor was 0.17 ms whatever the share of the frame).
+//     Closest-hit and any-hit results do not depend on the visit order, so sharing changes no result; it is compiled
+//     out of the instrumented kernels, whose node / triangle counts are defined by the serial walk.
+// This replaces the one-ray-per-thread loop whose VALU lane utilisation was 24 % on the atrium
+// (SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU), profiles/r01b_sq_counters.txt).
+//
+// ANY = false: closest hit in (tmin, tmax); ties on t go to the smaller world triangle id, so the result
+// does not depend on visit order.  ANY = true: the first accepted hit ends the ray.
+// Source: bool load(uint32_t ray, vec3& o, vec3& d, float& tmin, float& tmax)   (false = nothing to trace or report)
+// Sink:   void store(uint32_t ray, const HitRecord&)
+// lds_col: this lane's stack column; aux: this WAVE's 3 x 64 ints of LDS scratch (helpers per owner, donor list, stack bottoms)
+// ---------------------------------------------------------------------------------------------
+#ifndef GLZ_TRACE_WAVES
+#define GLZ_TRACE_WAVES 6   // waves per SIMD the tracers are compiled for (__launch_bounds__): 80 VGPRs; 7 waves (72 VGPRs) spills 40 registers with the 64-byte nodes and measured 5 % slower
+#endif
+#ifndef GLZ_REFILL
+#define GLZ_REFILL 16
+#endif
+#ifndef GLZ_LEAF_QUORUM
+#define GLZ_LEAF_QUORUM 16   // 4-wide nodes: 8 -> 0.815, 12 -> 0.790, 16 -> 0.781, 24 -> 0.810 ms per k_trace; with pair leaves 8 / 12 / 16 / 24 / 32 -> 0.650 / 0.606 / 0.589 / 0.583 / 0.598
+#endif
+#ifndef GLZ_LDS_TOP
+#define GLZ_LDS_TOP 1   // 1: the top kBvhTopNodes nodes of the tree are fetched from a per-block LDS copy ("LDS-staged node packets"), 0: every node from global memory
+#endif
+constexpr bool kLdsTop = GLZ_LDS_TOP != 0;
+constexpr int kRefill = GLZ_REFILL;
+constexpr int kLeafQuorum = GLZ_LEAF_QUORUM;
+#ifndef GLZ_REFILL_ANY
+#define GLZ_REFILL_ANY GLZ_REFILL
+#endif
+#ifndef GLZ_LEAF_QUORUM_ANY
+#define GLZ_LEAF_QUORUM_ANY GLZ_LEAF_QUORUM
+#endif
+#ifndef GLZ_SHARE_REPS
+#define GLZ_SHARE_REPS 1   // hand-overs per donor and node iteration while idle lanes are left: 1 / 2 / 3 -> 0.145 / 0.148 / 0.152 ms per launch of a 1/8 share (each costs its shuffles)
+#endif
+#ifndef GLZ_LEAF_QUORUM_TAIL
+#define GLZ_LEAF_QUORUM_TAIL GLZ_LEAF_QUORUM   // once the wave's sequence is exhausted (a small share of the frame: from the first round on); 4 / 8 / 16 / 24 / 32 -> 0.172 / 0.159 / 0.152 / 0.152 / 0.155 ms per launch of a 1/8 share: the same optimum
+#endif
+constexpr int kAuxPerWave = 3 * 64 + 4 * 64;   // work sharing (3 x 64) + the four child links of the node a lane is visiting
+
+__device__ __forceinline__ void sort2(uint32_t& a, uint32_t& b) {
+  const uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
+  a = lo;
+  b = hi;
+}
+
+// The staged nodes are read through a pointer that keeps its LDS address space: with a generic pointer the compiler
+// merges the LDS and the global fetch of a node into ONE flat_load behind a pointer select -- every node of the tree then
+// comes in through the flat path (measured: k_trace 0.586 -> 0.786 ms).
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(3))) u32x4* LdsNodePtr;
+
+// The rays a wave works through, in the order it takes them (all wave-uniform but the position asked for): the 64-ray groups are
+// dealt round-robin, group g to wave g % n_waves.  The rays left over after the whole rounds can be dealt in smaller pieces
+// (GLZ_PIECE_SHIFT < 6) so that every wave gets the same share of them -- a full frame leaves a quarter of the waves with a sixth
+// group and lasts as long as those, and a share with fewer groups than waves fills some waves and leaves the rest empty.  Measured
+// with pieces of 16: the full frame 0.932 -> 0.951 ms per launch, a 1/4 share 0.252 -> 0.343, a 1/8 share 0.148 -> 0.214 (8 and 32
+// likewise).  A wave's iteration costs the same whatever the number of its lanes that work, and the SIMDs are shared: the same rays
+// in more, emptier waves are slower even when there are waves to spare.  So whole groups it is.
+#ifndef GLZ_PIECE_SHIFT
+#define GLZ_PIECE_SHIFT 6
+#endif
+struct RaySequence {
+  static constexpr uint32_t kPieceShift = GLZ_PIECE_SHIFT, kPiece = 1u << GLZ_PIECE_SHIFT;
+  uint32_t wave, n_waves, total;
+  uint32_t own_full;     // rays this wave takes in whole groups
+  uint32_t piece_base;   // first ray that is dealt in pieces
+  __device__ __forceinline__ RaySequence(uint32_t wave_, uint32_t n_waves_, uint32_t total_) : wave(wave_), n_waves(n_waves_), total(total_) {
+    const uint32_t full_rounds = ((total + 63u) >> 6) / n_waves;
+    own_full = full_rounds * 64u;
+    piece_base = full_rounds * n_waves * 64u;
+  }
+  // ray at position `pos` of this wave's sequence; >= total: the sequence has ended (ray_at is monotonic in pos)
+  __device__ __forceinline__ uint32_t ray_at(uint32_t pos) const {
+    if (pos < own_full) return (wave + (pos >> 6) * n_waves) * 64u + (pos & 63u);
+    const uint32_t q = pos - own_full;
+    return piece_base + (wave + (q >> kPieceShift) * n_waves) * kPiece + (q & (kPiece - 1u));
+  }
+};
+
+#ifdef GLZ_WAVE_TIMES
+__device__ unsigned long long g_wave_times[3 * 8192];
+__device__ unsigned int g_wave_stats[8 * 8192];   // closest-hit phase: rounds, node iterations, lanes in them, leaf iterations, lanes in them, rounds with helpers
+__device__ unsigned long long g_tl_stats[8];      // two-level tracer, summed over lanes: rays, top-level node visits, mesh node visits, instances entered, triangle tests, node iterations, leaf iterations
+#endif
+
+// MIXED (with ANY = false): the sequence holds rays of both kinds, the source says which after every load (src.any) -- k_path
+// traces a wave's closest-hit rays and the shadow rays its previous launch queued in ONE pass, the shadow rays in the lanes
+// the closest-hit rays leave idle.
+template <bool ANY, bool COUNT, bool MIXED = false, class Source, class Sink>
+__device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Sink& sink, int* __restrict__ lds_col, int* aux, LdsNodePtr top_lds,
+                                           uint32_t* __restrict__ spill, uint32_t spill_depth, uint32_t total, uint32_t wave, uint32_t n_waves, TraceTally& tally) {
+  constexpr bool SHARE = !COUNT;
+  constexpr uint32_t kNone = 0xFFFFFFFFu;
+  const BvhNode4* __restrict__ nodes = S.bvh_nodes;
+  const BvhGrid grid = S.bvh_grid;
+  const BvhTri* __restrict__ tris = S.bvh_tris;
+  const int lane = threadIdx.x & 63;
+  const unsigned long long lanes_below = (1ull << lane) - 1ull;
+  int* aux_out = aux;          // [owner lane] helpers currently working for that lane's ray
+  uint32_t* aux_t = reinterpret_cast<uint32_t*>(aux) + 64;   // [owner lane] bits of the smallest hit distance the ray's owner or any helper has found (tail only)
+  int* aux_sb = aux + 128;     // [lane] lowest LDS stack level that may still hold a live entry
+  int* aux_pair = aux + 192;   // [k] lane of the k-th donor of this round; shares its words with the child links, which only live inside a node visit
+  if (SHARE) {
+    aux_out[lane] = 0;
+    aux_sb[lane] = 0;
+  }
+  uint32_t seq = 0;                                         // wave-uniform: rays of this wave's sequence handed out so far
+  const RaySequence rays(wave, n_waves, total);
+  // (giving each XCD one contiguous eighth of the groups -- rays of one image band per L2 -- measured 5 % slower: the bands
+  // differ in cost and the static split loses more to imbalance than the L2 gains)
+  // (Drawing the groups from a counter instead of the stride: the waves of a full-frame launch end between 257 and 406 us of a
+  // 410 us closest-hit phase -- 5 or 6 groups each -- tools/gpu_wave_times.py.  One counter: 577 us, device-scope atomics on one
+  // address are served at ~15 ns each; 32 interleaved counters: the ends move together, 306 - 400 us, but every wave gets slower --
+  // neighbouring groups no longer run on one CU at one time -- 0.572 ms per k_trace either way; whole rounds by the stride and
+  // only the last partial round drawn: 0.601 ms.  A wave's last group runs without refills behind it whoever hands it out.)
+  bool exhausted = rays.ray_at(0u) >= total;                // wave-uniform
+  // per-lane ray state
+  bool open = false;                                        // a ray of this lane's own is in flight and its result has not been stored
+  bool helper = false;                                      // this lane traverses a subtree of lane `ray`'s ray (work sharing)
+  bool any_lane = ANY;                                      // the ray in this lane ends with its first accepted hit (MIXED: per ray)
+  int cur = kRayDone;
+  uint32_t ray = 0;                                         // ray index (open) or owner lane (helper)
+  vec3 o = mk3(0.0f, 0.0f, 0.0f), d = mk3(0.0f, 0.0f, 1.0f);
+  vec3 ig = mk3(0.0f, 0.0f, 0.0f), cg = mk3(0.0f, 0.0f, 0.0f);   // grid-space ray: plane q is crossed at t = q * ig + cg
+  SlabSel sel{0x03020100u, 0x03020100u, 0x03020100u};          // near-plane selectors, from the signs of ig
+  float tmin = 0.0f, tmax = 0.0f;
+  HitRecord best{0.0f, 0.0f, 0.0f, kNone};
+  uint32_t best_id = kNone;
+  // the spill area is indexed by the physical lane slot of the grid (a lane traverses one ray or subtree at a time)
+  Stack st{lds_col, spill + ((size_t)(blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 64u + (uint32_t)lane) * spill_depth, 0};
+#ifdef GLZ_WAVE_TIMES
+  unsigned int wt_rounds = 0, wt_node_iters = 0, wt_node_lanes = 0, wt_leaf_iters = 0, wt_leaf_lanes = 0, wt_helper_rounds = 0, wt_wait_rounds = 0;
+#endif
+  // ---- share: idle lanes adopt the oldest pending subtree of a busy lane (called before every node iteration, see below) ----
+  auto share_step = [&]() {
+  if (SHARE && exhausted)
+  for (int rep = 0; rep < GLZ_SHARE_REPS; ++rep) {
+    bool more = false;
+    const bool busy = open || helper;
+    const unsigned long long idle_m = __ballot(!busy);
+    if (idle_m != 0ull) {
+      if (ANY || MIXED) {   // helpers of a ray whose hit has been found have nothing left to decide
+        const int owner_found = __shfl((int)(best.leaf != kNone), helper ? (int)ray : lane);
+        if (helper && any_lane && owner_found) cur = kRayDone;
+      }
+      int sb = 0, lim = 0;
+      if (busy && cur != kRayDone) {
+        sb = aux_sb[lane];
+        if (sb > st.sp) sb = st.sp;
+        lim = st.sp < kLdsStack ? st.sp : kLdsStack;
+        while (sb < lim && st.lds[sb * kBlock] == kStolen) ++sb;
+        aux_sb[lane] = sb;
+      }
+      const bool can_give = busy && cur != kRayDone && sb < lim;
+      const unsigned long long give_m = __ballot(can_give);
+      const int n_give = __popcll(give_m), n_take = __popcll(idle_m);
+      const int n_pairs = n_give < n_take ? n_give : n_take;
+      if (n_pairs > 0) {
+        int give = 0;
+        if (can_give && __popcll(give_m & lanes_below) < n_pairs) {
+          give = st.lds[sb * kBlock];
+          st.lds[sb * kBlock] = kStolen;
+          aux_sb[lane] = sb + 1;
+          aux_pair[__popcll(give_m & lanes_below)] = lane;
+        }
+        const int take_rank = __popcll(idle_m & lanes_below);
+        const bool take = !busy && take_rank < n_pairs;
+        const int donor = take ? aux_pair[take_rank] : lane;   // same-wave LDS: the stores above are complete (in-order)
+        // Every lane runs the shuffles.  Lanes that take nothing read their own lane (donor == lane), so the ray registers
+        // can be assigned unconditionally: no temporaries stay live across the block (register pressure: 72 VGPRs).
+        const int t_node = __shfl(give, donor);
+        const int t_owner = __shfl(helper ? (int)ray : lane, donor);
+        o.x = __shfl(o.x, donor); o.y = __shfl(o.y, donor); o.z = __shfl(o.z, donor);
+        d.x = __shfl(d.x, donor); d.y = __shfl(d.y, donor); d.z = __shfl(d.z, donor);
+        ig.x = __shfl(ig.x, donor); ig.y = __shfl(ig.y, donor); ig.z = __shfl(ig.z, donor);
+        cg.x = __shfl(cg.x, donor); cg.y = __shfl(cg.y, donor); cg.z = __shfl(cg.z, donor);
+        sel = SlabSel{ig.x < 0.0f ? 0x01000302u : 0x03020100u, ig.y < 0.0f ? 0x01000302u : 0x03020100u, ig.z < 0.0f ? 0x01000302u : 0x03020100u};
+        tmin = __shfl(tmin, donor); tmax = __shfl(tmax, donor);
+        best.t = __shfl(best.t, donor); best.u = __shfl(best.u, donor); best.v = __shfl(best.v, donor);
+        best.leaf = (uint32_t)__shfl((int)best.leaf, donor);
+        best_id = (uint32_t)__shfl((int)best_id, donor);
+        if (MIXED) any_lane = __shfl((int)any_lane, donor) != 0;
+        if (take) {
+          ray = (uint32_t)t_owner;
+          cur = t_node;
+          st.sp = 0;
+          aux_sb[lane] = 0;
+          helper = true;
+          atomicAdd(&aux_out[t_owner], 1);
+        }
+        more = n_take > n_give;   // idle lanes are left over: the donors may have more to give
+      }
+    }
+    if (!more) break;
+  }
+  };
+  for (;;) {
+#ifdef GLZ_WAVE_TIMES
+    wt_rounds += 1;
+    wt_helper_rounds += __ballot(helper) != 0ull;
+    wt_wait_rounds += __ballot(open && cur == kRayDone) != 0ull && __ballot(open && cur != kRayDone) == 0ull;   // owners only waiting for helpers
+#endif
+    // ---- refill ----
+    const unsigned long long idle = __ballot(!(open || helper));
+    const int n_idle = __popcll(idle);
+    if (!exhausted && n_idle >= (ANY ? GLZ_REFILL_ANY : kRefill)) {
+      if (COUNT && lane == 0) { tally.refill_iters += 1; tally.refill_lanes += (unsigned)n_idle; }
+      const uint32_t next_ray = rays.ray_at(seq + (uint32_t)__popcll(idle & lanes_below));
+      if (!open && next_ray < total) {
+        if (src.load(next_ray, o, d, tmin, tmax)) {
+          ray = next_ray;
+          best = HitRecord{tmax, 0.0f, 0.0f, kNone};
+          best_id = kNone;
+          if constexpr (MIXED) any_lane = src.any;
+          if (COUNT) tally.rays += 1;
+          if (S.n_world_tris == 0 || !ray_is_finite(o, d)) {
+            sink.store(ray, best);                          // nothing to intersect / nothing can be hit: a miss
+          } else {
+            const vec3 og = mk3((o.x - grid.lo[0]) * grid.inv_cell[0], (o.y - grid.lo[1]) * grid.inv_cell[1], (o.z - grid.lo[2]) * grid.inv_cell[2]);
+            ig = mk3(grid_inv_dir(d.x) * grid.cell[0], grid_inv_dir(d.y) * grid.cell[1], grid_inv_dir(d.z) * grid.cell[2]);
+            cg = mk3(-(og.x * ig.x), -(og.y * ig.y), -(og.z * ig.z));
+            sel = SlabSel{ig.x < 0.0f ? 0x01000302u : 0x03020100u, ig.y < 0.0f ? 0x01000302u : 0x03020100u, ig.z < 0.0f ? 0x01000302u : 0x03020100u};
+            st.sp = 0;
+            if (SHARE) aux_sb[lane] = 0;
+            cur = kLdsTop ? kBvhTopFlag : 0;   // the root (slot 0 of the staged table)
+            open = true;
+          }
+        }
+      }
+      seq += (uint32_t)n_idle;
+      exhausted = rays.ray_at(seq) >= total;
+      // The tail begins: from here on a ray may be worked on by several lanes, which tell each other the closest distance found so
+      // far through aux_t -- a helper walking a far subtree with the bound it was handed at the start would go through all of
+      // it after the owner has long found something nearer, and the owner cannot retire before its helpers are back.
+      if (SHARE && !ANY && exhausted && open) aux_t[lane] = __float_as_uint(best.t);
+    }
+    if (__ballot(open || helper) == 0ull) {
+      if (exhausted) break;
+      continue;
+    }
+    // ---- inner-node phase ----
+#ifdef GLZ_SHARE_ONCE_PER_ROUND
+    bool first_iter = true;
+#endif
+    for (;;) {
+      // Idle lanes take over pending subtrees before EVERY node iteration of the tail, not once per round: a round is several
+      // iterations long, and with one hand-over per round the helpers of a long ray multiplied too slowly to matter before it
+      // was over (a 1/8 share: 0.153 -> 0.147 ms per launch; the full frame, where only each wave's last group is a tail: 0.930 -> 0.914).
+#ifndef GLZ_SHARE_ONCE_PER_ROUND
+      share_step();
+#else
+      if (first_iter) share_step();
+      first_iter = false;
+#endif
+      // (Reading the first word of the triangle as soon as a lane of the tail arrives at a leaf, so that the line is on its way while
+      // the others finish their node iterations: slower, 0.146 -> 0.149 ms for a 1/8 share and 0.905 -> 0.924 ms for the full frame.)
+      const bool at_node = cur >= 0 && cur < kStolen;
+      const unsigned long long m_node = __ballot(at_node);
+      if (m_node == 0ull) break;
+#ifdef GLZ_TAIL_PRIO
+      // a wave down to its last few rays is on the launch's critical path and uses little of the SIMD: let it issue first
+      if (SHARE && exhausted) {
+        if (__popcll(m_node) <= GLZ_TAIL_PRIO) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
+      }
+#endif
+      if (COUNT && lane == 0) { tally.node_iters += 1; tally.node_lanes += (unsigned)__popcll(m_node); }
+#ifdef GLZ_WAVE_TIMES
+      wt_node_iters += 1; wt_node_lanes += (unsigned)__popcll(m_node);
+#endif
+      if (at_node) {
+        // 64-byte node = 4 x dwordx4: four child boxes in 16-bit grid coordinates (the ray was mapped into grid units at
+        // refill) and four links.  Children are entered nearest first; the others are pushed farthest first.
+        // Nodes of the top levels come out of the block's LDS copy (their `cur` carries kBvhTopFlag | slot); lanes that read the
+        // same staged node broadcast.
+        u32x4 w0, w1, w2, w3;
+        if (kLdsTop && (cur & kBvhTopFlag)) {
+          LdsNodePtr np = top_lds + 4 * (cur & 0xFFFF);
+          w0 = np[0]; w1 = np[1]; w2 = np[2]; w3 = np[3];
+        } else {
+          const u32x4* np = reinterpret_cast<const u32x4*>(nodes + cur);
+          w0 = np[0]; w1 = np[1]; w2 = np[2]; w3 = np[3];
+          // (A fifth 16-byte load from the node's own line costs 2.4 % of the kernel, 0.580 -> 0.594 ms: a 48-byte node format --
+          // 8-bit boxes relative to a per-node origin -- would buy about that and pay ~12 VALU instructions per visit for it.)
+        }
+        if (COUNT) tally.nodes += 1;
+        float bound = best.t;
+        if (SHARE && !ANY && exhausted) bound = fminf(bound, __uint_as_float(aux_t[helper ? (int)ray : lane]));   // positive floats order like their bits
+        uint32_t k0 = box_key(w0.x, w0.y, w0.z, w3.x, 0u, sel, ig, cg, cg, tmin, bound), k1 = box_key(w0.w, w1.x, w1.y, w3.y, 1u, sel, ig, cg, cg, tmin, bound);
+        uint32_t k2 = box_key(w1.z, w1.w, w2.x, w3.z, 2u, sel, ig, cg, cg, tmin, bound), k3 = box_key(w2.y, w2.z, w2.w, w3.w, 3u, sel, ig, cg, cg, tmin, bound);
+        sort2(k0, k1); sort2(k2, k3); sort2(k0, k2); sort2(k1, k3); sort2(k1, k2);
+        // The links go through LDS: picking one of four registers by a per-lane index costs 6 VALU instructions (the
+        // kernel's bottleneck), an LDS read at a computed address 2 (k_trace 0.714 -> 0.691 ms).  The scratch is laid out
+        // [child][lane] so that every access of a wave instruction has bank = lane % 32 (the [lane][child] layout with one
+        // 16-byte store put lanes l, l + 8, l + 16, l + 24 of a half-wave on the same banks: 4.6 M conflict cycles per launch,
+        // 22 % of the LDS-active cycles), and all four sorted links are fetched before the first one is used: the reads
+        // are independent, so one LDS round trip covers them instead of one per push (read -> wait -> write, four times over).
+        int* links = aux + 192 + lane;
+        links[0] = (int)w3.x; links[64] = (int)w3.y; links[128] = (int)w3.z; links[192] = (int)w3.w;
+        const int l0 = links[(k0 & 3u) * 64u], l1 = links[(k1 & 3u) * 64u], l2 = links[(k2 & 3u) * 64u], l3 = links[(k3 & 3u) * 64u];
+        // (Three unconditional stores with the stack pointer advancing by one per valid key -- the invalid links of the sorted
+        // sequence are overwritten by the next store or stay above the top -- remove 12 scalar / branch instructions per round
+        // and measured slower, 0.587 -> 0.597 ms: the extra DS stores cost more than the exec-mask branches.)
+        if (k0 == 0xFFFFFFFFu) {
+          cur = SHARE ? st.pop_live() : (st.sp ? st.pop() : kRayDone);
+        } else {
+          if (__ballot(st.sp + 3 > kLdsStack) == 0ull) {   // wave-uniform: every lane stays inside the LDS part of its stack (no spill branches)
+            if (k3 != 0xFFFFFFFFu) { st.lds[st.sp * kBlock] = l3; ++st.sp; }
+            if (k2 != 0xFFFFFFFFu) { st.lds[st.sp * kBlock] = l2; ++st.sp; }
+            if (k1 != 0xFFFFFFFFu) { st.lds[st.sp * kBlock] = l1; ++st.sp; }
+          } else {
+            if (k3 != 0xFFFFFFFFu) st.push(l3);
+            if (k2 != 0xFFFFFFFFu) st.push(l2);
+            if (k1 != 0xFFFFFFFFu) st.push(l1);
+          }
+          cur = l0;
+        }
+      }
+      if (__popcll(__ballot(cur < 0)) >= (exhausted ? GLZ_LEAF_QUORUM_TAIL : (ANY ? GLZ_LEAF_QUORUM_ANY : kLeafQuorum))) break;
+      // (Leaving for a refill as soon as kRefill finished lanes have piled up, without a leaf phase for the few lanes that wait
+      // on a leaf, measured slower: 0.588 -> 0.611 ms, node rounds 41.1 -> 42.1 of 64 lanes.  The idle lanes are not what
+      // holds the utilisation down.)
+    }
+    // ---- leaf phase ----
+    if (COUNT) {
+      const unsigned long long m_leaf = __ballot(cur < 0);
+      if (lane == 0 && m_leaf) { tally.leaf_iters += 1; tally.leaf_lanes += (unsigned)__popcll(m_leaf); }
+    }
+#ifdef GLZ_WAVE_TIMES
+    { const unsigned long long ml = __ballot(cur < 0); if (ml) { wt_leaf_iters += 1; wt_leaf_lanes += (unsigned)__popcll(ml); } }
+#endif
+    if (cur < 0) {
+      // A leaf is one triangle or two adjacent ones (kTriHasPartner on the first).  The partner is fetched after the
+      // first test: six 16-byte loads in flight at once cost 20 more spilled registers (0.64 -> 0.77 ms).
+      const uint32_t leaf = (uint32_t)~cur;
+      bool finished = false;
+      const RayShear rs = ray_shear(d);
+      for (uint32_t slot = leaf;; ++slot) {   // one copy of the test (inlined twice it spilt 15 more registers)
+        const float4* tp = reinterpret_cast<const float4*>(tris + slot);
+        const float4 a = tp[0], b = tp[1], c = tp[2];
+        if (COUNT) tally.tris += 1;
+        BvhTri tr;
+        tr.v0[0] = a.x; tr.v0[1] = a.y; tr.v0[2] = a.z; tr.world_id = __float_as_uint(a.w);
+        tr.v1[0] = b.x; tr.v1[1] = b.y; tr.v1[2] = b.z; tr.instance = __float_as_uint(b.w);
+        tr.v2[0] = c.x; tr.v2[1] = c.y; tr.v2[2] = c.z; tr.prim_flags = __float_as_uint(c.w);
+        float t, u, v;
+        if (ray_triangle(rs, tr, o, tmin, t, u, v) && t < tmax) {
+          const bool better = best.leaf == kNone ? true : (t < best.t || (t == best.t && tr.world_id < best_id));
+          if (better && (!(tr.prim_flags & kTriNonOpaque) || alpha_test(S, slot, u, v))) {
+            best = HitRecord{t, u, v, slot};
+            best_id = tr.world_id;
+            finished = any_lane;
+            if (SHARE && !ANY && exhausted) atomicMin(&aux_t[helper ? (int)ray : lane], __float_as_uint(t));
+          }
+        }
+        if (slot != leaf || !(tr.prim_flags & kTriHasPartner)) break;
+      }
+      cur = finished ? kRayDone : (SHARE ? st.pop_live() : (st.sp ? st.pop() : kRayDone));
+    }
+    // ---- merge: finished helpers hand their result to the owner of the ray ----
+    if (SHARE) {
+      unsigned long long fin = __ballot(helper && cur == kRayDone);
+      while (fin != 0ull) {
+        const int h = __ffsll((long long)fin) - 1;
+        fin &= fin - 1ull;
+        const int ow = __shfl((int)ray, h);
+        const float bt = __shfl(best.t, h), bu = __shfl(best.u, h), bv = __shfl(best.v, h);
+        const uint32_t bl = (uint32_t)__shfl((int)best.leaf, h), bi = (uint32_t)__shfl((int)best_id, h);
+        if (lane == ow && bl != kNone) {
+          const bool better = best.leaf == kNone ? true : (bt < best.t || (bt == best.t && bi < best_id));
+          if (better) {
+            best = HitRecord{bt, bu, bv, bl};
+            best_id = bi;
+          }
+          if (any_lane) cur = kRayDone;   // occluded: the rest of the owner's stack does not matter
+        }
+        if (lane == h) {
+          helper = false;
+          atomicSub(&aux_out[ow], 1);
+        }
+      }
+    }
+    // ---- retire ----
+    if (open && cur == kRayDone && (!SHARE || aux_out[lane] == 0)) {
+      if (COUNT) tally.hits += best.leaf != kNone;
+      sink.store(ray, best);
+      open = false;
+    }
+  }
+#ifdef GLZ_TAIL_PRIO
+  if (SHARE) __builtin_amdgcn_s_setprio(0);
+#endif
+#ifdef GLZ_WAVE_TIMES
+  if (!ANY && lane == 0 && wave < 8192u) {
+    unsigned int* o = g_wave_stats + 8 * wave;
+    o[0] = wt_rounds; o[1] = wt_node_iters; o[2] = wt_node_lanes; o[3] = wt_leaf_iters; o[4] = wt_leaf_lanes; o[5] = wt_helper_rounds; o[6] = wt_wait_rounds;
+  }
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// Two-level traversal (instanced scenes, DeviceScene::two_level; types.h TlasInstance): the same wave-persistent rounds over a
+// top level whose leaves are instances and, inside an instance, the mesh's object-space hierarchy.
+//   * Entering an instance (a top-level leaf, handled in the leaf phase) pushes an exit marker, takes the ray into object space
+//     ONLY to re-derive the grid-space ray of the mesh's own quantisation grid -- with every box widened by the instance's slack,
+//     folded into the slab test's addends -- and continues at the mesh's root.  Popping the marker re-derives the top-level
+//     grid-space ray from the world ray, which never leaves its registers.
+//   * A mesh leaf transforms its one or two OBJECT triangles to world space with the instance's matrix, operation for
+//     operation what k_world_tris does for the flattened build, and runs the same world-space Moeller-Trumbore test: hits
+//     (t, u, v, tie-break by world triangle id) are bit-identical to the flattened twin of the scene, whatever the hierarchy.
+// Simpler than trace_wave on purpose (no tail work sharing, no counters, no staged top): instanced scenes are about memory --
+// O(meshes + instances) instead of O(instances x triangles) -- and must not put the tuned flattened path at risk.
+// ---------------------------------------------------------------------------------------------
+constexpr int kExitInstance = 0x7FFFFFFD;   // stack marker: the entries below belong to the top level
+
+template <bool ANY, class Source, class Sink>
+__device__ __forceinline__ void trace_wave_tl(const DeviceScene& S, Source& src, Sink& sink, int* __restrict__ lds_col, int* aux, uint32_t* __restrict__ spill,
+                                              uint32_t spill_depth, uint32_t total, uint32_t wave, uint32_t n_waves) {
+  constexpr uint32_t kNone = 0xFFFFFFFFu;
+  const BvhNode4* __restrict__ nodes = S.bvh_nodes;        // top-level nodes first, the meshes' after them (TlasInstance::node_base)
+  const BvhTri* __restrict__ tris = S.bvh_tris;
+  const TlasInstance* __restrict__ instances = S.tlas_instances;
+  const int lane = threadIdx.x & 63;
+  const unsigned long long lanes_below = (1ull << lane) - 1ull;
+  uint32_t seq = 0;
+  const RaySequence rays(wave, n_waves, total);
+  bool exhausted = rays.ray_at(0u) >= total;
+  bool open = false;
+  int cur = kRayDone;
+  uint32_t ray = 0, nbase = 0, cur_inst = kNone;
+  vec3 o = mk3(0.0f, 0.0f, 0.0f), d = mk3(0.0f, 0.0f, 1.0f);                                  // the WORLD ray, always
+  vec3 ig = mk3(0.0f, 0.0f, 0.0f), cgn = mk3(0.0f, 0.0f, 0.0f), cgf = mk3(0.0f, 0.0f, 0.0f);    // grid-space ray of the level the lane is in
+  SlabSel sel{0x03020100u, 0x03020100u, 0x03020100u};
+  float tmin = 0.0f, tmax = 0.0f;
+  HitRecord best{0.0f, 0.0f, 0.0f, kNone, 0u, kNone};
+  Stack st{lds_col, spill + ((size_t)(blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 64u + (uint32_t)lane) * spill_depth, 0};
+  // grid-space ray for grid g from a ray (oo, dd) given in that grid's space; boxes widened by `slack` (a length in that space)
+  // plus `cells` cells on every side
+  auto set_grid_ray = [&](const float* glo, const float* gcell, const float* ginv, vec3 oo, vec3 dd, float slack, float cells) {
+    const vec3 og = mk3((oo.x - glo[0]) * ginv[0], (oo.y - glo[1]) * ginv[1], (oo.z - glo[2]) * ginv[2]);
+    ig = mk3(grid_inv_dir(dd.x) * gcell[0], grid_inv_dir(dd.y) * gcell[1], grid_inv_dir(dd.z) * gcell[2]);
+    const vec3 cg = mk3(-(og.x * ig.x), -(og.y * ig.y), -(og.z * ig.z));
+    const vec3 pad = mk3(fminf(slack * ginv[0] + cells, 65536.0f), fminf(slack * ginv[1] + cells, 65536.0f), fminf(slack * ginv[2] + cells, 65536.0f));
+    const vec3 w = mk3(pad.x * fabsf(ig.x), pad.y * fabsf(ig.y), pad.z * fabsf(ig.z));
+    cgn = cg - w;
+    cgf = cg + w;
+    sel = SlabSel{ig.x < 0.0f ? 0x01000302u : 0x03020100u, ig.y < 0.0f ? 0x01000302u : 0x03020100u, ig.z < 0.0f ? 0x01000302u : 0x03020100u};
+  };
+#ifdef GLZ_WAVE_TIMES
+  unsigned long long tl_rays = 0, tl_top = 0, tl_mesh = 0, tl_enter = 0, tl_tris = 0, tl_niter = 0, tl_liter = 0;
+#endif
+  auto to_top_level = [&]() {
+    cur_inst = kNone;
+    nbase = 0u;
+    set_grid_ray(S.bvh_grid.lo, S.bvh_grid.cell, S.bvh_grid.inv_cell, o, d, 0.0f, 0.0f);
+  };
+  auto pop_next = [&]() -> int {
+    for (;;) {
+      if (st.sp == 0) return kRayDone;
+      const int v = st.pop();
+      if (v != kExitInstance) return v;
+      to_top_level();
+    }
+  };
+  for (;;) {
+    // ---- refill ----
+    const unsigned long long idle = __ballot(!open);
+    const int n_idle = __popcll(idle);
+    if (!exhausted && n_idle >= kRefill) {
+      const uint32_t next_ray = rays.ray_at(seq + (uint32_t)__popcll(idle & lanes_below));
+      if (!open && next_ray < total) {
+        if (src.load(next_ray, o, d, tmin, tmax)) {
+          ray = next_ray;
+          best = HitRecord{tmax, 0.0f, 0.0f, kNone, 0u, kNone};
+          if (S.n_world_tris == 0 || !ray_is_finite(o, d)) {
+            sink.store(ray, best);
+          } else {
+            st.sp = 0;
+            to_top_level();
+            cur = 0;
+            open = true;
+#ifdef GLZ_WAVE_TIMES
+            tl_rays += 1;
+#endif
+          }
+        }
+      }
+      seq += (uint32_t)n_idle;
+      exhausted = rays.ray_at(seq) >= total;
+    }
+    if (__ballot(open) == 0ull) {
+      if (exhausted) break;
+      continue;
+    }
+    // ---- inner-node phase (either level) ----
+    for (;;) {
+      const bool at_node = cur >= 0 && cur < kExitInstance;
+      if (__ballot(at_node) == 0ull) break;
+#ifdef GLZ_WAVE_TIMES
+      if (lane == 0) tl_niter += 1;
+      if (at_node) { if (cur_inst == kNone) tl_top += 1; else tl_mesh += 1; }
+#endif
+      if (at_node) {
+        const u32x4* np = reinterpret_cast<const u32x4*>(nodes + nbase + (uint32_t)cur);
+        const u32x4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
+        uint32_t k0 = box_key(w0.x, w0.y, w0.z, w3.x, 0u, sel, ig, cgn, cgf, tmin, best.t), k1 = box_key(w0.w, w1.x, w1.y, w3.y, 1u, sel, ig, cgn, cgf, tmin, best.t);
+        uint32_t k2 = box_key(w1.z, w1.w, w2.x, w3.z, 2u, sel, ig, cgn, cgf, tmin, best.t), k3 = box_key(w2.y, w2.z, w2.w, w3.w, 3u, sel, ig, cgn, cgf, tmin, best.t);
+        sort2(k0, k1); sort2(k2, k3); sort2(k0, k2); sort2(k1, k3); sort2(k1, k2);
+        int* links = aux + 192 + lane;
+        links[0] = (int)w3.x; links[64] = (int)w3.y; links[128] = (int)w3.z; links[192] = (int)w3.w;
+        const int l0 = links[(k0 & 3u) * 64u], l1 = links[(k1 & 3u) * 64u], l2 = links[(k2 & 3u) * 64u], l3 = links[(k3 & 3u) * 64u];
+        if (k0 == 0xFFFFFFFFu) {
+          cur = pop_next();
+        } else {
+          if (k3 != 0xFFFFFFFFu) st.push(l3);
+          if (k2 != 0xFFFFFFFFu) st.push(l2);
+          if (k1 != 0xFFFFFFFFu) st.push(l1);
+          cur = l0;
+        }
+      }
+      if (__popcll(__ballot(cur < 0)) >= kLeafQuorum) break;
+    }
+    // ---- leaf phase: an instance to enter (top level) or triangles to test (inside an instance) ----
+#ifdef GLZ_WAVE_TIMES
+    if (lane == 0 && __ballot(cur < 0) != 0ull) tl_liter += 1;
+    if (cur < 0) { if (cur_inst == kNone) tl_enter += 1; else tl_tris += 1; }
+#endif
+    if (cur < 0) {
+      if (cur_inst == kNone) {
+        cur_inst = (uint32_t)~cur;
+        const TlasInstance* ti = instances + cur_inst;
+        const float4* q = reinterpret_cast<const float4*>(ti->w2o);
+        const float4 r0 = q[0], r1 = q[1], r2 = q[2];
+        // object-space ray (a point and a vector through the 3 x 4 matrix): only the box tests see it
+        const vec3 oo = mk3(((r0.x * o.x + r0.y * o.y) + r0.z * o.z) + r0.w, ((r1.x * o.x + r1.y * o.y) + r1.z * o.z) + r1.w, ((r2.x * o.x + r2.y * o.y) + r2.z * o.z) + r2.w);
+        const vec3 dd = mk3((r0.x * d.x + r0.y * d.y) + r0.z * d.z, (r1.x * d.x + r1.y * d.y) + r1.z * d.z, (r2.x * d.x + r2.y * d.y) + r2.z * d.z);
+        st.push(kExitInstance);
+        nbase = ti->node_base;
+        set_grid_ray(ti->grid.lo, ti->grid.cell, ti->grid.inv_cell, oo, dd, ti->slack, 1.0f);
+        cur = 0;   // the mesh's root
+      } else {
+        const TlasInstance* ti = instances + cur_inst;
+        const uint32_t tri_base = ti->tri_base, first = (uint32_t)~cur;
+        bool finished = false;
+        const RayShear rs = ray_shear(d);
+        for (uint32_t local = first;; ++local) {
+          const uint32_t slot = tri_base + local;
+          const uint32_t prim_flags = tris[slot].prim_flags;
+          const float4* rec = S.shade_tris + 8u * (size_t)slot;
+          const float4 pa = rec[0], pb = rec[2], pc = rec[4];
+          // world triangle exactly as k_world_tris builds it: three points through o2w
+          const vec3 v0 = xform_point(ti->o2w, mk3(pa.x, pa.y, pa.z)), v1 = xform_point(ti->o2w, mk3(pb.x, pb.y, pb.z)), v2 = xform_point(ti->o2w, mk3(pc.x, pc.y, pc.z));
+          BvhTri tr;
+          tr.v0[0] = v0.x; tr.v0[1] = v0.y; tr.v0[2] = v0.z;
+          tr.v1[0] = v1.x; tr.v1[1] = v1.y; tr.v1[2] = v1.z;
+          tr.v2[0] = v2.x; tr.v2[1] = v2.y; tr.v2[2] = v2.z;
+          float t, u, v;
+          if (ray_triangle(rs, tr, o, tmin, t, u, v) && t < tmax) {
+            const uint32_t world_id = ti->world_base + (prim_flags & kTriPrimMask);
+            const bool better = best.leaf == kNone ? true : (t < best.t || (t == best.t && world_id < best.world_id));
+            if (better && (ti->non_opaque == 0u || alpha_test_instance(S, slot, ti->instance, u, v))) {
+              best = HitRecord{t, u, v, slot, ti->instance, world_id};
+              finished = ANY;
+            }
+          }
+          if (local != first || !(prim_flags & kTriHasPartner)) break;
+        }
+        cur = finished ? kRayDone : pop_next();
+      }
+    }
+    // ---- retire ----
+    if (open && cur == kRayDone) {
+      sink.store(ray, best);
+      open = false;
+    }
+  }
+#ifdef GLZ_WAVE_TIMES
+  if (!ANY) {
+    atomicAdd(&g_tl_stats[0], tl_rays); atomicAdd(&g_tl_stats[1], tl_top); atomicAdd(&g_tl_stats[2], tl_mesh); atomicAdd(&g_tl_stats[3], tl_enter);
+    atomicAdd(&g_tl_stats[4], tl_tris); atomicAdd(&g_tl_stats[5], tl_niter); atomicAdd(&g_tl_stats[6], tl_liter);
+  }
+#endif
+}
+
+__device__ __forceinline__ void flush_counters(TraceCounters* c, bool shadow, TraceTally t) {
+  // wave-level reduction first, one atomic per wave and counter (Guideline 12)
+  for (int off = 32; off > 0; off >>= 1) {
+    t.rays += __shfl_down(t.rays, off);
+    t.nodes += __shfl_down(t.nodes, off);
+    t.tris += __shfl_down(t.tris, off);
+    t.hits += __shfl_down(t.hits, off);
+    t.fresh += __shfl_down(t.fresh, off);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    unsigned long long* ph = shadow ? c->phase + 6 : c->phase;
+    atomicAdd(&ph[0], t.node_iters); atomicAdd(&ph[1], t.node_lanes); atomicAdd(&ph[2], t.leaf_iters); atomicAdd(&ph[3], t.leaf_lanes);
+    atomicAdd(&ph[4], t.refill_iters); atomicAdd(&ph[5], t.refill_lanes);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (shadow) {
+      atomicAdd(&c->shadow_rays, t.rays); atomicAdd(&c->shadow_nodes, t.nodes); atomicAdd(&c->shadow_tris, t.tris);
+    } else {
+      atomicAdd(&c->closest_rays, t.rays); atomicAdd(&c->closest_nodes, t.nodes); atomicAdd(&c->closest_tris, t.tris);
+      atomicAdd(&c->hits, t.hits);
+      atomicAdd(&c->fresh, t.fresh);
+    }
+  }
+}
+
+// persistent launch geometry: every wave of the grid is one independent tracer
+// (XCD-aware numbering -- the blocks with b % 8 == x, which share an L2, taking one contiguous run of groups / pixels each,
+// cdna_hip_programming.md T1 -- measured slower for both kernels: k_trace 0.588 -> 0.621 ms, k_shade 0.348 -> 0.357 ms, a 1/8
+// share 0.162 -> 0.188 ms.  Neighbouring regions differ in cost; dealing them round-robin over the XCDs balances that, and
+// the L2s' hit rates are not what bounds either kernel.)
+__device__ __forceinline__ uint32_t wave_index() { return blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); }
+__device__ __forceinline__ uint32_t wave_count() { return gridDim.x * (kBlock / 64); }
+
+// ---------------------------------------------------------------------------------------------
+// closest-hit phase of k_trace: path_trace.rgen:143-169
+// ---------------------------------------------------------------------------------------------
+struct ClosestSource {
+  const LaunchArgs& A;
+  const FrameData& F;   // the launch's constants (k_trace: A.frame; k_path: one entry of its batch)
+  TraceTally& tally;
+  uint32_t base;        // ray i is local pixel base + i (k_trace: 0; k_path: the first pixel of the wave's group)
+  // ray generation / resume for local pixel `lid`
+  // (Dealing the rays of a group from 4, 16 or 64 different tiles instead of one row of one tile -- to level the waves of a small
+  // share, whose ends spread from 60 (median) to 105 us -- changes nothing: the spread is not regional, a wave is as slow as the
+  // longest dependent chain among its 64 rays.  Median and end of the phase moved by +3 ... +8 % with the coherence lost.)
+  __device__ __forceinline__ bool load(uint32_t i, vec3& origin, vec3& direction, float& tmin, float& tmax) {
+    const uint32_t lid = base + i;
+    const PixelId px = pixel_of(A.map, lid);
+    if (!px.active) return false;
+    const float4 ro = A.st.ray_o[lid], rd = A.st.ray_d[lid];
+    if (F.direct_only || ro.w == 0.0f) {
+      tally.fresh += 1;
+      // new path: camera ray through the jittered pixel (ray_origin / ray_dir, path_trace.rgen:47-73)
+      const float pxf = (float)px.x + F.pixel_offset[0], pyf = (float)px.y + F.pixel_offset[1];
+      const float ndcx = -1.0f + 2.0f * (pxf / F.scene_size[0]), ndcy = -1.0f + 2.0f * (pyf / F.scene_size[1]);
+      const float* c2w = A.cam.camera2world;
+      const float* s2c = A.cam.screen2camera;
+      const float ortho = gl_step(0.5f, F.camera_persp ? 0.0f : 1.0f), persp = gl_step(0.5f, F.camera_persp ? 1.0f : 0.0f);
+      const float ox = ndcx * ortho, oy = ndcy * ortho;
+      origin = mk3((c2w[0] * ox + c2w[4] * oy) + c2w[12], (c2w[1] * ox + c2w[5] * oy) + c2w[13], (c2w[2] * ox + c2w[6] * oy) + c2w[14]);
+      const float fx = ndcx * persp, fy = ndcy * persp;
+      const vec3 target = mk3(((s2c[0] * fx + s2c[4] * fy) + s2c[8]) + s2c[12], ((s2c[1] * fx + s2c[5] * fy) + s2c[9]) + s2c[13],
+                              ((s2c[2] * fx + s2c[6] * fy) + s2c[10]) + s2c[14]);
+      const vec3 nt = normalize3(target);
+      const float dx = (c2w[0] * nt.x + c2w[4] * nt.y) + c2w[8] * nt.z, dy = (c2w[1] * nt.x + c2w[5] * nt.y) + c2w[9] * nt.z;
+      const float dz = (c2w[2] * nt.x + c2w[6] * nt.y) + c2w[10] * nt.z, dw = (c2w[3] * nt.x + c2w[7] * nt.y) + c2w[11] * nt.z;
+      const float inv = 1.0f / sqrtf(((dx * dx + dy * dy) + dz * dz) + dw * dw);   // normalize() of the vec4
+      direction = mk3(dx * inv, dy * inv, dz * inv);
+      A.st.ray_o[lid] = make_float4(origin.x, origin.y, origin.z, ro.w);
+      A.st.ray_d[lid] = make_float4(direction.x, direction.y, direction.z, rd.w);
+    } else {
+      origin = mk3(ro.x, ro.y, ro.z);
+      direction = mk3(rd.x, rd.y, rd.z);
+    }
+    tmin = 0.0001f;
+    tmax = INFINITY;
+    return true;
+  }
+};
+struct ClosestSink {
+  const LaunchArgs& A;
+  __device__ __forceinline__ void store(uint32_t lid, const HitRecord& h) {
+    A.st.hit[lid] = make_float4(h.leaf == 0xFFFFFFFFu ? INFINITY : h.t, h.u, h.v, __uint_as_float(h.leaf));
+  }
+};
+
+// update_count() + update_result() of path_trace.rgen:119-133 for one pixel
+__device__ __forceinline__ void accumulate_pixel(const LaunchArgs& A, uint32_t lid, vec3 c, bool add, bool update, float exposure) {
+  float4 cum = A.st.cumulative[lid];
+  cum.w += 1.0f;
+  if (update) {
+    if (add) { cum.x += c.x; cum.y += c.y; cum.z += c.z; }
+    A.st.result[lid] = make_float4(cum.x * exposure / cum.w, cum.y * exposure / cum.w, cum.z * exposure / cum.w, 1.0f);
+  }
+  A.st.cumulative[lid] = cum;
+}
+
+// Shadow-ray queue: 8 sub-queues ("shards"), shard = blockIdx % 8.  Blocks b and b+8 are observed to land on
+// the same XCD, so a shard's counter line tends to stay in one XCD's L2; more importantly eight counters on
+// separate 128-byte lines take eight times the append rate of one word (MI355X_MICROARCH.md, row `dequeue`).
+// A shard only receives entries from its own blocks, so its capacity ceil(blocks/8) * kBlock can never overflow.
+__device__ __forceinline__ uint32_t queue_capacity(uint32_t n_local_pixels) {
+  const uint32_t blocks = (n_local_pixels + kBlock - 1) / kBlock;
+  return ((blocks + kQueueShards - 1) / kQueueShards) * kBlock;
+}
+// Appends the lanes with `push` set: one atomic per wave (ballot + popcount); the wave's entries are contiguous so
+// the three float4 stores stay coalesced.  Returns the entry index in the queue arrays.
+__device__ __forceinline__ uint32_t queue_slot(uint32_t* counters, uint32_t n_local_pixels, bool push) {
+  const unsigned long long m = __ballot(push);
+  uint32_t slot = 0;
+  if (push) {
+    const uint32_t shard = blockIdx.x % kQueueShards;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)m) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(counters + shard * kCounterStride, (uint32_t)__popcll(m));
+    base = __shfl(base, leader);
+    slot = shard * queue_capacity(n_local_pixels) + base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+  }
+  return slot;
+}
+
+// ---------------------------------------------------------------------------------------------
+// One pixel of path_trace.rgen:170-237 minus the two traceRayEXT calls, with raytrace_hit.rchit:30-71 in front: what k_shade
+// runs for the pixel at its sorted slot and what k_path (the per-wave launch loop of a small tile share) runs for each of a
+// wave's 64 pixels.  `hr` is the closest-hit record of this launch, `queue.slot(push)` hands out the shadow-queue entry (all
+// lanes that get this far call it together).
+// ---------------------------------------------------------------------------------------------
+struct SharedQueue {   // k_shade: the rank's sharded queue in HBM, drained by the next k_trace
+  const LaunchArgs& A;
+  __device__ __forceinline__ uint32_t slot(bool push) { return queue_slot(A.st.queue_count + A.shade_set * kQueueSetWords, A.map.n_local_pixels, push); }
+};
+template <class Queue>
+__device__ __forceinline__ void shade_pixel(const LaunchArgs& A, const DeviceScene& S, const FrameData& F, uint32_t lid, PixelId px, float4 ro, float4 rd, float4 hr, Queue& queue) {
+  const bool fresh = F.direct_only || ro.w == 0.0f;
+  float bounce = F.direct_only ? 0.0f : ro.w;
+  const vec3 direction = mk3(rd.x, rd.y, rd.z);
+  // The path's importance (16 floats) is read where it is used -- the radiance of the light sample, the roulette, the final product --
+  // instead of once up front: held through texture fetches, light sampling and the two BSDF calls it set the kernel's register peak.
+  // The re-reads hit the lines the first read brought in.
+  auto load_importance = [&]() {
+    asm volatile("" ::: "memory");   // a fresh read every time: merged with an earlier one the values would stay in registers in between
+    Spec imp;
+    if (fresh) {
+      imp = spec_set(1.0f);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 v = A.st.imp[q][lid];
+        imp.w[4 * q] = v.x; imp.w[4 * q + 1] = v.y; imp.w[4 * q + 2] = v.z; imp.w[4 * q + 3] = v.w;
+      }
+    }
+    return imp;
+  };
+  const uint32_t leaf = __float_as_uint(hr.w);
+  if (leaf == 0xFFFFFFFFu) {
+    // miss: optional sky radiance, path reset (path_trace.rgen:170-179)
+    uint32_t flags = 0;
+    vec3 c = mk3(0.0f, 0.0f, 0.0f);
+    if ((bounce == 0.0f || rd.w == 1.0f) && S.sky.tex_id > 0) {
+      const vec3 w = normalize3(xform_dir(S.sky.world2obj, direction));   // sky_radiance, :75-82
+      const float phi = glz_atan2f(w.y, w.x), theta = glz_acosf(w.z);
+      const vec3 texel = texture_rgb(S, S.sky.tex_id, vec2{phi * kInv2Pi, theta * kInvPi});
+      c = spec_to_rgb(spec_mul(load_importance(), from_illuminant_color(texel)));
+      flags = kFlagUpdate;
+    }
+    accumulate_pixel(A, lid, c, true, flags != 0, F.exposure);
+    if (!F.direct_only) A.st.ray_o[lid] = make_float4(ro.x, ro.y, ro.z, 0.0f);   // RESET_PATH
+    return;
+  }
+  // ---- closest-hit shader (raytrace_hit.rchit:30-71), inputs from the 128-byte per-leaf shading record ----
+  const float4* rec = S.shade_tris + 8u * (size_t)leaf;
+  const float4 va0 = rec[0], va1 = rec[1], vb0 = rec[2], vb1 = rec[3], vc0 = rec[4], vc1 = rec[5], dn = rec[6], du = rec[7];
+  uint32_t material_id = __float_as_uint(dn.w), xf_bits = __float_as_uint(du.w);
+  if (S.two_level) {   // the record is per OBJECT triangle: material and transform are the instance's
+    const RTInstance in = S.instances[A.st.hit_inst[lid]];
+    material_id = in.material_id;
+    xf_bits = in.transform_id | (S.xf_identity[in.transform_id] ? 0x80000000u : 0u);
+  }
+  const float b0 = 1.0f - hr.y - hr.z, b1 = hr.y, b2 = hr.z;
+  vec3 point = (mk3(va0.x, va0.y, va0.z) * b0 + mk3(vb0.x, vb0.y, vb0.z) * b1) + mk3(vc0.x, vc0.y, vc0.z) * b2;
+  const vec2 uv = vec2{(va1.z * b0 + vb1.z * b1) + vc1.z * b2, (va1.w * b0 + vb1.w * b1) + vc1.w * b2};
+  vec3 ng = mk3(dn.x, dn.y, dn.z), dpdu = mk3(du.x, du.y, du.z);   // dpdv is transformed by the reference but never read afterwards
+  vec3 ns = (mk3(va0.w, va1.x, va1.y) * b0 + mk3(vb0.w, vb1.x, vb1.y) * b1) + mk3(vc0.w, vc1.x, vc1.y) * b2;
+  const MatScalars mat = load_material(&S.materials[material_id]);
+  // ---- texture level of detail by ray cones (build-defined, off by default: the reference's stages sample level 0) ----
+  // The cone of a camera path starts cone_width0 wide and widens by cone_spread per unit of distance along the whole path;
+  // at a hit the footprint on the surface is width / |cos|, and a texture of W x H texels over a triangle with texture-space
+  // area A_uv and world area A_w is minified by sqrt(A_uv W H / A_w) texels per unit length:
+  // level = 0.5 log2(A_uv / A_w * width^2 / cos^2) + 0.5 log2(W H)      (Akenine-Moeller et al., ray cones)
+  float lod_base = kNoLod, cone_w = 0.0f;
+  if (F.lod_mode != 0u) {
+    cone_w = (fresh ? F.cone_width0 : A.st.cone[lid]) + F.cone_spread * hr.x;
+    vec3 e1 = mk3(vb0.x, vb0.y, vb0.z) - mk3(va0.x, va0.y, va0.z), e2 = mk3(vc0.x, vc0.y, vc0.z) - mk3(va0.x, va0.y, va0.z);
+    vec3 n = mk3(dn.x, dn.y, dn.z);
+    if (!(xf_bits >> 31)) {
+      const TransformPair* xf = &S.transforms[xf_bits & 0x7FFFFFFFu];
+      e1 = xform_dir(xf->o2w, e1);
+      e2 = xform_dir(xf->o2w, e2);
+      n = xform_tdir(xf->w2o, n);
+    }
+    const vec3 cr = cross3(e1, e2);
+    const float area2 = sqrtf(dot3(cr, cr));
+    const float uva2 = fabsf((vb1.z - va1.z) * (vc1.w - va1.w) - (vc1.z - va1.z) * (vb1.w - va1.w));
+    const float cosv = fabsf(dot3(n, direction)) / sqrtf(dot3(n, n));
+    const float x = ((uva2 / area2) * (cone_w * cone_w)) / (cosv * cosv);
+    if (x >= 1.17549435e-38f && x <= 3.4e38f) lod_base = 0.5f * glz_log2f(x);
+  }
+  if (mat.normal != 0) {
+    const vec4 tx = texture2d_lod(S, mat.normal, uv.x, uv.y, lod_base);
+    Frame old;
+    old.s = normalize3(dpdu);
+    old.n = ns;
+    old.t = normalize3(cross3(old.n, old.s));
+    ns = normalize3(to_world(mk3(tx.x * 2.0f - 1.0f, tx.y * 2.0f - 1.0f, tx.z * 2.0f - 1.0f), old));
+    ns = ns * gl_sign(dot3(ng, ns));
+  }
+  if (!(xf_bits >> 31)) {
+    // object -> world.  Skipped for an exact identity transform: m*x with m = I reproduces x bit for bit
+    // (x*1 + y*0 + z*0 + 0 for finite coordinates), so the result is unchanged and ~25 scalar loads are saved.
+    const float4* xq = reinterpret_cast<const float4*>(&S.transforms[xf_bits & 0x7FFFFFFFu]);
+    const float4 m0 = xq[0], m1 = xq[1], m2 = xq[2], m3 = xq[3], w0 = xq[4], w1 = xq[5], w2 = xq[6];
+    const float o2w[16] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w, m2.x, m2.y, m2.z, m2.w, m3.x, m3.y, m3.z, m3.w};
+    const float w2o[12] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
+    point = xform_point(o2w, point);
+    dpdu = xform_point(o2w, dpdu);   // transformed as a point, w = 1 (Q8)
+    ng = xform_tdir(w2o, ng);
+    ns = xform_tdir(w2o, ns);
+  }
+  (void)ng;
+  // ---- raygen continues (path_trace.rgen:180-237) ----
+  uint32_t rng = pcg(__float_as_uint((float)F.seed) ^ pcg(__float_as_uint((float)px.x) ^ pcg(__float_as_uint((float)px.y))));   // :143, Q11
+  SurfacePoint P;
+  P.woW = -direction;
+  P.uv = uv;
+  P.frame = make_frame(dpdu, ns);
+  P.mat = mat;
+  fetch_material_textures(S, P, lod_base);
+  float spec_flag;
+  float imp_lum = 0.0f;      // luminance of the importance, taken when the light-sampling block reads it: the roulette needs nothing else of it
+  bool have_lum = false;
+  if (mat.is_specular == 0) {
+    // direct_light(), :84-117
+    const uint32_t li = (uint32_t)gl_min(rand01(rng) * (float)F.lights_no, (float)(F.lights_no - 1u));
+    vec3 xi;
+    xi.x = rand01(rng); xi.y = rand01(rng); xi.z = rand01(rng);
+    LightSample ls;
+    ls.pdf = 0.0f;
+    sample_light(S, li, point, xi, F.scene_radius, ls);
+    vec3 c = mk3(0.0f, 0.0f, 0.0f);
+    uint32_t flags = kFlagUpdate;
+    vec3 sh_dir = mk3(0.0f, 0.0f, 0.0f);
+    float sh_tmax = 0.0f;
+    if (ls.pdf > 0.0f) {
+      const float xi_b = rand01(rng);
+      Spec value = spec_set(0.0f);
+      const float bpdf = bsdf_eval(S, P, ls.wiW, xi_b, value);
+      if (bpdf > 0.0f) {
+        // weight_light = (1 or 0) * |cos| / pdf; radiance = value*emission*weight*lights_no*importance
+        const float w_vis = 1.0f * (fabsf(dot3(ls.wiW, ns)) / ls.pdf);
+        const float w_occ = 0.0f * (fabsf(dot3(ls.wiW, ns)) / ls.pdf);
+        const float nl = (float)F.lights_no;
+        const Spec emission = light_emission(ls);
+        const Spec importance = load_importance();
+        imp_lum = spec_luminance(importance);
+        have_lum = true;
+        Spec rad;
+        float poison = 0.0f;
+        GLZ_BINS {
+          const float rl = value.w[i] * emission.w[i];
+          rad.w[i] = ((rl * w_vis) * nl) * importance.w[i];
+          poison += ((rl * w_occ) * nl) * importance.w[i];
+        }
+        c = spec_to_rgb(rad);
+        flags |= kFlagShadow | (poison == poison ? 0u : kFlagPoison);
+        sh_dir = ls.wiW;
+        sh_tmax = ls.distance - 1e-3f;
+      }
+    }
+    if (!(flags & kFlagShadow)) {
+      // no light sample: the reference still adds rgb(0 * lights_no * importance), which is NaN for a non-finite importance
+      const Spec importance = load_importance();
+      imp_lum = spec_luminance(importance);
+      have_lum = true;
+      float probe = 0.0f;
+      GLZ_BINS probe += 0.0f * importance.w[i];
+      if (probe != probe) c = spec_to_rgb(spec_scale(importance, 0.0f * (float)F.lights_no));
+    }
+    // shadow-ray queue (consumed by the next launch's k_trace); pixels without a shadow ray are accumulated right here
+    const bool push = (flags & kFlagShadow) != 0;
+    const uint32_t slot = queue.slot(push);
+    if (push) {
+      A.st.sh_o[slot] = make_float4(point.x, point.y, point.z, sh_tmax);
+      A.st.sh_d[slot] = make_float4(sh_dir.x, sh_dir.y, sh_dir.z, __uint_as_float(lid));
+      A.st.contrib[slot] = make_float4(c.x, c.y, c.z, __uint_as_float(flags));
+    } else {
+      accumulate_pixel(A, lid, c, true, true, F.exposure);
+    }
+    spec_flag = 0.0f;
+  } else {
+    accumulate_pixel(A, lid, mk3(0.0f, 0.0f, 0.0f), false, false, F.exposure);
+    spec_flag = 1.0f;
+  }
+  if (F.direct_only) return;
+  // Russian roulette (:197-210)
+  float rr_scale = 1.0f;   // importance * 1.0f is importance, bit for bit: the paths that skip the roulette multiply by it too
+  if (bounce > (float)(F.pt_steps / 2u)) {
+    const float kill = gl_max(0.05f, 1.0f - (have_lum ? imp_lum : spec_luminance(load_importance())));
+    if (rand01(rng) < kill) {
+      A.st.ray_o[lid] = make_float4(ro.x, ro.y, ro.z, 0.0f);
+      A.st.ray_d[lid] = make_float4(rd.x, rd.y, rd.z, spec_flag);
+      return;
+    }
+    rr_scale = 1.0f / (1.0f - kill);
+  }
+  vec3 xi;
+  xi.x = rand01(rng); xi.y = rand01(rng); xi.z = rand01(rng);
+  Spec value = spec_set(0.0f);
+  vec3 wiW = mk3(0.0f, 0.0f, 0.0f);
+  const float pdf = bsdf_sample(S, P, xi, value, wiW);   // :212-218
+  if (pdf == 0.0f) {
+    A.st.ray_o[lid] = make_float4(ro.x, ro.y, ro.z, 0.0f);
+    A.st.ray_d[lid] = make_float4(rd.x, rd.y, rd.z, spec_flag);
+    return;
+  }
+  float weight = fabsf(dot3(wiW, ns));
+  weight /= pdf;
+  const Spec importance = spec_scale(load_importance(), rr_scale);
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    A.st.imp[q][lid] = make_float4(importance.w[4 * q] * (value.w[4 * q] * weight), importance.w[4 * q + 1] * (value.w[4 * q + 1] * weight),
+                                   importance.w[4 * q + 2] * (value.w[4 * q + 2] * weight), importance.w[4 * q + 3] * (value.w[4 * q + 3] * weight));
+  bounce = bounce < (float)F.pt_steps ? bounce + 1.0f : 0.0f;   // :230-237
+  if (F.lod_mode != 0u) A.st.cone[lid] = cone_w;
+  A.st.ray_o[lid] = make_float4(point.x, point.y, point.z, bounce);
+  A.st.ray_d[lid] = make_float4(wiW.x, wiW.y, wiW.z, spec_flag);
+}
+
+constexpr uint32_t kShadeTableBytes = 16384;   // LDS copy of the material / light / texture-descriptor tables (78 materials alone would fill it)
+
+// ---------------------------------------------------------------------------------------------
+// Shadow rays: the shadow traceRayEXT (path_trace.rgen:106-110) for the compacted queue written by k_shade,
+// followed by update_count / update_result (:119-133) of the owning pixel (source / sink of k_trace's second phase).
+// ---------------------------------------------------------------------------------------------
+struct ShadowSource {
+  const LaunchArgs& A;
+  const uint32_t* start;   // prefix sums of the shard counts (kQueueShards + 1 entries)
+  uint32_t cap;
+  uint32_t lid;            // per-lane: owning pixel and contribution of the ray in flight
+  float4 contrib;
+  __device__ __forceinline__ bool load(uint32_t i, vec3& o, vec3& d, float& tmin, float& tmax) {
+    uint32_t shard = 0;
+#pragma unroll
+    for (uint32_t k = 1; k < kQueueShards; ++k) shard += i >= start[k] ? 1u : 0u;
+    const uint32_t q = shard * cap + (i - start[shard]);
+    const float4 so = A.st.sh_o[q], sd = A.st.sh_d[q];
+    contrib = A.st.contrib[q];
+    lid = __float_as_uint(sd.w);
+    o = mk3(so.x, so.y, so.z);
+    d = mk3(sd.x, sd.y, sd.z);
+    tmin = 0.001f;
+    tmax = so.w;
+    return true;
+  }
+};
+struct ShadowSink {
+  const LaunchArgs& A;
+  ShadowSource& src;
+  __device__ __forceinline__ void store(uint32_t, const HitRecord& h) {
+    const bool occluded = h.leaf != 0xFFFFFFFFu;
+    const uint32_t flags = __float_as_uint(src.contrib.w);
+    vec3 c = mk3(src.contrib.x, src.contrib.y, src.contrib.z);
+    bool add = !occluded;
+    if (occluded && (flags & kFlagPoison)) {
+      const float nan = __uint_as_float(0x7FC00000u);
+      c = mk3(nan, nan, nan);
+      add = true;
+    }
+    accumulate_pixel(A, src.lid, c, add, true, A.shadow_exposure);
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// k_trace: ONE persistent traversal kernel per launch.  Every wave first works through its share of the closest-hit
+// rays of launch L (ray generation / resume + traversal -> hit[lid]), then through its share of the shadow rays that
+// launch L-1's k_shade queued (any-hit traversal, then update_count / update_result of the owning pixel).  The shadow
+// test of a launch only gates an accumulation -- the path itself continues from k_shade's output -- so deferring it
+// into the next launch's traversal changes no result, takes one kernel and one dependent drain off every launch's
+// critical path, and lets waves that finish their closest-hit share early start on shadow rays instead of idling
+// (strong scaling: at 1/8 of a 1080p frame per GPU the launch was 0.146 + 0.073 + 0.183 ms with three kernels).
+// k_shade of launch L runs after this kernel, so the accumulations of launch L-1 land before those of launch L:
+// the per-pixel order of `cum += c` is the reference's.
+// Two counter sets: this kernel drains set shade_set ^ 1 and clears set shade_set for the k_shade that follows.
+// ---------------------------------------------------------------------------------------------
+// copies the scene's top-of-tree table (types.h kBvhTopNodes) into the block's LDS; ends with a block barrier
+__device__ __forceinline__ void stage_top(const DeviceScene& S, uint4* s_top) {
+  if (kLdsTop) {
+    const uint4* src = reinterpret_cast<const uint4*>(S.bvh_top);
+    if (threadIdx.x < kBvhTopNodes * 4) s_top[threadIdx.x] = src[threadIdx.x];
+    __syncthreads();
+  }
+}
+
+#ifdef GLZ_WAVE_TIMES   // tuning builds only (tools/build_variant.sh, tools/gpu_wave_times.py): when each wave of the last k_trace with closest-hit rays started, finished those and ended
+#define GLZ_WAVE_STAMP(k) do { if (A.do_closest && (threadIdx.x & 63) == 0 && wave_index() < 8192u) g_wave_times[3 * wave_index() + (k)] = wall_clock64(); } while (0)
+#else
+#define GLZ_WAVE_STAMP(k) do { } while (0)
+#endif
+
+}  // namespace glz

@@ -70,6 +70,7 @@ struct PathState {
   float4* result;    // result_image (out32)
   uint32_t* overflow;// traversal stack spill, `overflow_depth` words per lane slot of the k_trace grid
   uint32_t overflow_depth;
+  uint32_t* path_cost;// k_path: [0..7] two accumulators {sum of per-launch ticks (u64), groups (u32), pad}, then one word per 64-pixel group: its ticks per launch in the last batch
 };
 
 struct TileMap {
@@ -104,13 +105,13 @@ struct LaunchArgs {
   float shadow_exposure;     // exposure of the launch that queued the shadow rays (update_result uses it)
 };
 // The launches one k_path call runs (kernels_render.hip): what differs between launches, by value in the kernel arguments
-constexpr uint32_t kPathMaxLaunches = 16;
+constexpr uint32_t kPathMaxLaunches = 16;   // 16 x 100 bytes of FrameData + LaunchArgs stay inside the 4 KB of kernel arguments
 struct PathBatch {
   uint32_t n;                              // launches in this call
   uint32_t tables_in_lds;                  // filled by launch_path
-  uint32_t seed[kPathMaxLaunches];         // FrameData::seed of each
-  float offset[kPathMaxLaunches][2];       // FrameData::pixel_offset
-  float exposure[kPathMaxLaunches];        // FrameData::exposure
+  uint32_t parity;                         // which of the two cost accumulators this batch adds to (it reads the other one)
+  FrameData frame[kPathMaxLaunches];       // RTFrameData of each launch, whole: the kernel reads a launch's constants from the kernel
+                                           // arguments where it needs them (scalar loads) instead of carrying a copy through its loop
 };
 constexpr uint32_t kTraceBlock = 256;          // threads per block of the render kernels (4 waves)
 constexpr uint32_t kQueueSetWords = 8 * 32;   // 8 shard counters, 128 bytes apart

@@ -281,6 +281,8 @@ bool Renderer::allocate(Error& err) {
     // traversal spill: one slot of `od` entries per lane of the largest of the persistent grids
     if (!hip_ok(c->overflow.alloc((size_t)std::max(std::max(c->grid, c->grid_counting), c->grid_path) * kTraceBlock * od), "alloc traversal spill", err)) return false;
     if (!hip_ok(c->queue_count.alloc(2 * kQueueSetWords), "alloc queue counters", err)) return false;
+    if (!hip_ok(c->path_cost.alloc(8 + n / 64 + 1), "alloc path costs", err)) return false;
+    if (!hip_ok(hipMemsetAsync(c->path_cost.ptr, 0, sizeof(uint32_t) * (8 + n / 64 + 1), c->stream), "clear path costs", err)) return false;
     chains_.push_back(std::move(c));
   }
   if (!hip_ok(frame_tmp_.alloc((size_t)w_ * h_), "alloc frame", err)) return false;
@@ -338,6 +340,7 @@ void Renderer::fill_args(const Chain& c, LaunchArgs& a) const {
   a.st.result = c.result.ptr;
   a.st.overflow = c.overflow.ptr;
   a.st.overflow_depth = scene_->stack_overflow_depth;
+  a.st.path_cost = c.path_cost.ptr;
   a.map = c.map;
   a.cam = cam_;
   a.counters = counting_ ? counters_.ptr : nullptr;
@@ -477,10 +480,12 @@ bool Renderer::path_batch(uint32_t n, Error& err) {
   PathBatch b;
   memset(&b, 0, sizeof(b));
   b.n = n;
+  b.parity = chains_[0]->path_batches++ & 1u;
   for (uint32_t i = 0; i < n; ++i) {
-    b.seed[i] = rng_.next();
-    sched_.next(b.offset[i]);
-    b.exposure[i] = exposure_;
+    b.frame[i] = fd;
+    b.frame[i].seed = rng_.next();           // rng.gen::<u32>(), raytracer.rs:487
+    sched_.next(b.frame[i].pixel_offset);    // WorkScheduler::next(), :489
+    b.frame[i].exposure = exposure_;
   }
   launches_ += n;
   if (fd.lights_no == 0) return true;   // the raygen shader returns before touching anything (path_trace.rgen:137-141)
@@ -496,6 +501,8 @@ bool Renderer::path_batch(uint32_t n, Error& err) {
     ev.kind = 2;
     (void)hipEventRecord(ev.e[0], c.stream);
   }
+  // the cost accumulator this batch adds to starts empty (the kernel reads the other one, which the batch before filled)
+  if (!hip_ok(hipMemsetAsync(c.path_cost.ptr + 4u * b.parity, 0, 16, c.stream), "clear path cost accumulator", err)) return false;
   if (!hip_ok(launch_path(c.stream, a, b, c.grid_path), "k_path", err)) return false;
   if (profile_kernels_) {
     (void)hipEventRecord(ev.e[1], c.stream);
