@@ -19,6 +19,38 @@ inline int paeth(int a, int b, int c) {
 }
 }  // namespace
 
+// The container without the pixels: signature, chunk framing, every chunk's CRC, IHDR -- what catches a damaged file at a fraction
+// of the cost of inflating and un-filtering it (the parser checks the mip levels it does not need yet this way).
+bool png_check(const uint8_t* data, size_t size, uint32_t& width, uint32_t& height, std::string& err) {
+  static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+  if (size < 8 || memcmp(data, sig, 8) != 0) { err = "png: bad signature"; return false; }
+  size_t pos = 8;
+  bool have_ihdr = false, have_iend = false, have_idat = false;
+  while (pos + 12 <= size && !have_iend) {
+    const uint32_t len = be32(data + pos);
+    const uint8_t* type = data + pos + 4;
+    if (pos + 12 + (size_t)len > size) { err = "png: truncated chunk"; return false; }
+    const uint8_t* body = data + pos + 8;
+    if ((uint32_t)::crc32(::crc32(0, Z_NULL, 0), type, 4 + len) != be32(body + len)) { err = "png: chunk CRC mismatch"; return false; }
+    if (!memcmp(type, "IHDR", 4)) {
+      if (len != 13) { err = "png: bad IHDR"; return false; }
+      width = be32(body);
+      height = be32(body + 4);
+      if (body[10] != 0 || body[11] != 0) { err = "png: unknown compression/filter method"; return false; }
+      if (body[12] != 0) { err = "png: interlaced images are not supported"; return false; }
+      have_ihdr = true;
+    } else if (!memcmp(type, "IDAT", 4)) {
+      have_idat = true;
+    } else if (!memcmp(type, "IEND", 4)) {
+      have_iend = true;
+    }
+    pos += 12 + (size_t)len;
+  }
+  if (!have_ihdr || !have_iend || !have_idat) { err = "png: missing IHDR/IDAT/IEND"; return false; }
+  if (width == 0 || height == 0 || width > 65535 || height > 65535) { err = "png: bad dimensions"; return false; }
+  return true;
+}
+
 bool png_decode(const uint8_t* data, size_t size, int want, uint32_t& width, uint32_t& height,
                 std::vector<uint8_t>& pixels, std::string& err) {
   static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};

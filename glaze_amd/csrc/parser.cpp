@@ -12,6 +12,22 @@
 #include "codec/xz_dec.h"
 
 namespace glz {
+
+bool TextureData::decode_more_levels(std::string& err) {
+  if (more_levels.size() == more_png.size()) return true;
+  std::vector<std::vector<uint8_t>> levels(more_png.size());
+  for (size_t l = 0; l < more_png.size(); ++l) {
+    uint32_t w = 0, h = 0;
+    if (!png_decode(more_png[l].data(), more_png[l].size(), info.format == GLZ_TEX_GRAY ? 1 : 4, w, h, levels[l], err)) return false;
+    if (w != more_dims[2 * l] || h != more_dims[2 * l + 1]) {
+      err = "png: level dimensions changed";
+      return false;
+    }
+  }
+  more_levels = std::move(levels);
+  return true;
+}
+
 namespace {
 
 constexpr uint64_t kHasherSeed = 0x368262AAA1DEB64Dull;  // parser/v1.rs:41
@@ -400,7 +416,7 @@ bool Parsed::textures(const std::vector<TextureData>*& out, Error& err) {
           size_t ml = rd32(b + idx);
           idx += 4;
           if (idx + ml > n) { fail(errs[i], GLZ_E_INVALID_DATA, "Corrupted textures"); return; }
-          {  // level 0 is what the reference's ray-tracing stages sample; the other levels feed the opt-in texture LOD
+          if (lvl == 0) {   // level 0 is what the reference's ray-tracing stages sample
             std::string perr;
             uint32_t w, h;
             std::vector<uint8_t> px;
@@ -408,15 +424,19 @@ bool Parsed::textures(const std::vector<TextureData>*& out, Error& err) {
               fail(errs[i], GLZ_E_INVALID_DATA, "Corrupted image: " + perr);
               return;
             }
-            if (lvl == 0) {
-              t.level0 = std::move(px);
-              t.info.width = w;
-              t.info.height = h;
-            } else {
-              t.more_levels.push_back(std::move(px));
-              t.more_dims.push_back(w);
-              t.more_dims.push_back(h);
+            t.level0 = std::move(px);
+            t.info.width = w;
+            t.info.height = h;
+          } else {          // the other levels feed the opt-in texture LOD: checked now, decoded when the chain is wanted
+            std::string perr;
+            uint32_t w, h;
+            if (!png_check(b + idx, ml, w, h, perr)) {
+              fail(errs[i], GLZ_E_INVALID_DATA, "Corrupted image: " + perr);
+              return;
             }
+            t.more_png.emplace_back(b + idx, b + idx + ml);
+            t.more_dims.push_back(w);
+            t.more_dims.push_back(h);
           }
           idx += ml;
         }

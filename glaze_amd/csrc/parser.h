@@ -22,6 +22,12 @@ struct TextureData {
   // otherwise the chain is generated at upload (mipchain.h)
   std::vector<std::vector<uint8_t>> more_levels;
   std::vector<uint32_t> more_dims;   // width, height per stored level
+  // The parser keeps the stored levels 1.. as the PNG files they are (container and CRCs checked at parse, so a damaged file still
+  // fails there) and decodes them when the mip chain is first wanted (Scene::ensure_mips -> decode_more_levels): the reference's
+  // ray-tracing stages only sample level 0, and a file written with --gen-mipmaps would otherwise cost a third more decode time and
+  // host memory for nothing.
+  std::vector<std::vector<uint8_t>> more_png;
+  bool decode_more_levels(std::string& err);   // more_png -> more_levels (idempotent)
 };
 
 // Owned, fully decoded scene ("what Box<dyn ParsedScene> yields when every getter is called").

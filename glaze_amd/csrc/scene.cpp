@@ -284,8 +284,10 @@ bool Scene::ensure_mips(Error& err) {
   const size_t nt = data.textures.size();
   h_mips_.assign(nt, {});
   std::vector<std::vector<host::MipLevel>> chains(nt);
+  std::vector<std::string> decode_errs(nt);
   auto build_one = [&](size_t i) {
-    const TextureData& t = data.textures[i];
+    TextureData& t = data.textures[i];
+    if (!t.decode_more_levels(decode_errs[i])) return;   // the file's own levels 1.., still PNG-encoded since parse
     std::vector<host::MipLevel> given(1);
     given[0].width = t.info.width;
     given[0].height = t.info.height;
@@ -321,6 +323,12 @@ bool Scene::ensure_mips(Error& err) {
         return false;
       }
   }
+  for (size_t i = 0; i < nt; ++i)
+    if (!decode_errs[i].empty()) {
+      err.code = GLZ_E_INVALID_DATA;
+      err.msg = "Corrupted image: " + decode_errs[i];
+      return false;
+    }
   std::vector<uint8_t> pool;
   std::vector<TexDesc> desc;
   std::vector<uint32_t> base(nt, 0);

@@ -413,10 +413,25 @@ def test_concurrent_chains_do_not_change_the_image(instance, mattest_desc):
     assert s.launches == 23 and s.trace_closest_ms > 0 and s.shade_ms > 0
 
 
-def test_full_size_properties_atrium(instance):
-    """BASELINE config 4 shape (1920x1080, synthetic atrium): size-independent properties at full size."""
-    desc = atrium_scene()
-    scene = glaze_amd.RayTraceScene.from_desc(instance, desc)
+@pytest.fixture(scope="module")
+def atrium_file(tmp_path_factory):
+    """The atrium the way bench.py and glaze-cli hand a scene to the product (cli/src/main.rs:78-91): Serializer -> .glaze V1 file ->
+    parse -> RayTraceScene::new.  Returns the path and the scene as the ORACLE's own reader (oracle/glaze_v1.py: liblzma, PIL)
+    gets it out of the same file, so the full-size tests compare two independent readings of what the bench measures."""
+    from glaze_amd.scene_desc import save_scene
+    path = str(tmp_path_factory.mktemp("atrium") / "atrium.glaze")
+    save_scene(atrium_scene(), path)
+    return path, desc_from_oracle_parse(path)
+
+
+def file_scene(instance, atrium_file):
+    return glaze_amd.RayTraceScene.new(instance, glaze_amd.parse(atrium_file[0]))
+
+
+def test_full_size_properties_atrium(instance, atrium_file):
+    """BASELINE config 4 shape (1920x1080, synthetic atrium, through the file format): size-independent properties at full size."""
+    desc = atrium_file[1]
+    scene = file_scene(instance, atrium_file)
     info = scene.info()
     assert 200_000 <= info.n_world_triangles <= 330_000
     r = glaze_amd.RayTraceRenderer.new(instance, scene, 1920, 1080)
@@ -432,7 +447,7 @@ def test_full_size_properties_atrium(instance):
     r.step(16)
     assert np.array_equal(a.view(np.uint32), r.read_hdr().view(np.uint32))   # same seed stream -> bit-identical
     # the oracle on a crop-sized version of the same scene/camera agrees (same launch sequence)
-    small = glaze_amd.RayTraceRenderer.new(instance, glaze_amd.RayTraceScene.from_desc(instance, desc), 96, 54)
+    small = glaze_amd.RayTraceRenderer.new(instance, file_scene(instance, atrium_file), 96, 54)
     small.set_depth(8)
     small.step(8)
     o = OracleRenderer(OracleScene(desc), 96, 54)
@@ -441,11 +456,10 @@ def test_full_size_properties_atrium(instance):
     assert_parity(small, o, "atrium 96x54")
 
 
-def test_full_size_properties_4k_depth12(instance):
+def test_full_size_properties_4k_depth12(instance, atrium_file):
     """BASELINE config 5 shape (3840x2160, depth 12, tiles sharded over 8 GPUs) on one GPU: every rank's share of the 8-way
     partition rendered in turn (automatic chain count) sums to the whole frame bit for bit; counters and restart determinism."""
-    desc = atrium_scene()
-    scene = glaze_amd.RayTraceScene.from_desc(instance, desc)
+    scene = file_scene(instance, atrium_file)
     r = glaze_amd.RayTraceRenderer.new(instance, scene, 3840, 2160)
     r.set_depth(12)
     n = 13                                                   # one full path of depth 12 + the first segment of the next
@@ -677,29 +691,41 @@ def test_full_size_mattest_1024_tiles_vs_oracle(instance, mattest_desc):
     _assert_tiles_bit_equal(r, o, w, h, tiles, "mattest 1024^2")
 
 
-def test_full_size_atrium_1080p_tiles_vs_oracle(instance):
-    """Config 4: Sponza-class atrium, 1920 x 1080 (30 x 17 tiles, the bottom row 56 pixels high), depth 8."""
+def test_full_size_atrium_1080p_tiles_vs_oracle(instance, atrium_file):
+    """Config 4, what bench.py measures: the Sponza-class atrium as a .glaze file through the product's parse, 1920 x 1080 (30 x 17
+    tiles, the bottom row 56 pixels high), depth 8; the oracle renders the sampled tiles from its own reading of the same file."""
     w, h = 1920, 1080
     launches = 17
-    desc = atrium_scene()
-    r = glaze_amd.RayTraceRenderer.new(instance, glaze_amd.RayTraceScene.from_desc(instance, desc), w, h)
+    desc = atrium_file[1]
+    r = glaze_amd.RayTraceRenderer.new(instance, file_scene(instance, atrium_file), w, h)
     r.set_depth(8)
     r.step(launches)
-    tiles = _sample_tiles(w, h, 12, 2)
+    tiles = sorted(set(_sample_tiles(w, h, 12, 2)) | {3 + 8 * k for k in (0, 17, 40)})         # some of rank 3's of an 8-way partition among them
     o = OracleRenderer(OracleScene(desc), w, h)
     o.set_depth(8)
     o.set_tiles(tiles)
     o.step(launches)
     _assert_tiles_bit_equal(r, o, w, h, tiles, "atrium 1080p")
+    assert r.launch_mode() == "two_kernels"
+    # one GPU's share of the 8-way partition of this frame -- what bench.py --gpus 8 gives every device: 259 k pixels, rendered by the
+    # per-wave launch loop (k_path) in batches of 16 + 1 launches
+    r.set_partition(3, 8)
+    assert r.launch_mode() == "path"
+    r.step(launches)
+    mine = [t for t in tiles if t % 8 == 3]
+    part, c = r.read_hdr(), o.read_hdr()
+    m = _tile_mask(w, h, mine)
+    assert m.any() and ((part[m].view(np.uint32) == c[m].view(np.uint32)) | (np.isnan(part[m]) & np.isnan(c[m]))).all()
+    assert (part[~_tile_mask(w, h, list(range(3, 30 * 17, 8)))] == 0).all()                   # nothing outside its own tiles
 
 
-def test_full_size_atrium_4k_depth12_tiles_vs_oracle(instance):
-    """Config 5: 3840 x 2160 (60 x 34 tiles, ragged bottom row), depth 12, rendered as rank 3's share of the 8-way partition
-    plus the whole frame: the sampled tiles that rank 3 owns must match the oracle in both, the others in the whole frame."""
+def test_full_size_atrium_4k_depth12_tiles_vs_oracle(instance, atrium_file):
+    """Config 5: the same file, 3840 x 2160 (60 x 34 tiles, ragged bottom row), depth 12, rendered as rank 3's share of the 8-way
+    partition plus the whole frame: the sampled tiles that rank 3 owns must match the oracle in both, the others in the whole frame."""
     w, h = 3840, 2160
     launches = 14
-    desc = atrium_scene()
-    r = glaze_amd.RayTraceRenderer.new(instance, glaze_amd.RayTraceScene.from_desc(instance, desc), w, h)
+    desc = atrium_file[1]
+    r = glaze_amd.RayTraceRenderer.new(instance, file_scene(instance, atrium_file), w, h)
     r.set_depth(12)
     r.step(launches)
     tiles = _sample_tiles(w, h, 10, 3)
