@@ -148,7 +148,7 @@ struct alignas(16) TlasInstance {
   uint32_t world_base;    // world triangle id of the instance's primitive 0 (tie-break key, as in the flattened build)
   uint32_t instance;      // RTInstance index
   uint32_t non_opaque;    // the instance's material has an opacity map (acceleration.rs:136-141)
-  uint32_t _pad[1];
+  float w2o_norm;         // max row sum of |w2o|'s 3 x 3 part: how the rounding of a ray origin grows into object space (per-ray part of the slack)
 };
 static_assert(sizeof(TlasInstance) == 176, "TlasInstance is 11 x 16 bytes");
 

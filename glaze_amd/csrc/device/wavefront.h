@@ -636,9 +636,9 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
 // ---------------------------------------------------------------------------------------------
 constexpr int kExitInstance = 0x7FFFFFFD;   // stack marker: the entries below belong to the top level
 
-template <bool ANY, class Source, class Sink>
+template <bool ANY, bool COUNT, class Source, class Sink>
 __device__ __forceinline__ void trace_wave_tl(const DeviceScene& S, Source& src, Sink& sink, int* __restrict__ lds_col, int* aux, uint32_t* __restrict__ spill,
-                                              uint32_t spill_depth, uint32_t total, uint32_t wave, uint32_t n_waves) {
+                                              uint32_t spill_depth, uint32_t total, uint32_t wave, uint32_t n_waves, TraceTally& tally) {
   constexpr uint32_t kNone = 0xFFFFFFFFu;
   const BvhNode4* __restrict__ nodes = S.bvh_nodes;        // top-level nodes first, the meshes' after them (TlasInstance::node_base)
   const BvhTri* __restrict__ tris = S.bvh_tris;
@@ -695,6 +695,7 @@ __device__ __forceinline__ void trace_wave_tl(const DeviceScene& S, Source& src,
         if (src.load(next_ray, o, d, tmin, tmax)) {
           ray = next_ray;
           best = HitRecord{tmax, 0.0f, 0.0f, kNone, 0u, kNone};
+          if (COUNT) tally.rays += 1;
           if (S.n_world_tris == 0 || !ray_is_finite(o, d)) {
             sink.store(ray, best);
           } else {
@@ -724,6 +725,7 @@ __device__ __forceinline__ void trace_wave_tl(const DeviceScene& S, Source& src,
       if (at_node) { if (cur_inst == kNone) tl_top += 1; else tl_mesh += 1; }
 #endif
       if (at_node) {
+        if (COUNT) tally.nodes += 1;   // node visits of either level
         const u32x4* np = reinterpret_cast<const u32x4*>(nodes + nbase + (uint32_t)cur);
         const u32x4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
         uint32_t k0 = box_key(w0.x, w0.y, w0.z, w3.x, 0u, sel, ig, cgn, cgf, tmin, best.t), k1 = box_key(w0.w, w1.x, w1.y, w3.y, 1u, sel, ig, cgn, cgf, tmin, best.t);
@@ -759,7 +761,10 @@ __device__ __forceinline__ void trace_wave_tl(const DeviceScene& S, Source& src,
         const vec3 dd = mk3((r0.x * d.x + r0.y * d.y) + r0.z * d.z, (r1.x * d.x + r1.y * d.y) + r1.z * d.z, (r2.x * d.x + r2.y * d.y) + r2.z * d.z);
         st.push(kExitInstance);
         nbase = ti->node_base;
-        set_grid_ray(ti->grid.lo, ti->grid.cell, ti->grid.inv_cell, oo, dd, ti->slack, 1.0f);
+        // The slack the build computed covers ray origins inside the scene's bounds; the rounding of oo grows with |o|, wherever the
+        // ray starts (a camera far outside a small instanced scene): 32 eps |W2O|_inf |o|_1 on top, in object units like the rest.
+        const float slack = ti->slack + (3.8146973e-6f * ti->w2o_norm) * ((fabsf(o.x) + fabsf(o.y)) + fabsf(o.z));
+        set_grid_ray(ti->grid.lo, ti->grid.cell, ti->grid.inv_cell, oo, dd, slack, 1.0f);
         cur = 0;   // the mesh's root
       } else {
         const TlasInstance* ti = instances + cur_inst;
@@ -768,9 +773,12 @@ __device__ __forceinline__ void trace_wave_tl(const DeviceScene& S, Source& src,
         const RayShear rs = ray_shear(d);
         for (uint32_t local = first;; ++local) {
           const uint32_t slot = tri_base + local;
-          const uint32_t prim_flags = tris[slot].prim_flags;
-          const float4* rec = S.shade_tris + 8u * (size_t)slot;
-          const float4 pa = rec[0], pb = rec[2], pc = rec[4];
+          // the mesh's own triangle record: its hierarchy was built over the mesh under the identity transform, so the record's
+          // vertices are the object-space ones (one 48-byte line instead of three pieces of the 128-byte shading record)
+          const float4* tp = reinterpret_cast<const float4*>(tris + slot);
+          const float4 pa = tp[0], pb = tp[1], pc = tp[2];
+          const uint32_t prim_flags = __float_as_uint(pc.w);
+          if (COUNT) tally.tris += 1;
           // world triangle exactly as k_world_tris builds it: three points through o2w
           const vec3 v0 = xform_point(ti->o2w, mk3(pa.x, pa.y, pa.z)), v1 = xform_point(ti->o2w, mk3(pb.x, pb.y, pb.z)), v2 = xform_point(ti->o2w, mk3(pc.x, pc.y, pc.z));
           BvhTri tr;
@@ -793,6 +801,7 @@ __device__ __forceinline__ void trace_wave_tl(const DeviceScene& S, Source& src,
     }
     // ---- retire ----
     if (open && cur == kRayDone) {
+      if (COUNT) tally.hits += best.leaf != kNone;
       sink.store(ray, best);
       open = false;
     }

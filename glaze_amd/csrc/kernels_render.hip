@@ -205,6 +205,7 @@ struct ClosestSinkTl {
 #ifndef GLZ_TRACE_TL_WAVES
 #define GLZ_TRACE_TL_WAVES 4   // the instance entry and the on-the-fly world triangle need 153 VGPRs: at 6 waves per SIMD 201 of them live in scratch (forest x2000, tools/gpu_two_level_timing.py: 4.06 ms per launch), at 4 waves 34 (1.44 ms), at 3 none (1.45 ms)
 #endif
+template <bool COUNT>
 __global__ void __launch_bounds__(kBlock, GLZ_TRACE_TL_WAVES) k_trace_tl(const LaunchArgs A) {
   __shared__ int s_stack[kLdsStack * kBlock];
   __shared__ alignas(16) int s_aux[(kBlock / 64) * kAuxPerWave];
@@ -214,7 +215,8 @@ __global__ void __launch_bounds__(kBlock, GLZ_TRACE_TL_WAVES) k_trace_tl(const L
     TraceTally tally;
     ClosestSource src{A, A.frame, tally, 0u};
     ClosestSinkTl sink{A};
-    trace_wave_tl<false>(A.scene, src, sink, &s_stack[threadIdx.x], aux, A.st.overflow, A.st.overflow_depth, A.map.n_local_pixels, wave_index(), wave_count());
+    trace_wave_tl<false, COUNT>(A.scene, src, sink, &s_stack[threadIdx.x], aux, A.st.overflow, A.st.overflow_depth, A.map.n_local_pixels, wave_index(), wave_count(), tally);
+    if (COUNT) flush_counters(A.counters, false, tally);
   }
   if (A.do_shadow) {
     const uint32_t* counts = A.st.queue_count + (A.shade_set ^ 1u) * kQueueSetWords;
@@ -227,7 +229,9 @@ __global__ void __launch_bounds__(kBlock, GLZ_TRACE_TL_WAVES) k_trace_tl(const L
     const uint32_t n_waves = wave_count();
     const uint32_t closest_groups = A.do_closest ? (A.map.n_local_pixels + 63u) / 64u : 0u;
     const uint32_t wave = (wave_index() + n_waves - closest_groups % n_waves) % n_waves;
-    trace_wave_tl<true>(A.scene, src, sink, &s_stack[threadIdx.x], aux, A.st.overflow, A.st.overflow_depth, start[kQueueShards], wave, n_waves);
+    TraceTally tally;
+    trace_wave_tl<true, COUNT>(A.scene, src, sink, &s_stack[threadIdx.x], aux, A.st.overflow, A.st.overflow_depth, start[kQueueShards], wave, n_waves, tally);
+    if (COUNT) flush_counters(A.counters, true, tally);
   }
 }
 
@@ -318,7 +322,7 @@ __global__ void __launch_bounds__(kBlock) k_debug_closest(const DeviceScene S, c
   TraceTally tally;
   DebugSource src{o, d, nullptr, tmin};
   DebugClosestSink sink{S, t, tri, inst, u, v};
-  if (S.two_level) trace_wave_tl<false>(S, src, sink, &s_stack[threadIdx.x], &s_aux[(threadIdx.x >> 6) * kAuxPerWave], overflow, overflow_depth, n, wave_index(), wave_count());
+  if (S.two_level) trace_wave_tl<false, false>(S, src, sink, &s_stack[threadIdx.x], &s_aux[(threadIdx.x >> 6) * kAuxPerWave], overflow, overflow_depth, n, wave_index(), wave_count(), tally);
   else trace_wave<false, false>(S, src, sink, &s_stack[threadIdx.x], &s_aux[(threadIdx.x >> 6) * kAuxPerWave], (LdsNodePtr)s_top, overflow, overflow_depth, n, wave_index(), wave_count(), tally);
 }
 __global__ void __launch_bounds__(kBlock) k_debug_any(const DeviceScene S, const float* __restrict__ o, const float* __restrict__ d,
@@ -331,7 +335,7 @@ __global__ void __launch_bounds__(kBlock) k_debug_any(const DeviceScene S, const
   TraceTally tally;
   DebugSource src{o, d, tmax, tmin};
   DebugAnySink sink{out};
-  if (S.two_level) trace_wave_tl<true>(S, src, sink, &s_stack[threadIdx.x], &s_aux[(threadIdx.x >> 6) * kAuxPerWave], overflow, overflow_depth, n, wave_index(), wave_count());
+  if (S.two_level) trace_wave_tl<true, false>(S, src, sink, &s_stack[threadIdx.x], &s_aux[(threadIdx.x >> 6) * kAuxPerWave], overflow, overflow_depth, n, wave_index(), wave_count(), tally);
   else trace_wave<true, false>(S, src, sink, &s_stack[threadIdx.x], &s_aux[(threadIdx.x >> 6) * kAuxPerWave], (LdsNodePtr)s_top, overflow, overflow_depth, n, wave_index(), wave_count(), tally);
 }
 
@@ -362,14 +366,15 @@ static dim3 persistent_grid(Kernel kernel, uint32_t n_rays) {
 // measured 25-50 % slower for small shares: spread as wide as possible).
 uint32_t trace_grid_blocks(uint32_t n_local_pixels, bool counting, bool two_level) {
   uint32_t rays = 2u * n_local_pixels;
-  if (two_level) return persistent_grid(k_trace_tl, rays).x;   // compiled for fewer waves per SIMD: its own residency
+  if (two_level) return counting ? persistent_grid(k_trace_tl<true>, rays).x : persistent_grid(k_trace_tl<false>, rays).x;   // compiled for fewer waves per SIMD: its own residency
   return counting ? persistent_grid(k_trace<true>, rays).x : persistent_grid(k_trace<false>, rays).x;
 }
 
 hipError_t launch_trace(hipStream_t st, const LaunchArgs& a, uint32_t blocks) {
   if (a.map.n_local_pixels == 0) return hipSuccess;
   if (blocks == 0 || (uint64_t)blocks * kBlock > 2ull * a.map.n_local_pixels + kBlock) return hipErrorInvalidValue;   // the spill area holds one slot per lane of this bound
-  if (a.scene.two_level) hipLaunchKernelGGL(k_trace_tl, dim3(blocks), dim3(kBlock), 0, st, a);   // instanced scenes: no work counters
+  if (a.scene.two_level && a.counters) hipLaunchKernelGGL(k_trace_tl<true>, dim3(blocks), dim3(kBlock), 0, st, a);   // node visits of both levels, triangle tests inside the instances
+  else if (a.scene.two_level) hipLaunchKernelGGL(k_trace_tl<false>, dim3(blocks), dim3(kBlock), 0, st, a);
   else if (a.counters) hipLaunchKernelGGL(k_trace<true>, dim3(blocks), dim3(kBlock), 0, st, a);
   else hipLaunchKernelGGL(k_trace<false>, dim3(blocks), dim3(kBlock), 0, st, a);
   return hipGetLastError();

@@ -738,6 +738,7 @@ bool Scene::build_two_level(Error& err) {
     // (in object units: the tracer turns it into cells of each axis -- a thin mesh has tiny cells across its thin side, and the pad
     // that side needs, taken for all three, would make every box of the mesh as wide as the mesh)
     r.slack = (float)(32.0 * eps * (wnorm * reach + tr + objmax));
+    r.w2o_norm = (float)wnorm;   // the tracer adds 32 eps wnorm |o|_1 per ray: origins far outside the scene's bounds
     r.node_base = m.node_base;
     r.tri_base = m.tri_base;
     r.world_base = inst_base_[i];

@@ -242,3 +242,44 @@ def test_thin_meshes_keep_their_box_tests(instance):
     assert np.array_equal(bits(imgs[0]), bits(imgs[1]))
     assert imgs[0][..., :3].mean() > 0
     assert times[1] < 10.0 * times[0] + 0.02, times
+
+
+def test_two_level_work_counters(instance):
+    """enable_counters on an instanced scene: rays, hits, fresh paths and shadow rays do not depend on the shape of the structure and
+    equal the flattened build's; node visits (both levels) and triangle tests are counted too (they were silently zero)."""
+    desc = instanced_cubes(60, seed=21)
+    flat, two = scenes(instance, desc)
+    stats = []
+    for sc in (flat, two):
+        r = glaze_amd.RayTraceRenderer.new(instance, sc, 200, 136)
+        r.set_depth(4)
+        r.enable_counters(True, True)
+        r.step(9)
+        r.wait_idle()
+        stats.append(r.stats())
+    f, t = stats
+    assert t.closest_rays == f.closest_rays == 200 * 136 * 9
+    for name in ("shadow_rays", "hits", "fresh_paths"):
+        assert getattr(t, name) == getattr(f, name) > 0, name
+    assert t.closest_nodes > t.closest_rays and t.closest_tris > 0 and t.shadow_nodes > 0 and t.shadow_tris > 0
+
+
+def test_two_level_far_away_origins(instance):
+    """Ray origins far outside the scene's bounds (a telephoto or orthographic view of a small instanced scene): the rounding of the
+    object-space ray grows with |o|, the per-ray part of the slack covers it -- hits stay bit-identical to the flattened build."""
+    desc = instanced_cubes(120, seed=5, scale=(0.01, 0.05))
+    flat, two = scenes(instance, desc)
+    rng = np.random.default_rng(8)
+    n = 60_000
+    for far in (50.0, 2000.0, 100000.0):
+        target = rng.uniform(-0.9, 0.9, (n, 3))
+        dirs = rng.normal(size=(n, 3))
+        dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+        o = (target - far * dirs).astype(np.float32)
+        d = dirs.astype(np.float32)
+        a, b = flat.debug_trace_closest(o, d), two.debug_trace_closest(o, d)
+        for x, y, name in zip(a, b, ("t", "triangle", "instance", "u", "v")):
+            assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), (far, name)
+        assert np.isfinite(a[0]).mean() > 0.99
+        tmax = np.full(n, far * 3, np.float32)
+        assert np.array_equal(flat.debug_trace_any(o, d, tmax), two.debug_trace_any(o, d, tmax))
