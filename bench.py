@@ -62,19 +62,22 @@ def parse_args():
 
 
 def algorithmic_bytes(c):
-    """Algorithmic bytes per SAMPLE of each kernel, from counted per-sample work (DESIGN.md section 5).
+    """Algorithmic bytes per SAMPLE of each kernel, from counted per-sample work (DESIGN.md section 4).
 
-    node visit = 64 B (one quantised BVH4 node: four child boxes + four links), triangle test = 48 B (BvhTri: v0, e1, e2 and
-    the ids the tie-break / alpha test need), hit-attribute fetch = 192 B (128-B shading record + the 64 B of RTMaterial
-    scalars k_shade loads; texels are not counted), path state = 96 B (ray 32 + importance 64), hit record 16 B,
-    accumulator = 32 B r/w + 16 B result, shadow-queue entry = 48 B.
+    node visit = 64 B (one quantised BVH4 node: four child boxes + four links), triangle test = 48 B (BvhTri: the three vertices
+    and the ids the tie-break / alpha test need), hit-attribute fetch = 192 B (128-B shading record + the 64 B of RTMaterial
+    scalars k_shade loads), path state = 96 B (ray 32 + importance 64), hit record 16 B, accumulator = 32 B r/w + 16 B result,
+    shadow-queue entry = 48 B.  Counted too since round 3 (they were the unbooked part of k_shade's traffic): texels (16 B per
+    bilinear fetch of an RGBA texture, 4 B per gray one: SURVEY 8(d)'s "16 B/texture tap"), 112 B of RTLight per light sample, and
+    per sky-light sample the binary search of the marginal table (4 B a step), one marginal and two conditional values.
     """
     closest = 32 + 16 + 32 * c["f_fresh"] + 64 * c["nodes_closest"] + 48 * c["tris_closest"]
     shade = (16 + 32 + 64 * (1 - c["f_fresh"]) + 192 * c["f_hit"] + 48 * c["f_shadow"] + 48 * (1 - c["f_shadow"])
              + 96 * c["f_hit"])
+    shade += c.get("tex_bytes_shade", 0.0) + 112 * (c.get("light_samples", 0.0) + c.get("sky_samples", 0.0)) + c.get("sky_bytes_per_sample", 0.0) * c.get("sky_samples", 0.0)
     shadow = 48 * c["f_shadow"] + 48 * c["f_shadow"] + 64 * c["nodes_shadow"] + 48 * c["tris_shadow"]
     # k_trace traverses the closest-hit rays of a launch and the shadow rays of the launch before it in one kernel
-    return {"k_trace": closest + shadow, "k_shade": shade}
+    return {"k_trace": closest + shadow + c.get("tex_bytes_trace", 0.0), "k_shade": shade}
 
 
 def main():
@@ -139,6 +142,7 @@ def main():
         scene = glaze_amd.RayTraceScene.new(inst, glaze_amd.parse(path))
         setup_s = time.time() - t0
     info = scene.info()
+    sky_rows = max([desc.textures[l.resource_id][1].shape[0] for l in desc.lights if l.ltype == glaze_amd.abi.LIGHT_SKY] + [0])
     renderer = glaze_amd.RayTraceRenderer.new(inst, scene, W, H)
     renderer.set_depth(args.depth)
     renderer.set_seed(args.seed)
@@ -245,6 +249,12 @@ def main():
             "nodes_shadow": (sc.shadow_nodes - sa.shadow_nodes) / rays, "tris_shadow": (sc.shadow_tris - sa.shadow_tris) / rays,
             "f_hit": (sc.hits - sa.hits) / rays, "f_shadow": (sc.shadow_rays - sa.shadow_rays) / rays,
             "f_fresh": (sc.fresh_paths - sa.fresh_paths) / rays,
+            "tex_fetches": (sc.tex_fetches - sa.tex_fetches) / rays,
+            "tex_bytes_shade": ((sc.tex_bytes - sa.tex_bytes) - (sc.alpha_tex_bytes - sa.alpha_tex_bytes)) / rays,
+            "tex_bytes_trace": (sc.alpha_tex_bytes - sa.alpha_tex_bytes) / rays,
+            "light_samples": (sc.light_samples - sa.light_samples) / rays, "sky_samples": (sc.sky_samples - sa.sky_samples) / rays,
+            # per sky-light sample: ceil(log2(H + 1)) steps of the marginal search + one marginal value + two conditional ones
+            "sky_bytes_per_sample": 4.0 * (int(np.ceil(np.log2(sky_rows + 1))) + 3) if sky_rows else 0.0,
         }
         bytes_per_sample = algorithmic_bytes(counted)
         dominant = max(kern_ms, key=kern_ms.get)

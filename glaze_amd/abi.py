@@ -97,7 +97,9 @@ class RenderStats(C.Structure):
                 ("trace_closest_ms", C.c_double), ("shade_ms", C.c_double), ("trace_shadow_ms", C.c_double), ("other_ms", C.c_double),
                 ("closest_rays", C.c_uint64), ("shadow_rays", C.c_uint64),
                 ("closest_nodes", C.c_uint64), ("closest_tris", C.c_uint64), ("shadow_nodes", C.c_uint64), ("shadow_tris", C.c_uint64),
-                ("hits", C.c_uint64), ("fresh_paths", C.c_uint64), ("phase", C.c_uint64 * 12)]
+                ("hits", C.c_uint64), ("fresh_paths", C.c_uint64), ("phase", C.c_uint64 * 12),
+                ("tex_fetches", C.c_uint64), ("tex_bytes", C.c_uint64), ("alpha_tex_bytes", C.c_uint64), ("light_samples", C.c_uint64),
+                ("sky_samples", C.c_uint64)]
 
 
 DRAW_CALLBACK = C.CFUNCTYPE(None, C.c_void_p)

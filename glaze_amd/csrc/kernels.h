@@ -89,6 +89,8 @@ struct CameraConsts {
 struct TraceCounters {
   unsigned long long closest_rays, shadow_rays, closest_nodes, closest_tris, shadow_nodes, shadow_tris, hits, fresh;
   unsigned long long phase[12];   // {node_iters, node_lanes, leaf_iters, leaf_lanes, refill_iters, refill_lanes} x {closest, shadow}
+  // DeviceScene::tex_counter of k_shade / of k_trace (alpha tests): {fetches, texel bytes, light samples other than sky, sky-light samples}
+  unsigned long long shade_tex[4], trace_tex[4];
 };
 
 struct LaunchArgs {

@@ -59,6 +59,7 @@ __global__ void __launch_bounds__(kBlock, GLZ_SHADE_WAVES) k_shade(const LaunchA
   }
   __syncthreads();
   DeviceScene S = A.scene;
+  S.tex_counter = A.counters ? A.counters->shade_tex : nullptr;
   S.srgb_lut = s_lut;
   if (sky_in_lds) S.sky_marginal = s_sky;
   if (tables_in_lds) {

@@ -344,6 +344,7 @@ void Renderer::fill_args(const Chain& c, LaunchArgs& a) const {
   a.map = c.map;
   a.cam = cam_;
   a.counters = counting_ ? counters_.ptr : nullptr;
+  a.scene.tex_counter = counting_ ? counters_.ptr->trace_tex : nullptr;   // k_trace's alpha tests; k_shade points its copy at shade_tex
   a.do_closest = a.do_shadow = 0;
   a.shade_set = c.pending_set ^ 1u;
   a.shadow_exposure = c.pending_exposure;
@@ -584,6 +585,11 @@ bool Renderer::get_stats(glz_render_stats* out, Error& err) {
   out->hits = c.hits;
   out->fresh_paths = c.fresh;
   for (int i = 0; i < 12; ++i) out->phase[i] = c.phase[i];
+  out->tex_fetches = c.shade_tex[0] + c.trace_tex[0];
+  out->tex_bytes = c.shade_tex[1] + c.trace_tex[1];
+  out->alpha_tex_bytes = c.trace_tex[1];
+  out->light_samples = c.shade_tex[2];
+  out->sky_samples = c.shade_tex[3];
   // other GPUs of this process: work counters add up, kernel times overlap (the slowest device is what the job waits for)
   if (!peers_.empty()) {
     std::vector<glz_render_stats> ps(peers_.size());
@@ -611,6 +617,8 @@ bool Renderer::get_stats(glz_render_stats* out, Error& err) {
       out->shadow_nodes += q.shadow_nodes; out->shadow_tris += q.shadow_tris;
       out->hits += q.hits; out->fresh_paths += q.fresh_paths;
       for (int i = 0; i < 12; ++i) out->phase[i] += q.phase[i];
+      out->tex_fetches += q.tex_fetches; out->tex_bytes += q.tex_bytes; out->alpha_tex_bytes += q.alpha_tex_bytes;
+      out->light_samples += q.light_samples; out->sky_samples += q.sky_samples;
     }
     out->render_ms = out->trace_closest_ms + out->shade_ms + out->trace_shadow_ms + out->other_ms;
     (void)hipSetDevice(inst_->device);

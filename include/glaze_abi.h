@@ -416,6 +416,11 @@ typedef struct glz_render_stats {
   uint64_t fresh_paths;     /* closest rays that were new camera rays (bounce 0) */
   /* tracer phase occupancy, counting build only: {node rounds, node lanes, leaf rounds, leaf lanes, refills, refilled lanes} x {closest, shadow} */
   uint64_t phase[12];
+  /* shading-side work, counting build only: texture fetches that read memory (bilinear: four texels each; 1 x 1 textures live in
+   * their descriptor and are not counted) and their texel bytes (16 per RGBA fetch, 4 per gray one) -- of which alpha_tex_bytes in
+   * the traversal kernel's alpha tests --, light samples of omni / sun / area lights (one 112-byte RTLight each) and of the sky
+   * (a binary search of the marginal table, two values of the conditional tables, one texel fetch, counted above) */
+  uint64_t tex_fetches, tex_bytes, alpha_tex_bytes, light_samples, sky_samples;
 } glz_render_stats;
 /* bit 0: traversal work counters (slower kernels); bit 1: per-kernel hipEvent timing (on by default) */
 int glz_renderer_enable_counters(glz_renderer*, int flags);

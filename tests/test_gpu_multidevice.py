@@ -144,9 +144,13 @@ def test_loopback_devices_follow_every_update(instance, loopback):
     for x in (r, one):
         x.change_scene(glaze_amd.RayTraceScene.from_desc(instance, mat_desc))
     same("change_scene")
+    r.set_launch_mode("two_kernels")                                                           # chains belong to this mode; frames this small run as k_path otherwise
     r.set_chains(2)
     r.restart(); one.restart()
     same("two chains per device", 6)
+    r.set_launch_mode("path")
+    same("k_path on every device", 6)
+    r.set_launch_mode("auto")
     for x in (r, one):
         x.enable_counters(True, True)
         x.restart()
@@ -267,6 +271,7 @@ def test_packed_tiles_export_and_scatter(instance):
             r = glaze_amd.RayTraceRenderer.new(instance, glaze_amd.RayTraceScene.from_desc(instance, desc), w, h)
             r.set_depth(3)
             r.set_partition(rank, world)
+            r.set_launch_mode("two_kernels" if chains > 1 else "auto")                        # chains are the two-kernel mode's
             r.set_chains(chains)
             r.step(5)
             n = r.packed_pixels(rank, world)

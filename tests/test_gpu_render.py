@@ -390,6 +390,7 @@ def test_concurrent_chains_do_not_change_the_image(instance, mattest_desc):
     also under a tile partition (chain s of S is the finer partition (rank + s * world, world * S))."""
     scene = glaze_amd.RayTraceScene.from_desc(instance, mattest_desc)
     r = glaze_amd.RayTraceRenderer.new(instance, scene, 200, 136)             # 4 x 3 tiles, ragged right and bottom edges
+    r.set_launch_mode("two_kernels")                                          # chains belong to this mode (a frame this small would run as k_path)
     r.set_depth(5)
     r.set_chains(1)
     r.step(23)
@@ -825,3 +826,30 @@ def test_auto_launch_mode_goes_by_the_pixels_a_device_owns(instance):
     r.set_partition(0, 1)
     r.change_resolution(320, 200)
     assert r.launch_mode() == "path"
+
+
+def test_shading_side_work_counters(instance, mattest_desc):
+    """The counted quantities bench.py books for k_shade besides state and hit records: texture fetches that read memory, their texel
+    bytes, light samples.  Cube: every hit is Lambertian with the 512 x 512 checker as its diffuse texture (the 1 x 1 textures live in
+    their descriptors) and samples the one omni light -- one RGBA fetch and one light sample per hit, no sky."""
+    r = glaze_amd.RayTraceRenderer.new(instance, glaze_amd.RayTraceScene.from_desc(instance, cube_scene()), 200, 136)
+    r.set_depth(3)
+    r.enable_counters(True, True)
+    r.step(7)
+    r.wait_idle()
+    s = r.stats()
+    assert s.hits > 0 and s.tex_fetches == s.hits and s.tex_bytes == 16 * s.hits and s.alpha_tex_bytes == 0
+    assert s.light_samples == s.hits and s.sky_samples == 0
+    # mattest: a sky light (sampled by every non-specular hit; its texel fetch is counted) and sky texels on misses
+    r = glaze_amd.RayTraceRenderer.new(instance, glaze_amd.RayTraceScene.from_desc(instance, mattest_desc), 200, 136)
+    r.set_depth(4)
+    r.enable_counters(True, True)
+    r.step(9)
+    r.wait_idle()
+    s = r.stats()
+    assert 0 < s.sky_samples <= s.hits and s.light_samples == 0 and s.tex_fetches >= s.sky_samples and s.tex_bytes <= 16 * s.tex_fetches
+    r.enable_counters(False, True)
+    r.restart()
+    r.step(3)
+    r.wait_idle()
+    assert r.stats().tex_fetches == 0                                           # nothing is counted (or paid for) outside counting passes
