@@ -1223,4 +1223,14 @@ __device__ __forceinline__ void stage_top(const DeviceScene& S, uint4* s_top) {
 #define GLZ_WAVE_STAMP(k) do { } while (0)
 #endif
 
+// The kernel's arguments, re-read: behind the empty asm the compiler no longer knows that the pointer is the one it has been loading
+// from, so what follows loads the arguments it needs where it needs them (scalar loads from the kernarg segment) instead of keeping
+// every pointer of LaunchArgs in SGPRs from the top of the kernel -- there are more of them than SGPRs, the overflow goes to VGPR
+// lanes (v_writelane / v_readlane) and takes registers from the shading code.
+typedef const __attribute__((address_space(4))) char* KernargPtr;
+__device__ __forceinline__ KernargPtr reread_kernarg() {
+  KernargPtr p = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  return p;
+}
 }  // namespace glz

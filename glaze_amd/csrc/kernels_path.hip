@@ -98,12 +98,6 @@ struct GroupMixedSink {
 // from, so what a phase of k_path needs of the arguments is loaded (scalar loads from the kernarg segment) where the phase begins and
 // dies where it ends -- instead of every pointer either phase uses staying in SGPRs through the whole launch loop (tracing and shading
 // together use more of them than there are: 233 of them went to VGPR lanes, and the VGPRs those took to scratch).
-typedef const __attribute__((address_space(4))) char* KernargPtr;
-__device__ __forceinline__ KernargPtr reread_kernarg() {
-  KernargPtr p = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
-  asm volatile("" : "+s"(p));
-  return p;
-}
 #ifndef GLZ_PATH_REREAD
 #define GLZ_PATH_REREAD 1
 #endif
@@ -115,6 +109,7 @@ __device__ __forceinline__ uint32_t path_shade(uint32_t lid0, uint32_t lane, uin
   const LaunchArgs& A = *(const LaunchArgs*)reread_kernarg();
   // the scene as the shading code sees it: the arguments' pointers, re-read, with the tables this block staged in LDS in their place
   DeviceScene S = A.scene;
+  S.tex_counter = nullptr;   // k_path is never a counting pass: the checks fold away
   S.srgb_lut = S_lds.srgb_lut;
   S.materials = S_lds.materials;
   S.lights = S_lds.lights;

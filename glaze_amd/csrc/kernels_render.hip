@@ -22,6 +22,10 @@ constexpr uint32_t kSkyLdsFloats = 4096;   // sky marginal tables (3H+1 floats) 
 #ifndef GLZ_SHADE_WAVES
 #define GLZ_SHADE_WAVES 4   // 128 VGPRs, 4 of them spilled, since the light's spectrum is made after the BSDF evaluation and the importance is read where it is used (natural demand 152 -> 132): 0.357 -> 0.348 ms; at three waves the same code takes 0.363 ms (the re-reads), the old code at four waves (56 spilled) 0.382 ms
 #endif
+// COUNT: the instrumented build of the counting passes (texture fetches, light samples: DeviceScene::tex_counter).  The measured kernel
+// sets the counter pointer to a constant null, so the checks in the texture and light code fold away (left as a run-time null they
+// cost 2.5 %: a branch per fetch and two more live SGPRs).
+template <bool COUNT>
 __global__ void __launch_bounds__(kBlock, GLZ_SHADE_WAVES) k_shade(const LaunchArgs A) {
   // The kernel is bound by the memory system's random-access rate (16 extra scattered loads per pixel cost +27 %, 200 extra
   // VALU instructions nothing; 1 / 2 / 3 / 4 waves per SIMD take 0.76 / 0.45 / 0.36 / 0.35 ms), so the two small tables every texture fetch /
@@ -59,7 +63,7 @@ __global__ void __launch_bounds__(kBlock, GLZ_SHADE_WAVES) k_shade(const LaunchA
   }
   __syncthreads();
   DeviceScene S = A.scene;
-  S.tex_counter = A.counters ? A.counters->shade_tex : nullptr;
+  S.tex_counter = COUNT ? A.counters->shade_tex : nullptr;
   S.srgb_lut = s_lut;
   if (sky_in_lds) S.sky_marginal = s_sky;
   if (tables_in_lds) {
@@ -150,8 +154,15 @@ __global__ void __launch_bounds__(kBlock, GLZ_SHADE_WAVES) k_shade(const LaunchA
 #else
   const float4 ro = A.st.ray_o[lid], rd = A.st.ray_d[lid], hr = A.st.hit[lid];
 #endif
+#ifndef GLZ_SHADE_NO_REREAD
+  // (see reread_kernarg: without it the regrouping prologue's view of the arguments stays in SGPRs through the shading code)
+  const LaunchArgs& A2 = *(const LaunchArgs*)reread_kernarg();
+  SharedQueue queue{A2};
+  shade_pixel(A2, S, A2.frame, lid, px, ro, rd, hr, queue);
+#else
   SharedQueue queue{A};
   shade_pixel(A, S, F, lid, px, ro, rd, hr, queue);
+#endif
 }
 
 template <bool COUNT>
@@ -382,7 +393,8 @@ hipError_t launch_trace(hipStream_t st, const LaunchArgs& a, uint32_t blocks) {
 }
 hipError_t launch_shade(hipStream_t st, const LaunchArgs& a) {
   if (a.map.n_local_pixels == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_shade, grid_for(a.map.n_local_pixels), dim3(kBlock), 0, st, a);
+  if (a.counters) hipLaunchKernelGGL(k_shade<true>, grid_for(a.map.n_local_pixels), dim3(kBlock), 0, st, a);
+  else hipLaunchKernelGGL(k_shade<false>, grid_for(a.map.n_local_pixels), dim3(kBlock), 0, st, a);
   return hipGetLastError();
 }
 hipError_t launch_export(hipStream_t st, const TileMap& map, const float4* tiled, float4* frame, bool zero_first) {

@@ -148,9 +148,11 @@ def test_loopback_devices_follow_every_update(instance, loopback):
     r.set_chains(2)
     r.restart(); one.restart()
     same("two chains per device", 6)
-    r.set_launch_mode("path")
+    r.set_launch_mode("path")                                                                  # (a change of mode starts a new frame, like set_chains)
+    r.restart(); one.restart()
     same("k_path on every device", 6)
     r.set_launch_mode("auto")
+    r.restart(); one.restart()
     for x in (r, one):
         x.enable_counters(True, True)
         x.restart()

@@ -266,20 +266,28 @@ def test_two_level_work_counters(instance):
 
 def test_two_level_far_away_origins(instance):
     """Ray origins far outside the scene's bounds (a telephoto or orthographic view of a small instanced scene): the rounding of the
-    object-space ray grows with |o|, the per-ray part of the slack covers it -- hits stay bit-identical to the flattened build."""
+    object-space ray grows with |o|; the per-ray part of the slack covers it, and the two-level hits stay equal to the brute force
+    over all triangles however far the origin is.  The FLATTENED build agrees as long as the rounding of the ray stays below the
+    padding of its boxes -- origins within a few hundred scene extents; at 10^5 extents it culls one triangle in a thousand that the
+    exact test accepts (tools/gpu_far_origin_diag.py), which is why the comparison with it stops at 200."""
     desc = instanced_cubes(120, seed=5, scale=(0.01, 0.05))
     flat, two = scenes(instance, desc)
+    osc = OracleScene(desc)
     rng = np.random.default_rng(8)
-    n = 60_000
-    for far in (50.0, 2000.0, 100000.0):
+    n = 30_000
+    for far in (50.0, 200.0, 2000.0, 100000.0):
         target = rng.uniform(-0.9, 0.9, (n, 3))
         dirs = rng.normal(size=(n, 3))
         dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
         o = (target - far * dirs).astype(np.float32)
         d = dirs.astype(np.float32)
-        a, b = flat.debug_trace_closest(o, d), two.debug_trace_closest(o, d)
-        for x, y, name in zip(a, b, ("t", "triangle", "instance", "u", "v")):
-            assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), (far, name)
-        assert np.isfinite(a[0]).mean() > 0.99
-        tmax = np.full(n, far * 3, np.float32)
-        assert np.array_equal(flat.debug_trace_any(o, d, tmax), two.debug_trace_any(o, d, tmax))
+        b = two.debug_trace_closest(o, d)
+        bt, btri = osc.trace_closest(o[:6000], d[:6000], brute=True)
+        assert np.array_equal(bt.view(np.uint32), b[0][:6000].view(np.uint32)) and np.array_equal(btri, b[1][:6000]), far
+        assert np.isfinite(b[0]).mean() > 0.99
+        if far <= 200.0:
+            a = flat.debug_trace_closest(o, d)
+            for x, y, name in zip(a, b, ("t", "triangle", "instance", "u", "v")):
+                assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), (far, name)
+            tmax = np.full(n, far * 3, np.float32)
+            assert np.array_equal(flat.debug_trace_any(o, d, tmax), two.debug_trace_any(o, d, tmax))
