@@ -209,8 +209,9 @@ struct DeviceScene {
   const float* sky_marginal;       // cdf (H+1) | values (H) | conditional integrals (H)
   const float* sky_cond_values;    // W x H
   const float* sky_cond_cdf;       // (W+1) x H
-  // counting passes only (null otherwise): {texture fetches that read memory, their texel bytes, light samples, sky-light samples} of the
-  // kernel that runs with this copy of the scene -- what the algorithmic-bytes model of bench.py books for texels and light tables
+  // counting builds only (null otherwise; the host never sets it): the THREAD's tallies {texture fetches that read memory, their texel
+  // bytes, light samples, sky-light samples} -- the instrumented kernels point their copy of the scene at four registers and add
+  // them up per wave at their end (TraceCounters::shade_tex / trace_tex): what bench.py books for texels and light tables
   unsigned long long* tex_counter;
   uint32_t sky_w, sky_h;
 };

@@ -839,6 +839,18 @@ __device__ __forceinline__ void flush_counters(TraceCounters* c, bool shadow, Tr
   }
 }
 
+// a counting kernel's per-thread texture / light tallies (DeviceScene::tex_counter) -> the launch's counters: one atomic per wave and
+// tally; every lane of the wave must get here
+__device__ __forceinline__ void flush_tex_tallies(unsigned long long* dst, const unsigned long long* t) {
+  unsigned long long a = t[0], b = t[1], c = t[2], d = t[3];
+  for (int off = 32; off > 0; off >>= 1) {
+    a += __shfl_down(a, off); b += __shfl_down(b, off); c += __shfl_down(c, off); d += __shfl_down(d, off);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(dst, a); atomicAdd(dst + 1, b); atomicAdd(dst + 2, c); atomicAdd(dst + 3, d);
+  }
+}
+
 // persistent launch geometry: every wave of the grid is one independent tracer
 // (XCD-aware numbering -- the blocks with b % 8 == x, which share an L2, taking one contiguous run of groups / pixels each,
 // cdna_hip_programming.md T1 -- measured slower for both kernels: k_trace 0.588 -> 0.621 ms, k_shade 0.348 -> 0.357 ms, a 1/8

@@ -63,7 +63,8 @@ __global__ void __launch_bounds__(kBlock, GLZ_SHADE_WAVES) k_shade(const LaunchA
   }
   __syncthreads();
   DeviceScene S = A.scene;
-  S.tex_counter = COUNT ? A.counters->shade_tex : nullptr;
+  unsigned long long tex_tally[4] = {0ull, 0ull, 0ull, 0ull};
+  S.tex_counter = COUNT ? tex_tally : nullptr;
   S.srgb_lut = s_lut;
   if (sky_in_lds) S.sky_marginal = s_sky;
   if (tables_in_lds) {
@@ -148,21 +149,24 @@ __global__ void __launch_bounds__(kBlock, GLZ_SHADE_WAVES) k_shade(const LaunchA
   // 0.591 ms; sorted per block by the octant of the new direction, camera rays last, 0.590 -> 0.573 ms, less than the sort and the
   // indirection cost.)
   const PixelId px = pixel_of(A.map, lid);
-  if (!px.active) return;
+  if (!COUNT && !px.active) return;
+  if (px.active) {
 #if !defined(GLZ_SHADE_NO_REGROUP) && !defined(GLZ_SHADE_NO_HIT_HANDOVER)
-  const float4 ro = A.st.ray_o[lid], rd = A.st.ray_d[lid], hr = s_hit[s_perm[threadIdx.x]];
+    const float4 ro = A.st.ray_o[lid], rd = A.st.ray_d[lid], hr = s_hit[s_perm[threadIdx.x]];
 #else
-  const float4 ro = A.st.ray_o[lid], rd = A.st.ray_d[lid], hr = A.st.hit[lid];
+    const float4 ro = A.st.ray_o[lid], rd = A.st.ray_d[lid], hr = A.st.hit[lid];
 #endif
 #ifndef GLZ_SHADE_NO_REREAD
-  // (see reread_kernarg: without it the regrouping prologue's view of the arguments stays in SGPRs through the shading code)
-  const LaunchArgs& A2 = *(const LaunchArgs*)reread_kernarg();
-  SharedQueue queue{A2};
-  shade_pixel(A2, S, A2.frame, lid, px, ro, rd, hr, queue);
+    // (see reread_kernarg: without it the regrouping prologue's view of the arguments stays in SGPRs through the shading code)
+    const LaunchArgs& A2 = *(const LaunchArgs*)reread_kernarg();
+    SharedQueue queue{A2};
+    shade_pixel(A2, S, A2.frame, lid, px, ro, rd, hr, queue);
 #else
-  SharedQueue queue{A};
-  shade_pixel(A, S, F, lid, px, ro, rd, hr, queue);
+    SharedQueue queue{A};
+    shade_pixel(A, S, F, lid, px, ro, rd, hr, queue);
 #endif
+  }
+  if (COUNT) flush_tex_tallies(A.counters->shade_tex, tex_tally);   // every lane of the wave is here (the counting build returns nowhere above)
 }
 
 template <bool COUNT>
@@ -175,11 +179,19 @@ __global__ void __launch_bounds__(kBlock, GLZ_TRACE_WAVES) k_trace(const LaunchA
   stage_top(A.scene, s_top);
   int* aux = &s_aux[(threadIdx.x >> 6) * kAuxPerWave];
   if (blockIdx.x == 0 && threadIdx.x < kQueueShards) A.st.queue_count[A.shade_set * kQueueSetWords + threadIdx.x * kCounterStride] = 0;
+  // counting build: the alpha tests' texture fetches are tallied through a copy of the scene that points at this thread's registers
+  unsigned long long tex_tally[4] = {0ull, 0ull, 0ull, 0ull};
+  DeviceScene counted_scene;
+  if (COUNT) {
+    counted_scene = A.scene;
+    counted_scene.tex_counter = tex_tally;
+  }
+  const DeviceScene& TS = COUNT ? counted_scene : A.scene;
   if (A.do_closest) {
     TraceTally tally;
     ClosestSource src{A, A.frame, tally, 0u};
     ClosestSink sink{A};
-    trace_wave<false, COUNT>(A.scene, src, sink, &s_stack[threadIdx.x], aux, (LdsNodePtr)s_top, A.st.overflow, A.st.overflow_depth, A.map.n_local_pixels, wave_index(),
+    trace_wave<false, COUNT>(TS, src, sink, &s_stack[threadIdx.x], aux, (LdsNodePtr)s_top, A.st.overflow, A.st.overflow_depth, A.map.n_local_pixels, wave_index(),
                              wave_count(), tally);
     if (COUNT) flush_counters(A.counters, false, tally);
   }
@@ -200,9 +212,10 @@ __global__ void __launch_bounds__(kBlock, GLZ_TRACE_WAVES) k_trace(const LaunchA
     const uint32_t n_waves = wave_count();
     const uint32_t closest_groups = A.do_closest ? (A.map.n_local_pixels + 63u) / 64u : 0u;
     const uint32_t wave = (wave_index() + n_waves - closest_groups % n_waves) % n_waves;
-    trace_wave<true, COUNT>(A.scene, src, sink, &s_stack[threadIdx.x], aux, (LdsNodePtr)s_top, A.st.overflow, A.st.overflow_depth, start[kQueueShards], wave, n_waves, tally);
+    trace_wave<true, COUNT>(TS, src, sink, &s_stack[threadIdx.x], aux, (LdsNodePtr)s_top, A.st.overflow, A.st.overflow_depth, start[kQueueShards], wave, n_waves, tally);
     if (COUNT) flush_counters(A.counters, true, tally);
   }
+  if (COUNT) flush_tex_tallies(A.counters->trace_tex, tex_tally);
   GLZ_WAVE_STAMP(2);
 }
 

@@ -231,20 +231,21 @@ uint32_t Renderer::chains_for(uint32_t w, uint32_t h, uint32_t rank, uint32_t wo
 }
 uint32_t Renderer::pick_chains() const { return path_mode_ ? 1u : chains_for(w_, h_, rank_, world_, chains_wanted_); }
 
-// Below this many owned pixels a device runs its launches as k_path batches (0 = automatic launch mode).  Measured on the atrium
-// (tools/gpu_partition_timing.py, one MI355X rendering rank 0's share): see DESIGN.md section 6.
-#ifndef GLZ_PATH_PIXELS
-#define GLZ_PATH_PIXELS 400000u
-#endif
-
+// Automatic launch mode: a device runs its launches as k_path batches when every 64-pixel group it owns gets a resident wave of its
+// own (4 096 on an MI355X at k_path's four waves per SIMD: up to 262 144 pixels, e.g. 1/8 of a 1080p frame or a 512 x 512 one) -- with
+// more groups than waves some waves carry two groups one after the other and the launch loop loses to the two-kernel mode (a 1/6
+// share: 0.248 against 0.190 ms per launch; a 1/8 share: 0.153 against 0.153; tools/gpu_partition_timing.py).
 bool Renderer::allocate(Error& err) {
   release_chains();
   {
     const uint32_t tiles_x = (w_ + kTile - 1) / kTile, tiles_y = (h_ + kTile - 1) / kTile, tiles = tiles_x * tiles_y;
     const uint64_t pixels = (uint64_t)(tiles > rank_ ? (tiles - rank_ + world_ - 1) / world_ : 0) * kTile * kTile;
-    const char* px = getenv("GLAZE_PATH_PIXELS");
-    const uint64_t limit = px ? (uint64_t)atoll(px) : (uint64_t)GLZ_PATH_PIXELS;
-    path_mode_ = scene_->dev.two_level == 0 && (launch_mode_ == 2 || (launch_mode_ == 0 && pixels > 0 && pixels < limit));
+    bool fits = false;
+    if (launch_mode_ == 0 && pixels > 0 && pixels <= (1u << 22) && scene_->dev.two_level == 0) {
+      const uint32_t blocks = (uint32_t)((pixels / 64 + kTraceBlock / 64 - 1) / (kTraceBlock / 64));
+      fits = path_grid_blocks((uint32_t)pixels, scene_->dev) >= blocks;
+    }
+    path_mode_ = scene_->dev.two_level == 0 && (launch_mode_ == 2 || fits);
   }
   const uint32_t S = pick_chains();
   const uint32_t od = scene_->stack_overflow_depth;
@@ -344,7 +345,6 @@ void Renderer::fill_args(const Chain& c, LaunchArgs& a) const {
   a.map = c.map;
   a.cam = cam_;
   a.counters = counting_ ? counters_.ptr : nullptr;
-  a.scene.tex_counter = counting_ ? counters_.ptr->trace_tex : nullptr;   // k_trace's alpha tests; k_shade points its copy at shade_tex
   a.do_closest = a.do_shadow = 0;
   a.shade_set = c.pending_set ^ 1u;
   a.shadow_exposure = c.pending_exposure;
