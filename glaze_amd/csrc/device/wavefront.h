@@ -862,17 +862,34 @@ __device__ __forceinline__ uint32_t wave_count() { return gridDim.x * (kBlock / 
 // ---------------------------------------------------------------------------------------------
 // closest-hit phase of k_trace: path_trace.rgen:143-169
 // ---------------------------------------------------------------------------------------------
+// k_path deals a wave's 64 pixels from GLZ_PATH_PIECES different 64-pixel groups, n_groups / PIECES apart (different tiles of the
+// frame): piece p of wave g is piece p of group g + p * (n_groups / PIECES).  Groups differ in cost persistently -- a region of the
+// image stays as hard as it is -- and a wave that owns one group carries that difference through every launch of the batch; a wave
+// that owns pieces of several averages over them.  Each piece is 64 / PIECES consecutive pixels (whole 64-byte lines of every state
+// array at PIECES <= 16).  For every p the map g -> g + p K (mod n_groups) is a bijection, so every pixel has exactly one wave.
+#ifndef GLZ_PATH_PIECES
+#define GLZ_PATH_PIECES 1
+#endif
+__device__ __forceinline__ uint32_t group_pixel(uint32_t g, uint32_t i, uint32_t n_groups) {
+  constexpr uint32_t P = GLZ_PATH_PIECES, S = 64u / P;
+  if (P == 1u) return g * 64u + i;
+  const uint32_t p = i / S;
+  uint32_t src = g + p * (n_groups / P);
+  src = src >= n_groups ? src - n_groups : src;
+  return src * 64u + i;   // piece p of the source group: pixels p * S .. of it, i.e. the same position i inside the group
+}
 struct ClosestSource {
   const LaunchArgs& A;
   const FrameData& F;   // the launch's constants (k_trace: A.frame; k_path: one entry of its batch)
   TraceTally& tally;
-  uint32_t base;        // ray i is local pixel base + i (k_trace: 0; k_path: the first pixel of the wave's group)
+  uint32_t base;        // ray i is local pixel base + i (k_trace: 0; k_path: the first pixel of the wave's group) ...
+  uint32_t groups = 0;  // ... unless the wave's 64 rays are dealt from several groups (k_path: group_pixel), then `base` is the group
   // ray generation / resume for local pixel `lid`
   // (Dealing the rays of a group from 4, 16 or 64 different tiles instead of one row of one tile -- to level the waves of a small
   // share, whose ends spread from 60 (median) to 105 us -- changes nothing: the spread is not regional, a wave is as slow as the
   // longest dependent chain among its 64 rays.  Median and end of the phase moved by +3 ... +8 % with the coherence lost.)
   __device__ __forceinline__ bool load(uint32_t i, vec3& origin, vec3& direction, float& tmin, float& tmax) {
-    const uint32_t lid = base + i;
+    const uint32_t lid = groups ? group_pixel(base, i, groups) : base + i;
     const PixelId px = pixel_of(A.map, lid);
     if (!px.active) return false;
     const float4 ro = A.st.ray_o[lid], rd = A.st.ray_d[lid];

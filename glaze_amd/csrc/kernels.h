@@ -107,7 +107,7 @@ struct LaunchArgs {
   float shadow_exposure;     // exposure of the launch that queued the shadow rays (update_result uses it)
 };
 // The launches one k_path call runs (kernels_render.hip): what differs between launches, by value in the kernel arguments
-constexpr uint32_t kPathMaxLaunches = 16;   // 16 x 100 bytes of FrameData + LaunchArgs stay inside the 4 KB of kernel arguments
+constexpr uint32_t kPathMaxLaunches = 32;   // 32 x 84 bytes of FrameData + the 848 of LaunchArgs stay inside the 4 KB of kernel arguments
 struct PathBatch {
   uint32_t n;                              // launches in this call
   uint32_t tables_in_lds;                  // filled by launch_path

@@ -103,7 +103,8 @@ struct GroupMixedSink {
 #endif
 // the shading phase of k_path for the wave's 64 pixels; returns how many of them queued a shadow ray (entries lid0 .. of the queue arrays)
 constexpr uint32_t kPathBatchOffset = (uint32_t)(((sizeof(LaunchArgs) + alignof(PathBatch) - 1) / alignof(PathBatch)) * alignof(PathBatch));   // PathBatch in k_path's kernarg segment
-__device__ __forceinline__ uint32_t path_shade(uint32_t lid0, uint32_t lane, uint32_t L, const DeviceScene& S_lds, const float4* hit) {
+__device__ __forceinline__ uint32_t path_shade(uint32_t g, uint32_t n_groups, uint32_t lane, uint32_t L, const DeviceScene& S_lds, const float4* hit) {
+  const uint32_t lid0 = g * 64u;   // the wave's own 64 entries of the shadow-queue arrays
   const FrameData& F = ((const PathBatch*)(reread_kernarg() + kPathBatchOffset))->frame[L];
 #if GLZ_PATH_REREAD
   const LaunchArgs& A = *(const LaunchArgs*)reread_kernarg();
@@ -118,7 +119,7 @@ __device__ __forceinline__ uint32_t path_shade(uint32_t lid0, uint32_t lane, uin
   const LaunchArgs& A = *(const LaunchArgs*)__builtin_amdgcn_kernarg_segment_ptr();
   const DeviceScene& S = S_lds;
 #endif
-  const uint32_t lid = lid0 + lane;
+  const uint32_t lid = group_pixel(g, lane, n_groups);
   const PixelId px = pixel_of(A.map, lid);
   GroupQueue queue{lid0, false};
   if (px.active) {
@@ -208,7 +209,7 @@ __global__ void __launch_bounds__(kBlock, GLZ_PATH_WAVES) k_path(const LaunchArg
       if (L < B.n) {
         const FrameData& F = B.frame[L];
         // ONE traversal pass: the 64 closest-hit rays of launch L, then -- in the lanes those leave idle -- the shadow rays launch L-1 queued
-        GroupMixedSource src{ClosestSource{A, F, tally, lid0}, GroupShadowSource{A, lid0, 0u, make_float4(0.0f, 0.0f, 0.0f, 0.0f)}, false};
+        GroupMixedSource src{ClosestSource{A, F, tally, GLZ_PATH_PIECES > 1 ? g : lid0, GLZ_PATH_PIECES > 1 ? n_groups : 0u}, GroupShadowSource{A, lid0, 0u, make_float4(0.0f, 0.0f, 0.0f, 0.0f)}, false};
         GroupMixedSink sink{GroupHitSink{hit}, GroupShadowSink{A, src.shadow, queued_exposure}};
 #ifndef GLZ_PATH_NO_TRACE
         trace_wave<false, false, true>(A.scene, src, sink, &s_stack[threadIdx.x], aux, (LdsNodePtr)s_top, A.st.overflow, A.st.overflow_depth, 64u + n_shadow, 0u, 1u, tally);
@@ -229,7 +230,7 @@ __global__ void __launch_bounds__(kBlock, GLZ_PATH_WAVES) k_path(const LaunchArg
       pt_trace += pt1 - pt0;
 #endif
       if (L >= B.n) break;
-      n_shadow = path_shade(lid0, lane, L, S, hit);
+      n_shadow = path_shade(g, n_groups, lane, L, S, hit);
 #ifdef GLZ_PATH_ONE
       A.st.queue_count[wave_index()] = n_shadow; return;
 #endif
