@@ -106,14 +106,18 @@ struct LaunchArgs {
   uint32_t shade_set;        // which of the two shadow-queue counter sets this launch's k_shade fills (the other one is drained)
   float shadow_exposure;     // exposure of the launch that queued the shadow rays (update_result uses it)
 };
-// The launches one k_path call runs (kernels_render.hip): what differs between launches, by value in the kernel arguments
-constexpr uint32_t kPathMaxLaunches = 32;   // 32 x 84 bytes of FrameData + the 848 of LaunchArgs stay inside the 4 KB of kernel arguments
+// The launches one k_path call runs (kernels_path.hip): what differs between launches, by value in the kernel arguments (16 bytes a
+// launch next to the 848 of LaunchArgs: 192 launches stay inside the 4 KB the arguments may take).  Long batches matter: the kernel
+// ends when its slowest wave does, and a wave's time per launch scatters by ~20 % -- over 16 launches the slowest of 4 096 waves is
+// 27 % above the mean, over 192 launches 8 %.
+constexpr uint32_t kPathMaxLaunches = 192;
 struct PathBatch {
   uint32_t n;                              // launches in this call
   uint32_t tables_in_lds;                  // filled by launch_path
   uint32_t parity;                         // which of the two cost accumulators this batch adds to (it reads the other one)
-  FrameData frame[kPathMaxLaunches];       // RTFrameData of each launch, whole: the kernel reads a launch's constants from the kernel
-                                           // arguments where it needs them (scalar loads) instead of carrying a copy through its loop
+  uint32_t seed[kPathMaxLaunches];         // FrameData::seed of each launch (the rest of FrameData is LaunchArgs::frame)
+  float offset[kPathMaxLaunches][2];       // FrameData::pixel_offset
+  float exposure[kPathMaxLaunches];        // FrameData::exposure
 };
 constexpr uint32_t kTraceBlock = 256;          // threads per block of the render kernels (4 waves)
 constexpr uint32_t kQueueSetWords = 8 * 32;   // 8 shard counters, 128 bytes apart

@@ -102,10 +102,18 @@ struct GroupMixedSink {
 #define GLZ_PATH_REREAD 1
 #endif
 // the shading phase of k_path for the wave's 64 pixels; returns how many of them queued a shadow ray (entries lid0 .. of the queue arrays)
+// RTFrameData of launch L of the batch: what all launches share (LaunchArgs::frame) with the three per-launch fields from the batch
+__device__ __forceinline__ FrameData launch_frame(const LaunchArgs& A, const PathBatch& B, uint32_t L) {
+  FrameData F = A.frame;
+  F.seed = B.seed[L];
+  F.pixel_offset[0] = B.offset[L][0];
+  F.pixel_offset[1] = B.offset[L][1];
+  F.exposure = B.exposure[L];
+  return F;
+}
 constexpr uint32_t kPathBatchOffset = (uint32_t)(((sizeof(LaunchArgs) + alignof(PathBatch) - 1) / alignof(PathBatch)) * alignof(PathBatch));   // PathBatch in k_path's kernarg segment
 __device__ __forceinline__ uint32_t path_shade(uint32_t g, uint32_t n_groups, uint32_t lane, uint32_t L, const DeviceScene& S_lds, const float4* hit) {
   const uint32_t lid0 = g * 64u;   // the wave's own 64 entries of the shadow-queue arrays
-  const FrameData& F = ((const PathBatch*)(reread_kernarg() + kPathBatchOffset))->frame[L];
 #if GLZ_PATH_REREAD
   const LaunchArgs& A = *(const LaunchArgs*)reread_kernarg();
   // the scene as the shading code sees it: the arguments' pointers, re-read, with the tables this block staged in LDS in their place
@@ -119,6 +127,7 @@ __device__ __forceinline__ uint32_t path_shade(uint32_t g, uint32_t n_groups, ui
   const LaunchArgs& A = *(const LaunchArgs*)__builtin_amdgcn_kernarg_segment_ptr();
   const DeviceScene& S = S_lds;
 #endif
+  const FrameData F = launch_frame(A, *(const PathBatch*)(reread_kernarg() + kPathBatchOffset), L);
   const uint32_t lid = group_pixel(g, lane, n_groups);
   const PixelId px = pixel_of(A.map, lid);
   GroupQueue queue{lid0, false};
@@ -207,7 +216,7 @@ __global__ void __launch_bounds__(kBlock, GLZ_PATH_WAVES) k_path(const LaunchArg
       const unsigned long long pt0 = wall_clock64();
 #endif
       if (L < B.n) {
-        const FrameData& F = B.frame[L];
+        const FrameData F = launch_frame(A, B, L);
         // ONE traversal pass: the 64 closest-hit rays of launch L, then -- in the lanes those leave idle -- the shadow rays launch L-1 queued
         GroupMixedSource src{ClosestSource{A, F, tally, GLZ_PATH_PIECES > 1 ? g : lid0, GLZ_PATH_PIECES > 1 ? n_groups : 0u}, GroupShadowSource{A, lid0, 0u, make_float4(0.0f, 0.0f, 0.0f, 0.0f)}, false};
         GroupMixedSink sink{GroupHitSink{hit}, GroupShadowSink{A, src.shadow, queued_exposure}};
@@ -234,7 +243,7 @@ __global__ void __launch_bounds__(kBlock, GLZ_PATH_WAVES) k_path(const LaunchArg
 #ifdef GLZ_PATH_ONE
       A.st.queue_count[wave_index()] = n_shadow; return;
 #endif
-      queued_exposure = B.frame[L].exposure;
+      queued_exposure = B.exposure[L];
 #ifdef GLZ_PATH_TIMES
       pt_shade += wall_clock64() - pt1;
 #endif

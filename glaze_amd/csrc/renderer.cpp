@@ -483,10 +483,9 @@ bool Renderer::path_batch(uint32_t n, Error& err) {
   b.n = n;
   b.parity = chains_[0]->path_batches++ & 1u;
   for (uint32_t i = 0; i < n; ++i) {
-    b.frame[i] = fd;
-    b.frame[i].seed = rng_.next();           // rng.gen::<u32>(), raytracer.rs:487
-    sched_.next(b.frame[i].pixel_offset);    // WorkScheduler::next(), :489
-    b.frame[i].exposure = exposure_;
+    b.seed[i] = rng_.next();           // rng.gen::<u32>(), raytracer.rs:487
+    sched_.next(b.offset[i]);          // WorkScheduler::next(), :489
+    b.exposure[i] = exposure_;
   }
   launches_ += n;
   if (fd.lights_no == 0) return true;   // the raygen shader returns before touching anything (path_trace.rgen:137-141)
@@ -777,17 +776,17 @@ bool Renderer::draw(size_t spp, void (*cb)(void*), void* user, uint8_t* rgba8_ou
   restart();
   const size_t steps = steps_per_sample();
   const size_t substep = spp * steps;
-  (void)substep;
-  if (peers_.empty()) {
-    for (size_t sample = 0; sample < spp; ++sample) {
-      if (!run_launches((uint32_t)steps, err)) return false;
-      if (cb) cb(user);   // once per sample, on the caller's thread (raytracer.rs:651-653)
-    }
-  } else {
-    for (size_t sample = 0; sample < spp; ++sample) {   // one batch of launches per sample on every device, then the callback on this thread
-      if (!step((uint32_t)steps, err)) return false;
+  // The launches are enqueued in chunks -- one sample's worth, or as many as one k_path kernel takes (the longer its batch, the less
+  // the kernel's slowest wave weighs) -- and the callback fires on this thread once per sample, when the sample's first launch has
+  // been enqueued (raytracer.rs:651-653: `if i % steps == 0`); it never said anything about the GPU's progress.
+  size_t done = 0, fired = 0;
+  while (done < substep) {
+    const size_t chunk = use_path() ? (size_t)kPathMaxLaunches : steps;
+    const uint32_t m = (uint32_t)std::min(chunk, substep - done);
+    if (!(peers_.empty() ? run_launches(m, err) : step(m, err))) return false;
+    done += m;
+    for (; fired < (done + steps - 1) / steps; ++fired)
       if (cb) cb(user);
-    }
   }
   if (spp == 0 && request_new_frame_ && !reset_buffers(err)) return false;
   if (!wait_idle(err)) return false;

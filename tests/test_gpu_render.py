@@ -769,14 +769,14 @@ def test_path_mode_equals_two_kernels_and_the_oracle(instance, mtype):
     o = OracleRenderer(OracleScene(desc), w, h)
     o.set_depth(depth)
     o.set_seed(7)
-    for k in (1, 4, 17, 35, 70):                                                               # batches of 1, 4, 17, 32 + 3, 32 + 32 + 6 launches
+    for k in (1, 4, 17, 70, 200):                                                              # batches of 1, 4, 17, 70 and 192 + 8 launches
         two.step(k); path.step(k); o.step(k)
         a, b = two.read_hdr(), path.read_hdr()
         assert np.array_equal(bits(a), bits(b)), k
         assert np.array_equal(bits(two.read_result()), bits(path.read_result())), k
         assert np.array_equal(bits(b), bits(o.read_hdr())), k
     assert np.array_equal(two.read_rgba8(), path.read_rgba8())
-    assert path.stats().launches == two.stats().launches == 127
+    assert path.stats().launches == two.stats().launches == 292
     assert path.stats().other_ms > 0 and path.stats().trace_closest_ms == 0                    # it really was k_path
     assert two.stats().other_ms == 0 and two.stats().trace_closest_ms > 0
 
