@@ -58,7 +58,64 @@ def parse_args():
                     help="N > 1: rank 0 re-renders the whole frame alone and compares it bit for bit (default)")
     ap.add_argument("--no-verify", dest="verify", action="store_false")
     ap.add_argument("--repeats", type=int, default=0, help="timed regions of K steps each (0 = five when a region is shorter than 0.5 s, else one)")
+    ap.add_argument("--no-pmc", action="store_true", help="do not run the two rocprofv3 --pmc passes that measure roofline.traffic (N = 1 only)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)     # this process IS one of those passes: render only
     return ap.parse_args()
+
+
+def measure_hbm_traffic(args):
+    """roofline.traffic, measured by THIS invocation: two short runs of this very workload under `rocprofv3 --pmc` (FETCH_SIZE and
+    WRITE_SIZE in separate passes with --kernel-trace only, as MI355X_MICROARCH.md prescribes), per-kernel averages over their
+    launches.  HBM bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1 KiB: the counters are in KiB and on gfx950 FETCH_SIZE reports half
+    of the bytes of wide reads (the 2 x is calibrated for coalesced streams: an upper estimate for scattered 16-byte loads).
+    Returns ({kernel: bytes per launch}, note) or (None, why not)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 is not on PATH"
+    acc = {}
+    tmp = tempfile.mkdtemp(prefix="glaze_pmc_")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__),
+                   "--pmc-child", "--steps", "16", "--warmup", "8", "--width", str(args.width), "--height", str(args.height), "--depth", str(args.depth),
+                   "--seed", str(args.seed)]
+            env = dict(os.environ, TMPDIR="/tmp")
+            try:
+                p = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=150)
+            except subprocess.TimeoutExpired:
+                return None, "rocprofv3 --pmc %s did not finish within 150 s" % counter
+            if p.returncode != 0:
+                return None, "rocprofv3 --pmc %s: rc %d: %s" % (counter, p.returncode, (p.stderr or p.stdout)[-200:].replace("\n", " "))
+            files = glob.glob(os.path.join(out, "**", "*_counter_collection.csv"), recursive=True)
+            if not files:
+                return None, "rocprofv3 --pmc %s left no counter_collection.csv" % counter
+            per = {}
+            for f in files:
+                for row in csv.DictReader(open(f)):
+                    name = row["Kernel_Name"].replace(" ", "")
+                    if row["Counter_Name"] != counter or "<true" in name:
+                        continue
+                    for k in ("k_trace", "k_shade"):
+                        if "::" + k + "<" in name or "::" + k + "(" in name:
+                            per.setdefault(k, []).append(float(row["Counter_Value"]))
+            for k, v in per.items():
+                acc.setdefault(k, {})[counter] = (sum(v) / len(v), len(v))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    res = {}
+    for k, v in acc.items():
+        if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+            res[k] = {"hbm_bytes_per_launch": int((2.0 * v["FETCH_SIZE"][0] + v["WRITE_SIZE"][0]) * 1024),
+                      "uncorrected": int((v["FETCH_SIZE"][0] + v["WRITE_SIZE"][0]) * 1024), "launches": min(v["FETCH_SIZE"][1], v["WRITE_SIZE"][1])}
+    if not res:
+        return None, "no k_trace / k_shade rows in the counter files"
+    return res, "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes (with --kernel-trace only) of this workload, run by this invocation after its timed regions: 24 launches each, (2 x FETCH_SIZE + WRITE_SIZE) x 1 KiB per launch"
 
 
 def algorithmic_bytes(c):
@@ -177,6 +234,12 @@ def main():
             renderer.export_device(0, frame.data_ptr())
             reduce_frame(frame)
 
+    if args.pmc_child:
+        # one of the rocprofv3 --pmc passes of measure_hbm_traffic(): the same launches as the timed regions, nothing else
+        renderer.restart()
+        renderer.step(args.warmup + args.steps)
+        renderer.wait_idle()
+        return
     # ---- warmup (untimed): same accumulation continues afterwards, like the interactive draw_frame loop
     renderer.restart()
     renderer.step(args.warmup)
@@ -261,18 +324,24 @@ def main():
         owned = W * H / n_gpus      # per GPU: kernel times are per device (the slowest one when one process spans several)
         avg_ms = kern_ms[dominant] / total_steps
         achieved = bytes_per_sample[dominant] * owned / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        # HBM traffic is NOT measured in this run (PMC counters need rocprofv3): the number is the per-launch average of the
-        # committed rocprofv3 --pmc passes of this very command (tools/profile_gpu.sh -> profiles/pmc_summary.json)
-        traffic, traffic_source = None, None
+        # HBM traffic from the PMC counters: measured by this invocation (two rocprofv3 --pmc passes of the same workload as child
+        # processes, N = 1 only); if that is not possible, the per-launch average of the committed passes (profiles/pmc_summary.json)
+        traffic, traffic_source, traffic_all = None, None, None
+        if n_gpus == 1 and not args.no_pmc:
+            measured, note = measure_hbm_traffic(args)
+            if measured is not None and dominant in measured:
+                traffic, traffic_source, traffic_all = measured[dominant]["hbm_bytes_per_launch"], note, measured
+            else:
+                traffic_source = "not measured in this run (%s); " % note
         prof = os.path.join(ROOT, "profiles", "pmc_summary.json")
-        if os.path.exists(prof) and n_gpus == 1:      # the committed PMC passes profiled the N = 1 command
+        if traffic is None and os.path.exists(prof) and n_gpus == 1:      # the committed PMC passes profiled the N = 1 command
             try:
                 traffic = json.load(open(prof)).get(dominant, {}).get("hbm_bytes_per_launch")
-                traffic_source = "profiles/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `python bench.py`, not this run)"
+                traffic_source = (traffic_source or "") + "profiles/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `python bench.py`, not this run)"
             except Exception:
                 traffic = None
         roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
-                    "frac": round(achieved / 8000.0, 4), "traffic": traffic, "traffic_source": traffic_source,
+                    "frac": round(achieved / 8000.0, 4), "traffic": traffic, "traffic_source": traffic_source, "traffic_per_kernel": traffic_all,
                     "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_sample": {k: round(v, 1) for k, v in bytes_per_sample.items()},
                     "whole_job_achieved": round(sum(bytes_per_sample.values()) * samples / elapsed / 1e9, 1),
                     "counted_per_sample": {k: round(v, 3) for k, v in counted.items()},
