@@ -15,8 +15,10 @@ using namespace dev;
 // pays that maximum again, twice (k_trace, k_shade).  Pixels are independent (path_trace.rgen:143-168: state, RNG and accumulator are
 // per pixel), so nothing forces a wave to wait for the others: here every wave carries ITS 64 pixels through
 //     closest hits of launch L -> shadow rays queued by launch L-1 (+ update_count / update_result) -> shade of launch L
-// for all launches of the batch, with no grid-wide boundary in between.  A step then costs the slowest wave's SUM over the launches
-// instead of the sum over launches of the slowest wave.  Per pixel the operations and their order are those of k_trace / k_shade
+// for all launches of the batch (up to 192: only seed, jitter offset and exposure differ between launches, 16 bytes each in the kernel
+// arguments), with no grid-wide boundary in between.  A step then costs the slowest wave's SUM over the launches instead of the
+// sum over launches of the slowest wave.  (Measured, DESIGN.md section 6: a wave's mean per launch IS the throughput bound of a 1/8
+// share, 0.122 ms; the slowest wave's sum is 0.148 -- 6.3 x for eight GPUs against the two-kernel mode's 6.1 x, not the 6.5 x hoped for.)  Per pixel the operations and their order are those of k_trace / k_shade
 // (same sources, same shade_pixel, shadow rays of a launch resolved before the next launch's shading), so the image is bit-identical
 // -- tests/test_gpu_render.py compares the two modes and the oracle.
 // A wave's closest-hit records stay in LDS, its shadow queue is its own 64 entries of the queue arrays (no atomics, no shards), and
@@ -101,7 +103,6 @@ struct GroupMixedSink {
 #ifndef GLZ_PATH_REREAD
 #define GLZ_PATH_REREAD 1
 #endif
-// the shading phase of k_path for the wave's 64 pixels; returns how many of them queued a shadow ray (entries lid0 .. of the queue arrays)
 // RTFrameData of launch L of the batch: what all launches share (LaunchArgs::frame) with the three per-launch fields from the batch
 __device__ __forceinline__ FrameData launch_frame(const LaunchArgs& A, const PathBatch& B, uint32_t L) {
   FrameData F = A.frame;
@@ -112,6 +113,7 @@ __device__ __forceinline__ FrameData launch_frame(const LaunchArgs& A, const Pat
   return F;
 }
 constexpr uint32_t kPathBatchOffset = (uint32_t)(((sizeof(LaunchArgs) + alignof(PathBatch) - 1) / alignof(PathBatch)) * alignof(PathBatch));   // PathBatch in k_path's kernarg segment
+// the shading phase of k_path for the wave's 64 pixels; returns how many of them queued a shadow ray (entries 64 g .. of the queue arrays)
 __device__ __forceinline__ uint32_t path_shade(uint32_t g, uint32_t n_groups, uint32_t lane, uint32_t L, const DeviceScene& S_lds, const float4* hit) {
   const uint32_t lid0 = g * 64u;   // the wave's own 64 entries of the shadow-queue arrays
 #if GLZ_PATH_REREAD
