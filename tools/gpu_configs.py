@@ -13,8 +13,11 @@ for name, make, w, h, depth in cases:
     t = time.time(); scene = make(); setup = time.time() - t
     r = glaze_amd.RayTraceRenderer.new(inst, scene, w, h)
     r.set_depth(depth)
-    r.step(2 * depth); r.wait_idle()
-    n = 16 * depth
-    t = time.time(); r.step(n); r.wait_idle(); dt = time.time() - t
-    s = r.stats()
-    print("%-62s %8.1f Msamples/s  %.3f ms/launch  (scene setup %.3f s, %d tris)" % (name, w * h * n / dt / 1e6, dt / n * 1e3, setup, scene.info().n_world_triangles))
+    for mode in ("auto", "two_kernels", "path"):
+        if mode == "path" and w * h > 600000:
+            continue          # the per-wave launch loop with several groups per wave: of no interest
+        r.set_launch_mode(mode)
+        r.restart(); r.step(2 * depth); r.wait_idle()
+        n = 64 * depth
+        t = time.time(); r.step(n); r.wait_idle(); dt = time.time() - t
+        print("%-62s %-11s (%s) %8.1f Msamples/s  %.4f ms/launch  (scene setup %.3f s, %d tris)" % (name, mode, r.launch_mode(), w * h * n / dt / 1e6, dt / n * 1e3, setup, scene.info().n_world_triangles), flush=True)
