@@ -139,16 +139,18 @@ struct BvhGrid {
 // ray is used for the box tests alone); the triangle test stays in WORLD space on the triangle transformed exactly as the
 // flattened build transforms it (k_world_tris), so a two-level scene gives bit for bit the hits of its flattened twin.
 struct alignas(16) TlasInstance {
+  // what ENTERING the instance reads, in the record's first 96 bytes (a line and a half; the rest is only read at the mesh's leaves)
   float w2o[12];          // rows 0..2 of world -> object (x' = w2o[0..3] . (x, 1), ...): the ray into object space
-  float o2w[16];          // object -> world, column-major as TransformPair::o2w: the triangle into world space
   BvhGrid grid;           // quantisation grid of the mesh's nodes (object space)
   float slack;            // slack of the object-space box tests in object units (rounding of the transformed ray and triangle); every box is widened by slack / cell + 1 cells per axis
   uint32_t node_base;     // first node of the mesh in bvh_nodes
+  float w2o_norm;         // max row sum of |w2o|'s 3 x 3 part: how the rounding of a ray origin grows into object space (per-ray part of the slack)
+  // what a triangle test inside the instance reads
+  float o2w[16];          // object -> world, column-major as TransformPair::o2w: the triangle into world space
   uint32_t tri_base;      // first triangle / shading record of the mesh in bvh_tris / shade_tris
   uint32_t world_base;    // world triangle id of the instance's primitive 0 (tie-break key, as in the flattened build)
   uint32_t instance;      // RTInstance index
   uint32_t non_opaque;    // the instance's material has an opacity map (acceleration.rs:136-141)
-  float w2o_norm;         // max row sum of |w2o|'s 3 x 3 part: how the rounding of a ray origin grows into object space (per-ray part of the slack)
 };
 static_assert(sizeof(TlasInstance) == 176, "TlasInstance is 11 x 16 bytes");
 

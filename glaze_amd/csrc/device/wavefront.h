@@ -637,8 +637,8 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
 constexpr int kExitInstance = 0x7FFFFFFD;   // stack marker: the entries below belong to the top level
 
 template <bool ANY, bool COUNT, class Source, class Sink>
-__device__ __forceinline__ void trace_wave_tl(const DeviceScene& S, Source& src, Sink& sink, int* __restrict__ lds_col, int* aux, uint32_t* __restrict__ spill,
-                                              uint32_t spill_depth, uint32_t total, uint32_t wave, uint32_t n_waves, TraceTally& tally) {
+__device__ __forceinline__ void trace_wave_tl(const DeviceScene& S, Source& src, Sink& sink, int* __restrict__ lds_col, int* aux, float* __restrict__ top_ray,
+                                              uint32_t* __restrict__ spill, uint32_t spill_depth, uint32_t total, uint32_t wave, uint32_t n_waves, TraceTally& tally) {
   constexpr uint32_t kNone = 0xFFFFFFFFu;
   const BvhNode4* __restrict__ nodes = S.bvh_nodes;        // top-level nodes first, the meshes' after them (TlasInstance::node_base)
   const BvhTri* __restrict__ tris = S.bvh_tris;
@@ -672,17 +672,29 @@ __device__ __forceinline__ void trace_wave_tl(const DeviceScene& S, Source& src,
 #ifdef GLZ_WAVE_TIMES
   unsigned long long tl_rays = 0, tl_top = 0, tl_mesh = 0, tl_enter = 0, tl_tris = 0, tl_niter = 0, tl_liter = 0;
 #endif
-  auto to_top_level = [&]() {
+  // The top level's grid-space ray is derived once per ray and parked in the lane's LDS column top_ray[k * kBlock] (k = 0..8: ig, cgn,
+  // cgf): leaving an instance reloads it instead of re-deriving it from the world ray (three correctly rounded divisions).
+  auto to_top_level = [&](bool fresh) {
     cur_inst = kNone;
     nbase = 0u;
-    set_grid_ray(S.bvh_grid.lo, S.bvh_grid.cell, S.bvh_grid.inv_cell, o, d, 0.0f, 0.0f);
+    if (fresh) {
+      set_grid_ray(S.bvh_grid.lo, S.bvh_grid.cell, S.bvh_grid.inv_cell, o, d, 0.0f, 0.0f);
+      top_ray[0] = ig.x; top_ray[kBlock] = ig.y; top_ray[2 * kBlock] = ig.z;
+      top_ray[3 * kBlock] = cgn.x; top_ray[4 * kBlock] = cgn.y; top_ray[5 * kBlock] = cgn.z;
+      top_ray[6 * kBlock] = cgf.x; top_ray[7 * kBlock] = cgf.y; top_ray[8 * kBlock] = cgf.z;
+    } else {
+      ig = mk3(top_ray[0], top_ray[kBlock], top_ray[2 * kBlock]);
+      cgn = mk3(top_ray[3 * kBlock], top_ray[4 * kBlock], top_ray[5 * kBlock]);
+      cgf = mk3(top_ray[6 * kBlock], top_ray[7 * kBlock], top_ray[8 * kBlock]);
+      sel = SlabSel{ig.x < 0.0f ? 0x01000302u : 0x03020100u, ig.y < 0.0f ? 0x01000302u : 0x03020100u, ig.z < 0.0f ? 0x01000302u : 0x03020100u};
+    }
   };
   auto pop_next = [&]() -> int {
     for (;;) {
       if (st.sp == 0) return kRayDone;
       const int v = st.pop();
       if (v != kExitInstance) return v;
-      to_top_level();
+      to_top_level(false);
     }
   };
   for (;;) {
@@ -700,7 +712,7 @@ __device__ __forceinline__ void trace_wave_tl(const DeviceScene& S, Source& src,
             sink.store(ray, best);
           } else {
             st.sp = 0;
-            to_top_level();
+            to_top_level(true);
             cur = 0;
             open = true;
 #ifdef GLZ_WAVE_TIMES
