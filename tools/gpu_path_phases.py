@@ -21,3 +21,9 @@ for world in (8, 16, 32):
     t = buf[:n_waves].astype(np.float64) * 0.01 / 16      # us per launch
     q = lambda a: "mean %.1f p50 %.1f p90 %.1f max %.1f" % (a.mean(), np.median(a), np.percentile(a, 90), a.max())
     print("world %2d, %d waves, us per launch and wave: trace %s | shade %s | whole kernel / 16: %s" % (world, n_waves, q(t[:, 0]), q(t[:, 1]), q(t[:, 2])), flush=True)
+    # where does the spread between waves live?  waves 4b .. 4b+3 are one block (one CU, four SIMDs); blocks b, b + 8, .. share an XCD
+    tot = t[:n_waves - n_waves % 4, 2].reshape(-1, 4)
+    blk = tot.mean(axis=1)
+    xcd = [blk[x::8].mean() for x in range(8)]
+    print("          std over waves %.1f us; std of block means %.1f, mean std inside a block %.1f; XCD means %s" % (
+        tot.std(), blk.std(), tot.std(axis=1).mean(), " ".join("%.0f" % x for x in xcd)), flush=True)
