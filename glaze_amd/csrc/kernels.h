@@ -70,8 +70,6 @@ struct PathState {
   float4* result;    // result_image (out32)
   uint32_t* overflow;// traversal stack spill, `overflow_depth` words per lane slot of the k_trace grid
   uint32_t overflow_depth;
-  uint32_t* path_sched;// k_path, balanced dealing (kPathSched*): wave counters per CU and per slot, sweep counter, claim flag per group; zeroed before every batch
-  uint32_t* path_perm; // k_path, balanced dealing: the groups by descending cost of the previous batch (k_path_rank)
   uint32_t* path_cost;// k_path: [0..7] two accumulators {sum of per-launch ticks (u64), groups (u32), pad}, then one word per 64-pixel group: its ticks per launch in the last batch
 };
 
@@ -117,7 +115,6 @@ struct PathBatch {
   uint32_t n;                              // launches in this call
   uint32_t tables_in_lds;                  // filled by launch_path
   uint32_t parity;                         // which of the two cost accumulators this batch adds to (it reads the other one)
-  uint32_t balance;                        // 0: wave w owns groups w, w + n_waves, ..; else the number of CUs: groups are dealt by cost (k_path)
   uint32_t seed[kPathMaxLaunches];         // FrameData::seed of each launch (the rest of FrameData is LaunchArgs::frame)
   float offset[kPathMaxLaunches][2];       // FrameData::pixel_offset
   float exposure[kPathMaxLaunches];        // FrameData::exposure
@@ -132,11 +129,6 @@ hipError_t launch_shade(hipStream_t st, const LaunchArgs& a);
 // share; flattened scenes, no work counters); blocks from path_grid_blocks (device must be current)
 uint32_t path_grid_blocks(uint32_t n_local_pixels, const DeviceScene& scene);
 hipError_t launch_path(hipStream_t st, const LaunchArgs& a, const PathBatch& batch, uint32_t blocks);
-// balanced dealing of k_path: words of PathState::path_sched in front of the per-group claim flags, the largest share it is used for,
-// and the kernel that orders the groups by the cost the previous batch measured (n_groups <= kPathBalanceMaxGroups)
-constexpr uint32_t kPathSchedCu = 0, kPathSchedSlot = 1024, kPathSchedSweep = 1024 + 64, kPathSchedClaim = 1024 + 64 + 8;
-constexpr uint32_t kPathBalanceMaxGroups = 4096;
-hipError_t launch_path_rank(hipStream_t st, const uint32_t* path_cost, uint32_t n_groups, uint32_t* perm);
 // scatter the tile-major cumulative / result images into full-frame row-major RGBA32F buffers
 hipError_t launch_export(hipStream_t st, const TileMap& map, const float4* tiled, float4* frame, bool zero_first);
 // chain `chain` of `n_chains` -> the rank's packed tile order (local tile j = jl * n_chains + chain), see Renderer::export_packed

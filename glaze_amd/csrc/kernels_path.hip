@@ -140,70 +140,6 @@ __device__ __forceinline__ uint32_t path_shade(uint32_t g, uint32_t n_groups, ui
   return (uint32_t)__popcll(__ballot(queue.pushed));
 }
 
-// ---------------------------------------------------------------------------------------------
-// Balanced dealing (PathBatch::balance = number of CUs).  The waves of a block run at one pace and blocks differ -- by where their
-// pixels are and, at full load, by what the other blocks of their CU are doing (EXPERIMENTS.md, round 3).  A batch starts with nothing
-// pending in any wave, so WHICH wave runs a group may change from batch to batch: the groups are ordered by the cost the previous
-// batch measured (k_path_rank) and cut into strata of n_cu groups; the s-th wave to arrive on a CU takes a group of stratum s -- every CU
-// gets one group of every cost band, its waves' loads add up alike.  Exactly-once is not left to the dealing: a group is run by the
-// wave that sets its claim flag, and every wave ends by sweeping the flags for groups nobody took.
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t cu_key() {
-  const uint32_t hw = (uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);    // HW_ID: cu_id [11:8], sh_id [12], se_id [15:13]
-  const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);   // XCC_ID [3:0]
-  return ((xcc & 7u) << 7) | (((hw >> 13) & 3u) << 5) | (((hw >> 12) & 1u) << 4) | ((hw >> 8) & 15u);   // < 1024
-}
-constexpr uint32_t kNoGroup = 0xFFFFFFFFu;
-struct GroupDealer {
-  uint32_t* sched;
-  const uint32_t* perm;
-  uint32_t n_groups, n_cu;
-  bool first;
-  // wave-uniform; lane 0 does the atomics
-  __device__ __forceinline__ uint32_t claim(uint32_t g) { return atomicExch(&sched[kPathSchedClaim + g], 1u) == 0u ? g : kNoGroup; }
-  __device__ __forceinline__ uint32_t next() {
-    uint32_t g = kNoGroup;
-    if ((threadIdx.x & 63u) == 0u) {
-      if (first) {
-        const uint32_t slot = atomicAdd(&sched[kPathSchedCu + cu_key()], 1u);
-        if (slot < 64u) {
-          const uint32_t rank = atomicAdd(&sched[kPathSchedSlot + slot], 1u);
-          const uint32_t idx = slot * n_cu + rank;
-          if (rank < n_cu && idx < n_groups) g = claim(perm[idx]);
-        }
-      }
-      while (g == kNoGroup) {   // the sweep: whatever is still unclaimed, in the order of the ranking (dear groups first)
-        const uint32_t i = atomicAdd(&sched[kPathSchedSweep], 1u);
-        if (i >= n_groups) break;
-        g = claim(perm[i]);
-      }
-    }
-    first = false;
-    return (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
-  }
-};
-
-// groups by descending cost of the previous batch: one block, bitonic sort of (cost << 12 | group) keys in LDS
-__global__ void __launch_bounds__(1024) k_path_rank(const uint32_t* __restrict__ path_cost, uint32_t n_groups, uint32_t* __restrict__ perm) {
-  __shared__ uint32_t s_key[kPathBalanceMaxGroups];
-  for (uint32_t i = threadIdx.x; i < kPathBalanceMaxGroups; i += 1024u) {
-    const uint32_t c = i < n_groups ? path_cost[8u + i] : 0u;
-    s_key[i] = i < n_groups ? (((c < 0xFFFFEu ? c : 0xFFFFEu) + 1u) << 12) | i : 0u;   // a real key is never 0: the padding sorts last
-  }
-  __syncthreads();
-  for (uint32_t k = 2; k <= kPathBalanceMaxGroups; k <<= 1)
-    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-      for (uint32_t t = threadIdx.x; t < kPathBalanceMaxGroups / 2; t += 1024u) {
-        const uint32_t i = 2u * t - (t & (j - 1u));   // the lower index of the t-th pair at distance j
-        const uint32_t a = s_key[i], b = s_key[i + j];
-        const bool descending = (i & k) == 0u;
-        if (descending ? a < b : a > b) { s_key[i] = b; s_key[i + j] = a; }
-      }
-      __syncthreads();
-    }
-  for (uint32_t i = threadIdx.x; i < n_groups; i += 1024u) perm[i] = s_key[i] & 0xFFFu;
-}
-
 #ifdef GLZ_PATH_TIMES   // tuning builds only (tools/gpu_path_phases.py): 10 ns ticks every wave spent tracing / shading, summed over the launches of the last k_path
 __device__ unsigned long long g_path_times[3 * 8192];
 #endif
@@ -243,18 +179,11 @@ __global__ void __launch_bounds__(kBlock, GLZ_PATH_WAVES) k_path(const LaunchArg
   unsigned long long pt_trace = 0, pt_shade = 0, pt_begin = wall_clock64();
 #endif
   const uint32_t n_groups = (A.map.n_local_pixels + 63u) / 64u;
-  // which groups this wave runs: its own strided sequence, or what the dealer hands it (PathBatch::balance)
-  GroupDealer dealer{A.st.path_sched, A.st.path_perm, n_groups, B.balance, true};
-  uint32_t static_next = my_wave;
-  for (;;) {
-    uint32_t g;
-    if (B.balance != 0u) {
-      g = dealer.next();
-    } else {
-      g = static_next < n_groups ? static_next : kNoGroup;
-      static_next += wave_count();
-    }
-    if (g == kNoGroup) break;
+#ifdef GLZ_PATH_ONE
+  { const uint32_t g = my_wave; if (g >= n_groups) return;
+#else
+  for (uint32_t g = my_wave; g < n_groups; g += wave_count()) {
+#endif
     const uint32_t lid0 = g * 64u;
 #ifndef GLZ_PATH_NO_PRIO
     // Groups differ in cost, persistently (a region of the image stays as hard as it is), and the kernel lasts as long as its
@@ -313,6 +242,9 @@ __global__ void __launch_bounds__(kBlock, GLZ_PATH_WAVES) k_path(const LaunchArg
 #endif
       if (L >= B.n) break;
       n_shadow = path_shade(g, n_groups, lane, L, S, hit);
+#ifdef GLZ_PATH_ONE
+      A.st.queue_count[wave_index()] = n_shadow; return;
+#endif
       queued_exposure = B.exposure[L];
 #ifdef GLZ_PATH_TIMES
       pt_shade += wall_clock64() - pt1;
@@ -352,11 +284,6 @@ uint32_t path_grid_blocks(uint32_t n_local_pixels, const DeviceScene& sc) {
   per_cu = std::min(per_cu, 8);
   const uint32_t groups = (n_local_pixels + 63u) / 64u, blocks = (groups + kBlock / 64 - 1) / (kBlock / 64);
   return std::max<uint32_t>(1u, std::min<uint32_t>(blocks, (uint32_t)cus * (uint32_t)per_cu));
-}
-hipError_t launch_path_rank(hipStream_t st, const uint32_t* path_cost, uint32_t n_groups, uint32_t* perm) {
-  if (n_groups == 0 || n_groups > kPathBalanceMaxGroups) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(k_path_rank, dim3(1), dim3(1024), 0, st, path_cost, n_groups, perm);
-  return hipGetLastError();
 }
 hipError_t launch_path(hipStream_t st, const LaunchArgs& a, const PathBatch& batch, uint32_t blocks) {
   static_assert(sizeof(LaunchArgs) + sizeof(PathBatch) <= 4096, "kernel arguments of k_path");

@@ -284,19 +284,6 @@ bool Renderer::allocate(Error& err) {
     if (!hip_ok(c->queue_count.alloc(2 * kQueueSetWords), "alloc queue counters", err)) return false;
     if (!hip_ok(c->path_cost.alloc(8 + n / 64 + 1), "alloc path costs", err)) return false;
     if (!hip_ok(hipMemsetAsync(c->path_cost.ptr, 0, sizeof(uint32_t) * (8 + n / 64 + 1), c->stream), "clear path costs", err)) return false;
-    // balanced dealing of k_path's groups (kernels_path.hip): when every group has a resident wave and the ranking kernel can hold them
-    const uint32_t n_groups = (uint32_t)(n / 64);
-    const char* bal = getenv("GLAZE_PATH_BALANCE");
-    c->path_balance = 0;
-    if (path_mode_ && n_groups != 0 && n_groups <= kPathBalanceMaxGroups && c->grid_path * (kTraceBlock / 64) >= n_groups && !(bal && atoi(bal) == 0)) {
-      hipDeviceProp_t prop;
-      c->path_balance = hipGetDeviceProperties(&prop, inst_->device) == hipSuccess && prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256u;
-      if (!hip_ok(c->path_sched.alloc(kPathSchedClaim + n_groups), "alloc path dealer", err)) return false;
-      std::vector<uint32_t> ident(n_groups);
-      for (uint32_t i = 0; i < n_groups; ++i) ident[i] = i;
-      if (!hip_ok(c->path_perm.upload(ident.data(), n_groups, c->stream), "upload path ranking", err)) return false;
-      if (!hip_ok(hipStreamSynchronize(c->stream), "upload path ranking", err)) return false;   // ident is on this stack frame
-    }
     chains_.push_back(std::move(c));
   }
   if (!hip_ok(frame_tmp_.alloc((size_t)w_ * h_), "alloc frame", err)) return false;
@@ -355,8 +342,6 @@ void Renderer::fill_args(const Chain& c, LaunchArgs& a) const {
   a.st.overflow = c.overflow.ptr;
   a.st.overflow_depth = scene_->stack_overflow_depth;
   a.st.path_cost = c.path_cost.ptr;
-  a.st.path_sched = c.path_sched.ptr;
-  a.st.path_perm = c.path_perm.ptr;
   a.map = c.map;
   a.cam = cam_;
   a.counters = counting_ ? counters_.ptr : nullptr;
@@ -518,13 +503,6 @@ bool Renderer::path_batch(uint32_t n, Error& err) {
   }
   // the cost accumulator this batch adds to starts empty (the kernel reads the other one, which the batch before filled)
   if (!hip_ok(hipMemsetAsync(c.path_cost.ptr + 4u * b.parity, 0, 16, c.stream), "clear path cost accumulator", err)) return false;
-  b.balance = c.path_balance;
-  if (b.balance != 0u) {
-    // the groups in the order of the cost the batch before measured (the first batch keeps the identity), fresh dealer counters
-    const uint32_t n_groups = c.map.n_local_pixels / 64u;
-    if (c.path_batches > 1 && !hip_ok(launch_path_rank(c.stream, c.path_cost.ptr, n_groups, c.path_perm.ptr), "k_path_rank", err)) return false;
-    if (!hip_ok(hipMemsetAsync(c.path_sched.ptr, 0, sizeof(uint32_t) * (kPathSchedClaim + n_groups), c.stream), "clear path dealer", err)) return false;
-  }
   if (!hip_ok(launch_path(c.stream, a, b, c.grid_path), "k_path", err)) return false;
   if (profile_kernels_) {
     (void)hipEventRecord(ev.e[1], c.stream);

@@ -110,9 +110,8 @@ class Renderer {
     DeviceBuffer<float4> ray_o, ray_d, imp[4], hit, sh_o, sh_d, contrib, cumulative, result;
     DeviceBuffer<float> cone;
     DeviceBuffer<uint32_t> hit_inst;
-    DeviceBuffer<uint32_t> overflow, queue_count, path_cost, path_sched, path_perm;
+    DeviceBuffer<uint32_t> overflow, queue_count, path_cost;
     uint32_t path_batches = 0;
-    uint32_t path_balance = 0;   // number of CUs when k_path deals this chain's groups by cost (0: every wave owns a fixed sequence)
     uint32_t grid = 0, grid_counting = 0;   // blocks of k_trace's persistent grid (plain / instrumented kernel)
     uint32_t grid_path = 0;                 // blocks of k_path's grid (0: this chain never runs it)
     // shadow rays queued by the last launch's k_shade and not traced yet (they ride in the next launch's k_trace, or in
