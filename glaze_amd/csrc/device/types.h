@@ -111,7 +111,7 @@ struct TransformPair {
 //   child k (k = 0..3):  w[3k] = lo.x | hi.x << 16   w[3k+1] = lo.y | hi.y << 16   w[3k+2] = lo.z | hi.z << 16
 //   (one word per axis, so that a per-ray byte permutation puts the plane the ray meets first into the low half)
 //   w[12 + k] = link of child k: index of an inner node (>= 0), ~index of a leaf in bvh_tris (< 0), or kBvhEmptyChild
-//   for an unused slot (the tracer skips it by its link; its box words are lo = 65535, hi = 0).
+//   for an unused slot (the tracer skips it by its link; its box words are lo = kBvhGridMax, hi = 0).
 constexpr uint32_t kTriNonOpaque = 0x80000000u;   // BvhTri::prim_flags: candidates on this triangle go through the alpha test
 constexpr uint32_t kTriHasPartner = 0x40000000u;  // the next triangle in bvh_tris belongs to the same leaf
 constexpr uint32_t kTriPrimMask = 0x3FFFFFFFu;
@@ -126,6 +126,7 @@ constexpr int kBvhEmptyChild = 0x7FFFFFFF;
 // table are the ordinary ones.  Built once per scene (k_top_table), copied into LDS at the start of every tracer block.
 constexpr int kBvhTopNodes = 21;
 constexpr int kBvhTopFlag = 0x40000000;
+constexpr uint32_t kBvhGridMax = 32767u;   // 15-bit grid coordinates: 0x47000000 | q << 8 is the float 32768 + q (box_key)
 struct BvhGrid {
   float lo[3];
   float cell[3];

@@ -41,40 +41,46 @@ __device__ __forceinline__ PixelId pixel_of(const TileMap& m, uint32_t lid) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Ray / box and ray / triangle.  The triangle test is Moeller-Trumbore with the candidate accepted
-// iff tmin < t < tmax, no face culling (acceleration.rs:335-345); it stands in for the driver's
-// intersector ([ext]).  Ties on t are broken by the smaller world triangle id so that the result
-// does not depend on traversal order.
+// Ray / box and ray / triangle.  The triangle test (ray_triangle below) is watertight, accepts a candidate iff tmin < t < tmax and
+// culls no face (acceleration.rs:335-345); it stands in for the driver's intersector ([ext]).  Ties on t are broken by the smaller
+// world triangle id so that the result does not depend on traversal order.
 // ---------------------------------------------------------------------------------------------
 // Slab test on a quantised box.  It only prunes: boxes are padded by 1/16 cell when they are quantised, which covers the
-// rounding of the plane distances (< 0.01 cell), so it never rejects a box whose triangle the exact Moeller-Trumbore test
-// below accepts.  The ray is mapped into grid units once (ig = cell / d, cg = -(origin_grid * ig)); a node word holds
-// lo | hi << 16 of one axis, and a per-ray byte permutation (sel: identity for ig >= 0, halves swapped for ig < 0) moves the
-// plane the ray meets first into the low half -- no min / max per axis.  Both plane distances of an axis then come from one
-// packed v_pk_fma_f32.  The tracers are VALU-issue bound, so instructions per node visit are what counts.  ig is kept
-// finite (grid_inv_dir), so no plane distance is ever NaN: a ray parallel to a slab gets +-1e30-scale distances whose signs
+// rounding of the plane distances (< 0.01 cell), so it never rejects a box whose triangle the exact test below accepts.  The ray
+// is mapped into grid units once (ig = cell / d, the addend grid_addend); a node word holds lo | hi << 16 of one axis, and a per-ray
+// byte permutation picks the plane the ray meets first and the other one -- no min / max per axis.  Both plane distances of an axis
+// then come from one packed v_pk_fma_f32.  The tracers are VALU-issue bound, so instructions per node visit are what counts.  ig is
+// kept finite (grid_inv_dir), so no plane distance is ever NaN: a ray parallel to a slab gets +-1e30-scale distances whose signs
 // still say on which side of each plane the origin lies.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 struct SlabSel { uint32_t x, y, z; };   // v_perm_b32 selectors per axis
-// (Tried: 15-bit coordinates that a byte permute turns into floats directly -- 0x47000000 | q << 8 is 32768 + q -- with the 32768 folded
-// into the addend: two permutes per axis instead of one permute and two conversions, 12 VALU instructions fewer per node visit.  It
-// needs six selectors instead of three, and with three more live registers the compiler spills inside the node loop at the 80 this
-// kernel has: 0.58 -> 1.34 ms.  Same node and triangle counts, same images.)
 // returns the sort key of the child: entry distance (a positive float, so its bits order like the value) with the child index in
 // the two lowest bits -- nearer first, ties (to 2 ulp) by child index; 0xFFFFFFFF for a missed child or an unused slot
 // (the slab test is symmetric in lo / hi, so an unused slot cannot be excluded through its box: its link says so)
 // cgn / cgf: the addends of the near and the far plane.  The flattened tracer passes the same vector twice; the two-level tracer
 // widens every box by the instance's slack (cg -+ pad * |ig|) at no extra instruction.
+// Grid coordinates are 15 bits wide, so a byte permute turns one into a float without a conversion: the bytes {0, q_lo, q_hi, 0x47}
+// are 0x47000000 | q << 8, the float 32768 + q (exponent 2^15, q in the mantissa's bits 22..8).  The 32768 is folded into the addend
+// of the plane distance (grid_ray: cg - 32768 ig), the selector names which half of the node word -- the plane the ray meets first
+// (lo for ig >= 0, hi for ig < 0) or the other one: kSlabSelLo / kSlabSelHi, one XOR apart.  Two permutes per axis instead of one
+// permute and two v_cvt_f32_u32: 9 VALU instructions fewer per node visit (rounds 1-2 needed six live selectors for this and spilt).
+constexpr uint32_t kSlabSelLo = 0x0305040Cu, kSlabSelHi = 0x0307060Cu, kSlabSelFlip = kSlabSelLo ^ kSlabSelHi, kSlabMagic = 0x47000000u;
+__device__ __forceinline__ uint32_t slab_sel(float ig) { return ig < 0.0f ? kSlabSelHi : kSlabSelLo; }
 __device__ __forceinline__ uint32_t box_key(uint32_t wx, uint32_t wy, uint32_t wz, uint32_t link, uint32_t k, SlabSel sel, vec3 ig, vec3 cgn, vec3 cgf,
                                             float tmin, float tmax) {
-  const uint32_t px = __builtin_amdgcn_perm(wx, wx, sel.x), py = __builtin_amdgcn_perm(wy, wy, sel.y), pz = __builtin_amdgcn_perm(wz, wz, sel.z);
-  const f32x2 tx = __builtin_elementwise_fma(f32x2{(float)(px & 0xFFFFu), (float)(px >> 16)}, f32x2{ig.x, ig.x}, f32x2{cgn.x, cgf.x});
-  const f32x2 ty = __builtin_elementwise_fma(f32x2{(float)(py & 0xFFFFu), (float)(py >> 16)}, f32x2{ig.y, ig.y}, f32x2{cgn.y, cgf.y});
-  const f32x2 tz = __builtin_elementwise_fma(f32x2{(float)(pz & 0xFFFFu), (float)(pz >> 16)}, f32x2{ig.z, ig.z}, f32x2{cgn.z, cgf.z});
+  // v_perm_b32: bytes 0..3 of the selector index the second operand, 4..7 the first (the node word), 0x0C is a zero byte
+  const float nx = __uint_as_float(__builtin_amdgcn_perm(wx, kSlabMagic, sel.x)), fx = __uint_as_float(__builtin_amdgcn_perm(wx, kSlabMagic, sel.x ^ kSlabSelFlip));
+  const float ny = __uint_as_float(__builtin_amdgcn_perm(wy, kSlabMagic, sel.y)), fy = __uint_as_float(__builtin_amdgcn_perm(wy, kSlabMagic, sel.y ^ kSlabSelFlip));
+  const float nz = __uint_as_float(__builtin_amdgcn_perm(wz, kSlabMagic, sel.z)), fz = __uint_as_float(__builtin_amdgcn_perm(wz, kSlabMagic, sel.z ^ kSlabSelFlip));
+  const f32x2 tx = __builtin_elementwise_fma(f32x2{nx, fx}, f32x2{ig.x, ig.x}, f32x2{cgn.x, cgf.x});
+  const f32x2 ty = __builtin_elementwise_fma(f32x2{ny, fy}, f32x2{ig.y, ig.y}, f32x2{cgn.y, cgf.y});
+  const f32x2 tz = __builtin_elementwise_fma(f32x2{nz, fz}, f32x2{ig.z, ig.z}, f32x2{cgn.z, cgf.z});
   const float t0 = fmaxf(fmaxf(tx.x, ty.x), fmaxf(tz.x, tmin));
   const float t1 = fminf(fminf(tx.y, ty.y), fminf(tz.y, tmax));
   return (t0 <= t1 && link != (uint32_t)kBvhEmptyChild) ? ((__float_as_uint(t0) & 0xFFFFFFFCu) | k) : 0xFFFFFFFFu;
 }
+// the addend of a plane distance: plane q (a float 32768 + q out of box_key) is crossed at t = (32768 + q) ig + grid_addend = q ig - og ig
+__device__ __forceinline__ float grid_addend(float og, float ig) { return fmaf(-32768.0f, ig, -(og * ig)); }
 
 // 1 / d clamped to +-1e30: zero (or denormal) direction components must not produce inf - inf in the fma above --
 // a ray with a NaN plane distance on every axis would pass every box test and walk the whole tree.
@@ -346,7 +352,7 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
   uint32_t ray = 0;                                         // ray index (open) or owner lane (helper)
   vec3 o = mk3(0.0f, 0.0f, 0.0f), d = mk3(0.0f, 0.0f, 1.0f);
   vec3 ig = mk3(0.0f, 0.0f, 0.0f), cg = mk3(0.0f, 0.0f, 0.0f);   // grid-space ray: plane q is crossed at t = q * ig + cg
-  SlabSel sel{0x03020100u, 0x03020100u, 0x03020100u};          // near-plane selectors, from the signs of ig
+  SlabSel sel{kSlabSelLo, kSlabSelLo, kSlabSelLo};             // near-plane selectors, from the signs of ig
   float tmin = 0.0f, tmax = 0.0f;
   HitRecord best{0.0f, 0.0f, 0.0f, kNone};
   uint32_t best_id = kNone;
@@ -398,7 +404,7 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
         d.x = __shfl(d.x, donor); d.y = __shfl(d.y, donor); d.z = __shfl(d.z, donor);
         ig.x = __shfl(ig.x, donor); ig.y = __shfl(ig.y, donor); ig.z = __shfl(ig.z, donor);
         cg.x = __shfl(cg.x, donor); cg.y = __shfl(cg.y, donor); cg.z = __shfl(cg.z, donor);
-        sel = SlabSel{ig.x < 0.0f ? 0x01000302u : 0x03020100u, ig.y < 0.0f ? 0x01000302u : 0x03020100u, ig.z < 0.0f ? 0x01000302u : 0x03020100u};
+        sel = SlabSel{slab_sel(ig.x), slab_sel(ig.y), slab_sel(ig.z)};
         tmin = __shfl(tmin, donor); tmax = __shfl(tmax, donor);
         best.t = __shfl(best.t, donor); best.u = __shfl(best.u, donor); best.v = __shfl(best.v, donor);
         best.leaf = (uint32_t)__shfl((int)best.leaf, donor);
@@ -442,8 +448,8 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
           } else {
             const vec3 og = mk3((o.x - grid.lo[0]) * grid.inv_cell[0], (o.y - grid.lo[1]) * grid.inv_cell[1], (o.z - grid.lo[2]) * grid.inv_cell[2]);
             ig = mk3(grid_inv_dir(d.x) * grid.cell[0], grid_inv_dir(d.y) * grid.cell[1], grid_inv_dir(d.z) * grid.cell[2]);
-            cg = mk3(-(og.x * ig.x), -(og.y * ig.y), -(og.z * ig.z));
-            sel = SlabSel{ig.x < 0.0f ? 0x01000302u : 0x03020100u, ig.y < 0.0f ? 0x01000302u : 0x03020100u, ig.z < 0.0f ? 0x01000302u : 0x03020100u};
+            cg = mk3(grid_addend(og.x, ig.x), grid_addend(og.y, ig.y), grid_addend(og.z, ig.z));
+            sel = SlabSel{slab_sel(ig.x), slab_sel(ig.y), slab_sel(ig.z)};
             st.sp = 0;
             if (SHARE) aux_sb[lane] = 0;
             cur = kLdsTop ? kBvhTopFlag : 0;   // the root (slot 0 of the staged table)
@@ -653,7 +659,7 @@ __device__ __forceinline__ void trace_wave_tl(const DeviceScene& S, Source& src,
   uint32_t ray = 0, nbase = 0, cur_inst = kNone;
   vec3 o = mk3(0.0f, 0.0f, 0.0f), d = mk3(0.0f, 0.0f, 1.0f);                                  // the WORLD ray, always
   vec3 ig = mk3(0.0f, 0.0f, 0.0f), cgn = mk3(0.0f, 0.0f, 0.0f), cgf = mk3(0.0f, 0.0f, 0.0f);    // grid-space ray of the level the lane is in
-  SlabSel sel{0x03020100u, 0x03020100u, 0x03020100u};
+  SlabSel sel{kSlabSelLo, kSlabSelLo, kSlabSelLo};
   float tmin = 0.0f, tmax = 0.0f;
   HitRecord best{0.0f, 0.0f, 0.0f, kNone, 0u, kNone};
   Stack st{lds_col, spill + ((size_t)(blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 64u + (uint32_t)lane) * spill_depth, 0};
@@ -662,12 +668,12 @@ __device__ __forceinline__ void trace_wave_tl(const DeviceScene& S, Source& src,
   auto set_grid_ray = [&](const float* glo, const float* gcell, const float* ginv, vec3 oo, vec3 dd, float slack, float cells) {
     const vec3 og = mk3((oo.x - glo[0]) * ginv[0], (oo.y - glo[1]) * ginv[1], (oo.z - glo[2]) * ginv[2]);
     ig = mk3(grid_inv_dir(dd.x) * gcell[0], grid_inv_dir(dd.y) * gcell[1], grid_inv_dir(dd.z) * gcell[2]);
-    const vec3 cg = mk3(-(og.x * ig.x), -(og.y * ig.y), -(og.z * ig.z));
+    const vec3 cg = mk3(grid_addend(og.x, ig.x), grid_addend(og.y, ig.y), grid_addend(og.z, ig.z));
     const vec3 pad = mk3(fminf(slack * ginv[0] + cells, 65536.0f), fminf(slack * ginv[1] + cells, 65536.0f), fminf(slack * ginv[2] + cells, 65536.0f));
     const vec3 w = mk3(pad.x * fabsf(ig.x), pad.y * fabsf(ig.y), pad.z * fabsf(ig.z));
     cgn = cg - w;
     cgf = cg + w;
-    sel = SlabSel{ig.x < 0.0f ? 0x01000302u : 0x03020100u, ig.y < 0.0f ? 0x01000302u : 0x03020100u, ig.z < 0.0f ? 0x01000302u : 0x03020100u};
+    sel = SlabSel{slab_sel(ig.x), slab_sel(ig.y), slab_sel(ig.z)};
   };
 #ifdef GLZ_WAVE_TIMES
   unsigned long long tl_rays = 0, tl_top = 0, tl_mesh = 0, tl_enter = 0, tl_tris = 0, tl_niter = 0, tl_liter = 0;
@@ -686,7 +692,7 @@ __device__ __forceinline__ void trace_wave_tl(const DeviceScene& S, Source& src,
       ig = mk3(top_ray[0], top_ray[kBlock], top_ray[2 * kBlock]);
       cgn = mk3(top_ray[3 * kBlock], top_ray[4 * kBlock], top_ray[5 * kBlock]);
       cgf = mk3(top_ray[6 * kBlock], top_ray[7 * kBlock], top_ray[8 * kBlock]);
-      sel = SlabSel{ig.x < 0.0f ? 0x01000302u : 0x03020100u, ig.y < 0.0f ? 0x01000302u : 0x03020100u, ig.z < 0.0f ? 0x01000302u : 0x03020100u};
+      sel = SlabSel{slab_sel(ig.x), slab_sel(ig.y), slab_sel(ig.z)};
     }
   };
   auto pop_next = [&]() -> int {

@@ -998,14 +998,15 @@ __global__ void __launch_bounds__(256) k_dfs_ids(int n, const int2* __restrict__
   new_id[t] = id;
 }
 
-// Quantisation grid from the root box: 65535 cells per axis, stretched by 2^-16 so the top plane stays below 65535.
+// Quantisation grid from the root box: kBvhGridMax (32 767) cells per axis, stretched by 2^-16 so the top plane stays below it.  15 bits:
+// the tracer turns a coordinate into the float 32768 + q with one byte permute (device/wavefront.h box_key).
 __global__ void k_grid_params(const float4* __restrict__ node_lo, const float4* __restrict__ node_hi, BvhGrid* __restrict__ grid) {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
   const float lo[3] = {node_lo[0].x, node_lo[0].y, node_lo[0].z}, hi[3] = {node_hi[0].x, node_hi[0].y, node_hi[0].z};
   for (int k = 0; k < 3; ++k) {
     float ext = hi[k] - lo[k];
     if (!(ext > 0.0f)) ext = 1.0f;
-    const float cell = ext * 1.00002f / 65535.0f;
+    const float cell = ext * 1.00002f / (float)kBvhGridMax;
     grid->lo[k] = lo[k] - 0.5f * cell;
     grid->cell[k] = cell;
     grid->inv_cell[k] = 1.0f / cell;
@@ -1015,13 +1016,13 @@ __global__ void k_grid_params(const float4* __restrict__ node_lo, const float4* 
 // grid coordinate of a world coordinate; the SAME expression maps the ray origin in the tracer
 __device__ __forceinline__ float to_grid(float x, float lo, float inv_cell) { return (x - lo) * inv_cell; }
 __device__ __forceinline__ uint32_t quant_lo(float x, float lo, float inv_cell) {
-  // 1/16 cell of slack covers the rounding of to_grid() at grid coordinates up to 65535 (ulp 2^-8)
+  // 1/16 cell of slack covers the rounding of to_grid() at grid coordinates up to 32767 (ulp 2^-9)
   const float g = floorf(to_grid(x, lo, inv_cell) - 0.0625f);
-  return (uint32_t)fminf(fmaxf(g, 0.0f), 65535.0f);
+  return (uint32_t)fminf(fmaxf(g, 0.0f), (float)kBvhGridMax);
 }
 __device__ __forceinline__ uint32_t quant_hi(float x, float lo, float inv_cell) {
   const float g = ceilf(to_grid(x, lo, inv_cell) + 0.0625f);
-  return (uint32_t)fminf(fmaxf(g, 0.0f), 65535.0f);
+  return (uint32_t)fminf(fmaxf(g, 0.0f), (float)kBvhGridMax);
 }
 
 // ---- 4-wide collapse.  A BVH4 node starts from the two children of a binary node and keeps opening the inner child
@@ -1108,7 +1109,7 @@ __global__ void __launch_bounds__(256) k_emit_nodes4(int n, const int2* __restri
   for (int k = 0; k < 4; ++k) {
     const int ch = kids[k];
     if (k >= nk) {
-      nd.w[3 * k] = nd.w[3 * k + 1] = nd.w[3 * k + 2] = 65535u;   // lo = 65535, hi = 0 (the tracer skips the slot by its link)
+      nd.w[3 * k] = nd.w[3 * k + 1] = nd.w[3 * k + 2] = kBvhGridMax;   // lo = the grid's top, hi = 0 (the tracer skips the slot by its link)
       nd.w[12 + k] = (uint32_t)kBvhEmptyChild;
       continue;
     }
@@ -1501,10 +1502,10 @@ hipError_t build_lbvh(hipStream_t st, const LbvhInputs& in, LbvhOutputs& out) {
     GLZ_TRY(hipGetLastError());
     BvhNode4 nd{};
     for (int k = 0; k < 4; ++k) {
-      nd.w[3 * k] = nd.w[3 * k + 1] = nd.w[3 * k + 2] = 65535u;
+      nd.w[3 * k] = nd.w[3 * k + 1] = nd.w[3 * k + 2] = kBvhGridMax;
       nd.w[12 + k] = (uint32_t)kBvhEmptyChild;
     }
-    nd.w[0] = nd.w[1] = nd.w[2] = 0u | (65535u << 16);   // lo 0, hi 65535 on every axis
+    nd.w[0] = nd.w[1] = nd.w[2] = 0u | (kBvhGridMax << 16);   // lo 0, hi the grid's top on every axis
     nd.w[12] = ~0u;   // leaf 0
     GLZ_TRY(hipMalloc(&out.nodes, sizeof(BvhNode4)));
     out.n_nodes = 1;

@@ -692,7 +692,7 @@ bool Scene::build_two_level(Error& err) {
     if (ok && m.n_nodes == 0) {
       static BvhNode4 childless;
       for (int k = 0; k < 4; ++k) {
-        childless.w[3 * k] = childless.w[3 * k + 1] = childless.w[3 * k + 2] = 65535u;
+        childless.w[3 * k] = childless.w[3 * k + 1] = childless.w[3 * k + 2] = kBvhGridMax;
         childless.w[12 + k] = (uint32_t)kBvhEmptyChild;
       }
       ok = hip_ok(hipMemcpyAsync(d_nodes_.ptr + at, &childless, sizeof(BvhNode4), hipMemcpyHostToDevice, st), "copy nodes", err);

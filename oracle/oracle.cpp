@@ -994,10 +994,12 @@ inline uint32_t fbits(float f);
 struct ExtNode { uint32_t w[16]; };   // BvhNode4
 struct ExtTri { float v0[3]; uint32_t world_id; float v1[3]; uint32_t instance; float v2[3]; uint32_t prim_flags; };
 inline float box_entry_q(float lox, float loy, float loz, float hix, float hiy, float hiz, V3 ig, V3 cg, float tmin, float tmax) {
-  // plane distances as one correctly rounded fma each (kernels_render.hip box_entry: v_pk_fma_f32)
-  const float ax = fmaf(lox, ig.x, cg.x), bx = fmaf(hix, ig.x, cg.x);
-  const float ay = fmaf(loy, ig.y, cg.y), by = fmaf(hiy, ig.y, cg.y);
-  const float az = fmaf(loz, ig.z, cg.z), bz = fmaf(hiz, ig.z, cg.z);
+  // plane distances as one correctly rounded fma each (device/wavefront.h box_key: v_pk_fma_f32).  The kernel's byte permute hands the
+  // fma the float 32768 + q (exact: q < 32768) and the addend carries the - 32768 ig (grid_addend): restated here operation for operation
+  const float M = 32768.0f;
+  const float ax = fmaf(M + lox, ig.x, cg.x), bx = fmaf(M + hix, ig.x, cg.x);
+  const float ay = fmaf(M + loy, ig.y, cg.y), by = fmaf(M + hiy, ig.y, cg.y);
+  const float az = fmaf(M + loz, ig.z, cg.z), bz = fmaf(M + hiz, ig.z, cg.z);
   const float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin));
   const float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));   // (the kernel picks the near / far plane by the sign of ig: same values)
   return t0 <= fminf(t1, tmax) ? t0 : INF;
@@ -1015,7 +1017,7 @@ void ext_trace(const Scene& sc, V3 o, V3 d, float tmin, float tmax, bool any, Co
   }
   auto inv_dir = [](float x) { const float i = 1.0f / x; return fabsf(i) <= 1e30f ? i : copysignf(1e30f, i); };   // grid_inv_dir
   const V3 ig = v3(inv_dir(d.x) * G[3], inv_dir(d.y) * G[4], inv_dir(d.z) * G[5]);
-  const V3 cg = v3(-(og.x * ig.x), -(og.y * ig.y), -(og.z * ig.z));
+  const V3 cg = v3(fmaf(-32768.0f, ig.x, -(og.x * ig.x)), fmaf(-32768.0f, ig.y, -(og.y * ig.y)), fmaf(-32768.0f, ig.z, -(og.z * ig.z)));   // grid_addend
   float best = tmax; uint32_t best_id = 0xFFFFFFFFu; bool found = false;
   int stack[512]; int sp = 0; int cur = 0;
   for (;;) {
