@@ -66,6 +66,11 @@ struct SlabSel { uint32_t x, y, z; };   // v_perm_b32 selectors per axis
 // permute and two v_cvt_f32_u32: 9 VALU instructions fewer per node visit (rounds 1-2 needed six live selectors for this and spilt).
 constexpr uint32_t kSlabSelLo = 0x0305040Cu, kSlabSelHi = 0x0307060Cu, kSlabSelFlip = kSlabSelLo ^ kSlabSelHi, kSlabMagic = 0x47000000u;
 __device__ __forceinline__ uint32_t slab_sel(float ig) { return ig < 0.0f ? kSlabSelHi : kSlabSelLo; }
+// CHECK_LINK = false: an unused slot is excluded by its box alone -- lo = the grid's top, hi = 0 on every axis, and with the near /
+// far plane picked by the ray's sign such a box has t_near > t_far on every axis whatever the ray (the planes are 32 767 cells the
+// wrong way round; distances are never NaN) -- four compares fewer per node visit.  The two-level tracer widens boxes by a per-ray
+// pad that may exceed that in extreme cases and keeps the check.
+template <bool CHECK_LINK = true>
 __device__ __forceinline__ uint32_t box_key(uint32_t wx, uint32_t wy, uint32_t wz, uint32_t link, uint32_t k, SlabSel sel, vec3 ig, vec3 cgn, vec3 cgf,
                                             float tmin, float tmax) {
   // v_perm_b32: bytes 0..3 of the selector index the second operand, 4..7 the first (the node word), 0x0C is a zero byte
@@ -77,7 +82,7 @@ __device__ __forceinline__ uint32_t box_key(uint32_t wx, uint32_t wy, uint32_t w
   const f32x2 tz = __builtin_elementwise_fma(f32x2{nz, fz}, f32x2{ig.z, ig.z}, f32x2{cgn.z, cgf.z});
   const float t0 = fmaxf(fmaxf(tx.x, ty.x), fmaxf(tz.x, tmin));
   const float t1 = fminf(fminf(tx.y, ty.y), fminf(tz.y, tmax));
-  return (t0 <= t1 && link != (uint32_t)kBvhEmptyChild) ? ((__float_as_uint(t0) & 0xFFFFFFFCu) | k) : 0xFFFFFFFFu;
+  return (t0 <= t1 && (!CHECK_LINK || link != (uint32_t)kBvhEmptyChild)) ? ((__float_as_uint(t0) & 0xFFFFFFFCu) | k) : 0xFFFFFFFFu;
 }
 // the addend of a plane distance: plane q (a float 32768 + q out of box_key) is crossed at t = (32768 + q) ig + grid_addend = q ig - og ig
 __device__ __forceinline__ float grid_addend(float og, float ig) { return fmaf(-32768.0f, ig, -(og * ig)); }
@@ -515,8 +520,8 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
         if (COUNT) tally.nodes += 1;
         float bound = best.t;
         if (SHARE && !ANY && exhausted) bound = fminf(bound, __uint_as_float(aux_t[helper ? (int)ray : lane]));   // positive floats order like their bits
-        uint32_t k0 = box_key(w0.x, w0.y, w0.z, w3.x, 0u, sel, ig, cg, cg, tmin, bound), k1 = box_key(w0.w, w1.x, w1.y, w3.y, 1u, sel, ig, cg, cg, tmin, bound);
-        uint32_t k2 = box_key(w1.z, w1.w, w2.x, w3.z, 2u, sel, ig, cg, cg, tmin, bound), k3 = box_key(w2.y, w2.z, w2.w, w3.w, 3u, sel, ig, cg, cg, tmin, bound);
+        uint32_t k0 = box_key<false>(w0.x, w0.y, w0.z, w3.x, 0u, sel, ig, cg, cg, tmin, bound), k1 = box_key<false>(w0.w, w1.x, w1.y, w3.y, 1u, sel, ig, cg, cg, tmin, bound);
+        uint32_t k2 = box_key<false>(w1.z, w1.w, w2.x, w3.z, 2u, sel, ig, cg, cg, tmin, bound), k3 = box_key<false>(w2.y, w2.z, w2.w, w3.w, 3u, sel, ig, cg, cg, tmin, bound);
         sort2(k0, k1); sort2(k2, k3); sort2(k0, k2); sort2(k1, k3); sort2(k1, k2);
         // The links go through LDS: picking one of four registers by a per-lane index costs 6 VALU instructions (the
         // kernel's bottleneck), an LDS read at a computed address 2 (k_trace 0.714 -> 0.691 ms).  The scratch is laid out
@@ -560,7 +565,8 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
 #endif
     if (cur < 0) {
       // A leaf is one triangle or two adjacent ones (kTriHasPartner on the first).  The partner is fetched after the
-      // first test: six 16-byte loads in flight at once cost 20 more spilled registers (0.64 -> 0.77 ms).
+      // first test: six 16-byte loads in flight at once cost 20 more spilled registers in round 1 (0.64 -> 0.77 ms) and buy nothing now
+      // that they fit (0.554 against 0.555 ms, profiles/r03_variants_prefetch.txt).
       const uint32_t leaf = (uint32_t)~cur;
       bool finished = false;
       const RayShear rs = ray_shear(d);
