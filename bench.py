@@ -77,6 +77,9 @@ def measure_hbm_traffic(args):
     exe = shutil.which("rocprofv3")
     if exe is None:
         return None, "rocprofv3 is not on PATH"
+    # not from under a profiler: its preloaded library initialises the GPU in every child before the child's own exec
+    if any("rocprof" in v.lower() for v in (os.environ.get("LD_PRELOAD", ""), os.environ.get("ROCP_TOOL_LIBRARIES", ""), os.environ.get("HSA_TOOLS_LIB", ""))):
+        return None, "this process runs under a profiler"
     acc = {}
     tmp = tempfile.mkdtemp(prefix="glaze_pmc_")
     try:
