@@ -383,6 +383,7 @@ static dim3 persistent_grid(Kernel kernel, uint32_t n_rays) {
   }
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0) != hipSuccess || per_cu < 1) per_cu = 4;
   per_cu = std::min(per_cu, 8);
+  if (const char* cap = getenv("GLAZE_TRACE_BLOCKS_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(cap)));   // tuning: leave room for another chain's k_shade
   // (splitting the resident blocks between concurrent chains measured slower: a chain's blocks fill in as another's retire)
   const uint32_t resident = (uint32_t)cus * (uint32_t)per_cu;
   return dim3(std::max<uint32_t>(1u, std::min<uint32_t>((n_rays + kBlock - 1) / kBlock, resident)));

@@ -23,3 +23,28 @@ for rep in range(repeats):
         print("repeat %d chains %d: %s %s  (%.1f Msamples/s)" % (rep, chains, h, "ok" if ok else "DIFFERENT", 1920 * 1080 * launches / dt / 1e6), flush=True)
         assert ok
 print("soak ok")
+
+# The per-wave launch loop (k_path) hands data from lane to lane THROUGH GLOBAL MEMORY inside one wave -- shadow-queue entries written by
+# the shading lanes and read by whichever lane traces them, accumulators written by a tracing lane and read by the pixel's own lane --
+# and relies on a wave's vector memory operations staying in order.  A violation would show as a rare, unrepeatable difference:
+# one GPU's share of an 8-way partition, rendered over and over in both launch modes, batch lengths varied.
+import os
+r.set_chains(0)
+r.set_depth(8)
+r.set_partition(3, 8)
+r.set_launch_mode("two_kernels")
+r.restart(); r.step(77)
+ref = r.read_hdr().view(np.uint32).copy()
+r.set_launch_mode("path")
+runs = int(os.environ.get("SOAK_PATH", "60"))
+t0 = time.time()
+for i in range(runs):
+    r.restart()
+    left = 77
+    for k in ((77,), (1, 76), (13, 64), (40, 37), (5, 5, 67))[i % 5]:
+        r.step(k); left -= k
+    assert left == 0
+    img = r.read_hdr().view(np.uint32)
+    same = np.array_equal(np.nan_to_num(img.view(np.float32), nan=-1.0).view(np.uint32), np.nan_to_num(ref.view(np.float32), nan=-1.0).view(np.uint32))
+    assert same, "k_path run %d differs from the two-kernel image" % i
+print("k_path: %d renders of a 1/8 share (77 launches each, five batch patterns) bit-identical to the two-kernel image, %.1f s" % (runs, time.time() - t0))
