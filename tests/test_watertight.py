@@ -205,3 +205,64 @@ def test_hip_orthographic_wall_has_no_leaked_pixel(instance):
             o.set_integrator(abi.DIRECT)
             o.step(4)
             assert np.array_equal(img.view(np.uint32), o.read_hdr().view(np.uint32))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the intersector against mathematics (CPU): hit / miss, distance and barycentrics of random triangle soups against an independent
+# float64 statement (the plane equation and edge functions of the exact triangle, nothing shared with oracle.cpp)
+# ---------------------------------------------------------------------------------------------------------------------
+def exact_hits(pos, tris, o, d):
+    """closest intersection of each ray with the soup in float64: (t, triangle, u, v, margin) -- margin = how far inside the triangle the hit
+    is (smallest barycentric), so that rays within rounding of an edge can be left out of the hit / miss comparison"""
+    a, b, c = (pos[tris[:, k]].astype(np.float64) for k in range(3))
+    n = np.cross(b - a, c - a)                                                    # (T, 3)
+    o64, d64 = o.astype(np.float64), d.astype(np.float64)
+    best_t = np.full(len(o), np.inf)
+    best = np.full(len(o), -1)
+    best_uv = np.zeros((len(o), 2))
+    best_margin = np.full(len(o), np.inf)
+    closest_edge = np.full(len(o), np.inf)
+    for k in range(len(tris)):
+        den = d64 @ n[k]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            t = ((a[k] - o64) @ n[k]) / den
+        p = o64 + t[:, None] * d64
+        nn = n[k] @ n[k]
+        u = np.cross(p - a[k], c[k] - a[k]) @ n[k] / nn                           # weight of b: (p - a) x (c - a) = u n
+        v = np.cross(b[k] - a[k], p - a[k]) @ n[k] / nn                           # weight of c
+        w = 1.0 - u - v
+        m = np.minimum(np.minimum(u, v), w)
+        inside = (den != 0) & (m >= 0) & (t > 1e-4)
+        closest_edge = np.where((den != 0) & (t > 1e-4), np.minimum(closest_edge, np.abs(m)), closest_edge)
+        take = inside & (t < best_t)
+        best_t = np.where(take, t, best_t)
+        best = np.where(take, k, best)
+        best_uv[take] = np.stack([u, v], -1)[take]
+        best_margin = np.where(take, m, best_margin)
+    return best_t, best, best_uv, best_margin, closest_edge
+
+
+def test_intersector_matches_an_independent_float64_statement():
+    rng = np.random.default_rng(11)
+    nt = 60
+    centre = rng.uniform(-1, 1, (nt, 3))
+    pos = (centre[:, None, :] + rng.normal(0, 0.35, (nt, 3, 3))).reshape(-1, 3).astype(np.float32)      # a soup: nothing is shared
+    tris = np.arange(3 * nt, dtype=np.uint32).reshape(nt, 3)
+    sc = OracleScene(scene_of(pos, tris))
+    n = 40_000
+    o = rng.uniform(-1.5, 1.5, (n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3))
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True) * rng.uniform(0.5, 2.0, (n, 1))).astype(np.float32)   # not normalised: t is in units of d
+    t, tri, _, u, v = sc.trace_closest(o, d)
+    et, etri, euv, margin, edge = exact_hits(pos, tris, o, d)
+    clear = edge > 1e-5                                                            # no triangle's edge within rounding of the ray
+    hit, ehit = np.isfinite(t), np.isfinite(et)
+    assert clear.mean() > 0.98 and ehit[clear].mean() > 0.15
+    assert np.array_equal(hit[clear], ehit[clear])
+    both = clear & hit
+    assert np.array_equal(tri[both], etri[both].astype(np.uint32))
+    assert np.abs(t[both] - et[both]).max() < 2e-5 * np.maximum(1.0, et[both]).max()
+    assert np.abs(u[both] - euv[both, 0]).max() < 2e-5 and np.abs(v[both] - euv[both, 1]).max() < 2e-5
+    # and the brute-force walk agrees with the hierarchy (boxes are conservative for soups too)
+    tb, trib = sc.trace_closest(o[::5], d[::5], brute=True)
+    assert np.array_equal(tb.view(np.uint32), t[::5].view(np.uint32)) and np.array_equal(trib, tri[::5])
