@@ -195,7 +195,7 @@ import torch                      # before libglaze_hip.so: the process then car
 import torch.distributed as dist
 sys.path.insert(0, os.environ["GLAZE_ROOT"])
 import glaze_amd
-from glaze_amd.distributed import reduce_frame
+from glaze_amd.distributed import gather_frame, reduce_frame
 from glaze_amd.scenes import cube_scene
 torch.cuda.set_device(0)
 dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:%s" % os.environ["GLAZE_PORT"], rank=0, world_size=1,
@@ -219,8 +219,13 @@ r.export_device(0, frame.data_ptr())
 reduce_frame(frame, force=True)
 torch.cuda.synchronize()
 same2 = bool(np.array_equal(frame.cpu().numpy().view(np.uint32), r.read_hdr().view(np.uint32)))
+# the packed-tile exchange bench.py uses by default: export_packed -> dist.gather ("nccl": send / receive pairs) -> scatter on rank 0
+frame.fill_(-3.0)
+gather_frame(r, frame)
+torch.cuda.synchronize()
+same3 = bool(np.array_equal(frame.cpu().numpy().view(np.uint32), r.read_hdr().view(np.uint32)))
 dist.destroy_process_group()
-print(json.dumps({"same": same, "same_after_more_steps": same2, "t": float(t.item()), "backend": "nccl"}))
+print(json.dumps({"same": same, "same_after_more_steps": same2, "same_gathered": same3, "t": float(t.item()), "backend": "nccl"}))
 '''
 
 
@@ -230,7 +235,7 @@ def test_torch_nccl_backend_world_size_one():
     p = subprocess.run([sys.executable, "-c", NCCL_WORLD1], capture_output=True, text=True, env=env, timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]
     out = json.loads(p.stdout.strip().splitlines()[-1])
-    assert out == {"same": True, "same_after_more_steps": True, "t": 1.5, "backend": "nccl"}
+    assert out == {"same": True, "same_after_more_steps": True, "same_gathered": True, "t": 1.5, "backend": "nccl"}
 
 
 def test_replicas_take_the_shape_of_the_root_scene(instance, loopback):
