@@ -454,7 +454,8 @@ class RayTraceRenderer:
         abi.check(abi.lib().glz_renderer_refresh_binded_textures(self._h, t, nt))
 
     def set_texture_lod(self, mode):
-        """0 = level 0 always (the reference's ray-tracing stages), 1 = ray-cone level of detail over the mip chain.  Restarts."""
+        """0 = level 0 always (the reference's ray-tracing stages), 1 = ray-cone level of detail over the mip chain, 2 = ray cones
+        with an anisotropic footprint (up to 16 probes along the footprint's long axis).  Restarts."""
         abi.check(abi.lib().glz_renderer_set_texture_lod(self._h, int(mode)))
 
     def set_devices(self, devices):

@@ -67,6 +67,7 @@ void usage(const char* argv0) {
           "      --depth <N>               path depth (the reference's PT_STEPS) [default: 6]\n"
           "      --device <N>              HIP device ordinal [default: first gfx950]\n"
           "      --devices <A,B,..>        render on several GPUs (64x64 tiles sharded over them, RCCL reduce onto the first)\n"
+          "      --texture-lod <MODE>      [default: off] [possible values: off, cones, aniso] (off = level 0, what the reference's stages sample)\n"
           "      --hdr-out <FILE.pfm>      also write the float radiance image\n"
           "      --report                  print a JSON timing report on stdout\n",
           argv0);
@@ -75,7 +76,7 @@ void usage(const char* argv0) {
 }  // namespace
 
 int main(int argc, char** argv) {
-  std::string input, output, resolution = "1920x1080", integrator = "pt", hdr_out;
+  std::string input, output, resolution = "1920x1080", integrator = "pt", hdr_out, texture_lod = "off";
   size_t spp = 256;
   uint64_t seed = 0;
   uint32_t depth = 6;
@@ -111,6 +112,7 @@ int main(int argc, char** argv) {
         pos = comma + 1;
       }
     }
+    else if (a == "--texture-lod") texture_lod = value("--texture-lod");
     else if (a == "--hdr-out") hdr_out = value("--hdr-out");
     else if (a == "--report") report = true;
     else if (a == "-h" || a == "--help") { usage(argv[0]); return 0; }
@@ -122,6 +124,10 @@ int main(int argc, char** argv) {
   output = positional[1];
   if (integrator != "direct" && integrator != "pt") {
     fprintf(stderr, "error: invalid value '%s' for '--integrator' [possible values: direct, pt]\n", integrator.c_str());
+    return 2;
+  }
+  if (texture_lod != "off" && texture_lod != "cones" && texture_lod != "aniso") {
+    fprintf(stderr, "error: invalid value '%s' for '--texture-lod' [possible values: off, cones, aniso]\n", texture_lod.c_str());
     return 2;
   }
   // check output (cli/src/main.rs:46-55)
@@ -170,6 +176,10 @@ int main(int argc, char** argv) {
   if (!renderer) { fprintf(stderr, "\n[ERROR] %s\n", glz_last_error()); return 1; }
   glz_renderer_set_integrator(renderer, integrator == "direct" ? GLZ_DIRECT : GLZ_PATH_TRACE);
   if (glz_renderer_set_depth(renderer, depth) != GLZ_OK) { fprintf(stderr, "\n[ERROR] %s\n", glz_last_error()); return 1; }
+  if (texture_lod != "off" && glz_renderer_set_texture_lod(renderer, texture_lod == "aniso" ? GLZ_LOD_RAY_CONES_ANISO : GLZ_LOD_RAY_CONES) != GLZ_OK) {
+    fprintf(stderr, "\n[ERROR] %s\n", glz_last_error());
+    return 1;
+  }
   glz_renderer_set_seed(renderer, seed);
   if (devices.size() > 1 && glz_renderer_set_devices(renderer, devices.data(), (int)devices.size()) != GLZ_OK) {
     fprintf(stderr, "\n[ERROR] %s\n", glz_last_error());

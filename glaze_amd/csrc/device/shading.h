@@ -156,29 +156,35 @@ GLZ_D vec4 texture2d(const DeviceScene& S, uint32_t id, float u, float v) {
 // the texture-independent part of the ray-cone level, 0.5 log2(uv area / world area * cone width^2 / cos^2); the texture adds
 // 0.5 log2(width * height).  The level is clamped to the chain and the two nearest levels are blended (LINEAR mipmap mode of the
 // reference's sampler, scene.rs:716-749).  kNoLod, no mip chain on the device, or a level <= 0: exactly texture2d().
+// taps > 1 (lod mode 2, anisotropic footprint): that many trilinear probes spread evenly over the footprint's long axis (du, dv)
+// around (u, v), averaged -- what the anisotropy of the reference's sampler does in its raster viewer.
 constexpr float kNoLod = -1e30f;
-GLZ_D vec4 texture2d_lod(const DeviceScene& S, uint32_t id, float u, float v, float lod_base) {
+struct TexFootprint { float lod_base; float du, dv; uint32_t taps; };
+GLZ_D vec4 texture2d_lod(const DeviceScene& S, uint32_t id, float u, float v, const TexFootprint& fp) {
   const uint4 td = reinterpret_cast<const uint4*>(S.tex_desc)[id];
   const TexDesc t0{td.x, td.y, td.z, td.w};
-  uint32_t first = 0, l0 = 0, taps = 1;
+  uint32_t first = 0, l0 = 0, levels_used = 1, probes = 1;
   float frac = 0.0f;
-  if (lod_base > -1e29f && S.tex_mip_base != nullptr && !(t0.format & kTexInline)) {
+  if (fp.lod_base > -1e29f && S.tex_mip_base != nullptr && !(t0.format & kTexInline)) {
     const uint32_t b = S.tex_mip_base[id];
     const uint32_t levels = b >> 24;
     first = b & 0xFFFFFFu;
-    float lam = lod_base + 0.5f * glz_log2f((float)t0.width * (float)t0.height);
+    float lam = fp.lod_base + 0.5f * glz_log2f((float)t0.width * (float)t0.height);
     lam = lam > 0.0f ? lam : 0.0f;                                   // NaN -> 0
     const float top = (float)(levels - 1u);
     lam = lam < top ? lam : top;
     const float fl = glz_floorf(lam);
     l0 = (uint32_t)fl;
     frac = lam - fl;
-    taps = frac > 0.0f ? 2u : 1u;
+    levels_used = frac > 0.0f ? 2u : 1u;
+    probes = fp.taps;
   }
-  vec4 acc{0.0f, 0.0f, 0.0f, 0.0f};
+  vec4 sum{0.0f, 0.0f, 0.0f, 0.0f}, cur{0.0f, 0.0f, 0.0f, 0.0f};
+  const uint32_t fetches = probes * levels_used;
 #pragma unroll 1
-  for (uint32_t k = 0; k < taps; ++k) {   // one copy of the fetch code: level l0, then l0 + 1 when the level is fractional
-    const uint32_t level = l0 + k;
+  for (uint32_t k = 0; k < fetches; ++k) {   // one copy of the fetch code: per probe level l0, then l0 + 1 when the level is fractional
+    const uint32_t probe = levels_used == 2u ? k >> 1 : k, upper = levels_used == 2u ? k & 1u : 0u;
+    const uint32_t level = l0 + upper;
     TexDesc t = t0;
     const uint8_t* pool = S.tex_pool;
     if (level != 0u) {
@@ -186,14 +192,31 @@ GLZ_D vec4 texture2d_lod(const DeviceScene& S, uint32_t id, float u, float v, fl
       t = TexDesc{md.x, md.y, md.z, md.w};
       pool = S.tex_mip_pool;
     }
-    const vec4 r = bilinear_level(S, t, pool, u, v);
-    if (k == 0u) {
-      acc = r;
+    float uu = u, vv = v;
+    if (probes > 1u) {
+      const float s = ((float)probe + 0.5f) / (float)probes - 0.5f;
+      uu = u + s * fp.du;
+      vv = v + s * fp.dv;
+    }
+    const vec4 r = bilinear_level(S, t, pool, uu, vv);
+    if (upper == 0u) {
+      cur = r;
     } else {
-      acc.x = lerp_ab(acc.x, r.x, frac); acc.y = lerp_ab(acc.y, r.y, frac); acc.z = lerp_ab(acc.z, r.z, frac); acc.w = lerp_ab(acc.w, r.w, frac);
+      cur.x = lerp_ab(cur.x, r.x, frac); cur.y = lerp_ab(cur.y, r.y, frac); cur.z = lerp_ab(cur.z, r.z, frac); cur.w = lerp_ab(cur.w, r.w, frac);
+    }
+    if (upper + 1u == levels_used) {
+      if (probe == 0u) {
+        sum = cur;
+      } else {
+        sum.x += cur.x; sum.y += cur.y; sum.z += cur.z; sum.w += cur.w;
+      }
     }
   }
-  return acc;
+  if (probes > 1u) {
+    const float n = (float)probes;
+    sum.x = sum.x / n; sum.y = sum.y / n; sum.z = sum.z / n; sum.w = sum.w / n;
+  }
+  return sum;
 }
 GLZ_D vec3 texture_rgb(const DeviceScene& S, uint32_t id, vec2 uv) {
   vec4 t = texture2d(S, id, uv.x, uv.y);
@@ -396,16 +419,16 @@ GLZ_D float oren_nayar(float roughness, vec3 wo, vec3 wi) {
   return kInvPi * (A + B * maxcos * sinalpha * tanbeta);
 }
 
-GLZ_D void fetch_material_textures(const DeviceScene& S, SurfacePoint& P, float lod_base) {
+GLZ_D void fetch_material_textures(const DeviceScene& S, SurfacePoint& P, const TexFootprint& fp) {
   const uint32_t kind = P.mat.bsdf_index;
   P.tint = mk3(0.0f, 0.0f, 0.0f);
   P.rough_tex = P.metal_tex = 0.0f;
   if (kind == kBsdfLambert || kind == kBsdfUber) {
-    const vec4 tx = texture2d_lod(S, P.mat.diffuse, P.uv.x, P.uv.y, lod_base);
+    const vec4 tx = texture2d_lod(S, P.mat.diffuse, P.uv.x, P.uv.y, fp);
     P.tint = mk3(tx.x, tx.y, tx.z) * mk3(P.mat.diffuse_mul[0], P.mat.diffuse_mul[1], P.mat.diffuse_mul[2]);
   }
-  if (kind == kBsdfMetal || kind == kBsdfFrosted || kind == kBsdfUber) P.rough_tex = texture2d_lod(S, P.mat.roughness, P.uv.x, P.uv.y, lod_base).x;
-  if (kind == kBsdfUber) P.metal_tex = texture2d_lod(S, P.mat.metalness, P.uv.x, P.uv.y, lod_base).x;
+  if (kind == kBsdfMetal || kind == kBsdfFrosted || kind == kBsdfUber) P.rough_tex = texture2d_lod(S, P.mat.roughness, P.uv.x, P.uv.y, fp).x;
+  if (kind == kBsdfUber) P.metal_tex = texture2d_lod(S, P.mat.metalness, P.uv.x, P.uv.y, fp).x;
 }
 GLZ_D vec3 diffuse_tint(const DeviceScene&, const SurfacePoint& P) { return P.tint; }
 

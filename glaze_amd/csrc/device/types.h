@@ -25,7 +25,7 @@ struct FrameData {
   uint32_t pt_steps;
   uint32_t direct_only;
   // build-defined texture level of detail (the reference's ray-tracing stages sample level 0): 0 = level 0 always,
-  // 1 = ray cones.  The cone of a camera path starts `cone_width0` wide and widens by `cone_spread` per unit of distance.
+  // 1 = ray cones, 2 = ray cones with an anisotropic footprint.  The cone of a camera path starts `cone_width0` wide and widens by `cone_spread` per unit of distance.
   uint32_t lod_mode;
   float cone_spread;
   float cone_width0;

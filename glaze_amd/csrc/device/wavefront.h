@@ -999,7 +999,8 @@ struct SharedQueue {   // k_shade: the rank's sharded queue in HBM, drained by t
   const LaunchArgs& A;
   __device__ __forceinline__ uint32_t slot(bool push) { return queue_slot(A.st.queue_count + A.shade_set * kQueueSetWords, A.map.n_local_pixels, push); }
 };
-template <class Queue>
+// LOD: the build with the texture level of detail (FrameData::lod_mode != 0); the default build carries none of its code
+template <bool LOD, class Queue>
 __device__ __forceinline__ void shade_pixel(const LaunchArgs& A, const DeviceScene& S, const FrameData& F, uint32_t lid, PixelId px, float4 ro, float4 rd, float4 hr, Queue& queue) {
   const bool fresh = F.direct_only || ro.w == 0.0f;
   float bounce = F.direct_only ? 0.0f : ro.w;
@@ -1057,8 +1058,12 @@ __device__ __forceinline__ void shade_pixel(const LaunchArgs& A, const DeviceSce
   // at a hit the footprint on the surface is width / |cos|, and a texture of W x H texels over a triangle with texture-space
   // area A_uv and world area A_w is minified by sqrt(A_uv W H / A_w) texels per unit length:
   // level = 0.5 log2(A_uv / A_w * width^2 / cos^2) + 0.5 log2(W H)      (Akenine-Moeller et al., ray cones)
-  float lod_base = kNoLod, cone_w = 0.0f;
-  if (F.lod_mode != 0u) {
+  // lod mode 2 (anisotropic): the footprint is cone_w across and cone_w / |cos| along the projection m of the ray direction onto the
+  // surface; taps = ceil(min(1 / |cos|, 16)) probes along m, each at the level of a footprint cone_w / |cos| / taps wide; m written in
+  // the triangle's edges (least squares: it lies in their plane) gives the footprint's long axis in texture space.
+  TexFootprint fp{kNoLod, 0.0f, 0.0f, 1u};
+  float cone_w = 0.0f;
+  if constexpr (LOD) {
     cone_w = (fresh ? F.cone_width0 : A.st.cone[lid]) + F.cone_spread * hr.x;
     vec3 e1 = mk3(vb0.x, vb0.y, vb0.z) - mk3(va0.x, va0.y, va0.z), e2 = mk3(vc0.x, vc0.y, vc0.z) - mk3(va0.x, va0.y, va0.z);
     vec3 n = mk3(dn.x, dn.y, dn.z);
@@ -1071,12 +1076,36 @@ __device__ __forceinline__ void shade_pixel(const LaunchArgs& A, const DeviceSce
     const vec3 cr = cross3(e1, e2);
     const float area2 = sqrtf(dot3(cr, cr));
     const float uva2 = fabsf((vb1.z - va1.z) * (vc1.w - va1.w) - (vc1.z - va1.z) * (vb1.w - va1.w));
-    const float cosv = fabsf(dot3(n, direction)) / sqrtf(dot3(n, n));
+    const float nn = dot3(n, n), nd = dot3(n, direction);
+    const float cosv = fabsf(nd) / sqrtf(nn);
     const float x = ((uva2 / area2) * (cone_w * cone_w)) / (cosv * cosv);
-    if (x >= 1.17549435e-38f && x <= 3.4e38f) lod_base = 0.5f * glz_log2f(x);
+    if (x >= 1.17549435e-38f && x <= 3.4e38f) {
+      fp.lod_base = 0.5f * glz_log2f(x);
+      if (F.lod_mode == 2u) {
+        float ratio = 1.0f / cosv;
+        ratio = ratio < 16.0f ? ratio : 16.0f;
+        const float taps = -glz_floorf(-ratio);   // ceil
+        const vec3 m = direction - n * (nd / nn);
+        const float mm = dot3(m, m);
+        if (taps > 1.0f && mm > 0.0f) {
+          const float g11 = dot3(e1, e1), g12 = dot3(e1, e2), g22 = dot3(e2, e2), r1 = dot3(m, e1), r2 = dot3(m, e2);
+          const float det = g11 * g22 - g12 * g12;
+          const float ca = (r1 * g22 - r2 * g12) / det, cb = (r2 * g11 - r1 * g12) / det;
+          const float len = (cone_w / cosv) / sqrtf(mm);
+          const float du = (ca * (vb1.z - va1.z) + cb * (vc1.z - va1.z)) * len;
+          const float dv = (ca * (vb1.w - va1.w) + cb * (vc1.w - va1.w)) * len;
+          if (fabsf(du) <= 3.4e38f && fabsf(dv) <= 3.4e38f) {
+            fp.du = du;
+            fp.dv = dv;
+            fp.taps = (uint32_t)taps;
+            fp.lod_base = fp.lod_base - glz_log2f(taps);
+          }
+        }
+      }
+    }
   }
   if (mat.normal != 0) {
-    const vec4 tx = texture2d_lod(S, mat.normal, uv.x, uv.y, lod_base);
+    const vec4 tx = texture2d_lod(S, mat.normal, uv.x, uv.y, fp);
     Frame old;
     old.s = normalize3(dpdu);
     old.n = ns;
@@ -1104,7 +1133,7 @@ __device__ __forceinline__ void shade_pixel(const LaunchArgs& A, const DeviceSce
   P.uv = uv;
   P.frame = make_frame(dpdu, ns);
   P.mat = mat;
-  fetch_material_textures(S, P, lod_base);
+  fetch_material_textures(S, P, fp);
   float spec_flag;
   float imp_lum = 0.0f;      // luminance of the importance, taken when the light-sampling block reads it: the roulette needs nothing else of it
   bool have_lum = false;
@@ -1200,7 +1229,7 @@ __device__ __forceinline__ void shade_pixel(const LaunchArgs& A, const DeviceSce
     A.st.imp[q][lid] = make_float4(importance.w[4 * q] * (value.w[4 * q] * weight), importance.w[4 * q + 1] * (value.w[4 * q + 1] * weight),
                                    importance.w[4 * q + 2] * (value.w[4 * q + 2] * weight), importance.w[4 * q + 3] * (value.w[4 * q + 3] * weight));
   bounce = bounce < (float)F.pt_steps ? bounce + 1.0f : 0.0f;   // :230-237
-  if (F.lod_mode != 0u) A.st.cone[lid] = cone_w;
+  if constexpr (LOD) A.st.cone[lid] = cone_w;
   A.st.ray_o[lid] = make_float4(point.x, point.y, point.z, bounce);
   A.st.ray_d[lid] = make_float4(wiW.x, wiW.y, wiW.z, spec_flag);
 }

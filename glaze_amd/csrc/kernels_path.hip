@@ -114,6 +114,7 @@ __device__ __forceinline__ FrameData launch_frame(const LaunchArgs& A, const Pat
 }
 constexpr uint32_t kPathBatchOffset = (uint32_t)(((sizeof(LaunchArgs) + alignof(PathBatch) - 1) / alignof(PathBatch)) * alignof(PathBatch));   // PathBatch in k_path's kernarg segment
 // the shading phase of k_path for the wave's 64 pixels; returns how many of them queued a shadow ray (entries 64 g .. of the queue arrays)
+template <bool LOD>
 __device__ __forceinline__ uint32_t path_shade(uint32_t g, uint32_t n_groups, uint32_t lane, uint32_t L, const DeviceScene& S_lds, const float4* hit) {
   const uint32_t lid0 = g * 64u;   // the wave's own 64 entries of the shadow-queue arrays
 #if GLZ_PATH_REREAD
@@ -135,7 +136,7 @@ __device__ __forceinline__ uint32_t path_shade(uint32_t g, uint32_t n_groups, ui
   GroupQueue queue{lid0, false};
   if (px.active) {
     const float4 ro = A.st.ray_o[lid], rd = A.st.ray_d[lid];
-    shade_pixel(A, S, F, lid, px, ro, rd, hit[lane], queue);
+    shade_pixel<LOD>(A, S, F, lid, px, ro, rd, hit[lane], queue);
   }
   return (uint32_t)__popcll(__ballot(queue.pushed));
 }
@@ -143,6 +144,7 @@ __device__ __forceinline__ uint32_t path_shade(uint32_t g, uint32_t n_groups, ui
 #ifdef GLZ_PATH_TIMES   // tuning builds only (tools/gpu_path_phases.py): 10 ns ticks every wave spent tracing / shading, summed over the launches of the last k_path
 __device__ unsigned long long g_path_times[3 * 8192];
 #endif
+template <bool LOD>
 __global__ void __launch_bounds__(kBlock, GLZ_PATH_WAVES) k_path(const LaunchArgs A, const PathBatch B) {
   __shared__ int s_stack[kLdsStack * kBlock];
   __shared__ alignas(16) int s_aux[(kBlock / 64) * kAuxPerWave];
@@ -241,7 +243,7 @@ __global__ void __launch_bounds__(kBlock, GLZ_PATH_WAVES) k_path(const LaunchArg
       pt_trace += pt1 - pt0;
 #endif
       if (L >= B.n) break;
-      n_shadow = path_shade(g, n_groups, lane, L, S, hit);
+      n_shadow = path_shade<LOD>(g, n_groups, lane, L, S, hit);
 #ifdef GLZ_PATH_ONE
       A.st.queue_count[wave_index()] = n_shadow; return;
 #endif
@@ -280,7 +282,7 @@ uint32_t path_grid_blocks(uint32_t n_local_pixels, const DeviceScene& sc) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
   }
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_path, kBlock, path_table_bytes(sc)) != hipSuccess || per_cu < 1) per_cu = 2;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_path<false>, kBlock, path_table_bytes(sc)) != hipSuccess || per_cu < 1) per_cu = 2;
   per_cu = std::min(per_cu, 8);
   const uint32_t groups = (n_local_pixels + 63u) / 64u, blocks = (groups + kBlock / 64 - 1) / (kBlock / 64);
   return std::max<uint32_t>(1u, std::min<uint32_t>(blocks, (uint32_t)cus * (uint32_t)per_cu));
@@ -292,7 +294,8 @@ hipError_t launch_path(hipStream_t st, const LaunchArgs& a, const PathBatch& bat
   PathBatch b = batch;
   const uint32_t dyn = path_table_bytes(a.scene);
   b.tables_in_lds = dyn != 0u ? 1u : 0u;
-  hipLaunchKernelGGL(k_path, dim3(blocks), dim3(kBlock), dyn, st, a, b);
+  if (a.frame.lod_mode != 0u) hipLaunchKernelGGL(k_path<true>, dim3(blocks), dim3(kBlock), dyn, st, a, b);
+  else hipLaunchKernelGGL(k_path<false>, dim3(blocks), dim3(kBlock), dyn, st, a, b);
   return hipGetLastError();
 }
 }  // namespace glz

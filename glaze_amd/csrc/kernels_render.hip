@@ -25,7 +25,8 @@ constexpr uint32_t kSkyLdsFloats = 4096;   // sky marginal tables (3H+1 floats) 
 // COUNT: the instrumented build of the counting passes (texture fetches, light samples: DeviceScene::tex_counter).  The measured kernel
 // sets the counter pointer to a constant null, so the checks in the texture and light code fold away (left as a run-time null they
 // cost 2.5 %: a branch per fetch and two more live SGPRs).
-template <bool COUNT>
+// LOD: the build with the texture level of detail (shade_pixel<LOD>).
+template <bool COUNT, bool LOD>
 __global__ void __launch_bounds__(kBlock, GLZ_SHADE_WAVES) k_shade(const LaunchArgs A) {
   // The kernel is bound by the memory system's random-access rate (16 extra scattered loads per pixel cost +27 %, 200 extra
   // VALU instructions nothing; 1 / 2 / 3 / 4 waves per SIMD take 0.76 / 0.45 / 0.36 / 0.35 ms), so the two small tables every texture fetch /
@@ -160,10 +161,10 @@ __global__ void __launch_bounds__(kBlock, GLZ_SHADE_WAVES) k_shade(const LaunchA
     // (see reread_kernarg: without it the regrouping prologue's view of the arguments stays in SGPRs through the shading code)
     const LaunchArgs& A2 = *(const LaunchArgs*)reread_kernarg();
     SharedQueue queue{A2};
-    shade_pixel(A2, S, A2.frame, lid, px, ro, rd, hr, queue);
+    shade_pixel<LOD>(A2, S, A2.frame, lid, px, ro, rd, hr, queue);
 #else
     SharedQueue queue{A};
-    shade_pixel(A, S, F, lid, px, ro, rd, hr, queue);
+    shade_pixel<LOD>(A, S, F, lid, px, ro, rd, hr, queue);
 #endif
   }
   if (COUNT) flush_tex_tallies(A.counters->shade_tex, tex_tally);   // every lane of the wave is here (the counting build returns nowhere above)
@@ -410,8 +411,12 @@ hipError_t launch_trace(hipStream_t st, const LaunchArgs& a, uint32_t blocks) {
 }
 hipError_t launch_shade(hipStream_t st, const LaunchArgs& a) {
   if (a.map.n_local_pixels == 0) return hipSuccess;
-  if (a.counters) hipLaunchKernelGGL(k_shade<true>, grid_for(a.map.n_local_pixels), dim3(kBlock), 0, st, a);
-  else hipLaunchKernelGGL(k_shade<false>, grid_for(a.map.n_local_pixels), dim3(kBlock), 0, st, a);
+  const dim3 grid = grid_for(a.map.n_local_pixels);
+  const bool lod = a.frame.lod_mode != 0u;
+  if (a.counters && lod) hipLaunchKernelGGL((k_shade<true, true>), grid, dim3(kBlock), 0, st, a);
+  else if (a.counters) hipLaunchKernelGGL((k_shade<true, false>), grid, dim3(kBlock), 0, st, a);
+  else if (lod) hipLaunchKernelGGL((k_shade<false, true>), grid, dim3(kBlock), 0, st, a);
+  else hipLaunchKernelGGL((k_shade<false, false>), grid, dim3(kBlock), 0, st, a);
   return hipGetLastError();
 }
 hipError_t launch_export(hipStream_t st, const TileMap& map, const float4* tiled, float4* frame, bool zero_first) {

@@ -937,9 +937,9 @@ bool Renderer::read_rgba8(uint8_t* out, Error& err) {
 }
 
 bool Renderer::set_texture_lod(int mode, Error& err) {
-  if (mode != 0 && mode != 1) {
+  if (mode != 0 && mode != 1 && mode != 2) {
     err.code = GLZ_E_ARG;
-    err.msg = "texture LOD mode must be 0 (level 0) or 1 (ray cones)";
+    err.msg = "texture LOD mode must be 0 (level 0), 1 (ray cones) or 2 (ray cones, anisotropic footprint)";
     return false;
   }
   lod_mode_ = mode;

@@ -81,7 +81,7 @@ class Renderer {
   uint32_t w_ = 0, h_ = 0;
   int integrator_ = GLZ_PATH_TRACE;
   uint32_t pt_steps_ = 6;   // PT_STEPS, raytrace_structures.rs:87
-  int lod_mode_ = 0;        // texture level of detail: 0 = level 0 always (what the reference's ray-tracing stages do), 1 = ray cones
+  int lod_mode_ = 0;        // texture level of detail: 0 = level 0 always (what the reference's ray-tracing stages do), 1 = ray cones, 2 = ray cones with an anisotropic footprint
   float exposure_ = 1.0f;
   glz_camera camera_{};
   CameraConsts cam_{};

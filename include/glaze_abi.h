@@ -338,9 +338,13 @@ int glz_renderer_set_depth(glz_renderer*, uint32_t pt_steps);/* replaces const P
  * the implicit level, which outside fragment shaders is level 0: GLZ_LOD_BASE (the default) reproduces that bit for bit.
  * GLZ_LOD_RAY_CONES picks the level per hit from the ray's footprint (cone width carried along the path, triangle texture /
  * world area ratio, angle of incidence) and blends the two nearest levels; the chain is built on the first launch that needs it.
+ * GLZ_LOD_RAY_CONES_ANISO adds what the sampler's anisotropy (scene.rs:716-749: enabled at the device's maximum) does in the raster
+ * viewer: the footprint is the cone's width across and width / |cos| along the ray's projection onto the surface; up to 16
+ * trilinear probes along that axis, each at the level of its share of it, averaged.
  * Restarts accumulation. */
 #define GLZ_LOD_BASE 0
 #define GLZ_LOD_RAY_CONES 1
+#define GLZ_LOD_RAY_CONES_ANISO 2
 int glz_renderer_set_texture_lod(glz_renderer*, int mode);
 /* cumulative image (xyz = sum of rgb radiance, w = launch count; path_trace.rgen:119-133),
  * W*H*4 floats, row-major, to host memory. */

@@ -540,23 +540,43 @@ void build_mip_chain(Tex& t) {
     src = &t.mips.back();
   }
 }
-// LINEAR mip filtering: the two nearest levels blended (sampler of scene.rs:716-749).  lod_base = the texture-independent part of
-// the ray-cone level (raygen below); NO_LOD or a level <= 0 is texture_bilinear().
+// LINEAR mip filtering: the two nearest levels blended (sampler of scene.rs:716-749).  fp.lod_base = the texture-independent part of
+// the ray-cone level (raygen below); NO_LOD or a level <= 0 is texture_bilinear().  fp.taps > 1 (anisotropic footprint, lod mode 2):
+// that many trilinear probes spread evenly over the footprint's long axis (du, dv) around (u, v), averaged -- the scheme of the
+// reference sampler's anisotropy (scene.rs:716-749 enables it at the device's maximum; only the raster viewer uses that sampler with
+// derivatives, the ray-tracing stages sample level 0).
 constexpr float NO_LOD = -1e30f;
-V4 texture_lod(const Scene& sc, uint32_t id, float u, float v, float lod_base) {
+struct TexFootprint { float lod_base = NO_LOD; float du = 0.0f, dv = 0.0f; uint32_t taps = 1; };
+V4 texture_lod(const Scene& sc, uint32_t id, float u, float v, const TexFootprint& fp) {
   const Tex& t = sc.textures[id];
-  if (!(lod_base > -1e29f) || t.mips.empty()) return texture_bilinear_level(sc, t, u, v);
-  float lam = lod_base + 0.5f * glz_log2f((float)t.w * (float)t.h);
+  if (!(fp.lod_base > -1e29f) || t.mips.empty()) return texture_bilinear_level(sc, t, u, v);
+  float lam = fp.lod_base + 0.5f * glz_log2f((float)t.w * (float)t.h);
   lam = lam > 0.0f ? lam : 0.0f;
   float top = (float)t.mips.size();
   lam = lam < top ? lam : top;
   float fl = glz_floorf(lam);
   uint32_t l0 = (uint32_t)fl;
   float frac = lam - fl;
-  V4 a = texture_bilinear_level(sc, l0 == 0 ? t : t.mips[l0 - 1], u, v);
-  if (!(frac > 0.0f)) return a;
-  V4 b = texture_bilinear_level(sc, t.mips[l0], u, v);
-  return V4{lerp1(a.x, b.x, frac), lerp1(a.y, b.y, frac), lerp1(a.z, b.z, frac), lerp1(a.w, b.w, frac)};
+  V4 sum{0.0f, 0.0f, 0.0f, 0.0f};
+  for (uint32_t k = 0; k < fp.taps; ++k) {
+    float uu = u, vv = v;
+    if (fp.taps > 1) {
+      float s = ((float)k + 0.5f) / (float)fp.taps - 0.5f;
+      uu = u + s * fp.du;
+      vv = v + s * fp.dv;
+    }
+    V4 a = texture_bilinear_level(sc, l0 == 0 ? t : t.mips[l0 - 1], uu, vv);
+    if (frac > 0.0f) {
+      V4 b = texture_bilinear_level(sc, t.mips[l0], uu, vv);
+      a = V4{lerp1(a.x, b.x, frac), lerp1(a.y, b.y, frac), lerp1(a.z, b.z, frac), lerp1(a.w, b.w, frac)};
+    }
+    sum = k == 0 ? a : V4{sum.x + a.x, sum.y + a.y, sum.z + a.z, sum.w + a.w};
+  }
+  if (fp.taps > 1) {
+    float n = (float)fp.taps;
+    sum = V4{sum.x / n, sum.y / n, sum.z / n, sum.w / n};
+  }
+  return sum;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1181,9 +1201,9 @@ inline V2 to_anisotropic(float a, float anis) { return V2{a * (1.0f + anis), a *
 // ------------------------------------------------------------------------------------------
 // BSDF callables (mat_*_value.rcall / mat_*_sample_value.rcall)
 // ------------------------------------------------------------------------------------------
-struct BsdfIn { V3 woW, wiW; V2 uv; ShadingSpace sh; uint32_t material_id; float lod_base = NO_LOD; };
-inline V3 tex_rgb(const Scene& sc, uint32_t id, V2 uv, float lod_base = NO_LOD) { V4 t = texture_lod(sc, id, uv.x, uv.y, lod_base); return v3(t.x, t.y, t.z); }
-inline float tex_r(const Scene& sc, uint32_t id, V2 uv, float lod_base = NO_LOD) { return texture_lod(sc, id, uv.x, uv.y, lod_base).x; }
+struct BsdfIn { V3 woW, wiW; V2 uv; ShadingSpace sh; uint32_t material_id; TexFootprint fp; };
+inline V3 tex_rgb(const Scene& sc, uint32_t id, V2 uv, const TexFootprint& fp = TexFootprint()) { V4 t = texture_lod(sc, id, uv.x, uv.y, fp); return v3(t.x, t.y, t.z); }
+inline float tex_r(const Scene& sc, uint32_t id, V2 uv, const TexFootprint& fp = TexFootprint()) { return texture_lod(sc, id, uv.x, uv.y, fp).x; }
 
 // Oren-Nayar term shared by mat_uber_value.rcall:56-73 and mat_uber_sample_value.rcall:66-81
 float oren_nayar_term(float roughness, V3 wo, V3 wi) {
@@ -1223,7 +1243,7 @@ float bsdf_value(const Scene& sc, const BsdfIn& in, float rand_sample, Sp& value
     case 4: {   // mat_lambert_value.rcall:23-34
       V3 wo = to_shading_space(in.woW, in.sh), wi = to_shading_space(in.wiW, in.sh);
       float same_hemi = gstep(0.0f, wo.z * wi.z);
-      V3 tx = tex_rgb(sc, mat.diffuse, in.uv, in.lod_base);
+      V3 tx = tex_rgb(sc, mat.diffuse, in.uv, in.fp);
       V3 dm = v3(mat.diffuse_mul[0], mat.diffuse_mul[1], mat.diffuse_mul[2]);
       value = from_surface_color((tx * dm) * INV_PI);
       return same_hemi * fabsf(wi.z) * INV_PI;
@@ -1236,7 +1256,7 @@ float bsdf_value(const Scene& sc, const BsdfIn& in, float rand_sample, Sp& value
       float costwo = fabsf(wo.z), costwi = fabsf(wi.z);
       if (wo.z * wi.z > 0.0f) {
         Sp F = fresnel_conductor(dot(wi, wh), mat.metal_ior, mat.metal_fresnel);
-        float rough = tex_r(sc, mat.roughness, in.uv, in.lod_base);
+        float rough = tex_r(sc, mat.roughness, in.uv, in.fp);
         V2 a = to_anisotropic(rough * mat.roughness_mul, mat.anisotropy);
         float d = ggx_d(wh, a);
         float g = ggx_g(wo, wi, a);
@@ -1249,7 +1269,7 @@ float bsdf_value(const Scene& sc, const BsdfIn& in, float rand_sample, Sp& value
     }
     case 12: {  // mat_frosted_value.rcall:19-66
       V3 wo = to_shading_space(in.woW, in.sh), wi = to_shading_space(in.wiW, in.sh);
-      float rough = tex_r(sc, mat.roughness, in.uv, in.lod_base);
+      float rough = tex_r(sc, mat.roughness, in.uv, in.fp);
       V2 a = to_anisotropic(rough * mat.roughness_mul, mat.anisotropy);
       bool same_hemi = wo.z * wi.z > 0.0f;
       float from_outside = gstep(0.0f, wo.z);
@@ -1280,13 +1300,13 @@ float bsdf_value(const Scene& sc, const BsdfIn& in, float rand_sample, Sp& value
     }
     default: {  // 14: mat_uber_value.rcall:20-77
       V3 wo = to_shading_space(in.woW, in.sh), wi = to_shading_space(in.wiW, in.sh);
-      float rough_tex = tex_r(sc, mat.roughness, in.uv, in.lod_base);
+      float rough_tex = tex_r(sc, mat.roughness, in.uv, in.fp);
       float roughness = rough_tex * mat.roughness_mul;
       float same_hemi = gstep(0.0f, wo.z * wi.z);
       if (rand_sample < 0.5f) {
         V2 a = to_anisotropic(roughness * mat.roughness_mul, mat.anisotropy);   // Q5: roughness_mul twice
         V3 wh = normalize(wo + wi);
-        float metalness = tex_r(sc, mat.metalness, in.uv, in.lod_base) * mat.metalness_mul;
+        float metalness = tex_r(sc, mat.metalness, in.uv, in.fp) * mat.metalness_mul;
         float from_outside = gstep(0.0f, wo.z);
         float etai = gmix(mat.ior_dielectric, DEFAULT_IOR, from_outside);
         float etat = gmix(DEFAULT_IOR, mat.ior_dielectric, from_outside);
@@ -1298,7 +1318,7 @@ float bsdf_value(const Scene& sc, const BsdfIn& in, float rand_sample, Sp& value
         value = sp_mul(f, term);
         return checknan(same_hemi * 0.5f * s.pdf);
       } else {
-        V3 tx = tex_rgb(sc, mat.diffuse, in.uv, in.lod_base);
+        V3 tx = tex_rgb(sc, mat.diffuse, in.uv, in.fp);
         V3 dm = v3(mat.diffuse_mul[0], mat.diffuse_mul[1], mat.diffuse_mul[2]);
         float term = oren_nayar_term(roughness, wo, wi);
         value = from_surface_color((tx * dm) * term);
@@ -1329,7 +1349,7 @@ float bsdf_sample(const Scene& sc, const BsdfIn& in, V3 r, Sp& value, V3& wiW) {
       V3 wi = cosine_sample(r.x, r.y, wo.z);
       float pdf = fabsf(wi.z) * INV_PI;
       wiW = normalize(to_world_space(wi, in.sh));
-      V3 tx = tex_rgb(sc, mat.diffuse, in.uv, in.lod_base);
+      V3 tx = tex_rgb(sc, mat.diffuse, in.uv, in.fp);
       V3 dm = v3(mat.diffuse_mul[0], mat.diffuse_mul[1], mat.diffuse_mul[2]);
       value = from_surface_color((tx * dm) * INV_PI);
       return pdf;
@@ -1368,7 +1388,7 @@ float bsdf_sample(const Scene& sc, const BsdfIn& in, V3 r, Sp& value, V3& wiW) {
     }
     case 10: {  // mat_metal_sample_value.rcall:21-49
       V3 wo = to_shading_space(in.woW, in.sh);
-      float rough = tex_r(sc, mat.roughness, in.uv, in.lod_base);
+      float rough = tex_r(sc, mat.roughness, in.uv, in.fp);
       V2 a = to_anisotropic(rough * mat.roughness_mul, mat.anisotropy);
       V3 wh = normalize(ggx_sample_wh(wo, V2{r.x, r.y}, a));
       V3 wi = -normalize(reflect(wo, wh));
@@ -1388,7 +1408,7 @@ float bsdf_sample(const Scene& sc, const BsdfIn& in, V3 r, Sp& value, V3& wiW) {
     }
     case 12: {  // mat_frosted_sample_value.rcall:21-71
       V3 wo = to_shading_space(in.woW, in.sh);
-      float rough = tex_r(sc, mat.roughness, in.uv, in.lod_base);
+      float rough = tex_r(sc, mat.roughness, in.uv, in.fp);
       V2 a = to_anisotropic(rough * mat.roughness_mul, mat.anisotropy);
       V3 wh = normalize(ggx_sample_wh(wo, V2{r.x, r.y}, a));
       float from_outside = gstep(0.0f, wo.z);
@@ -1422,14 +1442,14 @@ float bsdf_sample(const Scene& sc, const BsdfIn& in, V3 r, Sp& value, V3& wiW) {
     }
     default: {  // 14: mat_uber_sample_value.rcall:21-86
       V3 wo = to_shading_space(in.woW, in.sh);
-      float rough_tex = tex_r(sc, mat.roughness, in.uv, in.lod_base);
+      float rough_tex = tex_r(sc, mat.roughness, in.uv, in.fp);
       float roughness = rough_tex * mat.roughness_mul;
       V3 wi;
       float pdf_out;
       if (r.z < 0.5f) {
         V2 a = to_anisotropic(roughness * mat.roughness_mul, mat.anisotropy);
         V3 wh = normalize(ggx_sample_wh(wo, V2{r.x, r.y}, a));
-        float metalness = tex_r(sc, mat.metalness, in.uv, in.lod_base) * mat.metalness_mul;
+        float metalness = tex_r(sc, mat.metalness, in.uv, in.fp) * mat.metalness_mul;
         float from_outside = gstep(0.0f, wo.z);
         float etai = gmix(mat.ior_dielectric, DEFAULT_IOR, from_outside);
         float etat = gmix(DEFAULT_IOR, mat.ior_dielectric, from_outside);
@@ -1443,7 +1463,7 @@ float bsdf_sample(const Scene& sc, const BsdfIn& in, V3 r, Sp& value, V3& wiW) {
         pdf_out = checknan(0.5f * s.pdf);
       } else {
         wi = cosine_sample(r.x, r.y, wo.z);
-        V3 tx = tex_rgb(sc, mat.diffuse, in.uv, in.lod_base);
+        V3 tx = tex_rgb(sc, mat.diffuse, in.uv, in.fp);
         V3 dm = v3(mat.diffuse_mul[0], mat.diffuse_mul[1], mat.diffuse_mul[2]);
         float term = oren_nayar_term(roughness, wo, wi);
         value = from_surface_color((tx * dm) * term);
@@ -1639,7 +1659,7 @@ struct Renderer {
   float push[32];
   std::vector<PTLastVertex> last;
   std::vector<float> cone;   // ray-cone width at the ray origin, per pixel (texture LOD)
-  int lod_mode = 0;          // 0 = level 0 (the reference), 1 = ray cones
+  int lod_mode = 0;          // 0 = level 0 (the reference), 1 = ray cones, 2 = ray cones with an anisotropic footprint
   std::vector<float> cumulative, out32;
   Xoshiro128pp rng{0};
   WorkScheduler sched;
@@ -1663,7 +1683,11 @@ struct HitData { V3 point, shading_normal, geometric_normal, dpdu, dpdv; V2 uv; 
 // triangle with texture-space area A_uv and world area A_w is minified by sqrt(A_uv W H / A_w) texels per unit length and the
 // footprint on the surface is width / |cos|:  level = 0.5 log2(A_uv / A_w * width^2 / cos^2) + 0.5 log2(W H).
 // Edges and the geometric normal are taken to world space when the instance's transform is not the identity (bitwise).
-float ray_cone_lod_base(const Scene& sc, const Tri& tr, V3 direction, float width) {
+// mode 2 (anisotropic): the footprint is `width` across and width / |cos| along the projection m of the ray direction onto the
+// surface; taps = ceil(min(1 / |cos|, 16)) probes along m, each at the level of a footprint width / |cos| / taps wide; m is written
+// in the triangle's edges (least squares: it lies in their plane) to get the footprint's long axis in texture space.
+TexFootprint ray_cone_footprint(const Scene& sc, const Tri& tr, V3 direction, float width, int mode) {
+  TexFootprint fp;
   const RTInstance& in = sc.instances[tr.instance];
   uint32_t triangle_id = in.index_offset / 3 + tr.prim;
   const uint32_t* ix = &sc.indices[triangle_id * 3];
@@ -1681,14 +1705,34 @@ float ray_cone_lod_base(const Scene& sc, const Tri& tr, V3 direction, float widt
   V3 cr = cross(e1, e2);
   float area2 = sqrtf(dot(cr, cr));
   float uva2 = fabsf((b.vt[0] - a.vt[0]) * (c.vt[1] - a.vt[1]) - (c.vt[0] - a.vt[0]) * (b.vt[1] - a.vt[1]));
-  float cosv = fabsf(dot(n, direction)) / sqrtf(dot(n, n));
+  float nn = dot(n, n), nd = dot(n, direction);
+  float cosv = fabsf(nd) / sqrtf(nn);
   float x = ((uva2 / area2) * (width * width)) / (cosv * cosv);
-  if (x >= 1.17549435e-38f && x <= 3.4e38f) return 0.5f * glz_log2f(x);
-  return NO_LOD;
+  if (!(x >= 1.17549435e-38f && x <= 3.4e38f)) return fp;
+  fp.lod_base = 0.5f * glz_log2f(x);
+  if (mode != 2) return fp;
+  float ratio = 1.0f / cosv;
+  ratio = ratio < 16.0f ? ratio : 16.0f;
+  float taps = -glz_floorf(-ratio);            // ceil
+  V3 m = direction - n * (nd / nn);
+  float mm = dot(m, m);
+  if (!(taps > 1.0f) || !(mm > 0.0f)) return fp;
+  float g11 = dot(e1, e1), g12 = dot(e1, e2), g22 = dot(e2, e2), r1 = dot(m, e1), r2 = dot(m, e2);
+  float det = g11 * g22 - g12 * g12;
+  float ca = (r1 * g22 - r2 * g12) / det, cb = (r2 * g11 - r1 * g12) / det;
+  float len = (width / cosv) / sqrtf(mm);
+  float du = (ca * (b.vt[0] - a.vt[0]) + cb * (c.vt[0] - a.vt[0])) * len;
+  float dvv = (ca * (b.vt[1] - a.vt[1]) + cb * (c.vt[1] - a.vt[1])) * len;
+  if (!(fabsf(du) <= 3.4e38f) || !(fabsf(dvv) <= 3.4e38f)) return fp;
+  fp.du = du;
+  fp.dv = dvv;
+  fp.taps = (uint32_t)taps;
+  fp.lod_base = fp.lod_base - glz_log2f(taps);
+  return fp;
 }
 
-// lod_base: NO_LOD (the reference: level 0) or the ray-cone level without the texture's own size term (ray_cone_lod_base below)
-void closest_hit_shader(const Scene& sc, const Tri& tr, float t, float u, float v, HitData& hit, float lod_base = NO_LOD) {
+// fp: the default (the reference: level 0) or the ray-cone footprint (ray_cone_footprint above)
+void closest_hit_shader(const Scene& sc, const Tri& tr, float t, float u, float v, HitData& hit, const TexFootprint& fp = TexFootprint()) {
   const RTInstance& in = sc.instances[tr.instance];
   uint32_t triangle_id = in.index_offset / 3 + tr.prim;
   float b0 = 1.0f - u - v, b1 = u, b2 = v;
@@ -1705,7 +1749,7 @@ void closest_hit_shader(const Scene& sc, const Tri& tr, float t, float u, float 
   hit.material_id = in.material_id;
   const RTMaterial& mat = sc.rt_materials[hit.material_id];
   if (mat.normal != 0) {
-    V4 tx = texture_lod(sc, mat.normal, hit.uv.x, hit.uv.y, lod_base);
+    V4 tx = texture_lod(sc, mat.normal, hit.uv.x, hit.uv.y, fp);
     ShadingSpace old;
     old.s = normalize(hit.dpdu);
     old.n = hit.shading_normal;
@@ -1820,7 +1864,8 @@ void raygen(Renderer& R, const FrameConsts& fc, uint32_t px, uint32_t py) {
     return;
   }
   HitData hit;
-  float lod_base = NO_LOD, cone_w = 0.0f;
+  TexFootprint fp;
+  float cone_w = 0.0f;
   if (R.lod_mode != 0) {
     // one pixel of the image plane at unit distance (perspective: the cone's spread) or in world units (orthographic: its width)
     const float pixel = 2.0f * fabsf(R.push[16 + 5]) / (float)R.h;
@@ -1828,14 +1873,14 @@ void raygen(Renderer& R, const FrameConsts& fc, uint32_t px, uint32_t py) {
     const float spread = persp ? pixel : 0.0f, width0 = persp ? 0.0f : pixel;
     const bool fresh = direct_only || last.hit[3] == 0.0f;
     cone_w = (fresh ? width0 : R.cone[path_id]) + spread * h.t;
-    lod_base = ray_cone_lod_base(sc, sc.tris[h.tri], direction, cone_w);
+    fp = ray_cone_footprint(sc, sc.tris[h.tri], direction, cone_w, R.lod_mode);
   }
-  closest_hit_shader(sc, sc.tris[h.tri], h.t, h.u, h.v, hit, lod_base);
+  closest_hit_shader(sc, sc.tris[h.tri], h.t, h.u, h.v, hit, fp);
   const RTMaterial& material = sc.rt_materials[hit.material_id];
   V3 woW = -direction;
   ShadingSpace matrix = new_shading_space(hit.dpdu, hit.shading_normal);
   BsdfIn bin;
-  bin.woW = woW; bin.uv = hit.uv; bin.sh = matrix; bin.material_id = hit.material_id; bin.lod_base = lod_base;
+  bin.woW = woW; bin.uv = hit.uv; bin.sh = matrix; bin.material_id = hit.material_id; bin.fp = fp;
   if (material.is_specular == 0) {                                       // :183-189, direct_light :84-117
     Sp radiance_light = sp_uniform(0.0f);
     float weight_light = 1.0f;
@@ -2134,7 +2179,7 @@ void orc_renderer_draw(void* r, uint64_t spp) {
 void orc_renderer_read_hdr(void* r, float* out) { Renderer* R = (Renderer*)r; if (R->request_new_frame) renderer_reset(*R); memcpy(out, R->cumulative.data(), R->cumulative.size() * 4); }
 void orc_renderer_read_result(void* r, float* out) { Renderer* R = (Renderer*)r; if (R->request_new_frame) renderer_reset(*R); memcpy(out, R->out32.data(), R->out32.size() * 4); }
 uint8_t orc_to_srgb8(float c) { return to_srgb8(c); }
-// texture level of detail: 0 = level 0 (the reference), 1 = ray cones (the mip chains are built here).  Restarts.
+// texture level of detail: 0 = level 0 (the reference), 1 = ray cones, 2 = anisotropic ray cones (the mip chains are built here).  Restarts.
 void orc_renderer_set_texture_lod(void* r, int mode) {
   Renderer* R = (Renderer*)r;
   R->lod_mode = mode;

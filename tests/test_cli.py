@@ -44,6 +44,8 @@ def test_cli_argument_errors(tmp_path):
     assert r.returncode == 2 and "unexpected argument" in r.stderr
     r = run(MATTEST, out, "--spp")
     assert r.returncode == 2 and "value is required" in r.stderr
+    r = run(MATTEST, out, "--texture-lod", "trilinear")
+    assert r.returncode == 2 and "possible values: off, cones, aniso" in r.stderr
 
 
 @pytest.mark.gpu
@@ -71,3 +73,7 @@ def test_cli_renders_what_the_library_renders(tmp_path, instance):
     assert r.returncode == 0
     im = Image.open(jpg)
     assert im.size == (96, 64) and im.mode == "RGB" and np.asarray(im).std() > 5
+    r = run(MATTEST, png, "-r", "96x64", "-s", "3", "--seed", "11", "--depth", "4", "--texture-lod", "aniso")
+    assert r.returncode == 0, r.stderr
+    ren.set_texture_lod(2)
+    assert np.array_equal(np.asarray(Image.open(png)), ren.draw(3)) and not np.array_equal(ren.read_rgba8(), want)

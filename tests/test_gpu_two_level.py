@@ -116,7 +116,7 @@ def test_two_level_alpha_maps_normal_maps_and_lod(instance):
     for sc in (flat, two):
         r = glaze_amd.RayTraceRenderer.new(instance, sc, 80, 64)
         r.set_depth(4)
-        r.set_texture_lod(1)
+        r.set_texture_lod(2)
         r.step(9)
         out.append(r.read_hdr())
     assert np.array_equal(bits(out[0]), bits(out[1]))

@@ -1,4 +1,4 @@
-"""Cost of texture level of detail: the 1080p atrium with level 0 everywhere (the default) and with ray-cone LOD."""
+"""Cost of texture level of detail: the 1080p atrium with level 0 everywhere (the default) with ray-cone LOD, and with the anisotropic footprint."""
 import sys, time
 sys.path.insert(0, ".")
 import glaze_amd
@@ -7,7 +7,7 @@ inst = glaze_amd.RayTraceInstance.new()
 scene = glaze_amd.RayTraceScene.from_desc(inst, atrium_scene())
 r = glaze_amd.RayTraceRenderer.new(inst, scene, 1920, 1080)
 r.set_depth(8)
-for name, mode in (("base", 0), ("ray_cones", 1), ("base", 0)):
+for name, mode in (("base", 0), ("ray_cones", 1), ("aniso", 2), ("base", 0)):
     r.set_texture_lod(mode)
     r.restart(); r.step(24); r.wait_idle(); r.stats()
     s0 = r.stats()
