@@ -643,13 +643,30 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
 //   * A mesh leaf transforms its one or two OBJECT triangles to world space with the instance's matrix, operation for
 //     operation what k_world_tris does for the flattened build, and runs the same world-space Moeller-Trumbore test: hits
 //     (t, u, v, tie-break by world triangle id) are bit-identical to the flattened twin of the scene, whatever the hierarchy.
-// Simpler than trace_wave on purpose (no tail work sharing, no counters, no staged top): instanced scenes are about memory --
-// O(meshes + instances) instead of O(instances x triangles) -- and must not put the tuned flattened path at risk.
+// Simpler than trace_wave on purpose (no tail work sharing; the staged top is built in and off, GLZ_TL_LDS_TOP): instanced scenes are about memory -- O(meshes + instances) instead of
+// O(instances x triangles) -- and must not put the tuned flattened path at risk.
 // ---------------------------------------------------------------------------------------------
 constexpr int kExitInstance = 0x7FFFFFFD;   // stack marker: the entries below belong to the top level
+// refill / leaf-phase thresholds of the two-level tracer (lanes): defaults = the flattened tracer's
+#ifndef GLZ_TL_REFILL
+#define GLZ_TL_REFILL GLZ_REFILL
+#endif
+#ifndef GLZ_TL_REFILL_ANY
+#define GLZ_TL_REFILL_ANY GLZ_REFILL
+#endif
+#ifndef GLZ_TL_LEAF_QUORUM
+#define GLZ_TL_LEAF_QUORUM 32   // 8 / 16 / 24 / 32 / 40 / 48 -> 0.993 / 0.889 / 0.844 / 0.825 / 0.822 / 0.835 ms per launch (forest x 200, flattened 0.672): a leaf visit here is an instance entry or a triangle taken to world space, dearer than the flattened tracer's
+#endif
+#ifndef GLZ_TL_LEAF_QUORUM_ANY
+#define GLZ_TL_LEAF_QUORUM_ANY 32
+#endif
+#ifndef GLZ_TL_LDS_TOP
+#define GLZ_TL_LDS_TOP 0   // the top level's first kBvhTopNodes nodes from a per-block LDS copy, as in the flattened tracer: 0.823 -> 0.833 ms (forest x 200), 1.167 -> 1.185 (x 2 000) -- off
+#endif
+constexpr bool kTlLdsTop = kLdsTop && GLZ_TL_LDS_TOP != 0;
 
 template <bool ANY, bool COUNT, class Source, class Sink>
-__device__ __forceinline__ void trace_wave_tl(const DeviceScene& S, Source& src, Sink& sink, int* __restrict__ lds_col, int* aux, float* __restrict__ top_ray,
+__device__ __forceinline__ void trace_wave_tl(const DeviceScene& S, Source& src, Sink& sink, int* __restrict__ lds_col, int* aux, float* __restrict__ top_ray, LdsNodePtr top_lds,
                                               uint32_t* __restrict__ spill, uint32_t spill_depth, uint32_t total, uint32_t wave, uint32_t n_waves, TraceTally& tally) {
   constexpr uint32_t kNone = 0xFFFFFFFFu;
   const BvhNode4* __restrict__ nodes = S.bvh_nodes;        // top-level nodes first, the meshes' after them (TlasInstance::node_base)
@@ -713,7 +730,7 @@ __device__ __forceinline__ void trace_wave_tl(const DeviceScene& S, Source& src,
     // ---- refill ----
     const unsigned long long idle = __ballot(!open);
     const int n_idle = __popcll(idle);
-    if (!exhausted && n_idle >= kRefill) {
+    if (!exhausted && n_idle >= (ANY ? GLZ_TL_REFILL_ANY : GLZ_TL_REFILL)) {
       const uint32_t next_ray = rays.ray_at(seq + (uint32_t)__popcll(idle & lanes_below));
       if (!open && next_ray < total) {
         if (src.load(next_ray, o, d, tmin, tmax)) {
@@ -725,7 +742,7 @@ __device__ __forceinline__ void trace_wave_tl(const DeviceScene& S, Source& src,
           } else {
             st.sp = 0;
             to_top_level(true);
-            cur = 0;
+            cur = kTlLdsTop ? kBvhTopFlag : 0;   // the top level's root (slot 0 of the staged table)
             open = true;
 #ifdef GLZ_WAVE_TIMES
             tl_rays += 1;
@@ -750,8 +767,15 @@ __device__ __forceinline__ void trace_wave_tl(const DeviceScene& S, Source& src,
 #endif
       if (at_node) {
         if (COUNT) tally.nodes += 1;   // node visits of either level
-        const u32x4* np = reinterpret_cast<const u32x4*>(nodes + nbase + (uint32_t)cur);
-        const u32x4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
+        // the top level's first kBvhTopNodes nodes come out of the block's LDS copy (`cur` = kBvhTopFlag | slot), like the flattened tracer's
+        u32x4 w0, w1, w2, w3;
+        if (kTlLdsTop && (cur & kBvhTopFlag)) {
+          LdsNodePtr np = top_lds + 4 * (cur & 0xFFFF);
+          w0 = np[0]; w1 = np[1]; w2 = np[2]; w3 = np[3];
+        } else {
+          const u32x4* np = reinterpret_cast<const u32x4*>(nodes + nbase + (uint32_t)cur);
+          w0 = np[0]; w1 = np[1]; w2 = np[2]; w3 = np[3];
+        }
         uint32_t k0 = box_key(w0.x, w0.y, w0.z, w3.x, 0u, sel, ig, cgn, cgf, tmin, best.t), k1 = box_key(w0.w, w1.x, w1.y, w3.y, 1u, sel, ig, cgn, cgf, tmin, best.t);
         uint32_t k2 = box_key(w1.z, w1.w, w2.x, w3.z, 2u, sel, ig, cgn, cgf, tmin, best.t), k3 = box_key(w2.y, w2.z, w2.w, w3.w, 3u, sel, ig, cgn, cgf, tmin, best.t);
         sort2(k0, k1); sort2(k2, k3); sort2(k0, k2); sort2(k1, k3); sort2(k1, k2);
@@ -761,13 +785,22 @@ __device__ __forceinline__ void trace_wave_tl(const DeviceScene& S, Source& src,
         if (k0 == 0xFFFFFFFFu) {
           cur = pop_next();
         } else {
-          if (k3 != 0xFFFFFFFFu) st.push(l3);
-          if (k2 != 0xFFFFFFFFu) st.push(l2);
-          if (k1 != 0xFFFFFFFFu) st.push(l1);
+#ifndef GLZ_TL_PLAIN_PUSH
+          if (__ballot(st.sp + 3 > kLdsStack) == 0ull) {   // wave-uniform: every lane stays inside the LDS part of its stack (no spill branches)
+            if (k3 != 0xFFFFFFFFu) { st.lds[st.sp * kBlock] = l3; ++st.sp; }
+            if (k2 != 0xFFFFFFFFu) { st.lds[st.sp * kBlock] = l2; ++st.sp; }
+            if (k1 != 0xFFFFFFFFu) { st.lds[st.sp * kBlock] = l1; ++st.sp; }
+          } else
+#endif
+          {
+            if (k3 != 0xFFFFFFFFu) st.push(l3);
+            if (k2 != 0xFFFFFFFFu) st.push(l2);
+            if (k1 != 0xFFFFFFFFu) st.push(l1);
+          }
           cur = l0;
         }
       }
-      if (__popcll(__ballot(cur < 0)) >= kLeafQuorum) break;
+      if (__popcll(__ballot(cur < 0)) >= (ANY ? GLZ_TL_LEAF_QUORUM_ANY : GLZ_TL_LEAF_QUORUM)) break;
     }
     // ---- leaf phase: an instance to enter (top level) or triangles to test (inside an instance) ----
 #ifdef GLZ_WAVE_TIMES

@@ -236,13 +236,15 @@ __global__ void __launch_bounds__(kBlock, GLZ_TRACE_TL_WAVES) k_trace_tl(const L
   __shared__ int s_stack[kLdsStack * kBlock];
   __shared__ alignas(16) int s_aux[(kBlock / 64) * kAuxPerWave];
   __shared__ float s_top_ray[9 * kBlock];   // per lane: the top level's grid-space ray (trace_wave_tl)
+  __shared__ uint4 s_top[kTlLdsTop ? kBvhTopNodes * 4 : 1];
+  if (kTlLdsTop) stage_top(A.scene, s_top);
   int* aux = &s_aux[(threadIdx.x >> 6) * kAuxPerWave];
   if (blockIdx.x == 0 && threadIdx.x < kQueueShards) A.st.queue_count[A.shade_set * kQueueSetWords + threadIdx.x * kCounterStride] = 0;
   if (A.do_closest) {
     TraceTally tally;
     ClosestSource src{A, A.frame, tally, 0u};
     ClosestSinkTl sink{A};
-    trace_wave_tl<false, COUNT>(A.scene, src, sink, &s_stack[threadIdx.x], aux, &s_top_ray[threadIdx.x], A.st.overflow, A.st.overflow_depth, A.map.n_local_pixels, wave_index(), wave_count(), tally);
+    trace_wave_tl<false, COUNT>(A.scene, src, sink, &s_stack[threadIdx.x], aux, &s_top_ray[threadIdx.x], (LdsNodePtr)s_top, A.st.overflow, A.st.overflow_depth, A.map.n_local_pixels, wave_index(), wave_count(), tally);
     if (COUNT) flush_counters(A.counters, false, tally);
   }
   if (A.do_shadow) {
@@ -257,7 +259,7 @@ __global__ void __launch_bounds__(kBlock, GLZ_TRACE_TL_WAVES) k_trace_tl(const L
     const uint32_t closest_groups = A.do_closest ? (A.map.n_local_pixels + 63u) / 64u : 0u;
     const uint32_t wave = (wave_index() + n_waves - closest_groups % n_waves) % n_waves;
     TraceTally tally;
-    trace_wave_tl<true, COUNT>(A.scene, src, sink, &s_stack[threadIdx.x], aux, &s_top_ray[threadIdx.x], A.st.overflow, A.st.overflow_depth, start[kQueueShards], wave, n_waves, tally);
+    trace_wave_tl<true, COUNT>(A.scene, src, sink, &s_stack[threadIdx.x], aux, &s_top_ray[threadIdx.x], (LdsNodePtr)s_top, A.st.overflow, A.st.overflow_depth, start[kQueueShards], wave, n_waves, tally);
     if (COUNT) flush_counters(A.counters, true, tally);
   }
 }
@@ -350,7 +352,7 @@ __global__ void __launch_bounds__(kBlock) k_debug_closest(const DeviceScene S, c
   TraceTally tally;
   DebugSource src{o, d, nullptr, tmin};
   DebugClosestSink sink{S, t, tri, inst, u, v};
-  if (S.two_level) trace_wave_tl<false, false>(S, src, sink, &s_stack[threadIdx.x], &s_aux[(threadIdx.x >> 6) * kAuxPerWave], &s_top_ray[threadIdx.x], overflow, overflow_depth, n, wave_index(), wave_count(), tally);
+  if (S.two_level) trace_wave_tl<false, false>(S, src, sink, &s_stack[threadIdx.x], &s_aux[(threadIdx.x >> 6) * kAuxPerWave], &s_top_ray[threadIdx.x], (LdsNodePtr)s_top, overflow, overflow_depth, n, wave_index(), wave_count(), tally);
   else trace_wave<false, false>(S, src, sink, &s_stack[threadIdx.x], &s_aux[(threadIdx.x >> 6) * kAuxPerWave], (LdsNodePtr)s_top, overflow, overflow_depth, n, wave_index(), wave_count(), tally);
 }
 __global__ void __launch_bounds__(kBlock) k_debug_any(const DeviceScene S, const float* __restrict__ o, const float* __restrict__ d,
@@ -364,7 +366,7 @@ __global__ void __launch_bounds__(kBlock) k_debug_any(const DeviceScene S, const
   TraceTally tally;
   DebugSource src{o, d, tmax, tmin};
   DebugAnySink sink{out};
-  if (S.two_level) trace_wave_tl<true, false>(S, src, sink, &s_stack[threadIdx.x], &s_aux[(threadIdx.x >> 6) * kAuxPerWave], &s_top_ray[threadIdx.x], overflow, overflow_depth, n, wave_index(), wave_count(), tally);
+  if (S.two_level) trace_wave_tl<true, false>(S, src, sink, &s_stack[threadIdx.x], &s_aux[(threadIdx.x >> 6) * kAuxPerWave], &s_top_ray[threadIdx.x], (LdsNodePtr)s_top, overflow, overflow_depth, n, wave_index(), wave_count(), tally);
   else trace_wave<true, false>(S, src, sink, &s_stack[threadIdx.x], &s_aux[(threadIdx.x >> 6) * kAuxPerWave], (LdsNodePtr)s_top, overflow, overflow_depth, n, wave_index(), wave_count(), tally);
 }
 

@@ -629,26 +629,56 @@ bool Scene::build_two_level(Error& err) {
       return false;
     }
   }
-  // ---- instance boxes (world AABB of the mesh's root box under the instance's transform, padded) ----
+  // ---- instance boxes: world AABB of the mesh's VERTICES under the instance's transform, padded.  (The eight corners of the
+  // mesh's object box, which is what a top level normally takes, give a box up to sqrt(2) too wide per axis for a rotated instance
+  // -- a quarter more instance entries per ray in the column forest.  The vertices cost meshes x instances x vertices on the host;
+  // past kExactBoxBudget point transforms the remaining instances fall back to the corners.) ----
   const size_t ni = h_instances.size();
   std::vector<float4> blo(ni), bhi(ni);
   double wlo[3] = {1e300, 1e300, 1e300}, whi[3] = {-1e300, -1e300, -1e300};
+  std::vector<std::vector<float>> mesh_points(meshes.size());   // xyz of the vertices a mesh references, once each
+  {
+    std::vector<uint8_t> seen(data.vertices.size(), 0);
+    for (size_t mi = 0; mi < meshes.size(); ++mi) {
+      const MeshAs& m = meshes[mi];
+      std::vector<float>& pts = mesh_points[mi];
+      for (uint32_t k = 0; k < m.index_count; ++k) {
+        const uint32_t v = data.indices[m.index_offset + k];
+        if (seen[v]) continue;
+        seen[v] = 1;
+        pts.insert(pts.end(), data.vertices[v].vv, data.vertices[v].vv + 3);
+      }
+      for (uint32_t k = 0; k < m.index_count; ++k) seen[data.indices[m.index_offset + k]] = 0;
+    }
+  }
+  constexpr uint64_t kExactBoxBudget = 50000000ull;
+  uint64_t spent = 0;
   for (size_t i = 0; i < ni; ++i) {
     const MeshAs& m = meshes[mesh_of[i]];
     const float* M = data.transforms[h_instances[i].transform_id].m;
     double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-    for (int c = 0; c < 8; ++c) {
-      const double p[3] = {(c & 1) ? m.hi[0] : m.lo[0], (c & 2) ? m.hi[1] : m.lo[1], (c & 4) ? m.hi[2] : m.lo[2]};
+    auto take = [&](double x, double y, double z) {
       for (int k = 0; k < 3; ++k) {
-        const double w = (double)M[k] * p[0] + (double)M[4 + k] * p[1] + (double)M[8 + k] * p[2] + (double)M[12 + k];
+        const double w = (double)M[k] * x + (double)M[4 + k] * y + (double)M[8 + k] * z + (double)M[12 + k];
         lo[k] = std::min(lo[k], w);
         hi[k] = std::max(hi[k], w);
       }
+    };
+    const std::vector<float>& pts = mesh_points[mesh_of[i]];
+    if (!pts.empty() && spent + pts.size() / 3 <= kExactBoxBudget) {
+      spent += pts.size() / 3;
+      for (size_t k = 0; k + 2 < pts.size(); k += 3) take(pts[k], pts[k + 1], pts[k + 2]);
+    } else {
+      for (int c = 0; c < 8; ++c) take((c & 1) ? m.hi[0] : m.lo[0], (c & 2) ? m.hi[1] : m.lo[1], (c & 4) ? m.hi[2] : m.lo[2]);
     }
     float l[3], h[3];
     for (int k = 0; k < 3; ++k) {
       if (!(lo[k] <= hi[k])) lo[k] = hi[k] = 0.0;   // a mesh without triangles / non-finite transform: a point nobody hits
-      const double pad = 1e-5 * std::max({std::fabs(lo[k]), std::fabs(hi[k]), 1e-3}) + 1e-6 * (hi[k] - lo[k]);
+      // the tracer's world vertices are single-precision sums of four terms: four roundings of the largest one can get
+      const double mag = std::fabs((double)M[k]) * std::max(std::fabs((double)m.lo[0]), std::fabs((double)m.hi[0])) +
+                         std::fabs((double)M[4 + k]) * std::max(std::fabs((double)m.lo[1]), std::fabs((double)m.hi[1])) +
+                         std::fabs((double)M[8 + k]) * std::max(std::fabs((double)m.lo[2]), std::fabs((double)m.hi[2])) + std::fabs((double)M[12 + k]);
+      const double pad = 1e-5 * std::max({std::fabs(lo[k]), std::fabs(hi[k]), 1e-3}) + 1e-6 * (hi[k] - lo[k]) + (std::isfinite(mag) ? 4.8e-7 * mag : 0.0);
       l[k] = std::nextafterf((float)(lo[k] - pad), -INFINITY);
       h[k] = std::nextafterf((float)(hi[k] + pad), INFINITY);
       wlo[k] = std::min(wlo[k], (double)l[k]);
