@@ -250,7 +250,7 @@ struct TraceTally {
 #define GLZ_REFILL 16
 #endif
 #ifndef GLZ_LEAF_QUORUM
-#define GLZ_LEAF_QUORUM 16   // 4-wide nodes: 8 -> 0.815, 12 -> 0.790, 16 -> 0.781, 24 -> 0.810 ms per k_trace; with pair leaves 8 / 12 / 16 / 24 / 32 -> 0.650 / 0.606 / 0.589 / 0.583 / 0.598
+#define GLZ_LEAF_QUORUM 24   // round 3 (watertight triangle test, 15-bit grid): 12 / 16 / 20 / 24 / 32 -> 0.571 / 0.554 / 0.542 / 0.541 / 0.557 ms per k_trace; earlier: 4-wide nodes: 8 -> 0.815, 12 -> 0.790, 16 -> 0.781, 24 -> 0.810 ms per k_trace; with pair leaves 8 / 12 / 16 / 24 / 32 -> 0.650 / 0.606 / 0.589 / 0.583 / 0.598
 #endif
 #ifndef GLZ_LDS_TOP
 #define GLZ_LDS_TOP 1   // 1: the top kBvhTopNodes nodes of the tree are fetched from a per-block LDS copy ("LDS-staged node packets"), 0: every node from global memory
@@ -271,6 +271,22 @@ constexpr int kLeafQuorum = GLZ_LEAF_QUORUM;
 #define GLZ_LEAF_QUORUM_TAIL GLZ_LEAF_QUORUM   // once the wave's sequence is exhausted (a small share of the frame: from the first round on); 4 / 8 / 16 / 24 / 32 -> 0.172 / 0.159 / 0.152 / 0.152 / 0.155 ms per launch of a 1/8 share: the same optimum
 #endif
 constexpr int kAuxPerWave = 3 * 64 + 4 * 64;   // work sharing (3 x 64) + the four child links of the node a lane is visiting
+
+// The SIMD issues its OLDEST ready wave first, and the tracers are bound by VALU issue: with one priority for all, the waves of the
+// blocks dispatched first ran 1.6 x faster than the last ones' through the same amount of work (1.67 against 2.66 us per node
+// iteration) and then sat idle while those finished -- the closest-hit phase of a full frame ended between 240 and 396 us
+// (tools/gpu_wave_times.py, by position in the grid, not by XCD).  Every wave changes its issue priority once per round, starting from
+// the sixth of the grid its block is in: all get the same share, the phase ends between 307 and 389 us, k_trace 0.540 -> 0.514 ms
+// (only for shares that give a wave at least two whole groups, see `rotate` in trace_wave).
+// (Per node iteration instead of per round, keyed by the hardware wave slot instead of the block index, every second round: the
+// same; every fourth round 0.523; priority by the wave's own progress -- groups behind first -- 0.545; the youngest first 0.566.)
+#ifndef GLZ_PRIO_ROTATE
+#define GLZ_PRIO_ROTATE 1
+#endif
+__device__ __forceinline__ void rotate_priority(uint32_t turn) {
+  const uint32_t p = turn & 3u;   // s_setprio takes an immediate
+  if (p == 0u) __builtin_amdgcn_s_setprio(0); else if (p == 1u) __builtin_amdgcn_s_setprio(1); else if (p == 2u) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(3);
+}
 
 __device__ __forceinline__ void sort2(uint32_t& a, uint32_t& b) {
   const uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
@@ -341,6 +357,10 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
   }
   uint32_t seq = 0;                                         // wave-uniform: rays of this wave's sequence handed out so far
   const RaySequence rays(wave, n_waves, total);
+  // A share of the frame that gives a wave fewer than two whole groups is one long tail (work sharing from the first round on): there
+  // the rotation costs 3 % (1/4 share 0.245 -> 0.253 ms per launch, 1/8 0.146 -> 0.150) where the full frame gains 4 % and a half 4.5 %.
+  // (Rotating only until the wave's sequence is exhausted gains nothing anywhere: what the rotation evens out is the waves' last groups.)
+  const bool rotate = rays.own_full >= 128u;
   // (giving each XCD one contiguous eighth of the groups -- rays of one image band per L2 -- measured 5 % slower: the bands
   // differ in cost and the static split loses more to imbalance than the L2 gains)
   // (Drawing the groups from a counter instead of the stride: the waves of a full-frame launch end between 257 and 406 us of a
@@ -366,6 +386,10 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
 #ifdef GLZ_WAVE_TIMES
   unsigned int wt_rounds = 0, wt_node_iters = 0, wt_node_lanes = 0, wt_leaf_iters = 0, wt_leaf_lanes = 0, wt_helper_rounds = 0, wt_wait_rounds = 0;
 #endif
+  // issue-priority rotation (rotate_priority above); k_path's MIXED pass keeps the priority its own kernel set
+  constexpr bool ROTATE = GLZ_PRIO_ROTATE != 0 && !MIXED;
+  const uint32_t prio_gen = (blockIdx.x * 6u) / gridDim.x;   // which sixth of the grid: the order the blocks of a CU were dispatched in
+  uint32_t prio_round = 0;
   // ---- share: idle lanes adopt the oldest pending subtree of a busy lane (called before every node iteration, see below) ----
   auto share_step = [&]() {
   if (SHARE && exhausted)
@@ -435,6 +459,7 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
     wt_helper_rounds += __ballot(helper) != 0ull;
     wt_wait_rounds += __ballot(open && cur == kRayDone) != 0ull && __ballot(open && cur != kRayDone) == 0ull;   // owners only waiting for helpers
 #endif
+    if (ROTATE && rotate) rotate_priority(prio_gen + prio_round++);
     // ---- refill ----
     const unsigned long long idle = __ballot(!(open || helper));
     const int n_idle = __popcll(idle);
@@ -625,6 +650,7 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
 #ifdef GLZ_TAIL_PRIO
   if (SHARE) __builtin_amdgcn_s_setprio(0);
 #endif
+  if (ROTATE) __builtin_amdgcn_s_setprio(0);
 #ifdef GLZ_WAVE_TIMES
   if (!ANY && lane == 0 && wave < 8192u) {
     unsigned int* o = g_wave_stats + 8 * wave;
@@ -659,6 +685,9 @@ constexpr int kExitInstance = 0x7FFFFFFD;   // stack marker: the entries below b
 #endif
 #ifndef GLZ_TL_LEAF_QUORUM_ANY
 #define GLZ_TL_LEAF_QUORUM_ANY 32
+#endif
+#ifndef GLZ_TL_PRIO_ROTATE
+#define GLZ_TL_PRIO_ROTATE GLZ_PRIO_ROTATE
 #endif
 #ifndef GLZ_TL_LDS_TOP
 #define GLZ_TL_LDS_TOP 0   // the top level's first kBvhTopNodes nodes from a per-block LDS copy, as in the flattened tracer: 0.823 -> 0.833 ms (forest x 200), 1.167 -> 1.185 (x 2 000) -- off
@@ -726,7 +755,10 @@ __device__ __forceinline__ void trace_wave_tl(const DeviceScene& S, Source& src,
       to_top_level(false);
     }
   };
+  const uint32_t prio_gen = (blockIdx.x * 4u) / gridDim.x;   // (four blocks per CU here)
+  uint32_t prio_round = 0;
   for (;;) {
+    if (GLZ_TL_PRIO_ROTATE && rays.own_full >= 128u) rotate_priority(prio_gen + prio_round++);
     // ---- refill ----
     const unsigned long long idle = __ballot(!open);
     const int n_idle = __popcll(idle);
@@ -863,6 +895,7 @@ __device__ __forceinline__ void trace_wave_tl(const DeviceScene& S, Source& src,
       open = false;
     }
   }
+  if (GLZ_TL_PRIO_ROTATE) __builtin_amdgcn_s_setprio(0);
 #ifdef GLZ_WAVE_TIMES
   if (!ANY) {
     atomicAdd(&g_tl_stats[0], tl_rays); atomicAdd(&g_tl_stats[1], tl_top); atomicAdd(&g_tl_stats[2], tl_mesh); atomicAdd(&g_tl_stats[3], tl_enter);

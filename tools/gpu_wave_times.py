@@ -49,6 +49,12 @@ for world in [int(w) for w in os.environ.get("WORLDS", "8,1").split(",")]:
             row("median tenth", ob[nb // 2 - nb // 20: nb // 2 + nb // 20])
             row("slowest tenth", ob[-(nb // 10):])
             row("slowest 1 %", ob[-max(nb // 100, 1):])
+        # where the slow waves are: by XCD (consecutive blocks go to consecutive XCDs) and by position in the grid (= in the image: wave w
+        # traces the groups w, w + n_waves, ...)
+        dur = us[:, 1] - us[:, 0]
+        blk_id = np.arange(len(dur)) // 4
+        print("   closest phase by XCD (block %% 8): %s us" % " ".join("%.0f" % dur[blk_id % 8 == x].mean() for x in range(8)), flush=True)
+        print("   closest phase by sixteenth of the grid: %s us" % " ".join("%.0f" % c.mean() for c in np.array_split(dur, 16)), flush=True)
         # waves still running as a function of time
         grid = np.linspace(0, end[-1], 11)
         print("   running at", " ".join("%.0fus:%d" % (g, int(((us[:, 0] <= g) & (us[:, 2] > g)).sum())) for g in grid), flush=True)
