@@ -283,6 +283,9 @@ constexpr int kAuxPerWave = 3 * 64 + 4 * 64;   // work sharing (3 x 64) + the fo
 #ifndef GLZ_PRIO_ROTATE
 #define GLZ_PRIO_ROTATE 1
 #endif
+#ifndef GLZ_PRIO_PERIOD6
+#define GLZ_PRIO_PERIOD6 1   // six waves per SIMD, four levels: a cycle of six turns (3 2 2 1 1 0) instead of four (where waves four turns apart always tie and the older one wins): 0.514 -> 0.509 ms
+#endif
 __device__ __forceinline__ void rotate_priority(uint32_t turn) {
   const uint32_t p = turn & 3u;   // s_setprio takes an immediate
   if (p == 0u) __builtin_amdgcn_s_setprio(0); else if (p == 1u) __builtin_amdgcn_s_setprio(1); else if (p == 2u) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(3);
@@ -321,6 +324,7 @@ struct RaySequence {
     piece_base = full_rounds * n_waves * 64u;
   }
   // ray at position `pos` of this wave's sequence; >= total: the sequence has ended (ray_at is monotonic in pos)
+  // (A wave's groups neighbours of EACH OTHER -- groups 6 w .. 6 w + 5 -- instead of its block-mates': k_trace 0.510 -> 0.561 ms.)
   __device__ __forceinline__ uint32_t ray_at(uint32_t pos) const {
     if (pos < own_full) return (wave + (pos >> 6) * n_waves) * 64u + (pos & 63u);
     const uint32_t q = pos - own_full;
@@ -459,7 +463,14 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
     wt_helper_rounds += __ballot(helper) != 0ull;
     wt_wait_rounds += __ballot(open && cur == kRayDone) != 0ull && __ballot(open && cur != kRayDone) == 0ull;   // owners only waiting for helpers
 #endif
+#if GLZ_PRIO_PERIOD6
+    if (ROTATE && rotate) {   // six waves per SIMD, four levels: a cycle of six turns 3 2 2 1 1 0 instead of 3 2 1 0 (where waves four turns apart always tie and the older wins)
+      const uint32_t pos = (prio_gen + prio_round++) % 6u;
+      rotate_priority(pos == 0u ? 3u : (pos < 3u ? 2u : (pos < 5u ? 1u : 0u)));
+    }
+#else
     if (ROTATE && rotate) rotate_priority(prio_gen + prio_round++);
+#endif
     // ---- refill ----
     const unsigned long long idle = __ballot(!(open || helper));
     const int n_idle = __popcll(idle);

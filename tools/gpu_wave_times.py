@@ -15,7 +15,7 @@ for world in [int(w) for w in os.environ.get("WORLDS", "8,1").split(",")]:
     r.set_chains(1)
     r.restart(); r.step(24); r.wait_idle()
     for rep in range(3):
-        r.step(1); r.wait_idle()
+        r.step(int(os.environ.get("LAUNCHES", "1"))); r.wait_idle()   # LAUNCHES=2: the last k_trace also traces the shadow rays of the launch before
         t = np.zeros(3 * 8192, dtype=np.uint64)
         assert lib.glz_debug_wave_times(t.ctypes.data_as(ctypes.c_void_p), 8192) == 0
         t = t.reshape(-1, 3).astype(np.int64)

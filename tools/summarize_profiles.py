@@ -19,7 +19,9 @@ import sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+if len(sys.argv) < 2:
+    sys.exit("usage: summarize_profiles.py <round tag, e.g. r03>")
+tag = sys.argv[1]
 out_dir = os.path.join(ROOT, "profiles")
 os.makedirs(out_dir, exist_ok=True)
 
