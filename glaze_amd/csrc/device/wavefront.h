@@ -1055,7 +1055,7 @@ __device__ __forceinline__ uint32_t queue_slot(uint32_t* counters, uint32_t n_lo
   const unsigned long long m = __ballot(push);
   uint32_t slot = 0;
   if (push) {
-    const uint32_t shard = blockIdx.x % kQueueShards;
+    const uint32_t shard = ((blockIdx.x * blockDim.x + threadIdx.x) / kBlock) % kQueueShards;   // by 256-pixel segment, whatever the block size (queue_capacity)
     const int lane = threadIdx.x & 63;
     const int leader = __ffsll((long long)m) - 1;
     uint32_t base = 0;

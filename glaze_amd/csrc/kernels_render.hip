@@ -26,8 +26,12 @@ constexpr uint32_t kSkyLdsFloats = 4096;   // sky marginal tables (3H+1 floats) 
 // sets the counter pointer to a constant null, so the checks in the texture and light code fold away (left as a run-time null they
 // cost 2.5 %: a branch per fetch and two more live SGPRs).
 // LOD: the build with the texture level of detail (shade_pixel<LOD>).
+#ifndef GLZ_SHADE_BLOCK
+#define GLZ_SHADE_BLOCK 256   // pixels regrouped together (a multiple of 256): 512 -> 0.354 against 0.352 ms, 1 024 -> 0.368: purer waves do not pay, the kernel waits for memory
+#endif
+constexpr uint32_t kShadeBlock = GLZ_SHADE_BLOCK, kShadeWavesPerBlock = kShadeBlock / 64;   // the regrouping domain: pixels sorted by code path per block
 template <bool COUNT, bool LOD>
-__global__ void __launch_bounds__(kBlock, GLZ_SHADE_WAVES) k_shade(const LaunchArgs A) {
+__global__ void __launch_bounds__(kShadeBlock, GLZ_SHADE_WAVES) k_shade(const LaunchArgs A) {
   // The kernel is bound by the memory system's random-access rate (16 extra scattered loads per pixel cost +27 %, 200 extra
   // VALU instructions nothing; 1 / 2 / 3 / 4 waves per SIMD take 0.76 / 0.45 / 0.36 / 0.35 ms), so the two small tables every texture fetch /
   // sky sample walks are staged in LDS once per block: the sRGB decode LUT (12 lookups per bilinear fetch) and the sky marginal CDF (an 11-step dependent search).
@@ -37,16 +41,16 @@ __global__ void __launch_bounds__(kBlock, GLZ_SHADE_WAVES) k_shade(const LaunchA
   // -> texels, light pick -> RTLight -- are staged in LDS when they fit: each lookup that stays on chip takes a dependent
   // memory round trip (1-2 us under load, the kernel's bound) off the hit's critical path.
   __shared__ uint4 s_tables[kShadeTableBytes / 16];
-  __shared__ uint32_t s_bin[4 * 64];   // [wave][key] counts, then start offsets
-  __shared__ uint16_t s_perm[kBlock];
+  __shared__ uint32_t s_bin[kShadeWavesPerBlock * 64];   // [wave][key] counts, then start offsets
+  __shared__ uint16_t s_perm[kShadeBlock];
 #ifndef GLZ_SHADE_NO_HIT_HANDOVER
-  __shared__ float4 s_hit[kBlock];   // hit records read by the regrouping prologue, handed to the thread that shades the pixel
+  __shared__ float4 s_hit[kShadeBlock];   // hit records read by the regrouping prologue, handed to the thread that shades the pixel
 #endif
   const uint32_t n_sky = 3u * (A.scene.sky_header.marginal_cdf_count - 1u) + 1u;
   const bool sky_in_lds = A.scene.sky_header.marginal_cdf_count > 1u && n_sky <= kSkyLdsFloats;
-  s_lut[threadIdx.x] = A.scene.srgb_lut[threadIdx.x];
+  if (threadIdx.x < 256u) s_lut[threadIdx.x] = A.scene.srgb_lut[threadIdx.x];
   if (sky_in_lds)
-    for (uint32_t i = threadIdx.x; i < n_sky; i += kBlock) s_sky[i] = A.scene.sky_marginal[i];
+    for (uint32_t i = threadIdx.x; i < n_sky; i += kShadeBlock) s_sky[i] = A.scene.sky_marginal[i];
   s_bin[threadIdx.x] = 0;
   // [RTMaterial x n_materials | RTLight x n_rt_lights | TexDesc x n_textures] in 16-byte pieces
   const uint32_t qm = A.scene.n_materials * (uint32_t)(sizeof(RTMaterial) / 16), ql = A.scene.n_rt_lights * (uint32_t)(sizeof(RTLight) / 16),
@@ -60,7 +64,7 @@ __global__ void __launch_bounds__(kBlock, GLZ_SHADE_WAVES) k_shade(const LaunchA
     const uint4* gm = reinterpret_cast<const uint4*>(A.scene.materials);
     const uint4* gl = reinterpret_cast<const uint4*>(A.scene.lights);
     const uint4* gt = reinterpret_cast<const uint4*>(A.scene.tex_desc);
-    for (uint32_t i = threadIdx.x; i < qm + ql + qt; i += kBlock) s_tables[i] = i < qm ? gm[i] : (i < qm + ql ? gl[i - qm] : gt[i - qm - ql]);
+    for (uint32_t i = threadIdx.x; i < qm + ql + qt; i += kShadeBlock) s_tables[i] = i < qm ? gm[i] : (i < qm + ql ? gl[i - qm] : gt[i - qm - ql]);
   }
   __syncthreads();
   DeviceScene S = A.scene;
@@ -82,7 +86,7 @@ __global__ void __launch_bounds__(kBlock, GLZ_SHADE_WAVES) k_shade(const LaunchA
   // all state is addressed by pixel, so the permutation changes no result; only the order of the shadow queue differs.
   uint32_t key = 63u;   // pixels outside the image sort last
   {
-    const uint32_t lid0 = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t lid0 = blockIdx.x * kShadeBlock + threadIdx.x;
     const PixelId px0 = pixel_of(A.map, lid0);
     if (px0.active) {
 #ifndef GLZ_SHADE_NO_HIT_HANDOVER
@@ -125,26 +129,32 @@ __global__ void __launch_bounds__(kBlock, GLZ_SHADE_WAVES) k_shade(const LaunchA
   }
   __syncthreads();
   if (threadIdx.x < 64) {   // exclusive prefix sum over the 64 keys of the per-key totals, then the per-wave starts inside a key
-    const uint32_t c0 = s_bin[threadIdx.x], c1 = s_bin[64 + threadIdx.x], c2 = s_bin[128 + threadIdx.x], c3 = s_bin[192 + threadIdx.x];
-    const uint32_t cnt = (c0 + c1) + (c2 + c3);
+    uint32_t c[kShadeWavesPerBlock];
+    uint32_t cnt = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < kShadeWavesPerBlock; ++w) {
+      c[w] = s_bin[w * 64u + threadIdx.x];
+      cnt += c[w];
+    }
     uint32_t incl = cnt;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
       const uint32_t up = __shfl_up(incl, off);
       if ((int)threadIdx.x >= off) incl += up;
     }
-    const uint32_t base = incl - cnt;
-    s_bin[threadIdx.x] = base;
-    s_bin[64 + threadIdx.x] = base + c0;
-    s_bin[128 + threadIdx.x] = base + c0 + c1;
-    s_bin[192 + threadIdx.x] = base + c0 + c1 + c2;
+    uint32_t at = incl - cnt;
+#pragma unroll
+    for (uint32_t w = 0; w < kShadeWavesPerBlock; ++w) {
+      s_bin[w * 64u + threadIdx.x] = at;
+      at += c[w];
+    }
   }
   __syncthreads();
   s_perm[s_bin[(threadIdx.x >> 6) * 64u + key] + rank] = (uint16_t)threadIdx.x;
   __syncthreads();
-  const uint32_t lid = blockIdx.x * kBlock + s_perm[threadIdx.x];
+  const uint32_t lid = blockIdx.x * kShadeBlock + s_perm[threadIdx.x];
 #else
-  const uint32_t lid = blockIdx.x * kBlock + threadIdx.x;
+  const uint32_t lid = blockIdx.x * kShadeBlock + threadIdx.x;
 #endif
   // (Handing the next k_trace the pixels in this regrouped order -- one more word per pixel -- does nothing for the traversal, 0.588 ->
   // 0.591 ms; sorted per block by the octant of the new direction, camera rays last, 0.590 -> 0.573 ms, less than the sort and the
@@ -413,12 +423,12 @@ hipError_t launch_trace(hipStream_t st, const LaunchArgs& a, uint32_t blocks) {
 }
 hipError_t launch_shade(hipStream_t st, const LaunchArgs& a) {
   if (a.map.n_local_pixels == 0) return hipSuccess;
-  const dim3 grid = grid_for(a.map.n_local_pixels);
+  const dim3 grid((a.map.n_local_pixels + kShadeBlock - 1) / kShadeBlock), block(kShadeBlock);
   const bool lod = a.frame.lod_mode != 0u;
-  if (a.counters && lod) hipLaunchKernelGGL((k_shade<true, true>), grid, dim3(kBlock), 0, st, a);
-  else if (a.counters) hipLaunchKernelGGL((k_shade<true, false>), grid, dim3(kBlock), 0, st, a);
-  else if (lod) hipLaunchKernelGGL((k_shade<false, true>), grid, dim3(kBlock), 0, st, a);
-  else hipLaunchKernelGGL((k_shade<false, false>), grid, dim3(kBlock), 0, st, a);
+  if (a.counters && lod) hipLaunchKernelGGL((k_shade<true, true>), grid, block, 0, st, a);
+  else if (a.counters) hipLaunchKernelGGL((k_shade<true, false>), grid, block, 0, st, a);
+  else if (lod) hipLaunchKernelGGL((k_shade<false, true>), grid, block, 0, st, a);
+  else hipLaunchKernelGGL((k_shade<false, false>), grid, block, 0, st, a);
   return hipGetLastError();
 }
 hipError_t launch_export(hipStream_t st, const TileMap& map, const float4* tiled, float4* frame, bool zero_first) {
