@@ -24,7 +24,9 @@ against the frame it renders alone (--no-verify skips it).  Two ways to get ther
     communicator (ncclCommInitAll) per GPU, packed tiles sent to GPU 0 (ncclSend / ncclRecv in one group);
   * started by torch.distributed.run: one process per GPU, glz_renderer_set_partition(rank, N), and the same packed-tile
     exchange through torch.distributed's "nccl" backend (= RCCL).
-GLAZE_MULTI_EXCHANGE=reduce switches both to one ncclReduce(sum) of the zero-padded W*H*4 frame.
+GLAZE_MULTI_EXCHANGE=reduce switches both to one ncclReduce(sum) of the zero-padded W*H*4 frame; =peer (in-process form only) sends
+the packed tiles by hipMemcpyPeerAsync instead of RCCL -- also what the in-process form falls back to, saying so, when RCCL cannot be
+loaded or its communicators / first exchange fail on this machine.
 
 The timed region is EXACTLY K steps between barrier + synchronize pairs, MAX over ranks.  A region shorter than 0.5 s is
 repeated (five regions in all, the accumulation simply continues) and `value` comes from the MEDIAN region; every
@@ -169,8 +171,12 @@ def main():
     # the tiles meet without RCCL.  Not a measurement either.
     loopback = n_dev > 1 and os.environ.get("GLAZE_MULTI_LOOPBACK") is not None
     exchange = os.environ.get("GLAZE_MULTI_EXCHANGE", "gather")
-    if exchange not in ("gather", "reduce"):
-        raise SystemExit("GLAZE_MULTI_EXCHANGE must be `gather` or `reduce`")
+    if exchange not in ("gather", "reduce", "peer"):
+        raise SystemExit("GLAZE_MULTI_EXCHANGE must be `gather`, `reduce` or `peer`")
+    if exchange == "peer" and world > 1:
+        raise SystemExit("GLAZE_MULTI_EXCHANGE=peer is the in-process exchange without RCCL (python bench.py --gpus N)")
+    if loopback and os.environ.get("GLAZE_MULTI_LOOPBACK") == "peer":
+        exchange = "peer"
     if n_dev > 1 and not loopback and torch.cuda.device_count() < n_dev:
         raise SystemExit("--gpus %d: this machine has %d GPU(s) (GLAZE_MULTI_LOOPBACK=1 rehearses the %d-device path on one)"
                          % (n_dev, torch.cuda.device_count(), n_dev))
@@ -207,11 +213,32 @@ def main():
     renderer.set_depth(args.depth)
     renderer.set_seed(args.seed)
     devices_s = None
+    rccl_fallback = None        # why the RCCL exchange was given up for peer copies, if it was
+
+    def span_devices():
+        """replicas + BVH builds + ncclCommInitAll.  RCCL that cannot be loaded or will not initialise on this machine does not
+        cost the measurement: the same packed tiles then travel by hipMemcpyPeerAsync (GLAZE_MULTI_EXCHANGE=peer), and the line
+        says so (`multi_gpu.exchange`, `multi_gpu.rccl_fallback`)."""
+        nonlocal exchange, rccl_fallback
+        ids = [0] * n_dev if loopback else list(range(n_dev))
+        try:
+            renderer.set_devices(ids)
+        except glaze_amd.abi.GlazeError as e:
+            if exchange == "peer" or (loopback and os.environ.get("GLAZE_MULTI_LOOPBACK") != "rccl"):
+                raise
+            rccl_fallback = str(e)
+            print("bench.py: %s -- falling back to peer copies (GLAZE_MULTI_EXCHANGE=peer)" % rccl_fallback, file=sys.stderr, flush=True)
+            exchange = "peer"
+            os.environ["GLAZE_MULTI_EXCHANGE"] = "peer"
+            if loopback:
+                os.environ["GLAZE_MULTI_LOOPBACK"] = "peer"     # (tests: the stand-in RCCL refused; n "devices" on the one GPU)
+            renderer.set_devices(ids)
+
     if world > 1:
         renderer.set_partition(rank, world)
     elif n_dev > 1:
         t0 = time.time()
-        renderer.set_devices([0] * n_dev if loopback else list(range(n_dev)))     # replicas + BVH builds + ncclCommInitAll
+        span_devices()
         devices_s = time.time() - t0
     frame = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
 
@@ -247,7 +274,23 @@ def main():
     renderer.restart()
     renderer.step(args.warmup)
     if n_gpus > 1:
-        exchange_to_gpu0()      # first use of the communicators / the process group belongs to the warm-up
+        try:
+            exchange_to_gpu0()      # first use of the communicators / the process group belongs to the warm-up
+        except glaze_amd.abi.GlazeError as e:
+            if n_dev == 1 or exchange == "peer" or (loopback and os.environ.get("GLAZE_MULTI_LOOPBACK") != "rccl"):
+                raise
+            # the communicators came up but the first send / receive did not work: same fallback as in span_devices()
+            rccl_fallback = str(e)
+            print("bench.py: %s -- falling back to peer copies (GLAZE_MULTI_EXCHANGE=peer)" % rccl_fallback, file=sys.stderr, flush=True)
+            exchange = "peer"
+            os.environ["GLAZE_MULTI_EXCHANGE"] = "peer"
+            if loopback:
+                os.environ["GLAZE_MULTI_LOOPBACK"] = "peer"
+            renderer.set_devices([0])
+            renderer.set_devices([0] * n_dev if loopback else list(range(n_dev)))
+            renderer.restart()
+            renderer.step(args.warmup)
+            exchange_to_gpu0()
     sync_all()
     renderer.stats()            # drains the warmup's kernel events
     s0 = renderer.stats()
@@ -382,9 +425,10 @@ def main():
         if n_gpus > 1:
             if n_dev > 1:
                 mode = "one process, glz_renderer_set_devices (a host thread, a scene replica and an RCCL communicator per GPU)"
-                how = "loop-back on ONE GPU, no RCCL (rehearsal)" if loopback else (
-                    "ncclSend/ncclRecv of packed tiles in one group" if exchange == "gather" else "ncclReduce(sum) of the zero-padded frame")
-                rccl = None if loopback else int(glaze_amd.abi.lib().glz_rccl_version())
+                how = "loop-back on ONE GPU, no RCCL (rehearsal)" if loopback and exchange != "peer" else {
+                    "gather": "ncclSend/ncclRecv of packed tiles in one group", "reduce": "ncclReduce(sum) of the zero-padded frame",
+                    "peer": "hipMemcpyPeerAsync of packed tiles, one per peer (no RCCL)"}[exchange]
+                rccl = None if loopback or exchange == "peer" else int(glaze_amd.abi.lib().glz_rccl_version())
                 seen = renderer.device_count()
             else:
                 mode = "one process per GPU (torch.distributed), glz_renderer_set_partition"
@@ -395,8 +439,8 @@ def main():
                 except Exception:       # noqa: BLE001
                     rccl = None
                 seen = dist.get_world_size()
-            multi = {"mode": mode, "exchange": how, "exchange_ms": round(exchange_ms, 4), "exchange_bytes_to_gpu0": int(W * H * 16 * (n_gpus - 1) / n_gpus) if exchange == "gather" or loopback else W * H * 16,
-                     "rccl_version": rccl, "gpus_seen": seen, "measurement": not (loopback or rehearsal), "set_devices_s": None if devices_s is None else round(devices_s, 3)}
+            multi = {"mode": mode, "exchange": how, "exchange_ms": round(exchange_ms, 4), "exchange_bytes_to_gpu0": int(W * H * 16 * (n_gpus - 1) / n_gpus) if exchange != "reduce" or loopback else W * H * 16,
+                     "rccl_version": rccl, "gpus_seen": seen, "measurement": not (loopback or rehearsal), "set_devices_s": None if devices_s is None else round(devices_s, 3), "rccl_fallback": rccl_fallback}
         out = {
             "metric": "Msamples/s + achieved HBM GB/s, Sponza 1080p, 1/2/4/8xMI355X",
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,

@@ -73,10 +73,12 @@ struct Renderer::Peer {
   std::unique_ptr<Instance> inst;
   std::unique_ptr<Renderer> r;
   DeviceBuffer<float4> frame;
+  hipEvent_t sent = nullptr;   // peer-copy exchange: this device's tiles have left (recorded on its stream, awaited by device 0's)
   Worker worker;
   ~Peer() {
     worker.stop();
     if (inst) (void)hipSetDevice(inst->device);
+    if (sent) (void)hipEventDestroy(sent);
     r.reset();
     frame.release();
   }
@@ -815,13 +817,16 @@ bool Renderer::gather(bool result, float4* dst, Error& err, bool zero_first) {
 //    n - 1 different links at the same time, each carrying 1/n of the frame (4 MB of a 1080p frame at n = 8).
 //  * reduce (GLAZE_MULTI_EXCHANGE=reduce): one ncclReduce(sum, float) of the zero-padded W*H*4 frame per device, in place on the
 //    root -- what SURVEY 8(e) names first; a ring moves the whole frame over every link (33 MB at 1080p).
+//  * peer (GLAZE_MULTI_EXCHANGE=peer): the gather shape without RCCL -- one hipMemcpyPeerAsync per peer on that peer's stream into
+//    the same staging area, an event per peer that device 0's stream waits for.  For machines whose RCCL cannot be loaded or will not
+//    initialise (bench.py falls back to it and says so); never chosen silently.
 // The tiles are disjoint, so both give the image of a one-GPU render bit for bit.  Loop-back mode (every "device" is this one;
 // tests): RCCL cannot put two ranks on one GPU, and there is nothing to move -- the peers scatter their tiles straight into `dst`.
 bool Renderer::reduce_peers(bool result, float4* dst, Error& err) {
   hipStream_t st = chains_[0]->stream;
   if (!hip_ok(hipStreamSynchronize(st), "exchange: local frame", err)) return false;
   const bool lb = loopback_;
-  const bool packed = !lb && exchange_ == kExchangeGather;
+  const bool packed = !lb && exchange_ != kExchangeReduce;
   if (!forward([=](Peer& p, Error& e) {
         if (!hip_ok(hipSetDevice(p.inst->device), "hipSetDevice", e)) return false;
         if (packed) {
@@ -847,6 +852,36 @@ bool Renderer::reduce_peers(bool result, float4* dst, Error& err) {
     return false;
   if (!hip_ok(hipSetDevice(inst_->device), "hipSetDevice", err)) return false;
   if (lb) return true;
+  if (exchange_ == kExchangePeerCopy) {
+    size_t total = 0;
+    for (auto& p : peers_)
+      for (auto& c : p->r->chains_) total += c->map.n_local_pixels;
+    if (recv_stage_.count < total && !hip_ok(recv_stage_.alloc(total), "alloc exchange staging", err)) return false;
+    size_t off = 0;
+    bool ok = true;
+    for (size_t i = 0; ok && i < peers_.size(); ++i) {
+      Peer& p = *peers_[i];
+      auto& ch = p.r->chains_;
+      size_t n = 0;
+      for (auto& c : ch) n += c->map.n_local_pixels;
+      if (!n) continue;
+      const float4* src = ch.size() > 1 ? p.frame.ptr : (result ? ch[0]->result.ptr : ch[0]->cumulative.ptr);
+      ok = hip_ok(hipSetDevice(p.inst->device), "hipSetDevice", err) && (p.sent || hip_ok(hipEventCreateWithFlags(&p.sent, hipEventDisableTiming), "event", err)) &&
+           hip_ok(hipMemcpyPeerAsync(recv_stage_.ptr + off, inst_->device, src, p.inst->device, sizeof(float4) * n, p.inst->stream), "peer copy", err) &&
+           hip_ok(hipEventRecord(p.sent, p.inst->stream), "peer copy", err);
+      (void)hipSetDevice(inst_->device);
+      ok = ok && hip_ok(hipStreamWaitEvent(st, p.sent, 0), "peer copy", err);
+      off += n;
+    }
+    if (!ok) return false;
+    off = 0;
+    for (auto& p : peers_)
+      for (auto& c : p->r->chains_) {
+        if (!hip_ok(launch_export(st, c->map, recv_stage_.ptr + off, dst, false), "k_export (received tiles)", err)) return false;
+        off += c->map.n_local_pixels;
+      }
+    return hip_ok(hipStreamSynchronize(st), "exchange (root)", err);   // the root waited for every peer's copy before it scattered
+  }
   std::string why;
   const Rccl* nc = Rccl::get(why);
   if (!nc || comms_.size() != peers_.size() + 1) {
@@ -1029,7 +1064,7 @@ bool Renderer::set_devices(const int* devices, int n, Error& err) {
   // a stand-in library named by GLAZE_RCCL_LIBRARY (tests/fake_rccl), so that the n >= 2 group construction itself runs.
   const char* lbenv = getenv("GLAZE_MULTI_LOOPBACK");
   const bool dup_ok = n > 1 && all_same && lbenv != nullptr;
-  const bool loopback = dup_ok && strcmp(lbenv, "rccl") != 0;
+  const bool loopback = dup_ok && strcmp(lbenv, "rccl") != 0 && strcmp(lbenv, "peer") != 0;   // `peer`: the peer-copy exchange with n "devices" on one GPU
   if (any_same && !dup_ok) return bad("set_devices: a device is listed twice (GLAZE_MULTI_LOOPBACK=1 allows n copies of ONE device, for tests)");
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess) count = 0;
@@ -1038,11 +1073,14 @@ bool Renderer::set_devices(const int* devices, int n, Error& err) {
   int exchange = kExchangeGather;
   if (const char* x = getenv("GLAZE_MULTI_EXCHANGE")) {
     if (!strcmp(x, "reduce")) exchange = kExchangeReduce;
-    else if (strcmp(x, "gather")) return bad("GLAZE_MULTI_EXCHANGE must be `gather` or `reduce`");
+    else if (!strcmp(x, "peer")) exchange = kExchangePeerCopy;
+    else if (strcmp(x, "gather")) return bad("GLAZE_MULTI_EXCHANGE must be `gather`, `reduce` or `peer`");
   }
+  if (dup_ok && !strcmp(lbenv, "peer")) exchange = kExchangePeerCopy;
+  const bool use_rccl = n > 1 && !loopback && exchange != kExchangePeerCopy;
   // RCCL first: without it nothing is touched (a renderer that already spans devices keeps them)
   const Rccl* nc = nullptr;
-  if (n > 1 && !loopback) {
+  if (use_rccl) {
     std::string why;
     nc = Rccl::get(why);
     if (!nc) {
@@ -1093,7 +1131,22 @@ bool Renderer::set_devices(const int* devices, int n, Error& err) {
   }, err);
   if (!built) return fail();
   if (!set_partition_local(0, world, err)) return fail();
-  if (!loopback) {
+  if (!loopback && !use_rccl) {
+    // direct access between device 0 and every peer (without it the copies are staged through the host); "already enabled" is fine
+    for (int i = 1; i < n; ++i) {
+      if (devices[i] == devices[0]) continue;
+      int can = 0;
+      if (hipDeviceCanAccessPeer(&can, devices[0], devices[i]) == hipSuccess && can) {
+        (void)hipSetDevice(devices[0]);
+        (void)hipDeviceEnablePeerAccess(devices[i], 0);
+        (void)hipSetDevice(devices[i]);
+        (void)hipDeviceEnablePeerAccess(devices[0], 0);
+      }
+    }
+    (void)hipGetLastError();
+    (void)hipSetDevice(inst_->device);
+  }
+  if (use_rccl) {
     std::vector<ncclComm_t> comms((size_t)n, nullptr);
     const ncclResult_t r = nc->CommInitAll(comms.data(), n, devices);
     (void)hipSetDevice(inst_->device);

@@ -137,7 +137,7 @@ class Renderer {
   std::vector<std::unique_ptr<Peer>> peers_;
   std::vector<void*> comms_;   // ncclComm_t per device (index 0 = this renderer); empty in loop-back mode
   bool loopback_ = false;      // all "devices" are this one device (GLAZE_MULTI_LOOPBACK=1, tests on a one-GPU box): no RCCL
-  enum { kExchangeGather = 0, kExchangeReduce = 1 };
+  enum { kExchangeGather = 0, kExchangeReduce = 1, kExchangePeerCopy = 2 };
   int exchange_ = kExchangeGather;      // how the peers' tiles reach device 0 (reduce_peers); GLAZE_MULTI_EXCHANGE at set_devices
   DeviceBuffer<float4> recv_stage_;     // device 0: the packed tiles received from the peers (gather shape)
   bool settle(Error& err);

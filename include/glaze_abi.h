@@ -397,7 +397,9 @@ int glz_renderer_launch_mode(glz_renderer*);
  * onto hip_devices[0] over RCCL / xGMI (one communicator per device from ncclCommInitAll, all calls of one exchange in one
  * ncclGroup): by default every device ncclSends its packed tiles (1 / n of the frame) and device 0 ncclRecvs and scatters
  * them; with GLAZE_MULTI_EXCHANGE=reduce in the environment at this call, one ncclReduce(sum, float) of the zero-padded
- * RGBA32F frame per device.  The tiles are disjoint, so the image is bit-identical to a one-device render.  n = 1 returns to one
+ * RGBA32F frame per device; with GLAZE_MULTI_EXCHANGE=peer no RCCL at all: one hipMemcpyPeerAsync of the packed tiles per device,
+ * ordered into device 0's stream by events (never chosen by the library itself).  The tiles are disjoint, so the image is
+ * bit-identical to a one-device render.  n = 1 returns to one
  * device; after a failure the renderer is a one-device renderer again.  Not combinable with glz_renderer_set_partition (one process per GPU).  RCCL is loaded on first use
  * (librccl.so.1); GLZ_E_DEVICE when it is missing.  With GLAZE_MULTI_LOOPBACK=1 in the environment the list may name ONE
  * device n times (tests on a one-GPU machine: same sharding, threads and replicas, the tiles meet without RCCL). */

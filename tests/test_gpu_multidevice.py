@@ -440,6 +440,38 @@ def test_rccl_failures_leave_a_usable_renderer(tmp_path, exchange, fail):
         assert out["hdr_again"] is True and out["result"] is True and out["hdr_after_more"] is True
 
 
+@pytest.mark.parametrize("n,chains", [(2, 0), (3, 2), (8, 0)])
+def test_peer_copy_exchange_reproduces_the_one_device_image(instance, monkeypatch, n, chains):
+    """GLAZE_MULTI_EXCHANGE=peer: the packed tiles travel by hipMemcpyPeerAsync on the peers' streams, ordered into device 0's stream by
+    events -- no RCCL anywhere.  n "devices" on the one GPU (GLAZE_MULTI_LOOPBACK=peer keeps the copies and the staging area)."""
+    monkeypatch.setenv("GLAZE_MULTI_LOOPBACK", "peer")
+    monkeypatch.setenv("GLAZE_RCCL_LIBRARY", "/nonexistent/librccl.so")                       # proves that nothing asks for it
+    desc = cube_scene(material_type=abi.MAT_UBER)
+    w, h = 520, 200
+    one = glaze_amd.RayTraceRenderer.new(instance, glaze_amd.RayTraceScene.from_desc(instance, desc), w, h)
+    r = glaze_amd.RayTraceRenderer.new(instance, glaze_amd.RayTraceScene.from_desc(instance, desc), w, h)
+    for x in (one, r):
+        x.set_depth(3)
+        x.set_seed(9)
+    r.set_devices([instance.device] * n)
+    if chains:
+        r.set_chains(chains)
+    assert r.device_count() == n
+    for k in (7, 2):
+        one.step(k)
+        r.step(k)
+        assert np.array_equal(bits(r.read_hdr()), bits(one.read_hdr())) and np.array_equal(bits(r.read_result()), bits(one.read_result()))
+        assert np.array_equal(r.read_rgba8(), one.read_rgba8())
+    for x in (one, r):
+        x.change_resolution(200, 136)                                                          # fewer tiles than devices x chains; staging areas shrink / stay
+        x.step(4)
+    assert np.array_equal(bits(r.read_hdr()), bits(one.read_hdr()))
+    r.set_devices([instance.device])
+    r.restart(); one.restart()
+    r.step(3); one.step(3)
+    assert np.array_equal(bits(r.read_hdr()), bits(one.read_hdr()))
+
+
 BENCH_LOOPBACK_ENV = {"GLAZE_MULTI_LOOPBACK": "1"}
 
 
@@ -464,3 +496,22 @@ def test_bench_in_process_multi_gpu(tmp_path):
     if instance_count() < 2:
         p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"], capture_output=True, text=True, env=env, timeout=600)
         assert p.returncode != 0 and "this machine has 1 GPU" in p.stderr
+
+
+def test_bench_falls_back_to_peer_copies_when_rccl_will_not_start(tmp_path):
+    """ncclCommInitAll fails (injected into the stand-in library): bench.py says why on stderr, switches to the peer-copy exchange, still
+    verifies the frame bit for bit and names the exchange and the reason in its line."""
+    lib = os.path.join(ROOT, "tests", "fake_rccl", "libfake_rccl.so")
+    if not os.path.exists(lib):
+        pytest.skip("tests/fake_rccl/libfake_rccl.so is not built (__graft_entry__.build())")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "3", "--warmup", "2", "--width", "640", "--height", "360", "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "GLAZE_MULTI_EXCHANGE")}
+    for fail in ("ncclCommInitAll", "ncclSend"):
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=900,
+                           env=dict(env, GLAZE_MULTI_LOOPBACK="rccl", GLAZE_RCCL_LIBRARY=lib, GLAZE_FAKE_RCCL_FAIL=fail + ":1", GLAZE_FAKE_RCCL_LOG=str(tmp_path / ("fb_%s.log" % fail))))
+        assert p.returncode == 0, p.stderr[-3000:]
+        assert "falling back to peer copies" in p.stderr
+        out = json.loads(p.stdout.strip().splitlines()[-1])
+        assert out["n_gpus"] == 4 and out["multi_gpu"]["gpus_seen"] == 4
+        assert "hipMemcpyPeerAsync" in out["multi_gpu"]["exchange"] and fail in out["multi_gpu"]["rccl_fallback"] and out["multi_gpu"]["rccl_version"] is None
+        assert out["verify"]["bit_identical_to_one_gpu"] is True
