@@ -588,6 +588,10 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
         }
       }
       if (__popcll(__ballot(cur < 0)) >= (exhausted ? GLZ_LEAF_QUORUM_TAIL : (ANY ? GLZ_LEAF_QUORUM_ANY : kLeafQuorum))) break;
+      // (Postponed leaves -- a lane parks the first leaf it arrives at and goes on with its stack, blocks at the second, the parked
+      // leaves are tested first in the next leaf phase; Aila & Laine's speculative traversal -- k_trace 0.512 -> 0.540 ms with the
+      // leaf phase at 24 waiting lanes, 0.542 / 0.555 at 16 / 32: the visits made without the parked leaf's bound and the second
+      // leaf pass cost more than the fuller node iterations save.)
       // (Leaving for a refill as soon as kRefill finished lanes have piled up, without a leaf phase for the few lanes that wait
       // on a leaf, measured slower: 0.588 -> 0.611 ms, node rounds 41.1 -> 42.1 of 64 lanes.  The idle lanes are not what
       // holds the utilisation down.)
