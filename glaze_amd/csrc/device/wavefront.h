@@ -685,6 +685,11 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
 //   * A mesh leaf transforms its one or two OBJECT triangles to world space with the instance's matrix, operation for
 //     operation what k_world_tris does for the flattened build, and runs the same world-space Moeller-Trumbore test: hits
 //     (t, u, v, tie-break by world triangle id) are bit-identical to the flattened twin of the scene, whatever the hierarchy.
+// (Tail work sharing of TOP-level entries -- an idle lane takes the oldest top-level entry below a busy lane's exit marker, with the
+// world ray through __shfl and the top-level grid ray from the donor's LDS column, and enters instances on its own -- was built and
+// measured: bit-identical, and slower everywhere, forest x 200 0.820 -> 0.864 ms per launch, a 1/8 share 0.160 -> 0.180; once per
+// round instead of per node iteration 0.856 / 0.174.  A stolen top-level subtree costs its helper instance entries that the owner,
+// with the bound of the hit it finds first, mostly never makes.)
 // Simpler than trace_wave on purpose (no tail work sharing; the staged top is built in and off, GLZ_TL_LDS_TOP): instanced scenes are about memory -- O(meshes + instances) instead of
 // O(instances x triangles) -- and must not put the tuned flattened path at risk.
 // ---------------------------------------------------------------------------------------------
