@@ -1087,8 +1087,36 @@ struct SharedQueue {   // k_shade: the rank's sharded queue in HBM, drained by t
   __device__ __forceinline__ uint32_t slot(bool push) { return queue_slot(A.st.queue_count + A.shade_set * kQueueSetWords, A.map.n_local_pixels, push); }
 };
 // LOD: the build with the texture level of detail (FrameData::lod_mode != 0); the default build carries none of its code
-template <bool LOD, class Queue>
-__device__ __forceinline__ void shade_pixel(const LaunchArgs& A, const DeviceScene& S, const FrameData& F, uint32_t lid, PixelId px, float4 ro, float4 rd, float4 hr, Queue& queue) {
+// Where the pixel's next path state goes.  DirectState: straight into the state arrays (k_path: a wave's 64 pixels are neighbours, every
+// store is whole lines).  StagedState (k_shade, whose threads shade pixels in regrouped order): kept in registers, the kernel writes
+// them after the block's last barrier, transposed through LDS so that thread i stores pixel i's state.
+#ifndef GLZ_SHADE_STAGED_STATE
+#define GLZ_SHADE_STAGED_STATE 1   // k_shade: 0 = every thread stores its pixel's state itself (0.346 ms), 1 = the path state goes through the LDS transpose (0.322), 2 = the accumulator update too (0.340: its colour stays live through the BSDF sampling)
+#endif
+struct DirectState {
+  const LaunchArgs& A;
+  __device__ __forceinline__ void ray_o(uint32_t lid, float4 v) { A.st.ray_o[lid] = v; }
+  __device__ __forceinline__ void ray_d(uint32_t lid, float4 v) { A.st.ray_d[lid] = v; }
+  __device__ __forceinline__ void imp(int q, uint32_t lid, float4 v) { A.st.imp[q][lid] = v; }
+  __device__ __forceinline__ void accumulate(uint32_t lid, vec3 c, bool add, bool update, float exposure) { accumulate_pixel(A, lid, c, add, update, exposure); }
+};
+struct StagedState {
+  float4 ro, rd, im[4];
+  vec3 c;
+  uint32_t mask = 0;   // 1: ro, 2: rd, 4: im, 8: the pixel is accumulated in this launch (16: with c added, 32: result updated)
+  __device__ __forceinline__ void ray_o(uint32_t, float4 v) { ro = v; mask |= 1u; }
+  __device__ __forceinline__ void ray_d(uint32_t, float4 v) { rd = v; mask |= 2u; }
+  __device__ __forceinline__ void imp(int q, uint32_t, float4 v) { im[q] = v; mask |= 4u; }
+#if GLZ_SHADE_STAGED_STATE == 1   // only the path state is staged: the accumulator is updated where the pixel is shaded
+  const LaunchArgs* A = nullptr;
+  __device__ __forceinline__ void accumulate(uint32_t lid, vec3 cc, bool add, bool update, float exposure) { accumulate_pixel(*A, lid, cc, add, update, exposure); }
+#else
+  __device__ __forceinline__ void accumulate(uint32_t, vec3 cc, bool add, bool update, float) { c = cc; mask |= 8u | (add ? 16u : 0u) | (update ? 32u : 0u); }
+#endif
+};
+template <bool LOD, class Queue, class State>
+__device__ __forceinline__ void shade_pixel(const LaunchArgs& A, const DeviceScene& S, const FrameData& F, uint32_t lid, PixelId px, float4 ro, float4 rd, float4 hr, Queue& queue,
+                                            State& out) {
   const bool fresh = F.direct_only || ro.w == 0.0f;
   float bounce = F.direct_only ? 0.0f : ro.w;
   const vec3 direction = mk3(rd.x, rd.y, rd.z);
@@ -1121,8 +1149,8 @@ __device__ __forceinline__ void shade_pixel(const LaunchArgs& A, const DeviceSce
       c = spec_to_rgb(spec_mul(load_importance(), from_illuminant_color(texel)));
       flags = kFlagUpdate;
     }
-    accumulate_pixel(A, lid, c, true, flags != 0, F.exposure);
-    if (!F.direct_only) A.st.ray_o[lid] = make_float4(ro.x, ro.y, ro.z, 0.0f);   // RESET_PATH
+    out.accumulate(lid, c, true, flags != 0, F.exposure);
+    if (!F.direct_only) out.ray_o(lid, make_float4(ro.x, ro.y, ro.z, 0.0f));   // RESET_PATH
     return;
   }
   // ---- closest-hit shader (raytrace_hit.rchit:30-71), inputs from the 128-byte per-leaf shading record ----
@@ -1279,11 +1307,11 @@ __device__ __forceinline__ void shade_pixel(const LaunchArgs& A, const DeviceSce
       A.st.sh_d[slot] = make_float4(sh_dir.x, sh_dir.y, sh_dir.z, __uint_as_float(lid));
       A.st.contrib[slot] = make_float4(c.x, c.y, c.z, __uint_as_float(flags));
     } else {
-      accumulate_pixel(A, lid, c, true, true, F.exposure);
+      out.accumulate(lid, c, true, true, F.exposure);
     }
     spec_flag = 0.0f;
   } else {
-    accumulate_pixel(A, lid, mk3(0.0f, 0.0f, 0.0f), false, false, F.exposure);
+    out.accumulate(lid, mk3(0.0f, 0.0f, 0.0f), false, false, F.exposure);
     spec_flag = 1.0f;
   }
   if (F.direct_only) return;
@@ -1292,8 +1320,8 @@ __device__ __forceinline__ void shade_pixel(const LaunchArgs& A, const DeviceSce
   if (bounce > (float)(F.pt_steps / 2u)) {
     const float kill = gl_max(0.05f, 1.0f - (have_lum ? imp_lum : spec_luminance(load_importance())));
     if (rand01(rng) < kill) {
-      A.st.ray_o[lid] = make_float4(ro.x, ro.y, ro.z, 0.0f);
-      A.st.ray_d[lid] = make_float4(rd.x, rd.y, rd.z, spec_flag);
+      out.ray_o(lid, make_float4(ro.x, ro.y, ro.z, 0.0f));
+      out.ray_d(lid, make_float4(rd.x, rd.y, rd.z, spec_flag));
       return;
     }
     rr_scale = 1.0f / (1.0f - kill);
@@ -1304,8 +1332,8 @@ __device__ __forceinline__ void shade_pixel(const LaunchArgs& A, const DeviceSce
   vec3 wiW = mk3(0.0f, 0.0f, 0.0f);
   const float pdf = bsdf_sample(S, P, xi, value, wiW);   // :212-218
   if (pdf == 0.0f) {
-    A.st.ray_o[lid] = make_float4(ro.x, ro.y, ro.z, 0.0f);
-    A.st.ray_d[lid] = make_float4(rd.x, rd.y, rd.z, spec_flag);
+    out.ray_o(lid, make_float4(ro.x, ro.y, ro.z, 0.0f));
+    out.ray_d(lid, make_float4(rd.x, rd.y, rd.z, spec_flag));
     return;
   }
   float weight = fabsf(dot3(wiW, ns));
@@ -1313,12 +1341,12 @@ __device__ __forceinline__ void shade_pixel(const LaunchArgs& A, const DeviceSce
   const Spec importance = spec_scale(load_importance(), rr_scale);
 #pragma unroll
   for (int q = 0; q < 4; ++q)
-    A.st.imp[q][lid] = make_float4(importance.w[4 * q] * (value.w[4 * q] * weight), importance.w[4 * q + 1] * (value.w[4 * q + 1] * weight),
-                                   importance.w[4 * q + 2] * (value.w[4 * q + 2] * weight), importance.w[4 * q + 3] * (value.w[4 * q + 3] * weight));
+    out.imp(q, lid, make_float4(importance.w[4 * q] * (value.w[4 * q] * weight), importance.w[4 * q + 1] * (value.w[4 * q + 1] * weight),
+                                importance.w[4 * q + 2] * (value.w[4 * q + 2] * weight), importance.w[4 * q + 3] * (value.w[4 * q + 3] * weight)));
   bounce = bounce < (float)F.pt_steps ? bounce + 1.0f : 0.0f;   // :230-237
   if constexpr (LOD) A.st.cone[lid] = cone_w;
-  A.st.ray_o[lid] = make_float4(point.x, point.y, point.z, bounce);
-  A.st.ray_d[lid] = make_float4(wiW.x, wiW.y, wiW.z, spec_flag);
+  out.ray_o(lid, make_float4(point.x, point.y, point.z, bounce));
+  out.ray_d(lid, make_float4(wiW.x, wiW.y, wiW.z, spec_flag));
 }
 
 constexpr uint32_t kShadeTableBytes = 16384;   // LDS copy of the material / light / texture-descriptor tables (78 materials alone would fill it)

@@ -136,7 +136,8 @@ __device__ __forceinline__ uint32_t path_shade(uint32_t g, uint32_t n_groups, ui
   GroupQueue queue{lid0, false};
   if (px.active) {
     const float4 ro = A.st.ray_o[lid], rd = A.st.ray_d[lid];
-    shade_pixel<LOD>(A, S, F, lid, px, ro, rd, hit[lane], queue);
+    DirectState state{A};
+    shade_pixel<LOD>(A, S, F, lid, px, ro, rd, hit[lane], queue, state);
   }
   return (uint32_t)__popcll(__ballot(queue.pushed));
 }

@@ -36,11 +36,15 @@ __global__ void __launch_bounds__(kShadeBlock, GLZ_SHADE_WAVES) k_shade(const La
   // VALU instructions nothing; 1 / 2 / 3 / 4 waves per SIMD take 0.76 / 0.45 / 0.36 / 0.35 ms), so the two small tables every texture fetch /
   // sky sample walks are staged in LDS once per block: the sRGB decode LUT (12 lookups per bilinear fetch) and the sky marginal CDF (an 11-step dependent search).
   __shared__ float s_lut[256];
-  __shared__ float s_sky[kSkyLdsFloats];
+  // one pool: the sky marginal table and the scene tables while the block shades; after its last barrier the staging area of the
+  // state the pixels leave (StagedState): 7 x 16 bytes per pixel, written where the pixel lives instead of where its thread sat
+  __shared__ uint4 s_pool[kSkyLdsFloats / 4 + kShadeTableBytes / 16];
+  float* s_sky = reinterpret_cast<float*>(s_pool);
+  uint4* s_tables = s_pool + kSkyLdsFloats / 4;
+  constexpr bool kStaged = GLZ_SHADE_STAGED_STATE != 0 && 7u * kShadeBlock <= kSkyLdsFloats / 4 + kShadeTableBytes / 16;
   // The small scene tables every hit walks through one after the other -- shading record -> RTMaterial -> texture descriptor
   // -> texels, light pick -> RTLight -- are staged in LDS when they fit: each lookup that stays on chip takes a dependent
   // memory round trip (1-2 us under load, the kernel's bound) off the hit's critical path.
-  __shared__ uint4 s_tables[kShadeTableBytes / 16];
   __shared__ uint32_t s_bin[kShadeWavesPerBlock * 64];   // [wave][key] counts, then start offsets
   __shared__ uint16_t s_perm[kShadeBlock];
 #ifndef GLZ_SHADE_NO_HIT_HANDOVER
@@ -160,7 +164,12 @@ __global__ void __launch_bounds__(kShadeBlock, GLZ_SHADE_WAVES) k_shade(const La
   // 0.591 ms; sorted per block by the octant of the new direction, camera rays last, 0.590 -> 0.573 ms, less than the sort and the
   // indirection cost.)
   const PixelId px = pixel_of(A.map, lid);
+#if !defined(GLZ_SHADE_NO_REGROUP) && !defined(GLZ_SHADE_NO_REREAD)
+  StagedState staged;
+  if (!kStaged && !COUNT && !px.active) return;
+#else
   if (!COUNT && !px.active) return;
+#endif
   if (px.active) {
 #if !defined(GLZ_SHADE_NO_REGROUP) && !defined(GLZ_SHADE_NO_HIT_HANDOVER)
     const float4 ro = A.st.ray_o[lid], rd = A.st.ray_d[lid], hr = s_hit[s_perm[threadIdx.x]];
@@ -171,12 +180,55 @@ __global__ void __launch_bounds__(kShadeBlock, GLZ_SHADE_WAVES) k_shade(const La
     // (see reread_kernarg: without it the regrouping prologue's view of the arguments stays in SGPRs through the shading code)
     const LaunchArgs& A2 = *(const LaunchArgs*)reread_kernarg();
     SharedQueue queue{A2};
-    shade_pixel<LOD>(A2, S, A2.frame, lid, px, ro, rd, hr, queue);
+#ifndef GLZ_SHADE_NO_REGROUP
+    if (kStaged) {
+#if GLZ_SHADE_STAGED_STATE == 1
+      staged.A = &A2;
+#endif
+      shade_pixel<LOD>(A2, S, A2.frame, lid, px, ro, rd, hr, queue, staged);
+    } else
+#endif
+    {
+      DirectState direct{A2};
+      shade_pixel<LOD>(A2, S, A2.frame, lid, px, ro, rd, hr, queue, direct);
+    }
 #else
     SharedQueue queue{A};
-    shade_pixel<LOD>(A, S, F, lid, px, ro, rd, hr, queue);
+    DirectState direct{A};
+    shade_pixel<LOD>(A, S, F, lid, px, ro, rd, hr, queue, direct);
 #endif
   }
+#if !defined(GLZ_SHADE_NO_REGROUP) && !defined(GLZ_SHADE_NO_REREAD)
+  if (kStaged) {
+    // The regrouped threads would store 16-byte pieces scattered over the block's 4 KB of each state array (six arrays); the L2 has
+    // to assemble the lines.  Thread i stores pixel i's state instead: the values travel through LDS, which nobody needs any more
+    // once the whole block is here (a block's LDS and wave slots are handed on when its last wave ends either way).
+    __syncthreads();
+    float4* stage = reinterpret_cast<float4*>(s_pool);
+    const uint32_t p = s_perm[threadIdx.x];   // the pixel (index in the block) this thread shaded
+    s_bin[p] = staged.mask;
+    if (staged.mask & 1u) stage[p] = staged.ro;
+    if (staged.mask & 2u) stage[kShadeBlock + p] = staged.rd;
+    if (staged.mask & 4u) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) stage[(2u + q) * kShadeBlock + p] = staged.im[q];
+    }
+    if (staged.mask & 8u) stage[6u * kShadeBlock + p] = make_float4(staged.c.x, staged.c.y, staged.c.z, 0.0f);
+    __syncthreads();
+    const LaunchArgs& A3 = *(const LaunchArgs*)reread_kernarg();
+    const uint32_t m = s_bin[threadIdx.x], at = blockIdx.x * kShadeBlock + threadIdx.x;
+    if (m & 1u) A3.st.ray_o[at] = stage[threadIdx.x];
+    if (m & 2u) A3.st.ray_d[at] = stage[kShadeBlock + threadIdx.x];
+    if (m & 4u) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) A3.st.imp[q][at] = stage[(2u + q) * kShadeBlock + threadIdx.x];
+    }
+    if (m & 8u) {   // update_count / update_result of the pixels without a shadow ray (accumulate_pixel), the accumulator read and written in whole lines
+      const float4 c = stage[6u * kShadeBlock + threadIdx.x];
+      accumulate_pixel(A3, at, mk3(c.x, c.y, c.z), (m & 16u) != 0u, (m & 32u) != 0u, A3.frame.exposure);
+    }
+  }
+#endif
   if (COUNT) flush_tex_tallies(A.counters->shade_tex, tex_tally);   // every lane of the wave is here (the counting build returns nowhere above)
 }
 
