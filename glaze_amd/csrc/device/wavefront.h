@@ -1091,7 +1091,7 @@ struct SharedQueue {   // k_shade: the rank's sharded queue in HBM, drained by t
 // store is whole lines).  StagedState (k_shade, whose threads shade pixels in regrouped order): kept in registers, the kernel writes
 // them after the block's last barrier, transposed through LDS so that thread i stores pixel i's state.
 #ifndef GLZ_SHADE_STAGED_STATE
-#define GLZ_SHADE_STAGED_STATE 1   // k_shade: 0 = every thread stores its pixel's state itself (0.346 ms), 1 = the path state goes through the LDS transpose (0.322), 2 = the accumulator update too (0.340: its colour stays live through the BSDF sampling)
+#define GLZ_SHADE_STAGED_STATE 1   // k_shade: 0 = every thread stores its pixel's state itself (0.346 ms), 1 = the path state goes through the LDS transpose (0.322), 2 = the accumulator update too, its colour parked in the pixel's LDS slot meanwhile (0.329; kept in registers 0.340)
 #endif
 struct DirectState {
   const LaunchArgs& A;
@@ -1102,7 +1102,7 @@ struct DirectState {
 };
 struct StagedState {
   float4 ro, rd, im[4];
-  vec3 c;
+  float4* acc_slot = nullptr;   // mode 2: the pixel's own LDS slot (its hit record came from there and nobody else looks at it again)
   uint32_t mask = 0;   // 1: ro, 2: rd, 4: im, 8: the pixel is accumulated in this launch (16: with c added, 32: result updated)
   __device__ __forceinline__ void ray_o(uint32_t, float4 v) { ro = v; mask |= 1u; }
   __device__ __forceinline__ void ray_d(uint32_t, float4 v) { rd = v; mask |= 2u; }
@@ -1111,7 +1111,10 @@ struct StagedState {
   const LaunchArgs* A = nullptr;
   __device__ __forceinline__ void accumulate(uint32_t lid, vec3 cc, bool add, bool update, float exposure) { accumulate_pixel(*A, lid, cc, add, update, exposure); }
 #else
-  __device__ __forceinline__ void accumulate(uint32_t, vec3 cc, bool add, bool update, float) { c = cc; mask |= 8u | (add ? 16u : 0u) | (update ? 32u : 0u); }
+  __device__ __forceinline__ void accumulate(uint32_t, vec3 cc, bool add, bool update, float) {
+    *acc_slot = make_float4(cc.x, cc.y, cc.z, 0.0f);
+    mask |= 8u | (add ? 16u : 0u) | (update ? 32u : 0u);
+  }
 #endif
 };
 template <bool LOD, class Queue, class State>

@@ -184,6 +184,8 @@ __global__ void __launch_bounds__(kShadeBlock, GLZ_SHADE_WAVES) k_shade(const La
     if (kStaged) {
 #if GLZ_SHADE_STAGED_STATE == 1
       staged.A = &A2;
+#else
+      staged.acc_slot = &s_hit[s_perm[threadIdx.x]];
 #endif
       shade_pixel<LOD>(A2, S, A2.frame, lid, px, ro, rd, hr, queue, staged);
     } else
@@ -213,7 +215,6 @@ __global__ void __launch_bounds__(kShadeBlock, GLZ_SHADE_WAVES) k_shade(const La
 #pragma unroll
       for (int q = 0; q < 4; ++q) stage[(2u + q) * kShadeBlock + p] = staged.im[q];
     }
-    if (staged.mask & 8u) stage[6u * kShadeBlock + p] = make_float4(staged.c.x, staged.c.y, staged.c.z, 0.0f);
     __syncthreads();
     const LaunchArgs& A3 = *(const LaunchArgs*)reread_kernarg();
     const uint32_t m = s_bin[threadIdx.x], at = blockIdx.x * kShadeBlock + threadIdx.x;
@@ -224,7 +225,7 @@ __global__ void __launch_bounds__(kShadeBlock, GLZ_SHADE_WAVES) k_shade(const La
       for (int q = 0; q < 4; ++q) A3.st.imp[q][at] = stage[(2u + q) * kShadeBlock + threadIdx.x];
     }
     if (m & 8u) {   // update_count / update_result of the pixels without a shadow ray (accumulate_pixel), the accumulator read and written in whole lines
-      const float4 c = stage[6u * kShadeBlock + threadIdx.x];
+      const float4 c = s_hit[threadIdx.x];
       accumulate_pixel(A3, at, mk3(c.x, c.y, c.z), (m & 16u) != 0u, (m & 32u) != 0u, A3.frame.exposure);
     }
   }
