@@ -37,11 +37,11 @@ __global__ void __launch_bounds__(kShadeBlock, GLZ_SHADE_WAVES) k_shade(const La
   // sky sample walks are staged in LDS once per block: the sRGB decode LUT (12 lookups per bilinear fetch) and the sky marginal CDF (an 11-step dependent search).
   __shared__ float s_lut[256];
   // one pool: the sky marginal table and the scene tables while the block shades; after its last barrier the staging area of the
-  // state the pixels leave (StagedState): 7 x 16 bytes per pixel, written where the pixel lives instead of where its thread sat
+  // state the pixels leave (StagedState): 6 x 16 bytes per pixel, written where the pixel lives instead of where its thread sat
   __shared__ uint4 s_pool[kSkyLdsFloats / 4 + kShadeTableBytes / 16];
   float* s_sky = reinterpret_cast<float*>(s_pool);
   uint4* s_tables = s_pool + kSkyLdsFloats / 4;
-  constexpr bool kStaged = GLZ_SHADE_STAGED_STATE != 0 && 7u * kShadeBlock <= kSkyLdsFloats / 4 + kShadeTableBytes / 16;
+  constexpr bool kStaged = GLZ_SHADE_STAGED_STATE != 0 && 6u * kShadeBlock <= kSkyLdsFloats / 4 + kShadeTableBytes / 16;
   // The small scene tables every hit walks through one after the other -- shading record -> RTMaterial -> texture descriptor
   // -> texels, light pick -> RTLight -- are staged in LDS when they fit: each lookup that stays on chip takes a dependent
   // memory round trip (1-2 us under load, the kernel's bound) off the hit's critical path.
