@@ -10,4 +10,5 @@ FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -I. -I../../include
 /opt/rocm/bin/hipcc $FLAGS "$@" ${PATH_FLAGS--mllvm -disable-machine-licm} -c kernels_path.hip -o build_var/kp_$NAME.o &
 wait
 /opt/rocm/bin/hipcc -shared -fPIC -o ../../variants/libglaze_hip_$NAME.so build/abi.o build/parser.o build/serializer.o build/converter.o build/scene.o build/renderer.o build/bvh_sah.o build/xz_dec.o build/xz_enc.o build/png_dec.o build/png_enc.o build/jpeg.o build/kernels_build.o build_var/kr_$NAME.o build_var/kp_$NAME.o -lz -lpthread -ldl
+rm -f build_var/kr_$NAME.o build_var/kp_$NAME.o   # (the snapshot gpurun sends would carry them)
 echo built variants/libglaze_hip_$NAME.so
