@@ -425,7 +425,8 @@ def main():
         if n_gpus > 1:
             if n_dev > 1:
                 mode = "one process, glz_renderer_set_devices (a host thread, a scene replica and an RCCL communicator per GPU)"
-                how = "loop-back on ONE GPU, no RCCL (rehearsal)" if loopback and exchange != "peer" else {
+                stand_in = loopback and os.environ.get("GLAZE_MULTI_LOOPBACK") == "rccl"      # the RCCL entry points of GLAZE_RCCL_LIBRARY, n "ranks" on one GPU
+                how = "loop-back on ONE GPU, no RCCL (rehearsal)" if loopback and exchange != "peer" and not stand_in else {
                     "gather": "ncclSend/ncclRecv of packed tiles in one group", "reduce": "ncclReduce(sum) of the zero-padded frame",
                     "peer": "hipMemcpyPeerAsync of packed tiles, one per peer (no RCCL)"}[exchange]
                 rccl = None if loopback or exchange == "peer" else int(glaze_amd.abi.lib().glz_rccl_version())
