@@ -17,8 +17,7 @@ using namespace dev;
 //     closest hits of launch L -> shadow rays queued by launch L-1 (+ update_count / update_result) -> shade of launch L
 // for all launches of the batch (up to 192: only seed, jitter offset and exposure differ between launches, 16 bytes each in the kernel
 // arguments), with no grid-wide boundary in between.  A step then costs the slowest wave's SUM over the launches instead of the
-// sum over launches of the slowest wave.  (Measured, DESIGN.md section 6: a wave's mean per launch IS the throughput bound of a 1/8
-// share, 0.122 ms; the slowest wave's sum is 0.148 -- 6.3 x for eight GPUs against the two-kernel mode's 6.1 x, not the 6.5 x hoped for.)  Per pixel the operations and their order are those of k_trace / k_shade
+// sum over launches of the slowest wave.  (Measured: DESIGN.md section 6.)  Per pixel the operations and their order are those of k_trace / k_shade
 // (same sources, same shade_pixel, shadow rays of a launch resolved before the next launch's shading), so the image is bit-identical
 // -- tests/test_gpu_render.py compares the two modes and the oracle.
 // A wave's closest-hit records stay in LDS, its shadow queue is its own 64 entries of the queue arrays (no atomics, no shards), and
@@ -26,6 +25,19 @@ using namespace dev;
 // 128 registers, four waves per SIMD -- the objection to a fused kernel at full-frame size, where throughput counts; here every wave of
 // the share is resident anyway.  The sky's marginal table stays in global memory (with it in LDS only three blocks fit a CU).
 // ---------------------------------------------------------------------------------------------
+// THE ORDERING CONTRACT of k_path.  Lanes of one wave hand data to each other through GLOBAL memory: the shading lane of a pixel
+// writes a shadow-queue entry (sh_o / sh_d / contrib) that whichever lane picks the ray up in the next traversal pass reads; the lane
+// that finishes a shadow ray read-modify-writes cumulative / result of the OWNING pixel, which that pixel's own lane reads and writes
+// again in the next shading phase.  (The two-kernel mode has a kernel boundary in each of these places.)  What makes this defined is a
+// release / acquire pair at WAVEFRONT scope at every phase boundary: all lanes of a wave go through one vector-memory pipeline and one
+// L1, which performs a wave's accesses to an address in program order, so at this scope the fence needs no cache action and no
+// s_waitcnt on gfx950 -- it costs no instruction -- but it forbids the compiler to move, merge or keep in registers any of these
+// accesses across the boundary, which nothing else did.  (Not valid under tgsplit / a per-lane L1 policy: the kernel is never built that way.)
+__device__ __forceinline__ void wave_handover_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 struct GroupHitSink {   // closest-hit record of ray i of the group -> the wave's LDS slots
   float4* hit;
   __device__ __forceinline__ void store(uint32_t i, const HitRecord& h) {
@@ -220,6 +232,7 @@ __global__ void __launch_bounds__(kBlock, GLZ_PATH_WAVES) k_path(const LaunchArg
 #ifdef GLZ_PATH_TIMES
       const unsigned long long pt0 = wall_clock64();
 #endif
+      wave_handover_fence();   // shading (or the previous group) -> tracing: queue entries, accumulators
       if (L < B.n) {
         const FrameData F = launch_frame(A, B, L);
         // ONE traversal pass: the 64 closest-hit rays of launch L, then -- in the lanes those leave idle -- the shadow rays launch L-1 queued
@@ -243,6 +256,7 @@ __global__ void __launch_bounds__(kBlock, GLZ_PATH_WAVES) k_path(const LaunchArg
       const unsigned long long pt1 = wall_clock64();
       pt_trace += pt1 - pt0;
 #endif
+      wave_handover_fence();   // tracing -> shading: the accumulators the shadow rays' lanes updated
       if (L >= B.n) break;
       n_shadow = path_shade<LOD>(g, n_groups, lane, L, S, hit);
 #ifdef GLZ_PATH_ONE

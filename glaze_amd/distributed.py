@@ -51,9 +51,23 @@ def gather_frame(renderer, frame, which=0, dst=0, group=None):
     import torch.distributed as dist
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     n_max = renderer.packed_pixels(0, world)      # rank 0 owns the most tiles; everybody sends that many (gather wants equal sizes)
-    packed = torch.zeros((n_max, 4), dtype=torch.float32, device=frame.device)
-    renderer.export_packed(which, packed.data_ptr())
-    parts = [torch.empty_like(packed) for _ in range(world)] if rank == dst else None
+    # The buffers are kept between calls (a frame is gathered once per timed region: no allocation inside it) and made with
+    # torch.empty: a torch.zeros would enqueue its fill on torch's CURRENT stream, while export_packed writes the same buffer on the
+    # renderer's own non-blocking stream -- nothing orders the two, and a late fill would wipe the tiles.  scatter_packed only reads
+    # the packed_pixels(r) pixels rank r really owns, so the tail of a shorter rank's buffer is never looked at.
+    key = (str(frame.device), n_max, world, rank == dst)
+    cache = getattr(renderer, "_gather_buffers", None)
+    if cache is None or cache[0] != key:
+        packed = torch.empty((n_max, 4), dtype=torch.float32, device=frame.device)
+        parts = [torch.empty_like(packed) for _ in range(world)] if rank == dst else None
+        cache = (key, packed, parts)
+        renderer._gather_buffers = cache
+    _, packed, parts = cache
+    if frame.is_cuda:
+        # whatever torch / RCCL still have in flight on `packed` (the allocator's work, the previous call's send on a rank that is
+        # not `dst`) is done before the renderer's stream writes it again
+        torch.cuda.synchronize(frame.device)
+    renderer.export_packed(which, packed.data_ptr())      # synchronised on return (the renderer's stream has finished writing `packed`)
     dist.gather(packed, parts, dst=dst, group=group)
     if rank == dst:
         if frame.is_cuda:
