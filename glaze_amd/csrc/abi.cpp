@@ -572,6 +572,19 @@ int64_t glz_debug_read_bvh(glz_scene* h, void* nodes_out, int64_t cap_nodes, voi
   if (nodes_out && cap_nodes > 0 && nn > 0 &&
       !hip_ok(hipMemcpy(nodes_out, s->dev.bvh_nodes, (size_t)std::min(cap_nodes, nn) * sizeof(BvhNode4), hipMemcpyDeviceToHost), "read nodes", e))
     return fail(e);
+  if (nodes_out && cap_nodes > 0 && nn > 0 && s->dev.bvh_quads && !s->dev.two_level) {
+    // The flattened build links its leaves by NUMBER (the tracer reads one 64-byte BvhQuad per leaf, which names the leaf's first
+    // triangle slot); what this hook hands out is the structure as its readers walk it -- nodes whose leaf links are ~(first slot in
+    // the triangle array), as in a two-level scene's meshes -- so the links are translated here.
+    std::vector<BvhQuad> quads(s->d_quads_count());
+    if (!quads.empty() && !hip_ok(hipMemcpy(quads.data(), s->dev.bvh_quads, quads.size() * sizeof(BvhQuad), hipMemcpyDeviceToHost), "read leaf records", e)) return fail(e);
+    BvhNode4* nd = static_cast<BvhNode4*>(nodes_out);
+    for (int64_t i = 0; i < std::min(cap_nodes, nn); ++i)
+      for (int k = 0; k < 4; ++k) {
+        const int link = (int)nd[i].w[12 + k];
+        if (link < 0 && (size_t)~link < quads.size()) nd[i].w[12 + k] = (uint32_t)~(int)quads[(size_t)~link].slot;
+      }
+  }
   if (tris_out && cap_tris > 0 && nt > 0 &&
       !hip_ok(hipMemcpy(tris_out, s->dev.bvh_tris, (size_t)std::min(cap_tris, nt) * sizeof(BvhTri), hipMemcpyDeviceToHost), "read tris", e))
     return fail(e);

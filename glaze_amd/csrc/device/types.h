@@ -164,6 +164,23 @@ struct alignas(16) BvhTri {
 };
 static_assert(sizeof(BvhTri) == 48, "BvhTri is 48 bytes");
 
+// What the flattened tracer reads at a leaf: ONE 64-byte, line-aligned record per leaf, indexed by the leaf's number (leaf links of the
+// flattened build are ~leaf number; bvh_tris / shade_tris stay indexed by triangle slot, which the record names).  A leaf of two
+// triangles is a quad: triangle A = (q0, q1, q2), triangle B = (q0, q2, q3) -- each in ITS OWN vertex order, so the watertight test
+// computes for each exactly what it computes from the 48-byte records (the builder pairs two triangles only when one of the two
+// orders of the pair has this shape, k_pair_triangles); the four vertices are sheared once and the edge q0-q2 they share is
+// evaluated once: B's edge function along it is exactly the negation of A's (the products commute, tie-break terms included).
+// A single triangle is A alone.  kQuadSwapped: A is the pair's SECOND triangle in slot / id order (B the first).
+constexpr uint32_t kQuadSwapped = 0x20000000u;   // in prim_flags, next to kTriNonOpaque / kTriHasPartner; the primitive number keeps 29 bits
+constexpr uint32_t kQuadPrimMask = 0x1FFFFFFFu;
+struct alignas(64) BvhQuad {
+  float q0[3]; uint32_t world_id;    // of the pair's first triangle (the second one's is + 1)
+  float q1[3]; uint32_t instance;
+  float q2[3]; uint32_t prim_flags;  // kTriNonOpaque | kTriHasPartner | kQuadSwapped | primitive of the pair's first triangle
+  float q3[3]; uint32_t slot;        // first triangle slot of the leaf in bvh_tris / shade_tris
+};
+static_assert(sizeof(BvhQuad) == 64, "BvhQuad is 64 bytes");
+
 // Sky table header following RTSky in the reference SSBO (light_sky_sample_visible.rcall:19-26)
 struct SkyHeader {
   uint32_t marginal_cdf_count;
@@ -193,6 +210,7 @@ struct DeviceScene {
   const BvhNode4* bvh_top;         // kBvhTopNodes nodes: the top levels with links into the table flagged (kBvhTopFlag)
   BvhGrid bvh_grid;
   const BvhTri* bvh_tris;
+  const BvhQuad* bvh_quads;        // flattened build: one record per leaf, what trace_wave reads (null for two-level scenes)
   // per-leaf shading record, 8 x float4 = 128 bytes, in leaf order: VertexPacked x 3 (object space), then
   // (geometric normal.xyz, material id), (dpdu.xyz, transform id | identity flag in bit 31)
   const float4* shade_tris;

@@ -151,6 +151,62 @@ __device__ __forceinline__ bool ray_triangle(const RayShear& rs, const BvhTri& t
   return !((lo < 0.0f) & (hi > 0.0f)) & (det != 0.0f) & (t > tmin);
 }
 
+// The same test on a leaf record of the flattened build (types.h BvhQuad): triangle A = (q0, q1, q2) and, for a leaf of two,
+// B = (q0, q2, q3).  Per triangle the operations and their order are ray_triangle's, so (t, u, v) and the verdict are bit for bit
+// what the 48-byte records give; what the record saves is work the two triangles share: four vertex images instead of six, and the
+// two products of the edge q0-q2 -- B's edge function along it is A's with the operands of the subtraction exchanged (the products
+// themselves commute), tie-break terms included.  Straight-line like ray_triangle: the four 16-byte loads of a leaf issue together.
+struct QuadHit {
+  float t[2], u[2], v[2];   // [0] = A, [1] = B
+  bool ok[2];
+};
+__device__ __forceinline__ vec3 shear_point(const RayShear& r, float px, float py, float pz, vec3 o) {
+  const vec3 a = mk3(px, py, pz) - o;
+  const float az = r.z_is_x ? a.x : (r.z_is_y ? a.y : a.z), ax = r.z_is_x ? a.y : (r.z_is_y ? a.z : a.x), ay = r.z_is_x ? a.z : (r.z_is_y ? a.x : a.y);
+  return mk3(fmaf(-r.sx, az, ax), fmaf(-r.sy, az, ay), r.sz * az);
+}
+// the part of ray_triangle behind the edge functions
+__device__ __forceinline__ bool triangle_finish(float U, float V, float W, float Az, float Bz, float Cz, float tmin, float& t, float& u, float& v) {
+  const float lo = fminf(fminf(U, V), W), hi = fmaxf(fmaxf(U, V), W);
+  const float det = (U + V) + W;
+  const float inv = 1.0f / det;
+  u = V * inv;
+  v = W * inv;
+  t = fmaf(W, Cz, fmaf(V, Bz, U * Az)) * inv;
+  return !((lo < 0.0f) & (hi > 0.0f)) & (det != 0.0f) & (t > tmin);
+}
+__device__ __forceinline__ QuadHit ray_quad(const RayShear& rs, float4 r0, float4 r1, float4 r2, float4 r3, bool pair, vec3 o, float tmin) {
+  QuadHit h;
+  const vec3 S0 = shear_point(rs, r0.x, r0.y, r0.z, o), S2 = shear_point(rs, r2.x, r2.y, r2.z, o);
+  const float pv = S0.x * S2.y, qv = S0.y * S2.x;   // the shared edge q0-q2: V of A, W of B
+  {
+    // A = (S0, S1, S2):  U = C x B, V = A x C, W = B x A  with  A = S0, B = S1, C = S2
+    const vec3 S1 = shear_point(rs, r1.x, r1.y, r1.z, o);
+    const float pu = S2.x * S1.y, qu = S2.y * S1.x, pw = S1.x * S0.y, qw = S1.y * S0.x;
+    float U = pu - qu, V = pv - qv, W = pw - qw;
+    if (__builtin_expect(__any((U == 0.0f) | (V == 0.0f) | (W == 0.0f)), 0)) {   // edge_fn's second branch, for the lanes that need it
+      if (U == 0.0f) U = fmaf(S2.x, S1.y, -pu) - fmaf(S2.y, S1.x, -qu);
+      if (V == 0.0f) V = fmaf(S0.x, S2.y, -pv) - fmaf(S0.y, S2.x, -qv);
+      if (W == 0.0f) W = fmaf(S1.x, S0.y, -pw) - fmaf(S1.y, S0.x, -qw);
+    }
+    h.ok[0] = triangle_finish(U, V, W, S0.z, S1.z, S2.z, tmin, h.t[0], h.u[0], h.v[0]);
+  }
+  __builtin_amdgcn_sched_barrier(0);   // A is finished before B begins: interleaved for ILP the two keep twice the values alive (20 registers spilt)
+  {
+    // B = (S0, S2, S3):  U = S3 x S2, V = S0 x S3, W = S2 x S0 = S2.x S0.y - S2.y S0.x = qv - pv
+    const vec3 S3 = shear_point(rs, r3.x, r3.y, r3.z, o);
+    const float pu = S3.x * S2.y, qu = S3.y * S2.x, pv2 = S0.x * S3.y, qv2 = S0.y * S3.x;
+    float U = pu - qu, V = pv2 - qv2, W = qv - pv;
+    if (__builtin_expect(__any(pair & ((U == 0.0f) | (V == 0.0f) | (W == 0.0f))), 0)) {
+      if (U == 0.0f) U = fmaf(S3.x, S2.y, -pu) - fmaf(S3.y, S2.x, -qu);
+      if (V == 0.0f) V = fmaf(S0.x, S3.y, -pv2) - fmaf(S0.y, S3.x, -qv2);
+      if (W == 0.0f) W = fmaf(S2.x, S0.y, -qv) - fmaf(S2.y, S0.x, -pv);
+    }
+    h.ok[1] = triangle_finish(U, V, W, S0.z, S2.z, S3.z, tmin, h.t[1], h.u[1], h.v[1]) & pair;
+  }
+  return h;
+}
+
 // raytrace_hit.rahit:24-39 -- candidates on non-opaque geometry are dropped when opacity.r < 0.5
 __device__ __forceinline__ bool alpha_test(const DeviceScene& S, uint32_t leaf, float u, float v) {
   // uv of the three vertices and the material id come from the leaf's 128-byte shading record (the same values the
@@ -348,7 +404,6 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
   constexpr uint32_t kNone = 0xFFFFFFFFu;
   const BvhNode4* __restrict__ nodes = S.bvh_nodes;
   const BvhGrid grid = S.bvh_grid;
-  const BvhTri* __restrict__ tris = S.bvh_tris;
   const int lane = threadIdx.x & 63;
   const unsigned long long lanes_below = (1ull << lane) - 1ull;
   int* aux_out = aux;          // [owner lane] helpers currently working for that lane's ray
@@ -605,31 +660,32 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
     { const unsigned long long ml = __ballot(cur < 0); if (ml) { wt_leaf_iters += 1; wt_leaf_lanes += (unsigned)__popcll(ml); } }
 #endif
     if (cur < 0) {
-      // A leaf is one triangle or two adjacent ones (kTriHasPartner on the first).  The partner is fetched after the
-      // first test: six 16-byte loads in flight at once cost 20 more spilled registers in round 1 (0.64 -> 0.77 ms) and buy nothing now
-      // that they fit (0.554 against 0.555 ms, profiles/r03_variants_prefetch.txt).
+      // A leaf is one 64-byte record (types.h BvhQuad): one triangle or two that share an edge, tested together (ray_quad).  The
+      // candidates are then taken in slot order, the order the 48-byte records were walked in (the alpha test's fetches are counted).
       const uint32_t leaf = (uint32_t)~cur;
-      bool finished = false;
+      const float4* qp = reinterpret_cast<const float4*>(S.bvh_quads + leaf);
+      const float4 r0 = qp[0], r1 = qp[1], r2 = qp[2], r3 = qp[3];
+      const uint32_t id0 = __float_as_uint(r0.w), qflags = __float_as_uint(r2.w), slot0 = __float_as_uint(r3.w);
+      const bool pair = (qflags & kTriHasPartner) != 0u;
+      if (COUNT) tally.tris += pair ? 2 : 1;
       const RayShear rs = ray_shear(d);   // (kept in registers with the ray instead: fits without spills, 0.555 against 0.552 ms -- no gain)
-      for (uint32_t slot = leaf;; ++slot) {   // one copy of the test (inlined twice it spilt 15 more registers)
-        const float4* tp = reinterpret_cast<const float4*>(tris + slot);
-        const float4 a = tp[0], b = tp[1], c = tp[2];
-        if (COUNT) tally.tris += 1;
-        BvhTri tr;
-        tr.v0[0] = a.x; tr.v0[1] = a.y; tr.v0[2] = a.z; tr.world_id = __float_as_uint(a.w);
-        tr.v1[0] = b.x; tr.v1[1] = b.y; tr.v1[2] = b.z; tr.instance = __float_as_uint(b.w);
-        tr.v2[0] = c.x; tr.v2[1] = c.y; tr.v2[2] = c.z; tr.prim_flags = __float_as_uint(c.w);
-        float t, u, v;
-        if (ray_triangle(rs, tr, o, tmin, t, u, v) && t < tmax) {
-          const bool better = best.leaf == kNone ? true : (t < best.t || (t == best.t && tr.world_id < best_id));
-          if (better && (!(tr.prim_flags & kTriNonOpaque) || alpha_test(S, slot, u, v))) {
+      const QuadHit qh = ray_quad(rs, r0, r1, r2, r3, pair, o, tmin);
+      const uint32_t swapped = (qflags & kQuadSwapped) ? 1u : 0u;
+      bool finished = false;
+#pragma nounroll
+      for (uint32_t which = 0; which < 2u; ++which) {   // the leaf's first triangle, then its partner
+        const bool is_b = (which ^ swapped) != 0u;
+        const float t = is_b ? qh.t[1] : qh.t[0], u = is_b ? qh.u[1] : qh.u[0], v = is_b ? qh.v[1] : qh.v[0];
+        if ((is_b ? qh.ok[1] : qh.ok[0]) && t < tmax) {
+          const uint32_t wid = id0 + which, slot = slot0 + which;
+          const bool better = best.leaf == kNone ? true : (t < best.t || (t == best.t && wid < best_id));
+          if (better && (!(qflags & kTriNonOpaque) || alpha_test(S, slot, u, v))) {
             best = HitRecord{t, u, v, slot};
-            best_id = tr.world_id;
+            best_id = wid;
             finished = any_lane;
             if (SHARE && !ANY && exhausted) atomicMin(&aux_t[helper ? (int)ray : lane], __float_as_uint(t));
           }
         }
-        if (slot != leaf || !(tr.prim_flags & kTriHasPartner)) break;
       }
       cur = finished ? kRayDone : (SHARE ? st.pop_live() : (st.sp ? st.pop() : kRayDone));
     }

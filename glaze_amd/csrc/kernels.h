@@ -25,6 +25,9 @@ struct LbvhInputs {
   // one-"triangle" leaf whose BvhTri::world_id is i; vertices / indices / instances are not read.  Device pointers; null = triangles.
   const float4* given_lo = nullptr;
   const float4* given_hi = nullptr;
+  // The flattened world build: also emit the 64-byte per-leaf records (BvhQuad) and make leaf links ~leaf number instead of
+  // ~first triangle slot (the record names the slot).  Pairs are only formed in the two vertex orders a quad record can hold.
+  bool emit_quads = false;
 };
 constexpr int kBvhBuilderLbvh = 0, kBvhBuilderPloc = 1, kBvhBuilderSah = 2, kBvhBuilderAuto = 3, kBvhBuilderSahHost = 4;   // = GLZ_BVH_LBVH / _PLOC / _SAH / _AUTO / _SAH_HOST
 // host side of the SAH builder (bvh_sah.cpp): binary hierarchy over n leaf boxes -> children / parent arrays
@@ -34,6 +37,7 @@ struct LbvhOutputs {
   uint32_t n_nodes;
   BvhGrid grid;     // quantisation grid of the node boxes
   BvhTri* tris;     // n_world + 1 entries (the tracer reads one past a leaf's first triangle), preallocated; leaf order, a leaf's triangles adjacent
+  BvhQuad* quads;   // emit_quads: n_leaves records, hipMalloc'ed by build_lbvh (the caller owns them), else null
   uint32_t n_leaves;
   uint32_t depth;   // number of 4-wide nodes above the deepest leaf (the traversal stack holds at most 3 * depth + 1 entries)
   float sah;

@@ -229,7 +229,8 @@ __device__ __forceinline__ float box_area3(float4 l, float4 h) {
 __global__ void __launch_bounds__(256) k_pair_triangles(uint32_t n_world, uint32_t parity, const BvhTri* __restrict__ tris,
                                                         const uint32_t* __restrict__ indices, const RTInstance* __restrict__ instances,
                                                         const float4* __restrict__ box_lo, const float4* __restrict__ box_hi,
-                                                        float area_ratio, uint8_t* role /* 0 single, 1 first of a pair, 2 second of a pair */) {
+                                                        float area_ratio, uint32_t quads_only,
+                                                        uint8_t* role /* 0 single, 1 / 5 first of a pair (5: kQuadSwapped order), 2 second of a pair */) {
   const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
   if (w + 1 >= n_world) return;
   const BvhTri a = tris[w], b = tris[w + 1];
@@ -243,12 +244,26 @@ __global__ void __launch_bounds__(256) k_pair_triangles(uint32_t n_world, uint32
   for (int i = 0; i < 3; ++i)
     for (int j = 0; j < 3; ++j) shared += ia[i] == ib[j] ? 1 : 0;
   if (shared != 2) return;
+  // The vertex order of the second triangle in terms of the first one's corners (3 = its own fourth vertex).  A quad record
+  // (types.h BvhQuad) holds A = (q0, q1, q2), B = (q0, q2, q3): the pair fits as it is when the second triangle reads (0, 2, 3), and
+  // with the two triangles in the other order when it reads (0, 3, 1) -- then the SECOND one is A = (p0, d, p1) and the first one
+  // (p0, p1, p2) = (q0, q2, q3) is B.  Together these are the two ways a quad is cut into a fan from a shared first vertex (all pairs of the
+  // atrium, 98 % of mattest.glaze's); other orders stay single triangles, because re-ordering a triangle's vertices would change the
+  // rounding of its (t, u, v).
+  uint32_t pat = 0;
+  for (int j = 0; j < 3; ++j) {
+    uint32_t m = 3;
+    for (int i = 0; i < 3; ++i) m = ia[i] == ib[j] ? (uint32_t)i : m;
+    pat |= m << (4 * j);
+  }
+  const bool fits = pat == 0x320u, fits_swapped = pat == 0x130u;   // (0, 2, 3) / (0, 3, 1), first entry in the low nibble
+  if (quads_only && !fits && !fits_swapped) return;
   const float4 la = box_lo[w], ha = box_hi[w], lb = box_lo[w + 1], hb = box_hi[w + 1];
   const float4 lm = make_float4(fminf(la.x, lb.x), fminf(la.y, lb.y), fminf(la.z, lb.z), 0.0f);
   const float4 hm = make_float4(fmaxf(ha.x, hb.x), fmaxf(ha.y, hb.y), fmaxf(ha.z, hb.z), 0.0f);
   // one box for both must not cost more than it saves: identical boxes give 0.5, two squares side by side 0.83
   if (!(box_area3(lm, hm) <= area_ratio * (box_area3(la, ha) + box_area3(lb, hb)))) return;
-  role[w] = 1;
+  role[w] = (quads_only && fits_swapped) ? 5 : 1;
   role[w + 1] = 2;
 }
 __global__ void __launch_bounds__(256) k_leaf_flags(uint32_t n_world, const uint8_t* __restrict__ role, unsigned long long* __restrict__ flags) {
@@ -263,7 +278,7 @@ __global__ void __launch_bounds__(256) k_leaf_boxes(uint32_t n_world, const uint
   if (w >= n_world || role[w] == 2) return;
   const uint32_t l = (uint32_t)pos[w];
   float4 lo = box_lo[w], hi = box_hi[w];
-  if (role[w] == 1) {
+  if (role[w] & 1) {
     const float4 l2 = box_lo[w + 1], h2 = box_hi[w + 1];
     lo = make_float4(fminf(lo.x, l2.x), fminf(lo.y, l2.y), fminf(lo.z, l2.z), 0.0f);
     hi = make_float4(fmaxf(hi.x, h2.x), fmaxf(hi.y, h2.y), fmaxf(hi.z, h2.z), 0.0f);
@@ -276,7 +291,7 @@ __global__ void __launch_bounds__(256) k_leaf_boxes(uint32_t n_world, const uint
 __global__ void __launch_bounds__(256) k_leaf_sizes(uint32_t n, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ leaf_first,
                                                     const uint8_t* __restrict__ role, unsigned long long* __restrict__ sizes) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j < n) sizes[j] = role[leaf_first[vals[j]]] == 1 ? 2ull : 1ull;
+  if (j < n) sizes[j] = (role[leaf_first[vals[j]]] & 1) ? 2ull : 1ull;
 }
 
 // gathers triangles and boxes into leaf (sorted) order
@@ -284,17 +299,38 @@ __global__ void __launch_bounds__(256) k_gather_leaves(const uint32_t* __restric
                                                        const uint8_t* __restrict__ role, const unsigned long long* __restrict__ slot,
                                                        const BvhTri* __restrict__ tris_in, const float4* __restrict__ lo_in,
                                                        const float4* __restrict__ hi_in, BvhTri* __restrict__ tris_out, float4* __restrict__ node_lo,
-                                                       float4* __restrict__ node_hi) {
+                                                       float4* __restrict__ node_hi, BvhQuad* __restrict__ quads_out /* null: none */) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
   const uint32_t leaf = vals[j], first = leaf_first[leaf];
   const uint32_t s = (uint32_t)slot[j];
   BvhTri t = tris_in[first];
-  if (role[first] == 1) {
+  if (role[first] & 1) {
     t.prim_flags |= kTriHasPartner;
     tris_out[s + 1] = tris_in[first + 1];
   }
   tris_out[s] = t;
+  if (quads_out) {
+    // the leaf's record for the flattened tracer (types.h BvhQuad): A = (q0, q1, q2), B = (q0, q2, q3)
+    BvhQuad q;
+    q.world_id = t.world_id;
+    q.instance = t.instance;
+    q.prim_flags = t.prim_flags;
+    q.slot = s;
+    const float* c[4] = {t.v0, t.v1, t.v2, t.v2};   // a single triangle: q3 repeats q2 (never looked at)
+    if (role[first] == 1) {            // second triangle = (p0, p2, d)
+      c[3] = tris_in[first + 1].v2;
+    } else if (role[first] == 5) {     // second triangle = (p0, d, p1): it is A, the first one B
+      const BvhTri& b = tris_in[first + 1];
+      c[1] = b.v1;
+      c[2] = t.v1;
+      c[3] = t.v2;
+      q.prim_flags |= kQuadSwapped;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { q.q0[k] = c[0][k]; q.q1[k] = c[1][k]; q.q2[k] = c[2][k]; q.q3[k] = c[3][k]; }
+    quads_out[j] = q;
+  }
   node_lo[(n - 1) + j] = lo_in[leaf];   // leaf j's box lives at slot (n-1)+j, inner node i's at slot i
   node_hi[(n - 1) + j] = hi_in[leaf];
 }
@@ -1088,7 +1124,7 @@ __global__ void __launch_bounds__(256) k_emit_nodes4(int n, const int2* __restri
                                                      const float4* __restrict__ node_hi, const BvhGrid* __restrict__ grid,
                                                      const int* __restrict__ new_id, const unsigned long long* __restrict__ flags,
                                                      const unsigned long long* __restrict__ pos, const unsigned long long* __restrict__ slot,
-                                                     BvhNode4* __restrict__ nodes, float* __restrict__ sah) {
+                                                     uint32_t leaf_links_by_number, BvhNode4* __restrict__ nodes, float* __restrict__ sah) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n - 1) return;
   const int2 c = children[i];
@@ -1120,8 +1156,9 @@ __global__ void __launch_bounds__(256) k_emit_nodes4(int n, const int2* __restri
     nd.w[3 * k] = q[0] | (q[3] << 16);       // one word per axis: lo | hi << 16
     nd.w[3 * k + 1] = q[1] | (q[4] << 16);
     nd.w[3 * k + 2] = q[2] | (q[5] << 16);
-    // inner: its number among the BVH4 nodes; leaf: ~(first slot of the leaf in bvh_tris)
-    nd.w[12 + k] = (uint32_t)(ch >= 0 ? (int)pos[new_id[ch]] : ~(int)slot[~ch]);
+    // inner: its number among the BVH4 nodes; leaf: ~(first slot of the leaf in bvh_tris), or ~(leaf number) when the tracer reads
+    // per-leaf records that name the slot (LbvhInputs::emit_quads)
+    nd.w[12 + k] = (uint32_t)(ch >= 0 ? (int)pos[new_id[ch]] : (leaf_links_by_number ? ch : ~(int)slot[~ch]));
   }
   nodes[pos[new_id[i]]] = nd;
 }
@@ -1237,6 +1274,7 @@ hipError_t build_lbvh(hipStream_t st, const LbvhInputs& in, LbvhOutputs& out) {
   out.sah = 0.0f;
   out.rounds = 0;
   out.nodes = nullptr;
+  out.quads = nullptr;
   out.n_nodes = 0;
   out.n_leaves = 0;
   if (nw == 0) return hipSuccess;
@@ -1309,7 +1347,7 @@ hipError_t build_lbvh(hipStream_t st, const LbvhInputs& in, LbvhOutputs& out) {
   // leaves: pairs of triangles where they qualify, single triangles otherwise
   if (in.pair_area_ratio > 0.0f && !in.given_lo) {
     for (uint32_t parity = 0; parity < 2; ++parity) {
-      hipLaunchKernelGGL(k_pair_triangles, grdw, blk, 0, st, nw, parity, tris_unsorted, in.indices, in.instances, lo, hi, in.pair_area_ratio, role);
+      hipLaunchKernelGGL(k_pair_triangles, grdw, blk, 0, st, nw, parity, tris_unsorted, in.indices, in.instances, lo, hi, in.pair_area_ratio, in.emit_quads ? 1u : 0u, role);
       GLZ_TRY(hipGetLastError());
     }
   }
@@ -1345,7 +1383,13 @@ hipError_t build_lbvh(hipStream_t st, const LbvhInputs& in, LbvhOutputs& out) {
   hipLaunchKernelGGL(k_leaf_sizes, grd, blk, 0, st, n, vals, leaf_first, role, flags);
   GLZ_TRY(hipGetLastError());
   GLZ_TRY(scan_exclusive(st, (int)n, flags, slot, scan_tmp));
-  hipLaunchKernelGGL(k_gather_leaves, grd, blk, 0, st, vals, n, leaf_first, role, slot, tris_unsorted, leaf_lo, leaf_hi, out.tris, node_lo, node_hi);
+  out.quads = nullptr;
+  if (in.emit_quads) {
+    BvhQuad* q = nullptr;
+    GLZ_TRY(hipMalloc(&q, sizeof(BvhQuad) * (size_t)n));
+    out.quads = q;   // the caller's from here on, also when a later step fails
+  }
+  hipLaunchKernelGGL(k_gather_leaves, grd, blk, 0, st, vals, n, leaf_first, role, slot, tris_unsorted, leaf_lo, leaf_hi, out.tris, node_lo, node_hi, out.quads);
   GLZ_TRY(hipGetLastError());
   if (n >= 2) {
     if (builder == kBvhBuilderLbvh) {
@@ -1485,7 +1529,7 @@ hipError_t build_lbvh(hipStream_t st, const LbvhInputs& in, LbvhOutputs& out) {
     GLZ_TRY(hipStreamSynchronize(st));
     out.n_nodes = (uint32_t)n4;
     GLZ_TRY(hipMalloc(&out.nodes, sizeof(BvhNode4) * (size_t)n4));
-    hipLaunchKernelGGL(k_emit_nodes4, grd, blk, 0, st, (int)n, children, node_lo, node_hi, grid, new_id, flags, pos, slot, out.nodes, sah);
+    hipLaunchKernelGGL(k_emit_nodes4, grd, blk, 0, st, (int)n, children, node_lo, node_hi, grid, new_id, flags, pos, slot, in.emit_quads ? 1u : 0u, out.nodes, sah);
     GLZ_TRY(hipGetLastError());
   }
   int host_scalars[8];

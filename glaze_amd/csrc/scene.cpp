@@ -808,6 +808,8 @@ bool Scene::build_two_level(Error& err) {
   dev.bvh_top = d_top_.ptr;
   dev.bvh_grid = top.grid;
   dev.bvh_tris = d_tris_.ptr;
+  dev.bvh_quads = nullptr;   // (the two-level tracer reads the meshes' 48-byte object-space records)
+  d_quads_.release();
   dev.shade_tris = d_shade_tris_.ptr;
   dev.tlas_nodes = d_nodes_.ptr;
   dev.tlas_instances = d_tlas_instances_.ptr;
@@ -845,8 +847,10 @@ bool Scene::build_bvh(Error& err) {
   if (!hip_ok(hipMemsetAsync(d_tris_.ptr + n, 0, sizeof(BvhTri), st), "clear BVH triangle padding", err)) return false;
   LbvhInputs in{d_vertices_.ptr, d_indices_.ptr, d_instances_.ptr, d_inst_base_.ptr, (uint32_t)h_instances.size(), d_transforms_.ptr,
                 d_materials_.ptr, n, instance->bvh_builder, instance->bvh_pair_area_ratio};
+  in.emit_quads = true;   // the flattened tracer reads one 64-byte record per leaf (types.h BvhQuad); leaf links are ~leaf number
   LbvhOutputs out{};
   out.tris = d_tris_.ptr;
+  d_quads_.release();
   hipEvent_t e0, e1;
   if (!hip_ok(hipEventCreate(&e0), "event", err) || !hip_ok(hipEventCreate(&e1), "event", err)) return false;
   (void)hipEventRecord(e0, st);
@@ -857,6 +861,8 @@ bool Scene::build_bvh(Error& err) {
   (void)hipEventElapsedTime(&ms, e0, e1);
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
+  d_quads_.ptr = out.quads;       // ours whatever the build returned
+  d_quads_.count = out.quads ? out.n_leaves : 0;
   if (!hip_ok(be, "LBVH build", err)) return false;
   d_nodes_.ptr = out.nodes;       // allocated by the build once the number of 4-wide nodes is known
   d_nodes_.count = out.n_nodes;
@@ -888,6 +894,7 @@ bool Scene::build_bvh(Error& err) {
     info.bvh_grid_cell[k] = out.grid.cell[k];
   }
   dev.bvh_tris = d_tris_.ptr;
+  dev.bvh_quads = d_quads_.ptr;
   // per-leaf shading records (the identity flags let k_shade skip the object->world transform exactly)
   std::vector<uint32_t> ident(data.transforms.size(), 0u);
   for (size_t i = 0; i < ident.size(); ++i) {
@@ -905,7 +912,7 @@ bool Scene::build_bvh(Error& err) {
   dev.n_world_tris = n;
   info.as_levels = 1;
   info.n_as_triangles = n;
-  info.as_bytes = (uint64_t)out.n_nodes * sizeof(BvhNode4) + (uint64_t)(n + 1) * sizeof(BvhTri) + (uint64_t)n * 128u;
+  info.as_bytes = (uint64_t)out.n_nodes * sizeof(BvhNode4) + (uint64_t)(n + 1) * sizeof(BvhTri) + (uint64_t)n * 128u + (uint64_t)out.n_leaves * sizeof(BvhQuad);
   return true;
 }
 
