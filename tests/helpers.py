@@ -8,33 +8,8 @@ from glaze_amd.scene_desc import (INSTANCE_DTYPE, MESH_DTYPE, VERTEX_DTYPE, Scen
 
 def desc_from_oracle_parse(path):
     """SceneDesc built from the ORACLE's python reader (oracle/glaze_v1.py) -- independent of the C++ reader."""
-    from oracle.glaze_v1 import parse
-    p = parse(path)
-    v = p.vertices()
-    vertices = np.zeros(v.shape[0], VERTEX_DTYPE)
-    vertices["vv"], vertices["vn"], vertices["vt"] = v[:, 0:3], v[:, 3:6], v[:, 6:8]
-    meshes, indices, off = [], [], 0
-    for m in p.meshes():
-        meshes.append((m["id"], m["material"], off, m["indices"].size))
-        indices.append(m["indices"])
-        off += m["indices"].size
-    mats = [make_material(m["name"], m["mtype"], m["metal"], m["diffuse_mul"], m["emissive"], m["ior"], m["roughness_mul"],
-                          m["metalness_mul"], m["anisotropy"], m["diffuse"], m["roughness"], m["metalness"], m["normal"], m["opacity"])
-            for m in p.materials()]
-    lights = [make_light(l["ltype"], l["name"], l["color"], l["position"], l["direction"], l["intensity"], l["resource_id"],
-                         l["yaw"], l["pitch"], l["roll"]) for l in p.lights()]
-    textures = [(t["format"], t["levels"][0], t["name"]) for t in p.textures()]
-    cams = p.cameras()
-    cam = None
-    if cams:
-        c = cams[-1]
-        cam = make_camera(c["position"], c["target"], c["up"], c["fovx_or_scale"], c["near"], c["far"],
-                          orthographic=c["type"] == 1, scale=c["fovx_or_scale"])
-    meta = p.meta()
-    meta = make_meta(meta["scene_centre"], meta["scene_radius"], meta["exposure"]) if meta else None
-    inst = np.array([tuple(x) for x in p.instances()], INSTANCE_DTYPE)
-    return SceneDesc(vertices, np.concatenate(indices) if indices else np.zeros(0, np.uint32), np.array(meshes, MESH_DTYPE),
-                     p.transforms(), inst, mats, lights, textures, cam, meta)
+    from oracle.pyoracle import desc_from_file
+    return desc_from_file(path)
 
 
 def camera_rays(push, width, height, offset=(0.5, 0.5)):

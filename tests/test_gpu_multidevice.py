@@ -493,6 +493,9 @@ def test_bench_in_process_multi_gpu(tmp_path):
     assert out["n_gpus"] == 8 and out["multi_gpu"]["gpus_seen"] == 8 and out["multi_gpu"]["measurement"] is False
     assert out["verify"]["bit_identical_to_one_gpu"] is True and out["verify"]["launches"] == 2 + 4 * len(out["regions_ms"])
     assert out["multi_gpu"]["exchange_ms"] > 0 and out["value"] > 0
+    # BASELINE configs[4] (3840 x 2160, depth 12) is timed next to the 1080p frame in the same invocation, under its own name
+    c5 = out["multi_gpu"]["config5"]
+    assert c5["value"] > 0 and c5["ms_per_step"] > 0 and "3840x2160" in c5["workload"] and "depth 12" in c5["workload"] and len(c5["regions_ms"]) == 3
     if instance_count() < 2:
         p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"], capture_output=True, text=True, env=env, timeout=600)
         assert p.returncode != 0 and "this machine has 1 GPU" in p.stderr
