@@ -388,6 +388,12 @@ struct RaySequence {
   }
 };
 
+#ifdef GLZ_SECTION_TIMES   // tuning builds only (tools/gpu_sections.py): shader clocks every wave spent in each part of trace_wave's round, and how often
+static __device__ unsigned long long g_sections[16 * 8192];   // per wave: clocks {refill, share, node visit, loop control, leaf, merge + retire}, counts {rounds, node iterations, leaf phases, hand-over steps with a taker}
+#define GLZ_SEC_STAMP(acc) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); (acc) += now_ - sec_t; sec_t = now_; } while (0)
+#else
+#define GLZ_SEC_STAMP(acc) do { } while (0)
+#endif
 #ifdef GLZ_WAVE_TIMES
 __device__ unsigned long long g_wave_times[3 * 8192];
 __device__ unsigned int g_wave_stats[8 * 8192];   // closest-hit phase: rounds, node iterations, lanes in them, leaf iterations, lanes in them, rounds with helpers
@@ -397,7 +403,12 @@ __device__ unsigned long long g_tl_stats[8];      // two-level tracer, summed ov
 // MIXED (with ANY = false): the sequence holds rays of both kinds, the source says which after every load (src.any) -- k_path
 // traces a wave's closest-hit rays and the shadow rays its previous launch queued in ONE pass, the shadow rays in the lanes
 // the closest-hit rays leave idle.
-template <bool ANY, bool COUNT, bool MIXED = false, class Source, class Sink>
+// PREFETCH (k_path): the four 16-byte loads of a lane's NEXT inner node are issued the moment the node is known -- at the end of the visit
+// that chose it, after a leaf phase's pop, when an idle lane takes a subtree over -- instead of at the top of the next node iteration, so
+// that they are in flight during the pushes, the loop's ballots and the hand-overs to idle lanes in between.  A small share of the frame is
+// bound by the LATENCY of this dependent chain (tools/gpu_sections.py: a node visit of a 1/32 share, on an otherwise idle chip, still takes
+// 1 800 clocks, most of them waiting for the node), not by issue; the full-frame k_trace is issue bound and has no 16 registers to spare.
+template <bool ANY, bool COUNT, bool MIXED = false, bool PREFETCH = false, class Source, class Sink>
 __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Sink& sink, int* __restrict__ lds_col, int* aux, LdsNodePtr top_lds,
                                            uint32_t* __restrict__ spill, uint32_t spill_depth, uint32_t total, uint32_t wave, uint32_t n_waves, TraceTally& tally) {
   constexpr bool SHARE = !COUNT;
@@ -431,6 +442,7 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
   // per-lane ray state
   bool open = false;                                        // a ray of this lane's own is in flight and its result has not been stored
   bool helper = false;                                      // this lane traverses a subtree of lane `ray`'s ray (work sharing)
+  bool found_own = false;                                   // ... and has accepted a hit of its own since it took the subtree over (merge)
   bool any_lane = ANY;                                      // the ray in this lane ends with its first accepted hit (MIXED: per ray)
   int cur = kRayDone;
   uint32_t ray = 0;                                         // ray index (open) or owner lane (helper)
@@ -442,8 +454,22 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
   uint32_t best_id = kNone;
   // the spill area is indexed by the physical lane slot of the grid (a lane traverses one ray or subtree at a time)
   Stack st{lds_col, spill + ((size_t)(blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 64u + (uint32_t)lane) * spill_depth, 0};
+  // PREFETCH: the node `pf_cur` as loaded (or on its way)
+  u32x4 pf0 = {0u, 0u, 0u, 0u}, pf1 = pf0, pf2 = pf0, pf3 = pf0;
+  int pf_cur = -1;
+  auto prefetch_node = [&]() {
+    if (PREFETCH && cur >= 0 && !(cur & kBvhTopFlag)) {   // a node of the table in memory (staged nodes, kRayDone and kStolen carry bit 30)
+      const u32x4* np = reinterpret_cast<const u32x4*>(nodes + cur);
+      pf0 = np[0]; pf1 = np[1]; pf2 = np[2]; pf3 = np[3];
+      pf_cur = cur;
+    }
+  };
 #ifdef GLZ_WAVE_TIMES
   unsigned int wt_rounds = 0, wt_node_iters = 0, wt_node_lanes = 0, wt_leaf_iters = 0, wt_leaf_lanes = 0, wt_helper_rounds = 0, wt_wait_rounds = 0;
+#endif
+#ifdef GLZ_SECTION_TIMES
+  unsigned long long sec_t = __builtin_amdgcn_s_memtime(), sec_refill = 0, sec_share = 0, sec_node = 0, sec_ctl = 0, sec_leaf = 0, sec_tail = 0;
+  unsigned long long sec_rounds = 0, sec_iters = 0, sec_leaves = 0, sec_takes = 0, sec_merges = 0, sec_merge = 0;
 #endif
   // issue-priority rotation (rotate_priority above); k_path's MIXED pass keeps the priority its own kernel set
   // (inside k_path's mixed pass as well: a 1/4 share 0.276 -> 0.263 ms per launch, 1/8 0.1456 -> 0.1449, 1/16 0.118 -> 0.123)
@@ -499,13 +525,18 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
         best.leaf = (uint32_t)__shfl((int)best.leaf, donor);
         best_id = (uint32_t)__shfl((int)best_id, donor);
         if (MIXED) any_lane = __shfl((int)any_lane, donor) != 0;
+#ifdef GLZ_SECTION_TIMES
+        sec_takes += 1;
+#endif
         if (take) {
           ray = (uint32_t)t_owner;
           cur = t_node;
           st.sp = 0;
           aux_sb[lane] = 0;
           helper = true;
+          found_own = false;
           atomicAdd(&aux_out[t_owner], 1);
+          prefetch_node();
         }
         more = n_take > n_give;   // idle lanes are left over: the donors may have more to give
       }
@@ -527,6 +558,10 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
 #else
     if (ROTATE && rotate) rotate_priority(prio_gen + prio_round++);
 #endif
+#ifdef GLZ_SECTION_TIMES
+    sec_rounds += 1;
+#endif
+    GLZ_SEC_STAMP(sec_tail);
     // ---- refill ----
     const unsigned long long idle = __ballot(!(open || helper));
     const int n_idle = __popcll(idle);
@@ -561,6 +596,7 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
       // it after the owner has long found something nearer, and the owner cannot retire before its helpers are back.
       if (SHARE && !ANY && exhausted && open) aux_t[lane] = __float_as_uint(best.t);
     }
+    GLZ_SEC_STAMP(sec_refill);
     if (__ballot(open || helper) == 0ull) {
       if (exhausted) break;
       continue;
@@ -574,7 +610,9 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
       // iterations long, and with one hand-over per round the helpers of a long ray multiplied too slowly to matter before it
       // was over (a 1/8 share: 0.153 -> 0.147 ms per launch; the full frame, where only each wave's last group is a tail: 0.930 -> 0.914).
 #ifndef GLZ_SHARE_ONCE_PER_ROUND
+      GLZ_SEC_STAMP(sec_ctl);
       share_step();
+      GLZ_SEC_STAMP(sec_share);
 #else
       if (first_iter) share_step();
       first_iter = false;
@@ -594,6 +632,10 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
 #ifdef GLZ_WAVE_TIMES
       wt_node_iters += 1; wt_node_lanes += (unsigned)__popcll(m_node);
 #endif
+#ifdef GLZ_SECTION_TIMES
+      sec_iters += 1;
+#endif
+      GLZ_SEC_STAMP(sec_ctl);
       if (at_node) {
         // 64-byte node = 4 x dwordx4: four child boxes in 16-bit grid coordinates (the ray was mapped into grid units at
         // refill) and four links.  Children are entered nearest first; the others are pushed farthest first.
@@ -603,6 +645,9 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
         if (kLdsTop && (cur & kBvhTopFlag)) {
           LdsNodePtr np = top_lds + 4 * (cur & 0xFFFF);
           w0 = np[0]; w1 = np[1]; w2 = np[2]; w3 = np[3];
+        } else if (PREFETCH) {
+          if (pf_cur != cur) prefetch_node();   // (the ray has just started, or its stack was popped by someone who could not know)
+          w0 = pf0; w1 = pf1; w2 = pf2; w3 = pf3;
         } else {
           const u32x4* np = reinterpret_cast<const u32x4*>(nodes + cur);
           w0 = np[0]; w1 = np[1]; w2 = np[2]; w3 = np[3];
@@ -629,6 +674,7 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
         // and measured slower, 0.587 -> 0.597 ms: the extra DS stores cost more than the exec-mask branches.)
         if (k0 == 0xFFFFFFFFu) {
           cur = SHARE ? st.pop_live() : (st.sp ? st.pop() : kRayDone);
+          prefetch_node();
         } else {
           if (__ballot(st.sp + 3 > kLdsStack) == 0ull) {   // wave-uniform: every lane stays inside the LDS part of its stack (no spill branches)
             if (k3 != 0xFFFFFFFFu) { st.lds[st.sp * kBlock] = l3; ++st.sp; }
@@ -640,8 +686,13 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
             if (k1 != 0xFFFFFFFFu) st.push(l1);
           }
           cur = l0;
+          prefetch_node();
         }
       }
+#ifdef GLZ_SECTION_TIMES
+      if (!PREFETCH) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the visit's loads and LDS traffic are charged to the visit
+#endif
+      GLZ_SEC_STAMP(sec_node);
       if (__popcll(__ballot(cur < 0)) >= (exhausted ? GLZ_LEAF_QUORUM_TAIL : (ANY ? GLZ_LEAF_QUORUM_ANY : kLeafQuorum))) break;
       // (Postponed leaves -- a lane parks the first leaf it arrives at and goes on with its stack, blocks at the second, the parked
       // leaves are tested first in the next leaf phase; Aila & Laine's speculative traversal -- k_trace 0.512 -> 0.540 ms with the
@@ -651,6 +702,10 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
       // on a leaf, measured slower: 0.588 -> 0.611 ms, node rounds 41.1 -> 42.1 of 64 lanes.  The idle lanes are not what
       // holds the utilisation down.)
     }
+    GLZ_SEC_STAMP(sec_ctl);
+#ifdef GLZ_SECTION_TIMES
+    sec_leaves += __ballot(cur < 0) != 0ull;
+#endif
     // ---- leaf phase ----
     if (COUNT) {
       const unsigned long long m_leaf = __ballot(cur < 0);
@@ -682,23 +737,44 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
           if (better && (!(qflags & kTriNonOpaque) || alpha_test(S, slot, u, v))) {
             best = HitRecord{t, u, v, slot};
             best_id = wid;
+            found_own = true;
             finished = any_lane;
             if (SHARE && !ANY && exhausted) atomicMin(&aux_t[helper ? (int)ray : lane], __float_as_uint(t));
           }
         }
       }
       cur = finished ? kRayDone : (SHARE ? st.pop_live() : (st.sp ? st.pop() : kRayDone));
+      prefetch_node();
     }
+#ifdef GLZ_SECTION_TIMES
+    if (!PREFETCH) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+    GLZ_SEC_STAMP(sec_leaf);
     // ---- merge: finished helpers hand their result to the owner of the ray ----
     if (SHARE) {
-      unsigned long long fin = __ballot(helper && cur == kRayDone);
+      // All helpers that are done leave together; only those that can have CHANGED their owner's result take a turn in the loop: a
+      // helper that accepted a hit of its own (it starts from a copy of the donor's best, which the owner has) and, for closest-hit
+      // rays, whose distance is still the smallest anyone has found for that ray (aux_t, kept by every lane of the tail at each
+      // accepted hit: a result behind it cannot win, and whoever holds the smallest one either is the owner or will be here when it is
+      // done).  A turn reads the helper's lane with v_readlane -- its index is wave uniform -- instead of through the LDS permute.
+      // (tools/gpu_sections.py: a 1/8 share merged 71 helper results per wave and launch one after the other, 457 clocks each, 17 % of
+      // the tracing time.)
+      const bool done = helper && cur == kRayDone;
+      bool cand = done && found_own;
+      if (cand && !ANY && !any_lane) cand = __float_as_uint(best.t) == aux_t[ray];
+      unsigned long long fin = __ballot(cand);
       while (fin != 0ull) {
-        const int h = __ffsll((long long)fin) - 1;
+#ifdef GLZ_SECTION_TIMES
+        sec_merges += 1;
+#endif
+        const int h = __ffsll((long long)fin) - 1;   // wave uniform
         fin &= fin - 1ull;
-        const int ow = __shfl((int)ray, h);
-        const float bt = __shfl(best.t, h), bu = __shfl(best.u, h), bv = __shfl(best.v, h);
-        const uint32_t bl = (uint32_t)__shfl((int)best.leaf, h), bi = (uint32_t)__shfl((int)best_id, h);
-        if (lane == ow && bl != kNone) {
+        const int ow = __builtin_amdgcn_readlane((int)ray, h);
+        const float bt = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(best.t), h));
+        const float bu = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(best.u), h));
+        const float bv = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(best.v), h));
+        const uint32_t bl = (uint32_t)__builtin_amdgcn_readlane((int)best.leaf, h), bi = (uint32_t)__builtin_amdgcn_readlane((int)best_id, h);
+        if (lane == ow) {
           const bool better = best.leaf == kNone ? true : (bt < best.t || (bt == best.t && bi < best_id));
           if (better) {
             best = HitRecord{bt, bu, bv, bl};
@@ -706,12 +782,13 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
           }
           if (any_lane) cur = kRayDone;   // occluded: the rest of the owner's stack does not matter
         }
-        if (lane == h) {
-          helper = false;
-          atomicSub(&aux_out[ow], 1);
-        }
+      }
+      if (done) {
+        helper = false;
+        atomicSub(&aux_out[ray], 1);
       }
     }
+    GLZ_SEC_STAMP(sec_merge);
     // ---- retire ----
     if (open && cur == kRayDone && (!SHARE || aux_out[lane] == 0)) {
       if (COUNT) tally.hits += best.leaf != kNone;
@@ -723,6 +800,17 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
   if (SHARE) __builtin_amdgcn_s_setprio(0);
 #endif
   if (ROTATE) __builtin_amdgcn_s_setprio(0);
+#ifdef GLZ_SECTION_TIMES
+  {
+    GLZ_SEC_STAMP(sec_tail);
+    const uint32_t gw = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (lane == 0 && gw < 8192u) {
+      unsigned long long* g = g_sections + 16 * gw;
+      g[0] += sec_refill; g[1] += sec_share; g[2] += sec_node; g[3] += sec_ctl; g[4] += sec_leaf; g[5] += sec_tail;
+      g[6] += sec_rounds; g[7] += sec_iters; g[8] += sec_leaves; g[9] += sec_takes; g[10] += 1; g[11] += sec_merges; g[12] += sec_merge;
+    }
+  }
+#endif
 #ifdef GLZ_WAVE_TIMES
   if (!ANY && lane == 0 && wave < 8192u) {
     unsigned int* o = g_wave_stats + 8 * wave;
@@ -1096,7 +1184,15 @@ struct ClosestSink {
   }
 };
 
-// update_count() + update_result() of path_trace.rgen:119-133 for one pixel
+// update_count() + update_result() of path_trace.rgen:119-133 for one pixel; `cum` = cumulative[lid] as read before
+__device__ __forceinline__ void accumulate_pixel(const LaunchArgs& A, uint32_t lid, vec3 c, bool add, bool update, float exposure, float4 cum) {
+  cum.w += 1.0f;
+  if (update) {
+    if (add) { cum.x += c.x; cum.y += c.y; cum.z += c.z; }
+    A.st.result[lid] = make_float4(cum.x * exposure / cum.w, cum.y * exposure / cum.w, cum.z * exposure / cum.w, 1.0f);
+  }
+  A.st.cumulative[lid] = cum;
+}
 __device__ __forceinline__ void accumulate_pixel(const LaunchArgs& A, uint32_t lid, vec3 c, bool add, bool update, float exposure) {
   float4 cum = A.st.cumulative[lid];
   cum.w += 1.0f;

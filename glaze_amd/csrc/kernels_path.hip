@@ -58,11 +58,17 @@ struct GroupShadowSource {
   uint32_t base;
   uint32_t lid;            // per-lane: owning pixel and contribution of the ray in flight
   float4 contrib;
+  // The owning pixel's accumulator, read when the ray STARTS: nobody else touches it while the ray is in flight (one shadow ray per pixel
+  // and launch, the pixel's own lane only shades after this pass), and it was last written a launch ago -- read at the ray's end, where
+  // update_count / update_result need it, the lane (and with it the wave's round) waited for it to come from HBM
+  // (tools/gpu_sections.py: merge + retire was a fifth of a wave's tracing time).
+  float4 cum;
   __device__ __forceinline__ bool load(uint32_t i, vec3& o, vec3& d, float& tmin, float& tmax) {
     const uint32_t q = base + i;
     const float4 so = A.st.sh_o[q], sd = A.st.sh_d[q];
     contrib = A.st.contrib[q];
     lid = __float_as_uint(sd.w);
+    cum = A.st.cumulative[lid];
     o = mk3(so.x, so.y, so.z);
     d = mk3(sd.x, sd.y, sd.z);
     tmin = 0.001f;
@@ -84,7 +90,7 @@ struct GroupShadowSink {
       c = mk3(nan, nan, nan);
       add = true;
     }
-    accumulate_pixel(A, src.lid, c, add, true, exposure);
+    accumulate_pixel(A, src.lid, c, add, true, exposure, src.cum);
   }
 };
 
@@ -107,6 +113,9 @@ struct GroupMixedSink {
 
 #ifndef GLZ_PATH_WAVES
 #define GLZ_PATH_WAVES 4
+#endif
+#ifndef GLZ_PATH_PREFETCH
+#define GLZ_PATH_PREFETCH 1   // trace_wave<PREFETCH>: the next node's loads issued as soon as the node is known
 #endif
 // The kernel's arguments, re-read: behind the empty asm the compiler no longer knows that the pointer is the one it has been loading
 // from, so what a phase of k_path needs of the arguments is loaded (scalar loads from the kernarg segment) where the phase begins and
@@ -236,19 +245,19 @@ __global__ void __launch_bounds__(kBlock, GLZ_PATH_WAVES) k_path(const LaunchArg
       if (L < B.n) {
         const FrameData F = launch_frame(A, B, L);
         // ONE traversal pass: the 64 closest-hit rays of launch L, then -- in the lanes those leave idle -- the shadow rays launch L-1 queued
-        GroupMixedSource src{ClosestSource{A, F, tally, GLZ_PATH_PIECES > 1 ? g : lid0, GLZ_PATH_PIECES > 1 ? n_groups : 0u}, GroupShadowSource{A, lid0, 0u, make_float4(0.0f, 0.0f, 0.0f, 0.0f)}, false};
+        GroupMixedSource src{ClosestSource{A, F, tally, GLZ_PATH_PIECES > 1 ? g : lid0, GLZ_PATH_PIECES > 1 ? n_groups : 0u}, GroupShadowSource{A, lid0, 0u, make_float4(0.0f, 0.0f, 0.0f, 0.0f), make_float4(0.0f, 0.0f, 0.0f, 0.0f)}, false};
         GroupMixedSink sink{GroupHitSink{hit}, GroupShadowSink{A, src.shadow, queued_exposure}};
 #ifndef GLZ_PATH_NO_TRACE
-        trace_wave<false, false, true>(A.scene, src, sink, &s_stack[threadIdx.x], aux, (LdsNodePtr)s_top, A.st.overflow, A.st.overflow_depth, 64u + n_shadow, 0u, 1u, tally);
+        trace_wave<false, false, true, GLZ_PATH_PREFETCH != 0>(A.scene, src, sink, &s_stack[threadIdx.x], aux, (LdsNodePtr)s_top, A.st.overflow, A.st.overflow_depth, 64u + n_shadow, 0u, 1u, tally);
 #else
         hit[lane] = A.st.hit[lid0 + lane];   // compile-time experiment: the shading phase's registers without the tracing phase around it
 #endif
         n_shadow = 0u;
       } else {
-        GroupShadowSource src{A, lid0, 0u, make_float4(0.0f, 0.0f, 0.0f, 0.0f)};
+        GroupShadowSource src{A, lid0, 0u, make_float4(0.0f, 0.0f, 0.0f, 0.0f), make_float4(0.0f, 0.0f, 0.0f, 0.0f)};
         GroupShadowSink sink{A, src, queued_exposure};
 #ifndef GLZ_PATH_NO_TRACE
-        trace_wave<true, false>(A.scene, src, sink, &s_stack[threadIdx.x], aux, (LdsNodePtr)s_top, A.st.overflow, A.st.overflow_depth, n_shadow, 0u, 1u, tally);
+        trace_wave<true, false, false, GLZ_PATH_PREFETCH != 0>(A.scene, src, sink, &s_stack[threadIdx.x], aux, (LdsNodePtr)s_top, A.st.overflow, A.st.overflow_depth, n_shadow, 0u, 1u, tally);
 #endif
         n_shadow = 0u;
       }
@@ -315,6 +324,16 @@ hipError_t launch_path(hipStream_t st, const LaunchArgs& a, const PathBatch& bat
 }
 }  // namespace glz
 
+#ifdef GLZ_SECTION_TIMES
+extern "C" int glz_debug_sections_path(unsigned long long* out, int reset) {
+  int e = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(glz::g_sections), sizeof(unsigned long long) * 16 * 8192);
+  if (reset) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(glz::g_sections)) == hipSuccess) e = (int)hipMemset(p, 0, sizeof(unsigned long long) * 16 * 8192);
+  }
+  return e;
+}
+#endif
 #ifdef GLZ_PATH_TIMES
 extern "C" int glz_debug_path_times(unsigned long long* out, int n_waves) {
   if (n_waves > 8192) n_waves = 8192;

@@ -518,6 +518,17 @@ hipError_t launch_debug_any(hipStream_t st, const DeviceScene& scene, const floa
 
 }  // namespace glz
 
+#ifdef GLZ_SECTION_TIMES
+// kernels_render.hip and kernels_path.hip each hold their own copy of g_sections (a __device__ array per translation unit): `which` 0 = k_trace's, see kernels_path.hip for k_path's
+extern "C" int glz_debug_sections_trace(unsigned long long* out, int reset) {
+  int e = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(glz::g_sections), sizeof(unsigned long long) * 16 * 8192);
+  if (reset) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(glz::g_sections)) == hipSuccess) e = (int)hipMemset(p, 0, sizeof(unsigned long long) * 16 * 8192);
+  }
+  return e;
+}
+#endif
 #ifdef GLZ_WAVE_TIMES
 extern "C" int glz_debug_wave_times(unsigned long long* out, int n_waves) {
   if (n_waves > 8192) n_waves = 8192;
