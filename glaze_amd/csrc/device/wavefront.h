@@ -257,10 +257,15 @@ struct Stack {
     --sp;
     return sp < kLdsStack ? lds[sp * kBlock] : (int)spill[sp - kLdsStack];
   }
+  // Hand-overs take the OLDEST live entry of a stack (the lowest level, aux_sb) and move that mark up by one, so the stolen entries are
+  // one run at the bottom: a pop that finds kStolen has found the end of the lane's own work -- everything below is stolen as well.
+  // (Walking down through the marks one LDS read at a time, as rounds 1-3 did, was most of the 1 100 clocks a node iteration of a small
+  // share spent behind its box tests: the whole wave waits while one lane scans.)
   __device__ __forceinline__ int pop_live() {
-    while (sp > 0) {
+    if (sp > 0) {
       const int v = pop();
       if (v != kStolen) return v;
+      sp = 0;
     }
     return kRayDone;
   }
@@ -463,13 +468,15 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
       pf0 = np[0]; pf1 = np[1]; pf2 = np[2]; pf3 = np[3];
       pf_cur = cur;
     }
+    // (The 64-byte record of a LEAF requested the same way, while the lane waits for the leaf phase's quorum: slower, a 1/8 share
+    // 0.1379 -> 0.1418 ms per launch, 1/16 0.0997 -> 0.1058.)
   };
 #ifdef GLZ_WAVE_TIMES
   unsigned int wt_rounds = 0, wt_node_iters = 0, wt_node_lanes = 0, wt_leaf_iters = 0, wt_leaf_lanes = 0, wt_helper_rounds = 0, wt_wait_rounds = 0;
 #endif
 #ifdef GLZ_SECTION_TIMES
   unsigned long long sec_t = __builtin_amdgcn_s_memtime(), sec_refill = 0, sec_share = 0, sec_node = 0, sec_ctl = 0, sec_leaf = 0, sec_tail = 0;
-  unsigned long long sec_rounds = 0, sec_iters = 0, sec_leaves = 0, sec_takes = 0, sec_merges = 0, sec_merge = 0;
+  unsigned long long sec_rounds = 0, sec_iters = 0, sec_leaves = 0, sec_takes = 0, sec_merges = 0, sec_merge = 0, sec_f0 = 0, sec_f1 = 0, sec_f2 = 0;
 #endif
   // issue-priority rotation (rotate_priority above); k_path's MIXED pass keeps the priority its own kernel set
   // (inside k_path's mixed pass as well: a 1/4 share 0.276 -> 0.263 ms per launch, 1/8 0.1456 -> 0.1449, 1/16 0.118 -> 0.123)
@@ -605,12 +612,18 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
 #ifdef GLZ_SHARE_ONCE_PER_ROUND
     bool first_iter = true;
 #endif
+#ifdef GLZ_SHARE_EVERY
+    uint32_t share_turn = 0;
+#endif
     for (;;) {
       // Idle lanes take over pending subtrees before EVERY node iteration of the tail, not once per round: a round is several
       // iterations long, and with one hand-over per round the helpers of a long ray multiplied too slowly to matter before it
       // was over (a 1/8 share: 0.153 -> 0.147 ms per launch; the full frame, where only each wave's last group is a tail: 0.930 -> 0.914).
 #ifndef GLZ_SHARE_ONCE_PER_ROUND
       GLZ_SEC_STAMP(sec_ctl);
+#ifdef GLZ_SHARE_EVERY
+      if (share_turn++ % GLZ_SHARE_EVERY == 0u)   // (every 2nd / 3rd node iteration instead of every one: a 1/8 share 0.1352 -> 0.1382 / 0.1404 ms per launch)
+#endif
       share_step();
       GLZ_SEC_STAMP(sec_share);
 #else
@@ -655,6 +668,10 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
           // 8-bit boxes relative to a per-node origin -- would buy about that and pay ~12 VALU instructions per visit for it.)
         }
         if (COUNT) tally.nodes += 1;
+#ifdef GLZ_SECTION_FINE
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        GLZ_SEC_STAMP(sec_f0);   // the node's words are here
+#endif
         float bound = best.t;
         if (SHARE && !ANY && exhausted) bound = fminf(bound, __uint_as_float(aux_t[helper ? (int)ray : lane]));   // positive floats order like their bits
         uint32_t k0 = box_key<false>(w0.x, w0.y, w0.z, w3.x, 0u, sel, ig, cg, cg, tmin, bound), k1 = box_key<false>(w0.w, w1.x, w1.y, w3.y, 1u, sel, ig, cg, cg, tmin, bound);
@@ -666,12 +683,20 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
         // 16-byte store put lanes l, l + 8, l + 16, l + 24 of a half-wave on the same banks: 4.6 M conflict cycles per launch,
         // 22 % of the LDS-active cycles), and all four sorted links are fetched before the first one is used: the reads
         // are independent, so one LDS round trip covers them instead of one per push (read -> wait -> write, four times over).
+#ifdef GLZ_SECTION_FINE
+        asm volatile("" : "+v"(k0), "+v"(k1), "+v"(k2), "+v"(k3));
+        GLZ_SEC_STAMP(sec_f1);   // box tests and sort
+#endif
         int* links = aux + 192 + lane;
         links[0] = (int)w3.x; links[64] = (int)w3.y; links[128] = (int)w3.z; links[192] = (int)w3.w;
         const int l0 = links[(k0 & 3u) * 64u], l1 = links[(k1 & 3u) * 64u], l2 = links[(k2 & 3u) * 64u], l3 = links[(k3 & 3u) * 64u];
         // (Three unconditional stores with the stack pointer advancing by one per valid key -- the invalid links of the sorted
         // sequence are overwritten by the next store or stay above the top -- remove 12 scalar / branch instructions per round
         // and measured slower, 0.587 -> 0.597 ms: the extra DS stores cost more than the exec-mask branches.)
+#ifdef GLZ_SECTION_FINE
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        GLZ_SEC_STAMP(sec_f2);   // links through LDS
+#endif
         if (k0 == 0xFFFFFFFFu) {
           cur = SHARE ? st.pop_live() : (st.sp ? st.pop() : kRayDone);
           prefetch_node();
@@ -807,7 +832,7 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
     if (lane == 0 && gw < 8192u) {
       unsigned long long* g = g_sections + 16 * gw;
       g[0] += sec_refill; g[1] += sec_share; g[2] += sec_node; g[3] += sec_ctl; g[4] += sec_leaf; g[5] += sec_tail;
-      g[6] += sec_rounds; g[7] += sec_iters; g[8] += sec_leaves; g[9] += sec_takes; g[10] += 1; g[11] += sec_merges; g[12] += sec_merge;
+      g[6] += sec_rounds; g[7] += sec_iters; g[8] += sec_leaves; g[9] += sec_takes; g[10] += 1; g[11] += sec_merges; g[12] += sec_merge; g[13] += sec_f0; g[14] += sec_f1; g[15] += sec_f2;
     }
   }
 #endif
