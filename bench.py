@@ -501,6 +501,10 @@ def main():
                 committed = json.load(open(prof))
             except Exception:       # noqa: BLE001
                 committed = None
+        if committed:       # (the summary's own key for the uncorrected reading, under the name this line uses)
+            for v in committed.values():
+                if isinstance(v, dict) and "hbm_bytes_per_launch" in v:
+                    v.setdefault("uncorrected", v.get("hbm_bytes_per_launch_uncorrected", v["hbm_bytes_per_launch"]))
         if traffic is None and committed:
             traffic = committed.get(dominant, {}).get("hbm_bytes_per_launch")
             traffic_all = {k: v for k, v in committed.items() if isinstance(v, dict) and "hbm_bytes_per_launch" in v}

@@ -119,6 +119,14 @@ constexpr float kPairAreaRatio = 0.85f;           // two triangles share a leaf 
 struct alignas(16) BvhNode4 {
   uint32_t w[16];
 };
+// EXPERIMENT (-DGLZ_NODE48, tools/build_variant_full.sh): the same node in 48 bytes = three dwordx4 fetches --
+// child planes as 8-bit offsets from a per-node origin on the global grid, in cells of 2^e grid cells per axis (after Ylitie et al. 2017):
+//   w[0] = origin.x | origin.y << 16      w[1] = origin.z | ex << 16 | ey << 20 | ez << 24
+//   w[2 + 2 a + p] = planes of axis a for children 2 p and 2 p + 1: lo | hi << 8 | lo' << 16 | hi' << 24      w[8 + k] = link of child k
+// Made from the 64-byte nodes after the build (k_compress_nodes: boxes only grow); the default build does not carry it.
+struct alignas(16) BvhNode48 {
+  uint32_t w[12];
+};
 constexpr int kBvhEmptyChild = 0x7FFFFFFF;
 // Top of the tree, staged in LDS by the tracers ("node packets"): the root, its inner children and their inner children in
 // breadth-first order, at most kBvhTopNodes nodes (1 + 4 + 16).  Inside this table -- and in `cur` of a lane that sits on
@@ -208,6 +216,8 @@ struct DeviceScene {
   const float* srgb_lut;           // 256 entries
   const BvhNode4* bvh_nodes;
   const BvhNode4* bvh_top;         // kBvhTopNodes nodes: the top levels with links into the table flagged (kBvhTopFlag)
+  const BvhNode48* bvh_nodes48;    // -DGLZ_NODE48 builds only (null otherwise): the same nodes / staged top in the 48-byte format
+  const BvhNode48* bvh_top48;
   BvhGrid bvh_grid;
   const BvhTri* bvh_tris;
   const BvhQuad* bvh_quads;        // flattened build: one record per leaf, what trace_wave reads (null for two-level scenes)

@@ -84,6 +84,24 @@ __device__ __forceinline__ uint32_t box_key(uint32_t wx, uint32_t wy, uint32_t w
   const float t1 = fminf(fminf(tx.y, ty.y), fminf(tz.y, tmax));
   return (t0 <= t1 && (!CHECK_LINK || link != (uint32_t)kBvhEmptyChild)) ? ((__float_as_uint(t0) & 0xFFFFFFFCu) | k) : 0xFFFFFFFFu;
 }
+#ifdef GLZ_NODE48
+// EXPERIMENT: the slab test on a 48-byte node's child (types.h BvhNode48).  `word` holds the planes of one axis for two children as bytes
+// lo | hi << 8 | lo' << 16 | hi' << 24; the selector puts one of them into bits 8..15 of 0x47000000 -- the float 32768 + q -- and the
+// node-local ray (a = ig 2^e, c = (origin - ray origin) ig - 32768 a, made once per visit) turns it into a distance with one fma.
+constexpr uint32_t kSel48Lo = 0x030C040Cu, kSel48Hi = 0x030C050Cu;   // byte 0 / byte 1 of the word -> byte 1 of the float; ^ 0x0200: the odd child's
+__device__ __forceinline__ uint32_t box_key48(uint32_t wx, uint32_t wy, uint32_t wz, uint32_t k, uint32_t odd, SlabSel sel, vec3 a, vec3 c, float tmin, float tmax) {
+  const uint32_t sx = sel.x ^ odd, sy = sel.y ^ odd, sz = sel.z ^ odd;
+  const float nx = __uint_as_float(__builtin_amdgcn_perm(wx, kSlabMagic, sx)), fx = __uint_as_float(__builtin_amdgcn_perm(wx, kSlabMagic, sx ^ 0x0100u));
+  const float ny = __uint_as_float(__builtin_amdgcn_perm(wy, kSlabMagic, sy)), fy = __uint_as_float(__builtin_amdgcn_perm(wy, kSlabMagic, sy ^ 0x0100u));
+  const float nz = __uint_as_float(__builtin_amdgcn_perm(wz, kSlabMagic, sz)), fz = __uint_as_float(__builtin_amdgcn_perm(wz, kSlabMagic, sz ^ 0x0100u));
+  const f32x2 tx = __builtin_elementwise_fma(f32x2{nx, fx}, f32x2{a.x, a.x}, f32x2{c.x, c.x});
+  const f32x2 ty = __builtin_elementwise_fma(f32x2{ny, fy}, f32x2{a.y, a.y}, f32x2{c.y, c.y});
+  const f32x2 tz = __builtin_elementwise_fma(f32x2{nz, fz}, f32x2{a.z, a.z}, f32x2{c.z, c.z});
+  const float t0 = fmaxf(fmaxf(tx.x, ty.x), fmaxf(tz.x, tmin));
+  const float t1 = fminf(fminf(tx.y, ty.y), fminf(tz.y, tmax));
+  return t0 <= t1 ? ((__float_as_uint(t0) & 0xFFFFFFFCu) | k) : 0xFFFFFFFFu;
+}
+#endif
 // the addend of a plane distance: plane q (a float 32768 + q out of box_key) is crossed at t = (32768 + q) ig + grid_addend = q ig - og ig
 __device__ __forceinline__ float grid_addend(float og, float ig) { return fmaf(-32768.0f, ig, -(og * ig)); }
 
@@ -464,8 +482,13 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
   int pf_cur = -1;
   auto prefetch_node = [&]() {
     if (PREFETCH && cur >= 0 && !(cur & kBvhTopFlag)) {   // a node of the table in memory (staged nodes, kRayDone and kStolen carry bit 30)
+#ifdef GLZ_NODE48
+      const u32x4* np = reinterpret_cast<const u32x4*>(S.bvh_nodes48 + cur);
+      pf0 = np[0]; pf1 = np[1]; pf2 = np[2];
+#else
       const u32x4* np = reinterpret_cast<const u32x4*>(nodes + cur);
       pf0 = np[0]; pf1 = np[1]; pf2 = np[2]; pf3 = np[3];
+#endif
       pf_cur = cur;
     }
     // (The 64-byte record of a LEAF requested the same way, while the lane waits for the leaf phase's quorum: slower, a 1/8 share
@@ -654,6 +677,30 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
         // refill) and four links.  Children are entered nearest first; the others are pushed farthest first.
         // Nodes of the top levels come out of the block's LDS copy (their `cur` carries kBvhTopFlag | slot); lanes that read the
         // same staged node broadcast.
+#ifdef GLZ_NODE48
+        u32x4 w0, w1, w3;
+        if (kLdsTop && (cur & kBvhTopFlag)) {
+          LdsNodePtr np = top_lds + 3 * (cur & 0xFFFF);
+          w0 = np[0]; w1 = np[1]; w3 = np[2];
+        } else if (PREFETCH) {
+          if (pf_cur != cur) prefetch_node();
+          w0 = pf0; w1 = pf1; w3 = pf2;
+        } else {
+          const u32x4* np = reinterpret_cast<const u32x4*>(S.bvh_nodes48 + cur);
+          w0 = np[0]; w1 = np[1]; w3 = np[2];
+        }
+        if (COUNT) tally.nodes += 1;
+        float bound = best.t;
+        if (SHARE && !ANY && exhausted) bound = fminf(bound, __uint_as_float(aux_t[helper ? (int)ray : lane]));
+        // the node-local ray: planes are origin + q 2^e grid cells
+        const float ox = __uint_as_float(__builtin_amdgcn_perm(w0.x, kSlabMagic, kSlabSelLo)), oy = __uint_as_float(__builtin_amdgcn_perm(w0.x, kSlabMagic, kSlabSelHi)),
+                    oz = __uint_as_float(__builtin_amdgcn_perm(w0.y, kSlabMagic, kSlabSelLo));   // 32768 + origin
+        const vec3 na = mk3(ldexpf(ig.x, (int)((w0.y >> 16) & 15u)), ldexpf(ig.y, (int)((w0.y >> 20) & 15u)), ldexpf(ig.z, (int)((w0.y >> 24) & 15u)));
+        const vec3 nc = mk3(fmaf(-32768.0f, na.x, fmaf(ox, ig.x, cg.x)), fmaf(-32768.0f, na.y, fmaf(oy, ig.y, cg.y)), fmaf(-32768.0f, na.z, fmaf(oz, ig.z, cg.z)));
+        const SlabSel s48{ig.x < 0.0f ? kSel48Hi : kSel48Lo, ig.y < 0.0f ? kSel48Hi : kSel48Lo, ig.z < 0.0f ? kSel48Hi : kSel48Lo};
+        uint32_t k0 = box_key48(w0.z, w1.x, w1.z, 0u, 0u, s48, na, nc, tmin, bound), k1 = box_key48(w0.z, w1.x, w1.z, 1u, 0x0200u, s48, na, nc, tmin, bound);
+        uint32_t k2 = box_key48(w0.w, w1.y, w1.w, 2u, 0u, s48, na, nc, tmin, bound), k3 = box_key48(w0.w, w1.y, w1.w, 3u, 0x0200u, s48, na, nc, tmin, bound);
+#else
         u32x4 w0, w1, w2, w3;
         if (kLdsTop && (cur & kBvhTopFlag)) {
           LdsNodePtr np = top_lds + 4 * (cur & 0xFFFF);
@@ -676,6 +723,7 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
         if (SHARE && !ANY && exhausted) bound = fminf(bound, __uint_as_float(aux_t[helper ? (int)ray : lane]));   // positive floats order like their bits
         uint32_t k0 = box_key<false>(w0.x, w0.y, w0.z, w3.x, 0u, sel, ig, cg, cg, tmin, bound), k1 = box_key<false>(w0.w, w1.x, w1.y, w3.y, 1u, sel, ig, cg, cg, tmin, bound);
         uint32_t k2 = box_key<false>(w1.z, w1.w, w2.x, w3.z, 2u, sel, ig, cg, cg, tmin, bound), k3 = box_key<false>(w2.y, w2.z, w2.w, w3.w, 3u, sel, ig, cg, cg, tmin, bound);
+#endif
         sort2(k0, k1); sort2(k2, k3); sort2(k0, k2); sort2(k1, k3); sort2(k1, k2);
         // The links go through LDS: picking one of four registers by a per-lane index costs 6 VALU instructions (the
         // kernel's bottleneck), an LDS read at a computed address 2 (k_trace 0.714 -> 0.691 ms).  The scratch is laid out
@@ -1588,8 +1636,13 @@ struct ShadowSink {
 // copies the scene's top-of-tree table (types.h kBvhTopNodes) into the block's LDS; ends with a block barrier
 __device__ __forceinline__ void stage_top(const DeviceScene& S, uint4* s_top) {
   if (kLdsTop) {
+#ifdef GLZ_NODE48
+    const uint4* src = reinterpret_cast<const uint4*>(S.bvh_top48);
+    if (threadIdx.x < kBvhTopNodes * 3) s_top[threadIdx.x] = src[threadIdx.x];
+#else
     const uint4* src = reinterpret_cast<const uint4*>(S.bvh_top);
     if (threadIdx.x < kBvhTopNodes * 4) s_top[threadIdx.x] = src[threadIdx.x];
+#endif
     __syncthreads();
   }
 }

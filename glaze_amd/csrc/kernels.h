@@ -47,6 +47,10 @@ struct LbvhOutputs {
 hipError_t build_lbvh(hipStream_t st, const LbvhInputs& in, LbvhOutputs& out);
 // top-of-tree table for LDS staging (types.h kBvhTopNodes): `top` receives kBvhTopNodes nodes
 hipError_t launch_top_table(hipStream_t st, const BvhNode4* nodes, uint32_t n_nodes, BvhNode4* top);
+#ifdef GLZ_NODE48
+// experiment: 64-byte nodes -> 48-byte nodes (types.h BvhNode48), n of them
+hipError_t launch_compress_nodes(hipStream_t st, const BvhNode4* nodes, uint32_t n, BvhNode48* out);
+#endif
 // 128-byte per-leaf shading records (see k_shade_records); xf_identity[t] != 0 marks an exact identity transform
 hipError_t launch_shade_records(hipStream_t st, uint32_t n, const BvhTri* tris, const RTInstance* instances, const uint32_t* indices,
                                 const float4* vertices, const float4* derivatives, const uint32_t* xf_identity, float4* out);

@@ -1234,6 +1234,60 @@ __global__ void k_top_table(const BvhNode4* __restrict__ nodes, uint32_t n_nodes
     top[s] = nd;
   }
 }
+#ifdef GLZ_NODE48
+// 64-byte node -> 48-byte node: origin = the children's lowest planes less one cell, per-axis cell = the smallest power of two (in
+// grid cells) that spans the children in 253 steps, every plane moved outwards to the next cell and one more (the plane distances of
+// the tracer are exact to 2^-9 of a node cell, which at e >= 5 is more than the 1/16 grid cell the global boxes were padded by).
+__global__ void __launch_bounds__(256) k_compress_nodes(const BvhNode4* __restrict__ nodes, uint32_t n, BvhNode48* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const BvhNode4 nd = nodes[i];
+  BvhNode48 o;
+  uint32_t org[3], ex[3];
+  uint32_t lo[4][3], hi[4][3];
+  bool used[4];
+  for (int k = 0; k < 4; ++k) {
+    used[k] = nd.w[12 + k] != (uint32_t)kBvhEmptyChild;
+    for (int a = 0; a < 3; ++a) { lo[k][a] = nd.w[3 * k + a] & 0xFFFFu; hi[k][a] = nd.w[3 * k + a] >> 16; }
+  }
+  for (int a = 0; a < 3; ++a) {
+    uint32_t mn = 0xFFFFu, mx = 0u;
+    for (int k = 0; k < 4; ++k)
+      if (used[k]) { mn = min(mn, lo[k][a]); mx = max(mx, hi[k][a]); }
+    if (mn > mx) { mn = 0; mx = 0; }
+    uint32_t e = 0;
+    while (e < 15u && (mx - mn) > (253u << e)) ++e;
+    const uint32_t cell = 1u << e;
+    org[a] = mn >= cell ? mn - cell : 0u;
+    if ((mx - org[a] + cell - 1u) / cell + 1u > 255u) { ++e; org[a] = mn >= (1u << e) ? mn - (1u << e) : 0u; }
+    ex[a] = e;
+  }
+  o.w[0] = org[0] | (org[1] << 16);
+  o.w[1] = org[2] | (ex[0] << 16) | (ex[1] << 20) | (ex[2] << 24);
+  for (int a = 0; a < 3; ++a)
+    for (int p2 = 0; p2 < 2; ++p2) {
+      uint32_t word = 0;
+      for (int h = 0; h < 2; ++h) {
+        const int k = 2 * p2 + h;
+        uint32_t bl = 255u, bh = 0u;   // an unused slot: an inverted box, as in the 64-byte format
+        if (used[k]) {
+          const uint32_t l = (lo[k][a] - org[a]) >> ex[a], u = ((hi[k][a] - org[a]) + (1u << ex[a]) - 1u) >> ex[a];
+          bl = l > 0u ? l - 1u : 0u;
+          bh = min(u + 1u, 255u);
+        }
+        word |= (bl | (bh << 8)) << (16 * h);
+      }
+      o.w[2 + 2 * a + p2] = word;
+    }
+  for (int k = 0; k < 4; ++k) o.w[8 + k] = nd.w[12 + k];
+  out[i] = o;
+}
+hipError_t launch_compress_nodes(hipStream_t st, const BvhNode4* nodes, uint32_t n, BvhNode48* out) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_compress_nodes, dim3((n + 255) / 256), dim3(256), 0, st, nodes, n, out);
+  return hipGetLastError();
+}
+#endif
 hipError_t launch_top_table(hipStream_t st, const BvhNode4* nodes, uint32_t n_nodes, BvhNode4* top) {
   hipLaunchKernelGGL(k_top_table, dim3(1), dim3(64), 0, st, nodes, n_nodes, top);
   return hipGetLastError();

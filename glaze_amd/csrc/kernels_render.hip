@@ -51,7 +51,11 @@ __global__ void __launch_bounds__(kShadeBlock, GLZ_SHADE_WAVES) k_shade(const La
   __shared__ float4 s_hit[kShadeBlock];   // hit records read by the regrouping prologue, handed to the thread that shades the pixel
 #endif
   const uint32_t n_sky = 3u * (A.scene.sky_header.marginal_cdf_count - 1u) + 1u;
+#ifndef GLZ_SHADE_NO_SKY_LDS
   const bool sky_in_lds = A.scene.sky_header.marginal_cdf_count > 1u && n_sky <= kSkyLdsFloats;
+#else
+  const bool sky_in_lds = false;
+#endif
   if (threadIdx.x < 256u) s_lut[threadIdx.x] = A.scene.srgb_lut[threadIdx.x];
   if (sky_in_lds)
     for (uint32_t i = threadIdx.x; i < n_sky; i += kShadeBlock) s_sky[i] = A.scene.sky_marginal[i];

@@ -888,6 +888,16 @@ bool Scene::build_bvh(Error& err) {
   if (!d_top_.ptr && !hip_ok(d_top_.alloc(kBvhTopNodes), "alloc BVH top table", err)) return false;
   if (!hip_ok(launch_top_table(st, d_nodes_.ptr, out.n_nodes, d_top_.ptr), "k_top_table", err)) return false;
   dev.bvh_top = d_top_.ptr;
+  dev.bvh_nodes48 = nullptr;
+  dev.bvh_top48 = nullptr;
+#ifdef GLZ_NODE48
+  if (!hip_ok(d_nodes48_.alloc(out.n_nodes), "alloc 48-byte nodes", err) || !hip_ok(d_top48_.alloc(kBvhTopNodes), "alloc 48-byte top table", err) ||
+      !hip_ok(launch_compress_nodes(st, d_nodes_.ptr, out.n_nodes, d_nodes48_.ptr), "k_compress_nodes", err) ||
+      !hip_ok(launch_compress_nodes(st, d_top_.ptr, kBvhTopNodes, d_top48_.ptr), "k_compress_nodes (top)", err))
+    return false;
+  dev.bvh_nodes48 = d_nodes48_.ptr;
+  dev.bvh_top48 = d_top48_.ptr;
+#endif
   dev.bvh_grid = out.grid;
   for (int k = 0; k < 3; ++k) {
     info.bvh_grid_lo[k] = out.grid.lo[k];
