@@ -263,17 +263,26 @@ struct HitRecord {
 // at the tail of trace_wave); pop_live() skips such entries.
 constexpr int kRayDone = 0x7FFFFFFF;   // `cur` of a lane without a node to visit (inner nodes are >= 0, leaves < 0)
 constexpr int kStolen = 0x7FFFFFFE;
+// The LDS column is addressed through a pointer that KEEPS its address space: with a generic pointer the compiler turned pop() -- LDS
+// level or spilt level -- into ONE flat_load_dword behind a pointer select, i.e. every pop of the traversal went through the flat path
+// and waited for vmcnt(0) AND lgkmcnt(0) (with it all of the lane's loads in flight): the largest single piece of a node iteration
+// (tools/gpu_sections.py, round 4: ~1 000 of ~2 400 clocks on an otherwise idle chip).  The staged top of the tree had the same
+// problem in round 2 (LdsNodePtr).
+typedef __attribute__((address_space(3))) int* LdsIntPtr;
 struct Stack {
-  int* lds;             // &s_stack[threadIdx.x]
+  LdsIntPtr lds;        // &s_stack[threadIdx.x]
   uint32_t* spill;      // overflow words of this lane
   int sp;
+  __device__ __forceinline__ Stack(int* lds_column, uint32_t* spill_words, int sp0) : lds((LdsIntPtr)lds_column), spill(spill_words), sp(sp0) {}
   __device__ __forceinline__ void push(int v) {
     if (sp < kLdsStack) lds[sp * kBlock] = v; else spill[sp - kLdsStack] = (uint32_t)v;
     ++sp;
   }
   __device__ __forceinline__ int pop() {
     --sp;
-    return sp < kLdsStack ? lds[sp * kBlock] : (int)spill[sp - kLdsStack];
+    int v;
+    if (__builtin_expect(sp < kLdsStack, 1)) v = lds[sp * kBlock]; else v = (int)spill[sp - kLdsStack];   // two loads of two address spaces: not to be merged
+    return v;
   }
   // Hand-overs take the OLDEST live entry of a stack (the lowest level, aux_sb) and move that mark up by one, so the stolen entries are
   // one run at the bottom: a pop that finds kStolen has found the end of the lane's own work -- everything below is stolen as well.
