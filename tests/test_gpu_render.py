@@ -692,6 +692,70 @@ def test_full_size_mattest_1024_tiles_vs_oracle(instance, mattest_desc):
     _assert_tiles_bit_equal(r, o, w, h, tiles, "mattest 1024^2")
 
 
+@pytest.mark.parametrize("mtype", [abi.MAT_LAMBERT, abi.MAT_GLASS, abi.MAT_MIRROR, abi.MAT_METAL, abi.MAT_UBER])
+def test_full_size_mattest_1024_outer_material_overrides(instance, mattest_desc, mtype):
+    """Config 3 AT ITS SIZE for each of the five BSDF overrides BASELINE names (OuterMat = material 4, as glaze-app changes it
+    interactively -- here through update_materials_and_lights on the live renderer of the parsed file): 1024 x 1024, depth 8, the whole
+    frame on the GPU, eight sampled tiles per material on the oracle, bit for bit (accumulator, out32, NaN sets, RGBA8)."""
+    w = h = 1024
+    launches = 17
+    desc = mattest_desc.copy()
+    desc.materials[4].mtype = mtype
+    gpu_scene = glaze_amd.RayTraceScene.new(instance, glaze_amd.parse(MATTEST))
+    r = glaze_amd.RayTraceRenderer.new(instance, gpu_scene, w, h)
+    r.set_depth(8)
+    r.step(3)
+    r.update_materials_and_lights(desc.materials, desc.lights)      # restarts the accumulation (raytracer.rs:268-326)
+    r.step(launches)
+    tiles = _sample_tiles(w, h, 4, 10 + mtype)
+    assert len(tiles) >= 6
+    o = OracleRenderer(OracleScene(desc), w, h)
+    o.set_depth(8)
+    o.set_exposure(desc.meta.exposure)
+    o.set_tiles(tiles)
+    o.step(launches)
+    m = _tile_mask(w, h, tiles)
+    g, c = r.read_hdr(), o.read_hdr()
+    assert ((g[m].view(np.uint32) == c[m].view(np.uint32)) | (np.isnan(g[m]) & np.isnan(c[m]))).all(), "mattest 1024^2 OuterMat=%d differs from the oracle" % mtype
+    gr, cr = r.read_result()[m], o.read_result()[m]
+    assert ((gr.view(np.uint32) == cr.view(np.uint32)) | (np.isnan(gr) & np.isnan(cr))).all()
+    assert np.array_equal(r.read_rgba8()[m], o.read_rgba8()[m])
+
+
+@pytest.mark.parametrize("size", [(512, 512), (512, 513), (513, 512)])
+def test_full_size_cube_config2_on_both_sides_of_the_residency_boundary(instance, size):
+    """Config 2 AT ITS SIZE: the cube, Lambert, omni light, 512 x 512, depth 2.  262 144 pixels are exactly the 4 096 groups of 64 that
+    get a resident wave each, the boundary at which the automatic mode takes the per-wave launch loop (k_path); one more row or column of
+    pixels (512 x 513: a ninth, 1-pixel-high row of tiles; 513 x 512: a ninth column) is on the other side of it and runs as two
+    kernels per launch.  Both against the oracle on sampled tiles, 24 launches = 12 spp, and against each other where they overlap."""
+    w, h = size
+    launches = 24
+    desc = cube_scene()
+    r = glaze_amd.RayTraceRenderer.new(instance, glaze_amd.RayTraceScene.from_desc(instance, desc), w, h)
+    r.set_depth(2)
+    assert r.launch_mode() == ("path" if (w, h) == (512, 512) else "two_kernels")
+    r.step(launches)
+    n_tiles = ((w + 63) // 64) * ((h + 63) // 64)
+    tiles = sorted(set(_sample_tiles(w, h, 6, w + h)) | {n_tiles - 1, ((w + 63) // 64) - 1})        # the ragged corner tiles among them
+    o = OracleRenderer(OracleScene(desc), w, h)
+    o.set_depth(2)
+    o.set_tiles(tiles)
+    o.step(launches)
+    m = _tile_mask(w, h, tiles)
+    g, c = r.read_hdr(), o.read_hdr()
+    assert m.sum() >= 6 * 4096 // 2
+    assert ((g[m].view(np.uint32) == c[m].view(np.uint32)) | (np.isnan(g[m]) & np.isnan(c[m]))).all(), "cube %dx%d differs from the oracle" % size
+    assert (g[..., 3] == launches).all()
+    assert np.array_equal(r.read_rgba8()[m], o.read_rgba8()[m])
+    # the other launch mode renders the same frame bit for bit
+    other = "two_kernels" if r.launch_mode() == "path" else "path"
+    r2 = glaze_amd.RayTraceRenderer.new(instance, glaze_amd.RayTraceScene.from_desc(instance, desc), w, h)
+    r2.set_launch_mode(other)
+    r2.set_depth(2)
+    r2.step(launches)
+    assert np.array_equal(r2.read_hdr().view(np.uint32), g.view(np.uint32))
+
+
 def test_full_size_atrium_1080p_tiles_vs_oracle(instance, atrium_file):
     """Config 4, what bench.py measures: the Sponza-class atrium as a .glaze file through the product's parse, 1920 x 1080 (30 x 17
     tiles, the bottom row 56 pixels high), depth 8; the oracle renders the sampled tiles from its own reading of the same file."""
