@@ -38,6 +38,11 @@ bool png_check(const uint8_t* data, size_t size, uint32_t& width, uint32_t& heig
       height = be32(body + 4);
       if (body[10] != 0 || body[11] != 0) { err = "png: unknown compression/filter method"; return false; }
       if (body[12] != 0) { err = "png: interlaced images are not supported"; return false; }
+      {   // the colour types and bit depths png_decode takes: a level that could not be decoded later is rejected at parse, like level 0
+        const unsigned depth = body[8], ctype = body[9];
+        if (!(ctype == 0 || ctype == 2 || ctype == 3 || ctype == 4 || ctype == 6)) { err = "png: bad colour type"; return false; }
+        if (!(depth == 8 || depth == 16) || (ctype == 3 && depth != 8)) { err = "png: unsupported bit depth"; return false; }
+      }
       have_ihdr = true;
     } else if (!memcmp(type, "IDAT", 4)) {
       have_idat = true;

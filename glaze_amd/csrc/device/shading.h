@@ -119,12 +119,10 @@ GLZ_D vec4 bilinear_level(const DeviceScene& S, const TexDesc& t, const uint8_t*
   if (t.format & kTexInline) {
     ta = tb = tc = tdx = t.offset;   // same arithmetic below, so NaN coordinates still give what four equal texels give
   } else {
-#ifndef GLZ_NO_TEX_COUNTER
     if (S.tex_counter) {   // counting pass: one fetch = four texels (the thread's own tallies, flushed once per wave at the kernel's end)
       S.tex_counter[0] += 1ull;
       S.tex_counter[1] += format == GLZ_TEX_GRAY ? 4ull : 16ull;
     }
-#endif
     const int x0 = wrap_coord((int)iu, (int)t.width), y0 = wrap_coord((int)iv, (int)t.height);
     const int x1 = wrap_coord((int)iu + 1, (int)t.width), y1 = wrap_coord((int)iv + 1, (int)t.height);
     if (format != GLZ_TEX_GRAY && x1 == x0 + 1 && (x0 & 7) != 7) {
@@ -663,11 +661,9 @@ GLZ_D float sample_cdf(float xi, int size, Fetch fetch, uint32_t& offset_out) {
 GLZ_D void sample_light(const DeviceScene& S, uint32_t light_index, vec3 p, vec3 xi, float scene_radius, LightSample& out) {
   const RTLight* L = &S.lights[light_index];
   const uint32_t kind = L->shader;
-#ifndef GLZ_NO_TEX_COUNTER
   if (S.tex_counter) {   // counting pass
     if (kind == kLightOmni || kind == kLightSun || kind == kLightArea) S.tex_counter[2] += 1ull; else S.tex_counter[3] += 1ull;
   }
-#endif
   out.kind = kind;
   out.light = L;
   out.k = 1.0f;

@@ -1,0 +1,44 @@
+// Every compile-time switch of the render kernels, in one place.  tools/build_variant.sh NAME "-DGLZ_X=..." builds a library with one
+// of them changed (variants/libglaze_hip_NAME.so, selected at run time with GLAZE_HIP_LIB); the product is built with the defaults.
+// What each value was measured against is in EXPERIMENTS.md; switches whose experiment ended in "no" are gone from the sources
+// (rounds 1-3 carried 37 of them), their result is in EXPERIMENTS.md as well.
+//
+//   switch                 default  what
+//   ---------------------  -------  ----------------------------------------------------------------------------------------------
+//   GLZ_TRACE_WAVES           6     waves per SIMD k_trace is compiled for (80 VGPRs)
+//   GLZ_TRACE_TL_WAVES        4     ... the two-level tracer (128 VGPRs)
+//   GLZ_SHADE_WAVES           4     ... k_shade (128 VGPRs)
+//   GLZ_PATH_WAVES            4     ... k_path (128 VGPRs)
+//   GLZ_REFILL               16     idle lanes at which a wave takes new rays
+//   GLZ_LEAF_QUORUM          24     lanes waiting on a leaf at which the inner-node phase ends
+//   GLZ_TL_LEAF_QUORUM       32     the same for the two-level tracer (a leaf visit there is an instance entry: dearer)
+//   GLZ_PATH_PREFETCH         1     k_path: the next node's loads issued as soon as the node is known (trace_wave<PREFETCH>)
+//   GLZ_NODE48               off    EXPERIMENT: 48-byte nodes (types.h BvhNode48; tools/build_variant_full.sh: scene.cpp needs it too)
+//   GLZ_WAVE_TIMES           off    instrumentation: per-wave time stamps of k_trace            (tools/gpu_wave_times.py)
+//   GLZ_PATH_TIMES           off    instrumentation: per-wave tracing / shading time of k_path  (tools/gpu_path_phases.py)
+//   GLZ_SECTION_TIMES        off    instrumentation: clocks per part of trace_wave's round; = 2: the node visit in pieces too (tools/gpu_sections.py)
+#pragma once
+#ifndef GLZ_TRACE_WAVES
+#define GLZ_TRACE_WAVES 6
+#endif
+#ifndef GLZ_TRACE_TL_WAVES
+#define GLZ_TRACE_TL_WAVES 4
+#endif
+#ifndef GLZ_SHADE_WAVES
+#define GLZ_SHADE_WAVES 4
+#endif
+#ifndef GLZ_PATH_WAVES
+#define GLZ_PATH_WAVES 4
+#endif
+#ifndef GLZ_REFILL
+#define GLZ_REFILL 16
+#endif
+#ifndef GLZ_LEAF_QUORUM
+#define GLZ_LEAF_QUORUM 24
+#endif
+#ifndef GLZ_TL_LEAF_QUORUM
+#define GLZ_TL_LEAF_QUORUM 32
+#endif
+#ifndef GLZ_PATH_PREFETCH
+#define GLZ_PATH_PREFETCH 1
+#endif

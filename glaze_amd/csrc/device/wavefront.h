@@ -8,6 +8,7 @@
 
 #include "device/math.h"
 #include "device/shading.h"
+#include "device/tuning.h"
 #include "device/types.h"
 #include "kernels.h"
 
@@ -331,33 +332,11 @@ struct TraceTally {
 // Sink:   void store(uint32_t ray, const HitRecord&)
 // lds_col: this lane's stack column; aux: this WAVE's 3 x 64 ints of LDS scratch (helpers per owner, donor list, stack bottoms)
 // ---------------------------------------------------------------------------------------------
-#ifndef GLZ_TRACE_WAVES
-#define GLZ_TRACE_WAVES 6   // waves per SIMD the tracers are compiled for (__launch_bounds__): 80 VGPRs; 7 waves (72 VGPRs) spills 40 registers with the 64-byte nodes and measured 5 % slower
-#endif
-#ifndef GLZ_REFILL
-#define GLZ_REFILL 16
-#endif
-#ifndef GLZ_LEAF_QUORUM
-#define GLZ_LEAF_QUORUM 24   // round 3 (watertight triangle test, 15-bit grid): 12 / 16 / 20 / 24 / 32 -> 0.571 / 0.554 / 0.542 / 0.541 / 0.557 ms per k_trace; earlier: 4-wide nodes: 8 -> 0.815, 12 -> 0.790, 16 -> 0.781, 24 -> 0.810 ms per k_trace; with pair leaves 8 / 12 / 16 / 24 / 32 -> 0.650 / 0.606 / 0.589 / 0.583 / 0.598
-#endif
-#ifndef GLZ_LDS_TOP
-#define GLZ_LDS_TOP 1   // 1: the top kBvhTopNodes nodes of the tree are fetched from a per-block LDS copy ("LDS-staged node packets"), 0: every node from global memory
-#endif
-constexpr bool kLdsTop = GLZ_LDS_TOP != 0;
+// (thresholds: device/tuning.h.  Leaf quorum: 12 / 16 / 20 / 24 / 32 lanes -> 0.571 / 0.554 / 0.542 / 0.541 / 0.557 ms per k_trace;
+// the tail of a small share and the shadow rays have the same optimum.)
+constexpr bool kLdsTop = true;   // the top kBvhTopNodes nodes of the tree come from a per-block LDS copy ("LDS-staged node packets")
 constexpr int kRefill = GLZ_REFILL;
 constexpr int kLeafQuorum = GLZ_LEAF_QUORUM;
-#ifndef GLZ_REFILL_ANY
-#define GLZ_REFILL_ANY GLZ_REFILL
-#endif
-#ifndef GLZ_LEAF_QUORUM_ANY
-#define GLZ_LEAF_QUORUM_ANY GLZ_LEAF_QUORUM
-#endif
-#ifndef GLZ_SHARE_REPS
-#define GLZ_SHARE_REPS 1   // hand-overs per donor and node iteration while idle lanes are left: 1 / 2 / 3 -> 0.145 / 0.148 / 0.152 ms per launch of a 1/8 share (each costs its shuffles)
-#endif
-#ifndef GLZ_LEAF_QUORUM_TAIL
-#define GLZ_LEAF_QUORUM_TAIL GLZ_LEAF_QUORUM   // once the wave's sequence is exhausted (a small share of the frame: from the first round on); 4 / 8 / 16 / 24 / 32 -> 0.172 / 0.159 / 0.152 / 0.152 / 0.155 ms per launch of a 1/8 share: the same optimum
-#endif
 constexpr int kAuxPerWave = 3 * 64 + 4 * 64;   // work sharing (3 x 64) + the four child links of the node a lane is visiting
 
 // The SIMD issues its OLDEST ready wave first, and the tracers are bound by VALU issue: with one priority for all, the waves of the
@@ -368,12 +347,7 @@ constexpr int kAuxPerWave = 3 * 64 + 4 * 64;   // work sharing (3 x 64) + the fo
 // (only for shares that give a wave at least two whole groups, see `rotate` in trace_wave).
 // (Per node iteration instead of per round, keyed by the hardware wave slot instead of the block index, every second round: the
 // same; every fourth round 0.523; priority by the wave's own progress -- groups behind first -- 0.545; the youngest first 0.566.)
-#ifndef GLZ_PRIO_ROTATE
-#define GLZ_PRIO_ROTATE 1
-#endif
-#ifndef GLZ_PRIO_PERIOD6
-#define GLZ_PRIO_PERIOD6 1   // six waves per SIMD, four levels: a cycle of six turns (3 2 2 1 1 0) instead of four (where waves four turns apart always tie and the older one wins): 0.514 -> 0.509 ms
-#endif
+// Six waves per SIMD, four levels: a cycle of six turns 3 2 2 1 1 0 (with four turns, waves four apart always tie and the older one wins: 0.514 -> 0.509 ms).
 __device__ __forceinline__ void rotate_priority(uint32_t turn) {
   const uint32_t p = turn & 3u;   // s_setprio takes an immediate
   if (p == 0u) __builtin_amdgcn_s_setprio(0); else if (p == 1u) __builtin_amdgcn_s_setprio(1); else if (p == 2u) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(3);
@@ -392,32 +366,18 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(3))) u32x4* LdsNodePtr;
 
 // The rays a wave works through, in the order it takes them (all wave-uniform but the position asked for): the 64-ray groups are
-// dealt round-robin, group g to wave g % n_waves.  The rays left over after the whole rounds can be dealt in smaller pieces
-// (GLZ_PIECE_SHIFT < 6) so that every wave gets the same share of them -- a full frame leaves a quarter of the waves with a sixth
-// group and lasts as long as those, and a share with fewer groups than waves fills some waves and leaves the rest empty.  Measured
-// with pieces of 16: the full frame 0.932 -> 0.951 ms per launch, a 1/4 share 0.252 -> 0.343, a 1/8 share 0.148 -> 0.214 (8 and 32
-// likewise).  A wave's iteration costs the same whatever the number of its lanes that work, and the SIMDs are shared: the same rays
-// in more, emptier waves are slower even when there are waves to spare.  So whole groups it is.
-#ifndef GLZ_PIECE_SHIFT
-#define GLZ_PIECE_SHIFT 6
-#endif
+// dealt round-robin, group g to wave g % n_waves.  (Dealing the left-over rays in pieces smaller than a group, so that every wave gets
+// the same share of them, is slower everywhere -- a wave's iteration costs the same whatever the number of its lanes that work:
+// EXPERIMENTS.md.)
 struct RaySequence {
-  static constexpr uint32_t kPieceShift = GLZ_PIECE_SHIFT, kPiece = 1u << GLZ_PIECE_SHIFT;
   uint32_t wave, n_waves, total;
-  uint32_t own_full;     // rays this wave takes in whole groups
-  uint32_t piece_base;   // first ray that is dealt in pieces
+  uint32_t own_full;     // rays this wave takes in whole rounds of the deal (a last, partial round may add one more group)
   __device__ __forceinline__ RaySequence(uint32_t wave_, uint32_t n_waves_, uint32_t total_) : wave(wave_), n_waves(n_waves_), total(total_) {
-    const uint32_t full_rounds = ((total + 63u) >> 6) / n_waves;
-    own_full = full_rounds * 64u;
-    piece_base = full_rounds * n_waves * 64u;
+    own_full = (((total + 63u) >> 6) / n_waves) * 64u;
   }
   // ray at position `pos` of this wave's sequence; >= total: the sequence has ended (ray_at is monotonic in pos)
   // (A wave's groups neighbours of EACH OTHER -- groups 6 w .. 6 w + 5 -- instead of its block-mates': k_trace 0.510 -> 0.561 ms.)
-  __device__ __forceinline__ uint32_t ray_at(uint32_t pos) const {
-    if (pos < own_full) return (wave + (pos >> 6) * n_waves) * 64u + (pos & 63u);
-    const uint32_t q = pos - own_full;
-    return piece_base + (wave + (q >> kPieceShift) * n_waves) * kPiece + (q & (kPiece - 1u));
-  }
+  __device__ __forceinline__ uint32_t ray_at(uint32_t pos) const { return (wave + (pos >> 6) * n_waves) * 64u + (pos & 63u); }
 };
 
 #ifdef GLZ_SECTION_TIMES   // tuning builds only (tools/gpu_sections.py): shader clocks every wave spent in each part of trace_wave's round, and how often
@@ -512,13 +472,13 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
 #endif
   // issue-priority rotation (rotate_priority above); k_path's MIXED pass keeps the priority its own kernel set
   // (inside k_path's mixed pass as well: a 1/4 share 0.276 -> 0.263 ms per launch, 1/8 0.1456 -> 0.1449, 1/16 0.118 -> 0.123)
-  constexpr bool ROTATE = GLZ_PRIO_ROTATE != 0 && !MIXED;
+  constexpr bool ROTATE = !MIXED;
   const uint32_t prio_gen = (blockIdx.x * 6u) / gridDim.x;   // which sixth of the grid: the order the blocks of a CU were dispatched in
   uint32_t prio_round = 0;
   // ---- share: idle lanes adopt the oldest pending subtree of a busy lane (called before every node iteration, see below) ----
   auto share_step = [&]() {
   if (SHARE && exhausted)
-  for (int rep = 0; rep < GLZ_SHARE_REPS; ++rep) {
+  for (int rep = 0; rep < 1; ++rep) {   // (more than one hand-over per donor and node iteration costs more in shuffles than it gains: 0.145 / 0.148 / 0.152 ms for 1 / 2 / 3)
     bool more = false;
     const bool busy = open || helper;
     const unsigned long long idle_m = __ballot(!busy);
@@ -589,14 +549,10 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
     wt_helper_rounds += __ballot(helper) != 0ull;
     wt_wait_rounds += __ballot(open && cur == kRayDone) != 0ull && __ballot(open && cur != kRayDone) == 0ull;   // owners only waiting for helpers
 #endif
-#if GLZ_PRIO_PERIOD6
-    if (ROTATE && rotate) {   // six waves per SIMD, four levels: a cycle of six turns 3 2 2 1 1 0 instead of 3 2 1 0 (where waves four turns apart always tie and the older wins)
+    if (ROTATE && rotate) {   // six waves per SIMD, four levels: a cycle of six turns 3 2 2 1 1 0
       const uint32_t pos = (prio_gen + prio_round++) % 6u;
       rotate_priority(pos == 0u ? 3u : (pos < 3u ? 2u : (pos < 5u ? 1u : 0u)));
     }
-#else
-    if (ROTATE && rotate) rotate_priority(prio_gen + prio_round++);
-#endif
 #ifdef GLZ_SECTION_TIMES
     sec_rounds += 1;
 #endif
@@ -604,7 +560,7 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
     // ---- refill ----
     const unsigned long long idle = __ballot(!(open || helper));
     const int n_idle = __popcll(idle);
-    if (!exhausted && n_idle >= (ANY ? GLZ_REFILL_ANY : kRefill)) {
+    if (!exhausted && n_idle >= kRefill) {
       if (COUNT && lane == 0) { tally.refill_iters += 1; tally.refill_lanes += (unsigned)n_idle; }
       const uint32_t next_ray = rays.ray_at(seq + (uint32_t)__popcll(idle & lanes_below));
       if (!open && next_ray < total) {
@@ -641,38 +597,19 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
       continue;
     }
     // ---- inner-node phase ----
-#ifdef GLZ_SHARE_ONCE_PER_ROUND
-    bool first_iter = true;
-#endif
-#ifdef GLZ_SHARE_EVERY
-    uint32_t share_turn = 0;
-#endif
     for (;;) {
       // Idle lanes take over pending subtrees before EVERY node iteration of the tail, not once per round: a round is several
       // iterations long, and with one hand-over per round the helpers of a long ray multiplied too slowly to matter before it
       // was over (a 1/8 share: 0.153 -> 0.147 ms per launch; the full frame, where only each wave's last group is a tail: 0.930 -> 0.914).
-#ifndef GLZ_SHARE_ONCE_PER_ROUND
+      // (Every 2nd / 3rd node iteration instead: a 1/8 share 0.1352 -> 0.1382 / 0.1404 ms per launch.)
       GLZ_SEC_STAMP(sec_ctl);
-#ifdef GLZ_SHARE_EVERY
-      if (share_turn++ % GLZ_SHARE_EVERY == 0u)   // (every 2nd / 3rd node iteration instead of every one: a 1/8 share 0.1352 -> 0.1382 / 0.1404 ms per launch)
-#endif
       share_step();
       GLZ_SEC_STAMP(sec_share);
-#else
-      if (first_iter) share_step();
-      first_iter = false;
-#endif
       // (Reading the first word of the triangle as soon as a lane of the tail arrives at a leaf, so that the line is on its way while
       // the others finish their node iterations: slower, 0.146 -> 0.149 ms for a 1/8 share and 0.905 -> 0.924 ms for the full frame.)
       const bool at_node = cur >= 0 && cur < kStolen;
       const unsigned long long m_node = __ballot(at_node);
       if (m_node == 0ull) break;
-#ifdef GLZ_TAIL_PRIO
-      // a wave down to its last few rays is on the launch's critical path and uses little of the SIMD: let it issue first
-      if (SHARE && exhausted) {
-        if (__popcll(m_node) <= GLZ_TAIL_PRIO) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
-      }
-#endif
       if (COUNT && lane == 0) { tally.node_iters += 1; tally.node_lanes += (unsigned)__popcll(m_node); }
 #ifdef GLZ_WAVE_TIMES
       wt_node_iters += 1; wt_node_lanes += (unsigned)__popcll(m_node);
@@ -724,7 +661,7 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
           // 8-bit boxes relative to a per-node origin -- would buy about that and pay ~12 VALU instructions per visit for it.)
         }
         if (COUNT) tally.nodes += 1;
-#ifdef GLZ_SECTION_FINE
+#if defined(GLZ_SECTION_TIMES) && GLZ_SECTION_TIMES >= 2   // -DGLZ_SECTION_TIMES=2: the node visit in pieces
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         GLZ_SEC_STAMP(sec_f0);   // the node's words are here
 #endif
@@ -740,7 +677,7 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
         // 16-byte store put lanes l, l + 8, l + 16, l + 24 of a half-wave on the same banks: 4.6 M conflict cycles per launch,
         // 22 % of the LDS-active cycles), and all four sorted links are fetched before the first one is used: the reads
         // are independent, so one LDS round trip covers them instead of one per push (read -> wait -> write, four times over).
-#ifdef GLZ_SECTION_FINE
+#if defined(GLZ_SECTION_TIMES) && GLZ_SECTION_TIMES >= 2   // -DGLZ_SECTION_TIMES=2: the node visit in pieces
         asm volatile("" : "+v"(k0), "+v"(k1), "+v"(k2), "+v"(k3));
         GLZ_SEC_STAMP(sec_f1);   // box tests and sort
 #endif
@@ -750,7 +687,7 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
         // (Three unconditional stores with the stack pointer advancing by one per valid key -- the invalid links of the sorted
         // sequence are overwritten by the next store or stay above the top -- remove 12 scalar / branch instructions per round
         // and measured slower, 0.587 -> 0.597 ms: the extra DS stores cost more than the exec-mask branches.)
-#ifdef GLZ_SECTION_FINE
+#if defined(GLZ_SECTION_TIMES) && GLZ_SECTION_TIMES >= 2   // -DGLZ_SECTION_TIMES=2: the node visit in pieces
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         GLZ_SEC_STAMP(sec_f2);   // links through LDS
 #endif
@@ -775,7 +712,7 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
       if (!PREFETCH) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the visit's loads and LDS traffic are charged to the visit
 #endif
       GLZ_SEC_STAMP(sec_node);
-      if (__popcll(__ballot(cur < 0)) >= (exhausted ? GLZ_LEAF_QUORUM_TAIL : (ANY ? GLZ_LEAF_QUORUM_ANY : kLeafQuorum))) break;
+      if (__popcll(__ballot(cur < 0)) >= kLeafQuorum) break;
       // (Postponed leaves -- a lane parks the first leaf it arrives at and goes on with its stack, blocks at the second, the parked
       // leaves are tested first in the next leaf phase; Aila & Laine's speculative traversal -- k_trace 0.512 -> 0.540 ms with the
       // leaf phase at 24 waiting lanes, 0.542 / 0.555 at 16 / 32: the visits made without the parked leaf's bound and the second
@@ -878,9 +815,6 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
       open = false;
     }
   }
-#ifdef GLZ_TAIL_PRIO
-  if (SHARE) __builtin_amdgcn_s_setprio(0);
-#endif
   if (ROTATE) __builtin_amdgcn_s_setprio(0);
 #ifdef GLZ_SECTION_TIMES
   {
@@ -916,30 +850,16 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
 // measured: bit-identical, and slower everywhere, forest x 200 0.820 -> 0.864 ms per launch, a 1/8 share 0.160 -> 0.180; once per
 // round instead of per node iteration 0.856 / 0.174.  A stolen top-level subtree costs its helper instance entries that the owner,
 // with the bound of the hit it finds first, mostly never makes.)
-// Simpler than trace_wave on purpose (no tail work sharing; the staged top is built in and off, GLZ_TL_LDS_TOP): instanced scenes are about memory -- O(meshes + instances) instead of
+// Simpler than trace_wave on purpose (no tail work sharing; the staged top is built in and off, kTlLdsTop): instanced scenes are about memory -- O(meshes + instances) instead of
 // O(instances x triangles) -- and must not put the tuned flattened path at risk.
 // ---------------------------------------------------------------------------------------------
 constexpr int kExitInstance = 0x7FFFFFFD;   // stack marker: the entries below belong to the top level
 // refill / leaf-phase thresholds of the two-level tracer (lanes): defaults = the flattened tracer's
-#ifndef GLZ_TL_REFILL
-#define GLZ_TL_REFILL GLZ_REFILL
-#endif
-#ifndef GLZ_TL_REFILL_ANY
-#define GLZ_TL_REFILL_ANY GLZ_REFILL
-#endif
-#ifndef GLZ_TL_LEAF_QUORUM
-#define GLZ_TL_LEAF_QUORUM 32   // 8 / 16 / 24 / 32 / 40 / 48 -> 0.993 / 0.889 / 0.844 / 0.825 / 0.822 / 0.835 ms per launch (forest x 200, flattened 0.672): a leaf visit here is an instance entry or a triangle taken to world space, dearer than the flattened tracer's
-#endif
-#ifndef GLZ_TL_LEAF_QUORUM_ANY
-#define GLZ_TL_LEAF_QUORUM_ANY 32
-#endif
-#ifndef GLZ_TL_PRIO_ROTATE
-#define GLZ_TL_PRIO_ROTATE GLZ_PRIO_ROTATE
-#endif
-#ifndef GLZ_TL_LDS_TOP
-#define GLZ_TL_LDS_TOP 0   // the top level's first kBvhTopNodes nodes from a per-block LDS copy, as in the flattened tracer: 0.823 -> 0.833 ms (forest x 200), 1.167 -> 1.185 (x 2 000) -- off
-#endif
-constexpr bool kTlLdsTop = kLdsTop && GLZ_TL_LDS_TOP != 0;
+// (Leaf quorum of this tracer, GLZ_TL_LEAF_QUORUM in device/tuning.h: 8 / 16 / 24 / 32 / 40 / 48 lanes -> 0.993 / 0.889 / 0.844 / 0.825 / 0.822 / 0.835 ms
+// per launch (forest x 200): a leaf visit here is an instance entry or a triangle taken to world space, dearer than the flattened tracer's.
+// The top level's first nodes from a per-block LDS copy, as in the flattened tracer: 0.823 -> 0.833 ms -- built in, off.)
+constexpr bool kTlLdsTop = false;
+
 
 template <bool ANY, bool COUNT, class Source, class Sink>
 __device__ __forceinline__ void trace_wave_tl(const DeviceScene& S, Source& src, Sink& sink, int* __restrict__ lds_col, int* aux, float* __restrict__ top_ray, LdsNodePtr top_lds,
@@ -1005,11 +925,11 @@ __device__ __forceinline__ void trace_wave_tl(const DeviceScene& S, Source& src,
   const uint32_t prio_gen = (blockIdx.x * 4u) / gridDim.x;   // (four blocks per CU here)
   uint32_t prio_round = 0;
   for (;;) {
-    if (GLZ_TL_PRIO_ROTATE && rays.own_full >= 128u) rotate_priority(prio_gen + prio_round++);
+    if (rays.own_full >= 128u) rotate_priority(prio_gen + prio_round++);
     // ---- refill ----
     const unsigned long long idle = __ballot(!open);
     const int n_idle = __popcll(idle);
-    if (!exhausted && n_idle >= (ANY ? GLZ_TL_REFILL_ANY : GLZ_TL_REFILL)) {
+    if (!exhausted && n_idle >= kRefill) {
       const uint32_t next_ray = rays.ray_at(seq + (uint32_t)__popcll(idle & lanes_below));
       if (!open && next_ray < total) {
         if (src.load(next_ray, o, d, tmin, tmax)) {
@@ -1064,14 +984,11 @@ __device__ __forceinline__ void trace_wave_tl(const DeviceScene& S, Source& src,
         if (k0 == 0xFFFFFFFFu) {
           cur = pop_next();
         } else {
-#ifndef GLZ_TL_PLAIN_PUSH
           if (__ballot(st.sp + 3 > kLdsStack) == 0ull) {   // wave-uniform: every lane stays inside the LDS part of its stack (no spill branches)
             if (k3 != 0xFFFFFFFFu) { st.lds[st.sp * kBlock] = l3; ++st.sp; }
             if (k2 != 0xFFFFFFFFu) { st.lds[st.sp * kBlock] = l2; ++st.sp; }
             if (k1 != 0xFFFFFFFFu) { st.lds[st.sp * kBlock] = l1; ++st.sp; }
-          } else
-#endif
-          {
+          } else {
             if (k3 != 0xFFFFFFFFu) st.push(l3);
             if (k2 != 0xFFFFFFFFu) st.push(l2);
             if (k1 != 0xFFFFFFFFu) st.push(l1);
@@ -1079,7 +996,7 @@ __device__ __forceinline__ void trace_wave_tl(const DeviceScene& S, Source& src,
           cur = l0;
         }
       }
-      if (__popcll(__ballot(cur < 0)) >= (ANY ? GLZ_TL_LEAF_QUORUM_ANY : GLZ_TL_LEAF_QUORUM)) break;
+      if (__popcll(__ballot(cur < 0)) >= GLZ_TL_LEAF_QUORUM) break;
     }
     // ---- leaf phase: an instance to enter (top level) or triangles to test (inside an instance) ----
 #ifdef GLZ_WAVE_TIMES
@@ -1142,7 +1059,7 @@ __device__ __forceinline__ void trace_wave_tl(const DeviceScene& S, Source& src,
       open = false;
     }
   }
-  if (GLZ_TL_PRIO_ROTATE) __builtin_amdgcn_s_setprio(0);
+  __builtin_amdgcn_s_setprio(0);
 #ifdef GLZ_WAVE_TIMES
   if (!ANY) {
     atomicAdd(&g_tl_stats[0], tl_rays); atomicAdd(&g_tl_stats[1], tl_top); atomicAdd(&g_tl_stats[2], tl_mesh); atomicAdd(&g_tl_stats[3], tl_enter);
@@ -1199,34 +1116,19 @@ __device__ __forceinline__ uint32_t wave_count() { return gridDim.x * (kBlock / 
 // ---------------------------------------------------------------------------------------------
 // closest-hit phase of k_trace: path_trace.rgen:143-169
 // ---------------------------------------------------------------------------------------------
-// k_path deals a wave's 64 pixels from GLZ_PATH_PIECES different 64-pixel groups, n_groups / PIECES apart (different tiles of the
-// frame): piece p of wave g is piece p of group g + p * (n_groups / PIECES).  Groups differ in cost persistently -- a region of the
-// image stays as hard as it is -- and a wave that owns one group carries that difference through every launch of the batch; a wave
-// that owns pieces of several averages over them.  Each piece is 64 / PIECES consecutive pixels (whole 64-byte lines of every state
-// array at PIECES <= 16).  For every p the map g -> g + p K (mod n_groups) is a bijection, so every pixel has exactly one wave.
-#ifndef GLZ_PATH_PIECES
-#define GLZ_PATH_PIECES 1
-#endif
-__device__ __forceinline__ uint32_t group_pixel(uint32_t g, uint32_t i, uint32_t n_groups) {
-  constexpr uint32_t P = GLZ_PATH_PIECES, S = 64u / P;
-  if (P == 1u) return g * 64u + i;
-  const uint32_t p = i / S;
-  uint32_t src = g + p * (n_groups / P);
-  src = src >= n_groups ? src - n_groups : src;
-  return src * 64u + i;   // piece p of the source group: pixels p * S .. of it, i.e. the same position i inside the group
-}
+// (k_path with a wave's 64 pixels dealt from 4 ... 64 different groups, to average the groups' persistent cost differences: it does at a
+// half-empty machine and not at a 1/8 share, where the coherence lost costs more: EXPERIMENTS.md.)
 struct ClosestSource {
   const LaunchArgs& A;
   const FrameData& F;   // the launch's constants (k_trace: A.frame; k_path: one entry of its batch)
   TraceTally& tally;
-  uint32_t base;        // ray i is local pixel base + i (k_trace: 0; k_path: the first pixel of the wave's group) ...
-  uint32_t groups = 0;  // ... unless the wave's 64 rays are dealt from several groups (k_path: group_pixel), then `base` is the group
+  uint32_t base;        // ray i is local pixel base + i (k_trace: 0; k_path: the first pixel of the wave's group)
   // ray generation / resume for local pixel `lid`
   // (Dealing the rays of a group from 4, 16 or 64 different tiles instead of one row of one tile -- to level the waves of a small
   // share, whose ends spread from 60 (median) to 105 us -- changes nothing: the spread is not regional, a wave is as slow as the
   // longest dependent chain among its 64 rays.  Median and end of the phase moved by +3 ... +8 % with the coherence lost.)
   __device__ __forceinline__ bool load(uint32_t i, vec3& origin, vec3& direction, float& tmin, float& tmax) {
-    const uint32_t lid = groups ? group_pixel(base, i, groups) : base + i;
+    const uint32_t lid = base + i;
     const PixelId px = pixel_of(A.map, lid);
     if (!px.active) return false;
     const float4 ro = A.st.ray_o[lid], rd = A.st.ray_d[lid];
@@ -1324,9 +1226,8 @@ struct SharedQueue {   // k_shade: the rank's sharded queue in HBM, drained by t
 // Where the pixel's next path state goes.  DirectState: straight into the state arrays (k_path: a wave's 64 pixels are neighbours, every
 // store is whole lines).  StagedState (k_shade, whose threads shade pixels in regrouped order): kept in registers, the kernel writes
 // them after the block's last barrier, transposed through LDS so that thread i stores pixel i's state.
-#ifndef GLZ_SHADE_STAGED_STATE
-#define GLZ_SHADE_STAGED_STATE 1   // k_shade: 0 = every thread stores its pixel's state itself (0.346 ms), 1 = the path state goes through the LDS transpose (0.322), 2 = the accumulator update too, its colour parked in the pixel's LDS slot meanwhile (0.329; kept in registers 0.340)
-#endif
+// (k_shade: every thread storing its pixel's state itself 0.346 ms, the path state through the LDS transpose 0.322, the accumulator
+// update through it too 0.329 -- so only the path state is staged.)
 struct DirectState {
   const LaunchArgs& A;
   __device__ __forceinline__ void ray_o(uint32_t lid, float4 v) { A.st.ray_o[lid] = v; }
@@ -1336,20 +1237,12 @@ struct DirectState {
 };
 struct StagedState {
   float4 ro, rd, im[4];
-  float4* acc_slot = nullptr;   // mode 2: the pixel's own LDS slot (its hit record came from there and nobody else looks at it again)
-  uint32_t mask = 0;   // 1: ro, 2: rd, 4: im, 8: the pixel is accumulated in this launch (16: with c added, 32: result updated)
+  uint32_t mask = 0;   // 1: ro, 2: rd, 4: im
   __device__ __forceinline__ void ray_o(uint32_t, float4 v) { ro = v; mask |= 1u; }
   __device__ __forceinline__ void ray_d(uint32_t, float4 v) { rd = v; mask |= 2u; }
   __device__ __forceinline__ void imp(int q, uint32_t, float4 v) { im[q] = v; mask |= 4u; }
-#if GLZ_SHADE_STAGED_STATE == 1   // only the path state is staged: the accumulator is updated where the pixel is shaded
-  const LaunchArgs* A = nullptr;
+  const LaunchArgs* A = nullptr;   // the accumulator is updated where the pixel is shaded
   __device__ __forceinline__ void accumulate(uint32_t lid, vec3 cc, bool add, bool update, float exposure) { accumulate_pixel(*A, lid, cc, add, update, exposure); }
-#else
-  __device__ __forceinline__ void accumulate(uint32_t, vec3 cc, bool add, bool update, float) {
-    *acc_slot = make_float4(cc.x, cc.y, cc.z, 0.0f);
-    mask |= 8u | (add ? 16u : 0u) | (update ? 32u : 0u);
-  }
-#endif
 };
 template <bool LOD, class Queue, class State>
 __device__ __forceinline__ void shade_pixel(const LaunchArgs& A, const DeviceScene& S, const FrameData& F, uint32_t lid, PixelId px, float4 ro, float4 rd, float4 hr, Queue& queue,

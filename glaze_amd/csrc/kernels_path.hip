@@ -111,19 +111,10 @@ struct GroupMixedSink {
   }
 };
 
-#ifndef GLZ_PATH_WAVES
-#define GLZ_PATH_WAVES 4
-#endif
-#ifndef GLZ_PATH_PREFETCH
-#define GLZ_PATH_PREFETCH 1   // trace_wave<PREFETCH>: the next node's loads issued as soon as the node is known
-#endif
 // The kernel's arguments, re-read: behind the empty asm the compiler no longer knows that the pointer is the one it has been loading
 // from, so what a phase of k_path needs of the arguments is loaded (scalar loads from the kernarg segment) where the phase begins and
 // dies where it ends -- instead of every pointer either phase uses staying in SGPRs through the whole launch loop (tracing and shading
 // together use more of them than there are: 233 of them went to VGPR lanes, and the VGPRs those took to scratch).
-#ifndef GLZ_PATH_REREAD
-#define GLZ_PATH_REREAD 1
-#endif
 // RTFrameData of launch L of the batch: what all launches share (LaunchArgs::frame) with the three per-launch fields from the batch
 __device__ __forceinline__ FrameData launch_frame(const LaunchArgs& A, const PathBatch& B, uint32_t L) {
   FrameData F = A.frame;
@@ -138,7 +129,6 @@ constexpr uint32_t kPathBatchOffset = (uint32_t)(((sizeof(LaunchArgs) + alignof(
 template <bool LOD>
 __device__ __forceinline__ uint32_t path_shade(uint32_t g, uint32_t n_groups, uint32_t lane, uint32_t L, const DeviceScene& S_lds, const float4* hit) {
   const uint32_t lid0 = g * 64u;   // the wave's own 64 entries of the shadow-queue arrays
-#if GLZ_PATH_REREAD
   const LaunchArgs& A = *(const LaunchArgs*)reread_kernarg();
   // the scene as the shading code sees it: the arguments' pointers, re-read, with the tables this block staged in LDS in their place
   DeviceScene S = A.scene;
@@ -147,12 +137,8 @@ __device__ __forceinline__ uint32_t path_shade(uint32_t g, uint32_t n_groups, ui
   S.materials = S_lds.materials;
   S.lights = S_lds.lights;
   S.tex_desc = S_lds.tex_desc;
-#else
-  const LaunchArgs& A = *(const LaunchArgs*)__builtin_amdgcn_kernarg_segment_ptr();
-  const DeviceScene& S = S_lds;
-#endif
   const FrameData F = launch_frame(A, *(const PathBatch*)(reread_kernarg() + kPathBatchOffset), L);
-  const uint32_t lid = group_pixel(g, lane, n_groups);
+  const uint32_t lid = g * 64u + lane;
   const PixelId px = pixel_of(A.map, lid);
   GroupQueue queue{lid0, false};
   if (px.active) {
@@ -203,13 +189,8 @@ __global__ void __launch_bounds__(kBlock, GLZ_PATH_WAVES) k_path(const LaunchArg
   unsigned long long pt_trace = 0, pt_shade = 0, pt_begin = wall_clock64();
 #endif
   const uint32_t n_groups = (A.map.n_local_pixels + 63u) / 64u;
-#ifdef GLZ_PATH_ONE
-  { const uint32_t g = my_wave; if (g >= n_groups) return;
-#else
   for (uint32_t g = my_wave; g < n_groups; g += wave_count()) {
-#endif
     const uint32_t lid0 = g * 64u;
-#ifndef GLZ_PATH_NO_PRIO
     // Groups differ in cost, persistently (a region of the image stays as hard as it is), and the kernel lasts as long as its
     // slowest wave: a wave whose group took longer than the mean in the last batch issues ahead of the others on its SIMD.
     const unsigned long long group_begin = wall_clock64();
@@ -225,14 +206,11 @@ __global__ void __launch_bounds__(kBlock, GLZ_PATH_WAVES) k_path(const LaunchArg
       prio = __builtin_amdgcn_readfirstlane(prio);
       if (prio == 3) __builtin_amdgcn_s_setprio(3); else if (prio == 2) __builtin_amdgcn_s_setprio(2); else if (prio == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
     }
-#endif
     uint32_t n_shadow = 0;      // wave-uniform: shadow rays the group's last shading queued
     float queued_exposure = 0.0f;
     for (uint32_t L = 0;; ++L) {
-#if GLZ_PATH_REREAD
       const LaunchArgs& A = *(const LaunchArgs*)reread_kernarg();   // the tracing phase's view of the arguments (shadows the parameter)
       const PathBatch& B = *(const PathBatch*)(reread_kernarg() + kPathBatchOffset);
-#endif
       if (n_shadow != 0u && L == B.n) {
         // the batch ends with the shadow rays of its last launch (nothing of the next launch depends on them)
       } else if (L >= B.n) {
@@ -245,20 +223,14 @@ __global__ void __launch_bounds__(kBlock, GLZ_PATH_WAVES) k_path(const LaunchArg
       if (L < B.n) {
         const FrameData F = launch_frame(A, B, L);
         // ONE traversal pass: the 64 closest-hit rays of launch L, then -- in the lanes those leave idle -- the shadow rays launch L-1 queued
-        GroupMixedSource src{ClosestSource{A, F, tally, GLZ_PATH_PIECES > 1 ? g : lid0, GLZ_PATH_PIECES > 1 ? n_groups : 0u}, GroupShadowSource{A, lid0, 0u, make_float4(0.0f, 0.0f, 0.0f, 0.0f), make_float4(0.0f, 0.0f, 0.0f, 0.0f)}, false};
+        GroupMixedSource src{ClosestSource{A, F, tally, lid0}, GroupShadowSource{A, lid0, 0u, make_float4(0.0f, 0.0f, 0.0f, 0.0f), make_float4(0.0f, 0.0f, 0.0f, 0.0f)}, false};
         GroupMixedSink sink{GroupHitSink{hit}, GroupShadowSink{A, src.shadow, queued_exposure}};
-#ifndef GLZ_PATH_NO_TRACE
         trace_wave<false, false, true, GLZ_PATH_PREFETCH != 0>(A.scene, src, sink, &s_stack[threadIdx.x], aux, (LdsNodePtr)s_top, A.st.overflow, A.st.overflow_depth, 64u + n_shadow, 0u, 1u, tally);
-#else
-        hit[lane] = A.st.hit[lid0 + lane];   // compile-time experiment: the shading phase's registers without the tracing phase around it
-#endif
         n_shadow = 0u;
       } else {
         GroupShadowSource src{A, lid0, 0u, make_float4(0.0f, 0.0f, 0.0f, 0.0f), make_float4(0.0f, 0.0f, 0.0f, 0.0f)};
         GroupShadowSink sink{A, src, queued_exposure};
-#ifndef GLZ_PATH_NO_TRACE
         trace_wave<true, false, false, GLZ_PATH_PREFETCH != 0>(A.scene, src, sink, &s_stack[threadIdx.x], aux, (LdsNodePtr)s_top, A.st.overflow, A.st.overflow_depth, n_shadow, 0u, 1u, tally);
-#endif
         n_shadow = 0u;
       }
 #ifdef GLZ_PATH_TIMES
@@ -268,15 +240,11 @@ __global__ void __launch_bounds__(kBlock, GLZ_PATH_WAVES) k_path(const LaunchArg
       wave_handover_fence();   // tracing -> shading: the accumulators the shadow rays' lanes updated
       if (L >= B.n) break;
       n_shadow = path_shade<LOD>(g, n_groups, lane, L, S, hit);
-#ifdef GLZ_PATH_ONE
-      A.st.queue_count[wave_index()] = n_shadow; return;
-#endif
       queued_exposure = B.exposure[L];
 #ifdef GLZ_PATH_TIMES
       pt_shade += wall_clock64() - pt1;
 #endif
     }
-#ifndef GLZ_PATH_NO_PRIO
     if (lane == 0u && B.n != 0u) {
       const uint32_t ticks = (uint32_t)((wall_clock64() - group_begin) / B.n);
       A.st.path_cost[8u + g] = ticks;
@@ -284,7 +252,6 @@ __global__ void __launch_bounds__(kBlock, GLZ_PATH_WAVES) k_path(const LaunchArg
       atomicAdd(reinterpret_cast<unsigned long long*>(acc), (unsigned long long)ticks);
       atomicAdd(acc + 2, 1u);
     }
-#endif
   }
 #ifdef GLZ_PATH_TIMES
   if ((threadIdx.x & 63) == 0 && wave_index() < 8192u) {

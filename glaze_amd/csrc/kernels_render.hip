@@ -19,17 +19,13 @@ using namespace dev;
 // ---------------------------------------------------------------------------------------------
 constexpr uint32_t kSkyLdsFloats = 4096;   // sky marginal tables (3H+1 floats) are staged in LDS when they fit: H <= 1365 rows
 
-#ifndef GLZ_SHADE_WAVES
-#define GLZ_SHADE_WAVES 4   // 128 VGPRs, 4 of them spilled, since the light's spectrum is made after the BSDF evaluation and the importance is read where it is used (natural demand 152 -> 132): 0.357 -> 0.348 ms; at three waves the same code takes 0.363 ms (the re-reads), the old code at four waves (56 spilled) 0.382 ms
-#endif
+// (GLZ_SHADE_WAVES = 4, device/tuning.h: 128 VGPRs, 4 of them spilled, since the light's spectrum is made after the BSDF evaluation and the
+// importance is read where it is used (natural demand 152 -> 132): 0.357 -> 0.348 ms; at three waves the same code takes 0.363 ms.)
 // COUNT: the instrumented build of the counting passes (texture fetches, light samples: DeviceScene::tex_counter).  The measured kernel
 // sets the counter pointer to a constant null, so the checks in the texture and light code fold away (left as a run-time null they
 // cost 2.5 %: a branch per fetch and two more live SGPRs).
 // LOD: the build with the texture level of detail (shade_pixel<LOD>).
-#ifndef GLZ_SHADE_BLOCK
-#define GLZ_SHADE_BLOCK 256   // pixels regrouped together (a multiple of 256): 512 -> 0.354 against 0.352 ms, 1 024 -> 0.368: purer waves do not pay, the kernel waits for memory
-#endif
-constexpr uint32_t kShadeBlock = GLZ_SHADE_BLOCK, kShadeWavesPerBlock = kShadeBlock / 64;   // the regrouping domain: pixels sorted by code path per block
+constexpr uint32_t kShadeBlock = 256, kShadeWavesPerBlock = kShadeBlock / 64;   // the regrouping domain: pixels sorted by code path per block (512 -> 0.354 against 0.352 ms, 1 024 -> 0.368: purer waves do not pay, the kernel waits for memory)
 template <bool COUNT, bool LOD>
 __global__ void __launch_bounds__(kShadeBlock, GLZ_SHADE_WAVES) k_shade(const LaunchArgs A) {
   // The kernel is bound by the memory system's random-access rate (16 extra scattered loads per pixel cost +27 %, 200 extra
@@ -41,21 +37,15 @@ __global__ void __launch_bounds__(kShadeBlock, GLZ_SHADE_WAVES) k_shade(const La
   __shared__ uint4 s_pool[kSkyLdsFloats / 4 + kShadeTableBytes / 16];
   float* s_sky = reinterpret_cast<float*>(s_pool);
   uint4* s_tables = s_pool + kSkyLdsFloats / 4;
-  constexpr bool kStaged = GLZ_SHADE_STAGED_STATE != 0 && 6u * kShadeBlock <= kSkyLdsFloats / 4 + kShadeTableBytes / 16;
+  static_assert(6u * kShadeBlock <= kSkyLdsFloats / 4 + kShadeTableBytes / 16, "the staging area of the path state fits the pool");
   // The small scene tables every hit walks through one after the other -- shading record -> RTMaterial -> texture descriptor
   // -> texels, light pick -> RTLight -- are staged in LDS when they fit: each lookup that stays on chip takes a dependent
   // memory round trip (1-2 us under load, the kernel's bound) off the hit's critical path.
   __shared__ uint32_t s_bin[kShadeWavesPerBlock * 64];   // [wave][key] counts, then start offsets
   __shared__ uint16_t s_perm[kShadeBlock];
-#ifndef GLZ_SHADE_NO_HIT_HANDOVER
   __shared__ float4 s_hit[kShadeBlock];   // hit records read by the regrouping prologue, handed to the thread that shades the pixel
-#endif
   const uint32_t n_sky = 3u * (A.scene.sky_header.marginal_cdf_count - 1u) + 1u;
-#ifndef GLZ_SHADE_NO_SKY_LDS
   const bool sky_in_lds = A.scene.sky_header.marginal_cdf_count > 1u && n_sky <= kSkyLdsFloats;
-#else
-  const bool sky_in_lds = false;
-#endif
   if (threadIdx.x < 256u) s_lut[threadIdx.x] = A.scene.srgb_lut[threadIdx.x];
   if (sky_in_lds)
     for (uint32_t i = threadIdx.x; i < n_sky; i += kShadeBlock) s_sky[i] = A.scene.sky_marginal[i];
@@ -63,11 +53,7 @@ __global__ void __launch_bounds__(kShadeBlock, GLZ_SHADE_WAVES) k_shade(const La
   // [RTMaterial x n_materials | RTLight x n_rt_lights | TexDesc x n_textures] in 16-byte pieces
   const uint32_t qm = A.scene.n_materials * (uint32_t)(sizeof(RTMaterial) / 16), ql = A.scene.n_rt_lights * (uint32_t)(sizeof(RTLight) / 16),
                  qt = A.scene.n_textures * (uint32_t)(sizeof(TexDesc) / 16);
-#ifndef GLZ_SHADE_NO_TABLES
   const bool tables_in_lds = (qm + ql + qt) * 16u <= kShadeTableBytes;   // uniform over the grid
-#else
-  const bool tables_in_lds = false;
-#endif
   if (tables_in_lds) {
     const uint4* gm = reinterpret_cast<const uint4*>(A.scene.materials);
     const uint4* gl = reinterpret_cast<const uint4*>(A.scene.lights);
@@ -86,7 +72,6 @@ __global__ void __launch_bounds__(kShadeBlock, GLZ_SHADE_WAVES) k_shade(const La
     S.tex_desc = reinterpret_cast<const TexDesc*>(s_tables + qm + ql);
   }
   const FrameData& F = A.frame;
-#ifndef GLZ_SHADE_NO_REGROUP
   // Block-local regrouping: the 256 pixels of the block are bucketed by the code path they are going to take -- miss,
   // or (BSDF kind, light kind of the NEE sample) -- and every thread then shades the pixel at its sorted position, so
   // a wave mostly runs one material and one light routine instead of all of them one after the other (lane utilisation
@@ -97,13 +82,9 @@ __global__ void __launch_bounds__(kShadeBlock, GLZ_SHADE_WAVES) k_shade(const La
     const uint32_t lid0 = blockIdx.x * kShadeBlock + threadIdx.x;
     const PixelId px0 = pixel_of(A.map, lid0);
     if (px0.active) {
-#ifndef GLZ_SHADE_NO_HIT_HANDOVER
       const float4 h0 = A.st.hit[lid0];
       s_hit[threadIdx.x] = h0;   // the thread at this pixel's sorted slot reads it back after the barriers below: one dependent global load less
       const uint32_t leaf0 = __float_as_uint(h0.w);
-#else
-      const uint32_t leaf0 = __float_as_uint(A.st.hit[lid0].w);
-#endif
       key = 0u;
       if (leaf0 != 0xFFFFFFFFu) {
         const RTMaterial* m0 = &S.materials[S.two_level ? S.instances[A.st.hit_inst[lid0]].material_id : __float_as_uint(S.shade_tris[8u * (size_t)leaf0 + 6u].w)];
@@ -161,51 +142,20 @@ __global__ void __launch_bounds__(kShadeBlock, GLZ_SHADE_WAVES) k_shade(const La
   s_perm[s_bin[(threadIdx.x >> 6) * 64u + key] + rank] = (uint16_t)threadIdx.x;
   __syncthreads();
   const uint32_t lid = blockIdx.x * kShadeBlock + s_perm[threadIdx.x];
-#else
-  const uint32_t lid = blockIdx.x * kShadeBlock + threadIdx.x;
-#endif
   // (Handing the next k_trace the pixels in this regrouped order -- one more word per pixel -- does nothing for the traversal, 0.588 ->
   // 0.591 ms; sorted per block by the octant of the new direction, camera rays last, 0.590 -> 0.573 ms, less than the sort and the
   // indirection cost.)
   const PixelId px = pixel_of(A.map, lid);
-#if !defined(GLZ_SHADE_NO_REGROUP) && !defined(GLZ_SHADE_NO_REREAD)
   StagedState staged;
-  if (!kStaged && !COUNT && !px.active) return;
-#else
-  if (!COUNT && !px.active) return;
-#endif
   if (px.active) {
-#if !defined(GLZ_SHADE_NO_REGROUP) && !defined(GLZ_SHADE_NO_HIT_HANDOVER)
     const float4 ro = A.st.ray_o[lid], rd = A.st.ray_d[lid], hr = s_hit[s_perm[threadIdx.x]];
-#else
-    const float4 ro = A.st.ray_o[lid], rd = A.st.ray_d[lid], hr = A.st.hit[lid];
-#endif
-#ifndef GLZ_SHADE_NO_REREAD
     // (see reread_kernarg: without it the regrouping prologue's view of the arguments stays in SGPRs through the shading code)
     const LaunchArgs& A2 = *(const LaunchArgs*)reread_kernarg();
     SharedQueue queue{A2};
-#ifndef GLZ_SHADE_NO_REGROUP
-    if (kStaged) {
-#if GLZ_SHADE_STAGED_STATE == 1
-      staged.A = &A2;
-#else
-      staged.acc_slot = &s_hit[s_perm[threadIdx.x]];
-#endif
-      shade_pixel<LOD>(A2, S, A2.frame, lid, px, ro, rd, hr, queue, staged);
-    } else
-#endif
-    {
-      DirectState direct{A2};
-      shade_pixel<LOD>(A2, S, A2.frame, lid, px, ro, rd, hr, queue, direct);
-    }
-#else
-    SharedQueue queue{A};
-    DirectState direct{A};
-    shade_pixel<LOD>(A, S, F, lid, px, ro, rd, hr, queue, direct);
-#endif
+    staged.A = &A2;
+    shade_pixel<LOD>(A2, S, A2.frame, lid, px, ro, rd, hr, queue, staged);
   }
-#if !defined(GLZ_SHADE_NO_REGROUP) && !defined(GLZ_SHADE_NO_REREAD)
-  if (kStaged) {
+  {
     // The regrouped threads would store 16-byte pieces scattered over the block's 4 KB of each state array (six arrays); the L2 has
     // to assemble the lines.  Thread i stores pixel i's state instead: the values travel through LDS, which nobody needs any more
     // once the whole block is here (a block's LDS and wave slots are handed on when its last wave ends either way).
@@ -228,12 +178,7 @@ __global__ void __launch_bounds__(kShadeBlock, GLZ_SHADE_WAVES) k_shade(const La
 #pragma unroll
       for (int q = 0; q < 4; ++q) A3.st.imp[q][at] = stage[(2u + q) * kShadeBlock + threadIdx.x];
     }
-    if (m & 8u) {   // update_count / update_result of the pixels without a shadow ray (accumulate_pixel), the accumulator read and written in whole lines
-      const float4 c = s_hit[threadIdx.x];
-      accumulate_pixel(A3, at, mk3(c.x, c.y, c.z), (m & 16u) != 0u, (m & 32u) != 0u, A3.frame.exposure);
-    }
   }
-#endif
   if (COUNT) flush_tex_tallies(A.counters->shade_tex, tex_tally);   // every lane of the wave is here (the counting build returns nowhere above)
 }
 
@@ -295,9 +240,7 @@ struct ClosestSinkTl {
     A.st.hit_inst[lid] = h.inst;
   }
 };
-#ifndef GLZ_TRACE_TL_WAVES
-#define GLZ_TRACE_TL_WAVES 4   // the instance entry and the on-the-fly world triangle need 153 VGPRs: at 6 waves per SIMD 201 of them live in scratch (forest x2000, tools/gpu_two_level_timing.py: 4.06 ms per launch), at 4 waves 34 (1.44 ms), at 3 none (1.45 ms)
-#endif
+// GLZ_TRACE_TL_WAVES = 4 (device/tuning.h): the instance entry and the on-the-fly world triangle need 153 VGPRs: at 6 waves per SIMD 201 of them live in scratch (forest x2000, tools/gpu_two_level_timing.py: 4.06 ms per launch), at 4 waves 34 (1.44 ms), at 3 none (1.45 ms)
 template <bool COUNT>
 __global__ void __launch_bounds__(kBlock, GLZ_TRACE_TL_WAVES) k_trace_tl(const LaunchArgs A) {
   __shared__ int s_stack[kLdsStack * kBlock];

@@ -25,6 +25,10 @@ bool TextureData::decode_more_levels(std::string& err) {
     }
   }
   more_levels = std::move(levels);
+  // the encoded levels are not needed again (a scene replica copies the decoded ones): a LOD scene does not hold both on the host.
+  // (What png_check cannot see at parse -- a damaged deflate stream inside intact chunks -- is reported here, i.e. by
+  // glz_renderer_set_texture_lod or the first launch that wants the chain: GLZ_E_INVALID_DATA.)
+  for (auto& e : more_png) std::vector<uint8_t>().swap(e);
   return true;
 }
 

@@ -783,7 +783,12 @@ bool Renderer::draw(size_t spp, void (*cb)(void*), void* user, uint8_t* rgba8_ou
   // been enqueued (raytracer.rs:651-653: `if i % steps == 0`); it never said anything about the GPU's progress.
   size_t done = 0, fired = 0;
   while (done < substep) {
-    const size_t chunk = use_path() ? (size_t)kPathMaxLaunches : steps;
+    // any device in the per-wave launch loop wants long batches (a root over the residency limit must not hold its peers to one
+    // sample per call); with a callback -- a progress bar, a cancel hook -- at most four samples go out between two calls of it
+    bool any_path = use_path();
+    for (const auto& p : peers_) any_path = any_path || p->r->use_path();
+    size_t chunk = any_path ? (size_t)kPathMaxLaunches : steps;
+    if (cb && chunk > 4 * steps) chunk = 4 * steps;
     const uint32_t m = (uint32_t)std::min(chunk, substep - done);
     if (!(peers_.empty() ? run_launches(m, err) : step(m, err))) return false;
     done += m;

@@ -34,7 +34,7 @@ for world, mode in ((1, "two_kernels"), (8, "two_kernels"), (8, "path"), (32, "p
     b = b[used]
     merges, merge_clk = b[:, 11].sum(), b[:, 12].sum()
     fine = b[:, 13:16].sum(axis=0)
-    if fine.sum() > 0:     # -DGLZ_SECTION_FINE: the node visit in pieces (their clocks are not in `node visit` then)
+    if fine.sum() > 0:     # -DGLZ_SECTION_TIMES=2: the node visit in pieces (their clocks are not in `node visit` then)
         print("      node visit in pieces, clocks per iteration: wait for the node %.0f, box tests + sort %.0f, links through LDS %.0f, pushes / pop + the rest %.0f" % (
             fine[0] / b[:, 7].sum(), fine[1] / b[:, 7].sum(), fine[2] / b[:, 7].sum(), b[:, 2].sum() / b[:, 7].sum()))
         b[:, 2] += b[:, 13:16].sum(axis=1)
