@@ -707,7 +707,8 @@ GLZ_D void sample_light(const DeviceScene& S, uint32_t light_index, vec3 p, vec3
   // Sky: light_sky_sample_visible.rcall:100-135
   uint32_t row, col;
   const float* marg = S.sky_marginal;
-  float v = sample_cdf(xi.y, (int)S.sky_header.marginal_cdf_count, [&](int i) { return marg[i]; }, row);
+  const float* cdf = S.sky_cdf;   // (k_shade: in LDS -- the search is ten dependent reads; the two values read once below come from memory)
+  float v = sample_cdf(xi.y, (int)S.sky_header.marginal_cdf_count, [&](int i) { return cdf[i]; }, row);
   float v_pdf = marg[S.sky_header.marginal_cdf_count + row] / S.sky_header.marginal_integral;
   // The conditional lookups hand integer texel coordinates to a normalised REPEAT/NEAREST sampler: every
   // fetch lands on texel (0,0) of the image (Q3).

@@ -238,6 +238,7 @@ struct DeviceScene {
   RTSky sky;
   SkyHeader sky_header;
   const float* sky_marginal;       // cdf (H+1) | values (H) | conditional integrals (H)
+  const float* sky_cdf;            // the H + 1 cdf entries the row search walks: sky_marginal, or k_shade's LDS copy of them
   const float* sky_cond_values;    // W x H
   const float* sky_cond_cdf;       // (W+1) x H
   // counting builds only (null otherwise; the host never sets it): the THREAD's tallies {texture fetches that read memory, their texel

@@ -1228,14 +1228,31 @@ struct SharedQueue {   // k_shade: the rank's sharded queue in HBM, drained by t
 // them after the block's last barrier, transposed through LDS so that thread i stores pixel i's state.
 // (k_shade: every thread storing its pixel's state itself 0.346 ms, the path state through the LDS transpose 0.322, the accumulator
 // update through it too 0.329 -- so only the path state is staged.)
+#ifdef GLZ_SECTION_TIMES   // tools/gpu_shade_sections.py: shader clocks between the stamps of shade_pixel, per wave (k_shade only)
+#define GLZ_SHADE_STAMP(k) out.stamp(k)
+#else
+#define GLZ_SHADE_STAMP(k) do { } while (0)
+#endif
 struct DirectState {
   const LaunchArgs& A;
+  __device__ __forceinline__ void stamp(int) {}
   __device__ __forceinline__ void ray_o(uint32_t lid, float4 v) { A.st.ray_o[lid] = v; }
   __device__ __forceinline__ void ray_d(uint32_t lid, float4 v) { A.st.ray_d[lid] = v; }
   __device__ __forceinline__ void imp(int q, uint32_t lid, float4 v) { A.st.imp[q][lid] = v; }
   __device__ __forceinline__ void accumulate(uint32_t lid, vec3 c, bool add, bool update, float exposure) { accumulate_pixel(A, lid, c, add, update, exposure); }
 };
 struct StagedState {
+#ifdef GLZ_SECTION_TIMES
+  unsigned long long sec[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sec_last = 0;
+  __device__ __forceinline__ void stamp(int k) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // what a section asked for is charged to it
+    const unsigned long long now = __builtin_amdgcn_s_memtime();
+    sec[k] += now - sec_last;
+    sec_last = now;
+  }
+#else
+  __device__ __forceinline__ void stamp(int) {}
+#endif
   float4 ro, rd, im[4];
   uint32_t mask = 0;   // 1: ro, 2: rd, 4: im
   __device__ __forceinline__ void ray_o(uint32_t, float4 v) { ro = v; mask |= 1u; }
@@ -1298,6 +1315,7 @@ __device__ __forceinline__ void shade_pixel(const LaunchArgs& A, const DeviceSce
   vec3 ng = mk3(dn.x, dn.y, dn.z), dpdu = mk3(du.x, du.y, du.z);   // dpdv is transformed by the reference but never read afterwards
   vec3 ns = (mk3(va0.w, va1.x, va1.y) * b0 + mk3(vb0.w, vb1.x, vb1.y) * b1) + mk3(vc0.w, vc1.x, vc1.y) * b2;
   const MatScalars mat = load_material(&S.materials[material_id]);
+  GLZ_SHADE_STAMP(0);   // hit record -> shading record -> material scalars
   // ---- texture level of detail by ray cones (build-defined, off by default: the reference's stages sample level 0) ----
   // The cone of a camera path starts cone_width0 wide and widens by cone_spread per unit of distance along the whole path;
   // at a hit the footprint on the surface is width / |cos|, and a texture of W x H texels over a triangle with texture-space
@@ -1379,6 +1397,7 @@ __device__ __forceinline__ void shade_pixel(const LaunchArgs& A, const DeviceSce
   P.frame = make_frame(dpdu, ns);
   P.mat = mat;
   fetch_material_textures(S, P, fp);
+  GLZ_SHADE_STAMP(1);   // normal map, transform, frame, the material's textures
   float spec_flag;
   float imp_lum = 0.0f;      // luminance of the importance, taken when the light-sampling block reads it: the roulette needs nothing else of it
   bool have_lum = false;
@@ -1390,6 +1409,7 @@ __device__ __forceinline__ void shade_pixel(const LaunchArgs& A, const DeviceSce
     LightSample ls;
     ls.pdf = 0.0f;
     sample_light(S, li, point, xi, F.scene_radius, ls);
+    GLZ_SHADE_STAMP(2);   // light sample
     vec3 c = mk3(0.0f, 0.0f, 0.0f);
     uint32_t flags = kFlagUpdate;
     vec3 sh_dir = mk3(0.0f, 0.0f, 0.0f);
@@ -1431,6 +1451,7 @@ __device__ __forceinline__ void shade_pixel(const LaunchArgs& A, const DeviceSce
     }
     // shadow-ray queue (consumed by the next launch's k_trace); pixels without a shadow ray are accumulated right here
     const bool push = (flags & kFlagShadow) != 0;
+    GLZ_SHADE_STAMP(3);   // BSDF evaluation, radiance, importance read
     const uint32_t slot = queue.slot(push);
     if (push) {
       A.st.sh_o[slot] = make_float4(point.x, point.y, point.z, sh_tmax);
@@ -1445,6 +1466,7 @@ __device__ __forceinline__ void shade_pixel(const LaunchArgs& A, const DeviceSce
     spec_flag = 1.0f;
   }
   if (F.direct_only) return;
+  GLZ_SHADE_STAMP(4);   // queue entry / accumulator update
   // Russian roulette (:197-210)
   float rr_scale = 1.0f;   // importance * 1.0f is importance, bit for bit: the paths that skip the roulette multiply by it too
   if (bounce > (float)(F.pt_steps / 2u)) {
@@ -1474,6 +1496,7 @@ __device__ __forceinline__ void shade_pixel(const LaunchArgs& A, const DeviceSce
     out.imp(q, lid, make_float4(importance.w[4 * q] * (value.w[4 * q] * weight), importance.w[4 * q + 1] * (value.w[4 * q + 1] * weight),
                                 importance.w[4 * q + 2] * (value.w[4 * q + 2] * weight), importance.w[4 * q + 3] * (value.w[4 * q + 3] * weight)));
   bounce = bounce < (float)F.pt_steps ? bounce + 1.0f : 0.0f;   // :230-237
+  GLZ_SHADE_STAMP(5);   // roulette, BSDF sample, new importance
   if constexpr (LOD) A.st.cone[lid] = cone_w;
   out.ray_o(lid, make_float4(point.x, point.y, point.z, bounce));
   out.ray_d(lid, make_float4(wiW.x, wiW.y, wiW.z, spec_flag));

@@ -17,7 +17,7 @@ using namespace dev;
 // ---------------------------------------------------------------------------------------------
 // k_shade: path_trace.rgen:170-237 minus the two traceRayEXT calls, raytrace_hit.rchit:30-71
 // ---------------------------------------------------------------------------------------------
-constexpr uint32_t kSkyLdsFloats = 4096;   // sky marginal tables (3H+1 floats) are staged in LDS when they fit: H <= 1365 rows
+constexpr uint32_t kSkyLdsFloats = 4096;   // the sky's marginal cdf (H + 1 floats) is staged in LDS when it fits (the values and row integrals next to it are read once per sample, from memory: staging all 3 H + 1 floats was 12 of the 19 KB a block copies before it starts)
 
 // (GLZ_SHADE_WAVES = 4, device/tuning.h: 128 VGPRs, 4 of them spilled, since the light's spectrum is made after the BSDF evaluation and the
 // importance is read where it is used (natural demand 152 -> 132): 0.357 -> 0.348 ms; at three waves the same code takes 0.363 ms.)
@@ -26,8 +26,17 @@ constexpr uint32_t kSkyLdsFloats = 4096;   // sky marginal tables (3H+1 floats) 
 // cost 2.5 %: a branch per fetch and two more live SGPRs).
 // LOD: the build with the texture level of detail (shade_pixel<LOD>).
 constexpr uint32_t kShadeBlock = 256, kShadeWavesPerBlock = kShadeBlock / 64;   // the regrouping domain: pixels sorted by code path per block (512 -> 0.354 against 0.352 ms, 1 024 -> 0.368: purer waves do not pay, the kernel waits for memory)
+#ifdef GLZ_SECTION_TIMES
+static __device__ unsigned long long g_shade_sections[16];   // clocks summed over waves: {prologue, key, sort, [shade_pixel's six], epilogue}, [15] = waves
+#endif
 template <bool COUNT, bool LOD>
 __global__ void __launch_bounds__(kShadeBlock, GLZ_SHADE_WAVES) k_shade(const LaunchArgs A) {
+#ifdef GLZ_SECTION_TIMES
+  unsigned long long ks[4] = {0, 0, 0, 0}, ks_last = __builtin_amdgcn_s_memtime();
+#define GLZ_KS(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ks[k] += now_ - ks_last; ks_last = now_; } while (0)
+#else
+#define GLZ_KS(k) do { } while (0)
+#endif
   // The kernel is bound by the memory system's random-access rate (16 extra scattered loads per pixel cost +27 %, 200 extra
   // VALU instructions nothing; 1 / 2 / 3 / 4 waves per SIMD take 0.76 / 0.45 / 0.36 / 0.35 ms), so the two small tables every texture fetch /
   // sky sample walks are staged in LDS once per block: the sRGB decode LUT (12 lookups per bilinear fetch) and the sky marginal CDF (an 11-step dependent search).
@@ -44,7 +53,7 @@ __global__ void __launch_bounds__(kShadeBlock, GLZ_SHADE_WAVES) k_shade(const La
   __shared__ uint32_t s_bin[kShadeWavesPerBlock * 64];   // [wave][key] counts, then start offsets
   __shared__ uint16_t s_perm[kShadeBlock];
   __shared__ float4 s_hit[kShadeBlock];   // hit records read by the regrouping prologue, handed to the thread that shades the pixel
-  const uint32_t n_sky = 3u * (A.scene.sky_header.marginal_cdf_count - 1u) + 1u;
+  const uint32_t n_sky = A.scene.sky_header.marginal_cdf_count;
   const bool sky_in_lds = A.scene.sky_header.marginal_cdf_count > 1u && n_sky <= kSkyLdsFloats;
   if (threadIdx.x < 256u) s_lut[threadIdx.x] = A.scene.srgb_lut[threadIdx.x];
   if (sky_in_lds)
@@ -61,11 +70,12 @@ __global__ void __launch_bounds__(kShadeBlock, GLZ_SHADE_WAVES) k_shade(const La
     for (uint32_t i = threadIdx.x; i < qm + ql + qt; i += kShadeBlock) s_tables[i] = i < qm ? gm[i] : (i < qm + ql ? gl[i - qm] : gt[i - qm - ql]);
   }
   __syncthreads();
+  GLZ_KS(0);   // tables staged
   DeviceScene S = A.scene;
   unsigned long long tex_tally[4] = {0ull, 0ull, 0ull, 0ull};
   S.tex_counter = COUNT ? tex_tally : nullptr;
   S.srgb_lut = s_lut;
-  if (sky_in_lds) S.sky_marginal = s_sky;
+  if (sky_in_lds) S.sky_cdf = s_sky;
   if (tables_in_lds) {
     S.materials = reinterpret_cast<const RTMaterial*>(s_tables);
     S.lights = reinterpret_cast<const RTLight*>(s_tables + qm);
@@ -98,6 +108,7 @@ __global__ void __launch_bounds__(kShadeBlock, GLZ_SHADE_WAVES) k_shade(const La
       }
     }
   }
+  GLZ_KS(1);   // hit record -> material -> code-path key
   // Counting sort without same-address atomics (256 atomicAdds on a handful of LDS words serialise: SQ_LDS_BANK_CONFLICT was
   // twice the LDS-active cycles of this kernel): every wave peels off its distinct keys with ballots -- a thread's rank among
   // the wave's threads with the same key is a popcount -- and leaves one count per (wave, key); 64 threads then turn the
@@ -141,6 +152,7 @@ __global__ void __launch_bounds__(kShadeBlock, GLZ_SHADE_WAVES) k_shade(const La
   __syncthreads();
   s_perm[s_bin[(threadIdx.x >> 6) * 64u + key] + rank] = (uint16_t)threadIdx.x;
   __syncthreads();
+  GLZ_KS(2);   // regrouped
   const uint32_t lid = blockIdx.x * kShadeBlock + s_perm[threadIdx.x];
   // (Handing the next k_trace the pixels in this regrouped order -- one more word per pixel -- does nothing for the traversal, 0.588 ->
   // 0.591 ms; sorted per block by the octant of the new direction, camera rays last, 0.590 -> 0.573 ms, less than the sort and the
@@ -153,8 +165,14 @@ __global__ void __launch_bounds__(kShadeBlock, GLZ_SHADE_WAVES) k_shade(const La
     const LaunchArgs& A2 = *(const LaunchArgs*)reread_kernarg();
     SharedQueue queue{A2};
     staged.A = &A2;
+#ifdef GLZ_SECTION_TIMES
+    staged.sec_last = __builtin_amdgcn_s_memtime();
+#endif
     shade_pixel<LOD>(A2, S, A2.frame, lid, px, ro, rd, hr, queue, staged);
   }
+#ifdef GLZ_SECTION_TIMES
+  ks_last = __builtin_amdgcn_s_memtime();
+#endif
   {
     // The regrouped threads would store 16-byte pieces scattered over the block's 4 KB of each state array (six arrays); the L2 has
     // to assemble the lines.  Thread i stores pixel i's state instead: the values travel through LDS, which nobody needs any more
@@ -180,6 +198,24 @@ __global__ void __launch_bounds__(kShadeBlock, GLZ_SHADE_WAVES) k_shade(const La
     }
   }
   if (COUNT) flush_tex_tallies(A.counters->shade_tex, tex_tally);   // every lane of the wave is here (the counting build returns nowhere above)
+#ifdef GLZ_SECTION_TIMES
+  if (!COUNT) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    GLZ_KS(3);   // the state leaves through LDS
+    unsigned long long v[10] = {ks[0], ks[1], ks[2], staged.sec[0], staged.sec[1], staged.sec[2], staged.sec[3], staged.sec[4], staged.sec[5], ks[3]};
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {   // the wave's value of a section: the largest any of its lanes saw
+      unsigned int lo = (unsigned int)v[k], hi = (unsigned int)(v[k] >> 32);
+      for (int off = 32; off > 0; off >>= 1) {
+        const unsigned int lo2 = __shfl_xor(lo, off), hi2 = __shfl_xor(hi, off);
+        const unsigned long long a = ((unsigned long long)hi << 32) | lo, b = ((unsigned long long)hi2 << 32) | lo2;
+        if (b > a) { lo = lo2; hi = hi2; }
+      }
+      if ((threadIdx.x & 63u) == 0u) atomicAdd(&g_shade_sections[k], ((unsigned long long)hi << 32) | lo);
+    }
+    if ((threadIdx.x & 63u) == 0u) atomicAdd(&g_shade_sections[15], 1ull);
+  }
+#endif
 }
 
 template <bool COUNT>
@@ -466,6 +502,14 @@ hipError_t launch_debug_any(hipStream_t st, const DeviceScene& scene, const floa
 }  // namespace glz
 
 #ifdef GLZ_SECTION_TIMES
+extern "C" int glz_debug_shade_sections(unsigned long long* out, int reset) {
+  int e = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(glz::g_shade_sections), sizeof(unsigned long long) * 16);
+  if (reset) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(glz::g_shade_sections)) == hipSuccess) e = (int)hipMemset(p, 0, sizeof(unsigned long long) * 16);
+  }
+  return e;
+}
 // kernels_render.hip and kernels_path.hip each hold their own copy of g_sections (a __device__ array per translation unit): `which` 0 = k_trace's, see kernels_path.hip for k_path's
 extern "C" int glz_debug_sections_trace(unsigned long long* out, int reset) {
   int e = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(glz::g_sections), sizeof(unsigned long long) * 16 * 8192);

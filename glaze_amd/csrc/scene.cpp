@@ -535,6 +535,7 @@ bool Scene::build_lights_and_sky(Error& err) {
   dev.sky = h_sky;
   dev.sky_header = h_sky_header;
   dev.sky_marginal = d_sky_marginal_.ptr;
+  dev.sky_cdf = d_sky_marginal_.ptr;
   dev.sky_cond_values = d_sky_cond_values_.ptr;
   dev.sky_cond_cdf = d_sky_cond_cdf_.ptr;
   return true;
