@@ -55,8 +55,11 @@ __device__ __forceinline__ PixelId pixel_of(const TileMap& m, uint32_t lid) {
 // still say on which side of each plane the origin lies.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 struct SlabSel { uint32_t x, y, z; };   // v_perm_b32 selectors per axis
-// returns the sort key of the child: entry distance (a positive float, so its bits order like the value) with the child index in
-// the two lowest bits -- nearer first, ties (to 2 ulp) by child index; 0xFFFFFFFF for a missed child or an unused slot
+// returns the sort key of the child: entry distance (a positive float, so its bits order like the value) with its ten lowest bits
+// replaced by the child index in bits 8..9 (`k` = child << 8) -- nearer first, ties (to 2^-13 of the distance) by child index; 0xFFFFFFFF
+// for a missed child or an unused slot.  Bits 8..9 because (key & 0x300) IS the byte offset of the child's link in the wave's link
+// scratch ([child][lane], 256 bytes a child, the area 1 KB aligned): the address of a sorted link is one v_and_or_b32 (it was three
+// instructions per link with the index in the low bits)
 // (the slab test is symmetric in lo / hi, so an unused slot cannot be excluded through its box: its link says so)
 // cgn / cgf: the addends of the near and the far plane.  The flattened tracer passes the same vector twice; the two-level tracer
 // widens every box by the instance's slack (cg -+ pad * |ig|) at no extra instruction.
@@ -65,6 +68,7 @@ struct SlabSel { uint32_t x, y, z; };   // v_perm_b32 selectors per axis
 // of the plane distance (grid_ray: cg - 32768 ig), the selector names which half of the node word -- the plane the ray meets first
 // (lo for ig >= 0, hi for ig < 0) or the other one: kSlabSelLo / kSlabSelHi, one XOR apart.  Two permutes per axis instead of one
 // permute and two v_cvt_f32_u32: 9 VALU instructions fewer per node visit (rounds 1-2 needed six live selectors for this and spilt).
+constexpr uint32_t kKeyDistanceMask = 0xFFFFFC00u, kKeyChild = 0x100u, kKeyChildMask = 0x300u;   // sort key = distance bits | child << 8
 constexpr uint32_t kSlabSelLo = 0x0305040Cu, kSlabSelHi = 0x0307060Cu, kSlabSelFlip = kSlabSelLo ^ kSlabSelHi, kSlabMagic = 0x47000000u;
 __device__ __forceinline__ uint32_t slab_sel(float ig) { return ig < 0.0f ? kSlabSelHi : kSlabSelLo; }
 // CHECK_LINK = false: an unused slot is excluded by its box alone -- lo = the grid's top, hi = 0 on every axis, and with the near /
@@ -83,7 +87,7 @@ __device__ __forceinline__ uint32_t box_key(uint32_t wx, uint32_t wy, uint32_t w
   const f32x2 tz = __builtin_elementwise_fma(f32x2{nz, fz}, f32x2{ig.z, ig.z}, f32x2{cgn.z, cgf.z});
   const float t0 = fmaxf(fmaxf(tx.x, ty.x), fmaxf(tz.x, tmin));
   const float t1 = fminf(fminf(tx.y, ty.y), fminf(tz.y, tmax));
-  return (t0 <= t1 && (!CHECK_LINK || link != (uint32_t)kBvhEmptyChild)) ? ((__float_as_uint(t0) & 0xFFFFFFFCu) | k) : 0xFFFFFFFFu;
+  return (t0 <= t1 && (!CHECK_LINK || link != (uint32_t)kBvhEmptyChild)) ? ((__float_as_uint(t0) & kKeyDistanceMask) | k) : 0xFFFFFFFFu;
 }
 #ifdef GLZ_NODE48
 // EXPERIMENT: the slab test on a 48-byte node's child (types.h BvhNode48).  `word` holds the planes of one axis for two children as bytes
@@ -100,7 +104,7 @@ __device__ __forceinline__ uint32_t box_key48(uint32_t wx, uint32_t wy, uint32_t
   const f32x2 tz = __builtin_elementwise_fma(f32x2{nz, fz}, f32x2{a.z, a.z}, f32x2{c.z, c.z});
   const float t0 = fmaxf(fmaxf(tx.x, ty.x), fmaxf(tz.x, tmin));
   const float t1 = fminf(fminf(tx.y, ty.y), fminf(tz.y, tmax));
-  return t0 <= t1 ? ((__float_as_uint(t0) & 0xFFFFFFFCu) | k) : 0xFFFFFFFFu;
+  return t0 <= t1 ? ((__float_as_uint(t0) & kKeyDistanceMask) | k) : 0xFFFFFFFFu;
 }
 #endif
 // the addend of a plane distance: plane q (a float 32768 + q out of box_key) is crossed at t = (32768 + q) ig + grid_addend = q ig - og ig
@@ -338,6 +342,11 @@ constexpr bool kLdsTop = true;   // the top kBvhTopNodes nodes of the tree come 
 constexpr int kRefill = GLZ_REFILL;
 constexpr int kLeafQuorum = GLZ_LEAF_QUORUM;
 constexpr int kAuxPerWave = 3 * 64 + 4 * 64;   // work sharing (3 x 64) + the four child links of the node a lane is visiting
+// The block's scratch, as the kernels declare it (__shared__ alignas(1024) int s_aux[kAuxPerBlock]): the waves' link areas first -- 256 ints
+// each, so that every one of them starts on a 1 KB boundary (sorted_link) -- then their work-sharing words.
+constexpr int kAuxPerBlock = (kBlock / 64) * kAuxPerWave;
+__device__ __forceinline__ int* wave_links(int* s_aux, uint32_t wave_in_block) { return s_aux + 256u * wave_in_block; }
+__device__ __forceinline__ int* wave_aux(int* s_aux, uint32_t wave_in_block) { return s_aux + 256u * (kBlock / 64) + 192u * wave_in_block; }
 
 // The SIMD issues its OLDEST ready wave first, and the tracers are bound by VALU issue: with one priority for all, the waves of the
 // blocks dispatched first ran 1.6 x faster than the last ones' through the same amount of work (1.67 against 2.66 us per node
@@ -353,6 +362,10 @@ __device__ __forceinline__ void rotate_priority(uint32_t turn) {
   if (p == 0u) __builtin_amdgcn_s_setprio(0); else if (p == 1u) __builtin_amdgcn_s_setprio(1); else if (p == 2u) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(3);
 }
 
+// the link of the child a sort key names, out of the wave's link scratch (`base` = LDS byte address of this lane's word of child 0, bits 8..9 zero)
+__device__ __forceinline__ int sorted_link(uint32_t base, uint32_t key) {
+  return *(LdsIntPtr)(uintptr_t)((key & kKeyChildMask) | base);
+}
 __device__ __forceinline__ void sort2(uint32_t& a, uint32_t& b) {
   const uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
   a = lo;
@@ -401,7 +414,7 @@ __device__ unsigned long long g_tl_stats[8];      // two-level tracer, summed ov
 // bound by the LATENCY of this dependent chain (tools/gpu_sections.py: a node visit of a 1/32 share, on an otherwise idle chip, still takes
 // 1 800 clocks, most of them waiting for the node), not by issue; the full-frame k_trace is issue bound and has no 16 registers to spare.
 template <bool ANY, bool COUNT, bool MIXED = false, bool PREFETCH = false, class Source, class Sink>
-__device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Sink& sink, int* __restrict__ lds_col, int* aux, LdsNodePtr top_lds,
+__device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Sink& sink, int* __restrict__ lds_col, int* aux, int* link_scratch, LdsNodePtr top_lds,
                                            uint32_t* __restrict__ spill, uint32_t spill_depth, uint32_t total, uint32_t wave, uint32_t n_waves, TraceTally& tally) {
   constexpr bool SHARE = !COUNT;
   constexpr uint32_t kNone = 0xFFFFFFFFu;
@@ -412,7 +425,7 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
   int* aux_out = aux;          // [owner lane] helpers currently working for that lane's ray
   uint32_t* aux_t = reinterpret_cast<uint32_t*>(aux) + 64;   // [owner lane] bits of the smallest hit distance the ray's owner or any helper has found (tail only)
   int* aux_sb = aux + 128;     // [lane] lowest LDS stack level that may still hold a live entry
-  int* aux_pair = aux + 192;   // [k] lane of the k-th donor of this round; shares its words with the child links, which only live inside a node visit
+  int* aux_pair = link_scratch;   // [k] lane of the k-th donor of this round; shares its words with the child links, which only live inside a node visit
   if (SHARE) {
     aux_out[lane] = 0;
     aux_sb[lane] = 0;
@@ -644,8 +657,8 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
         const vec3 na = mk3(ldexpf(ig.x, (int)((w0.y >> 16) & 15u)), ldexpf(ig.y, (int)((w0.y >> 20) & 15u)), ldexpf(ig.z, (int)((w0.y >> 24) & 15u)));
         const vec3 nc = mk3(fmaf(-32768.0f, na.x, fmaf(ox, ig.x, cg.x)), fmaf(-32768.0f, na.y, fmaf(oy, ig.y, cg.y)), fmaf(-32768.0f, na.z, fmaf(oz, ig.z, cg.z)));
         const SlabSel s48{ig.x < 0.0f ? kSel48Hi : kSel48Lo, ig.y < 0.0f ? kSel48Hi : kSel48Lo, ig.z < 0.0f ? kSel48Hi : kSel48Lo};
-        uint32_t k0 = box_key48(w0.z, w1.x, w1.z, 0u, 0u, s48, na, nc, tmin, bound), k1 = box_key48(w0.z, w1.x, w1.z, 1u, 0x0200u, s48, na, nc, tmin, bound);
-        uint32_t k2 = box_key48(w0.w, w1.y, w1.w, 2u, 0u, s48, na, nc, tmin, bound), k3 = box_key48(w0.w, w1.y, w1.w, 3u, 0x0200u, s48, na, nc, tmin, bound);
+        uint32_t k0 = box_key48(w0.z, w1.x, w1.z, 0u, 0u, s48, na, nc, tmin, bound), k1 = box_key48(w0.z, w1.x, w1.z, kKeyChild, 0x0200u, s48, na, nc, tmin, bound);
+        uint32_t k2 = box_key48(w0.w, w1.y, w1.w, 2u * kKeyChild, 0u, s48, na, nc, tmin, bound), k3 = box_key48(w0.w, w1.y, w1.w, 3u * kKeyChild, 0x0200u, s48, na, nc, tmin, bound);
 #else
         u32x4 w0, w1, w2, w3;
         if (kLdsTop && (cur & kBvhTopFlag)) {
@@ -667,8 +680,8 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
 #endif
         float bound = best.t;
         if (SHARE && !ANY && exhausted) bound = fminf(bound, __uint_as_float(aux_t[helper ? (int)ray : lane]));   // positive floats order like their bits
-        uint32_t k0 = box_key<false>(w0.x, w0.y, w0.z, w3.x, 0u, sel, ig, cg, cg, tmin, bound), k1 = box_key<false>(w0.w, w1.x, w1.y, w3.y, 1u, sel, ig, cg, cg, tmin, bound);
-        uint32_t k2 = box_key<false>(w1.z, w1.w, w2.x, w3.z, 2u, sel, ig, cg, cg, tmin, bound), k3 = box_key<false>(w2.y, w2.z, w2.w, w3.w, 3u, sel, ig, cg, cg, tmin, bound);
+        uint32_t k0 = box_key<false>(w0.x, w0.y, w0.z, w3.x, 0u, sel, ig, cg, cg, tmin, bound), k1 = box_key<false>(w0.w, w1.x, w1.y, w3.y, kKeyChild, sel, ig, cg, cg, tmin, bound);
+        uint32_t k2 = box_key<false>(w1.z, w1.w, w2.x, w3.z, 2u * kKeyChild, sel, ig, cg, cg, tmin, bound), k3 = box_key<false>(w2.y, w2.z, w2.w, w3.w, 3u * kKeyChild, sel, ig, cg, cg, tmin, bound);
 #endif
         sort2(k0, k1); sort2(k2, k3); sort2(k0, k2); sort2(k1, k3); sort2(k1, k2);
         // The links go through LDS: picking one of four registers by a per-lane index costs 6 VALU instructions (the
@@ -681,9 +694,10 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
         asm volatile("" : "+v"(k0), "+v"(k1), "+v"(k2), "+v"(k3));
         GLZ_SEC_STAMP(sec_f1);   // box tests and sort
 #endif
-        int* links = aux + 192 + lane;
+        int* links = link_scratch + lane;
         links[0] = (int)w3.x; links[64] = (int)w3.y; links[128] = (int)w3.z; links[192] = (int)w3.w;
-        const int l0 = links[(k0 & 3u) * 64u], l1 = links[(k1 & 3u) * 64u], l2 = links[(k2 & 3u) * 64u], l3 = links[(k3 & 3u) * 64u];
+        const uint32_t link_base = (uint32_t)(uintptr_t)(LdsIntPtr)links;   // the wave's area is 1 KB aligned: bits 8..9 are the child's
+        const int l0 = sorted_link(link_base, k0), l1 = sorted_link(link_base, k1), l2 = sorted_link(link_base, k2), l3 = sorted_link(link_base, k3);
         // (Three unconditional stores with the stack pointer advancing by one per valid key -- the invalid links of the sorted
         // sequence are overwritten by the next store or stay above the top -- remove 12 scalar / branch instructions per round
         // and measured slower, 0.587 -> 0.597 ms: the extra DS stores cost more than the exec-mask branches.)
@@ -862,7 +876,7 @@ constexpr bool kTlLdsTop = false;
 
 
 template <bool ANY, bool COUNT, class Source, class Sink>
-__device__ __forceinline__ void trace_wave_tl(const DeviceScene& S, Source& src, Sink& sink, int* __restrict__ lds_col, int* aux, float* __restrict__ top_ray, LdsNodePtr top_lds,
+__device__ __forceinline__ void trace_wave_tl(const DeviceScene& S, Source& src, Sink& sink, int* __restrict__ lds_col, int* aux, int* link_scratch, float* __restrict__ top_ray, LdsNodePtr top_lds,
                                               uint32_t* __restrict__ spill, uint32_t spill_depth, uint32_t total, uint32_t wave, uint32_t n_waves, TraceTally& tally) {
   constexpr uint32_t kNone = 0xFFFFFFFFu;
   const BvhNode4* __restrict__ nodes = S.bvh_nodes;        // top-level nodes first, the meshes' after them (TlasInstance::node_base)
@@ -975,12 +989,13 @@ __device__ __forceinline__ void trace_wave_tl(const DeviceScene& S, Source& src,
           const u32x4* np = reinterpret_cast<const u32x4*>(nodes + nbase + (uint32_t)cur);
           w0 = np[0]; w1 = np[1]; w2 = np[2]; w3 = np[3];
         }
-        uint32_t k0 = box_key(w0.x, w0.y, w0.z, w3.x, 0u, sel, ig, cgn, cgf, tmin, best.t), k1 = box_key(w0.w, w1.x, w1.y, w3.y, 1u, sel, ig, cgn, cgf, tmin, best.t);
-        uint32_t k2 = box_key(w1.z, w1.w, w2.x, w3.z, 2u, sel, ig, cgn, cgf, tmin, best.t), k3 = box_key(w2.y, w2.z, w2.w, w3.w, 3u, sel, ig, cgn, cgf, tmin, best.t);
+        uint32_t k0 = box_key(w0.x, w0.y, w0.z, w3.x, 0u, sel, ig, cgn, cgf, tmin, best.t), k1 = box_key(w0.w, w1.x, w1.y, w3.y, kKeyChild, sel, ig, cgn, cgf, tmin, best.t);
+        uint32_t k2 = box_key(w1.z, w1.w, w2.x, w3.z, 2u * kKeyChild, sel, ig, cgn, cgf, tmin, best.t), k3 = box_key(w2.y, w2.z, w2.w, w3.w, 3u * kKeyChild, sel, ig, cgn, cgf, tmin, best.t);
         sort2(k0, k1); sort2(k2, k3); sort2(k0, k2); sort2(k1, k3); sort2(k1, k2);
-        int* links = aux + 192 + lane;
+        int* links = link_scratch + lane;
         links[0] = (int)w3.x; links[64] = (int)w3.y; links[128] = (int)w3.z; links[192] = (int)w3.w;
-        const int l0 = links[(k0 & 3u) * 64u], l1 = links[(k1 & 3u) * 64u], l2 = links[(k2 & 3u) * 64u], l3 = links[(k3 & 3u) * 64u];
+        const uint32_t link_base = (uint32_t)(uintptr_t)(LdsIntPtr)links;   // the wave's area is 1 KB aligned: bits 8..9 are the child's
+        const int l0 = sorted_link(link_base, k0), l1 = sorted_link(link_base, k1), l2 = sorted_link(link_base, k2), l3 = sorted_link(link_base, k3);
         if (k0 == 0xFFFFFFFFu) {
           cur = pop_next();
         } else {

@@ -155,7 +155,7 @@ __device__ unsigned long long g_path_times[3 * 8192];
 template <bool LOD>
 __global__ void __launch_bounds__(kBlock, GLZ_PATH_WAVES) k_path(const LaunchArgs A, const PathBatch B) {
   __shared__ int s_stack[kLdsStack * kBlock];
-  __shared__ alignas(16) int s_aux[(kBlock / 64) * kAuxPerWave];
+  __shared__ alignas(1024) int s_aux[kAuxPerBlock];
   __shared__ uint4 s_top[kLdsTop ? kBvhTopNodes * 4 : 1];
   __shared__ float s_lut[256];
   __shared__ float4 s_hit[kBlock];
@@ -181,7 +181,8 @@ __global__ void __launch_bounds__(kBlock, GLZ_PATH_WAVES) k_path(const LaunchArg
   // wave-uniform values in scalar registers: the compiler cannot see that threadIdx.x >> 6 is the same in all lanes of a wave
   const uint32_t wave_in_block = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const uint32_t my_wave = blockIdx.x * (kBlock / 64) + wave_in_block;
-  int* aux = &s_aux[wave_in_block * kAuxPerWave];
+  int* aux = wave_aux(s_aux, wave_in_block);
+  int* links = wave_links(s_aux, wave_in_block);
   float4* hit = &s_hit[wave_in_block * 64u];
   const uint32_t lane = threadIdx.x & 63u;
   TraceTally tally;
@@ -225,12 +226,12 @@ __global__ void __launch_bounds__(kBlock, GLZ_PATH_WAVES) k_path(const LaunchArg
         // ONE traversal pass: the 64 closest-hit rays of launch L, then -- in the lanes those leave idle -- the shadow rays launch L-1 queued
         GroupMixedSource src{ClosestSource{A, F, tally, lid0}, GroupShadowSource{A, lid0, 0u, make_float4(0.0f, 0.0f, 0.0f, 0.0f), make_float4(0.0f, 0.0f, 0.0f, 0.0f)}, false};
         GroupMixedSink sink{GroupHitSink{hit}, GroupShadowSink{A, src.shadow, queued_exposure}};
-        trace_wave<false, false, true, GLZ_PATH_PREFETCH != 0>(A.scene, src, sink, &s_stack[threadIdx.x], aux, (LdsNodePtr)s_top, A.st.overflow, A.st.overflow_depth, 64u + n_shadow, 0u, 1u, tally);
+        trace_wave<false, false, true, GLZ_PATH_PREFETCH != 0>(A.scene, src, sink, &s_stack[threadIdx.x], aux, links, (LdsNodePtr)s_top, A.st.overflow, A.st.overflow_depth, 64u + n_shadow, 0u, 1u, tally);
         n_shadow = 0u;
       } else {
         GroupShadowSource src{A, lid0, 0u, make_float4(0.0f, 0.0f, 0.0f, 0.0f), make_float4(0.0f, 0.0f, 0.0f, 0.0f)};
         GroupShadowSink sink{A, src, queued_exposure};
-        trace_wave<true, false, false, GLZ_PATH_PREFETCH != 0>(A.scene, src, sink, &s_stack[threadIdx.x], aux, (LdsNodePtr)s_top, A.st.overflow, A.st.overflow_depth, n_shadow, 0u, 1u, tally);
+        trace_wave<true, false, false, GLZ_PATH_PREFETCH != 0>(A.scene, src, sink, &s_stack[threadIdx.x], aux, links, (LdsNodePtr)s_top, A.st.overflow, A.st.overflow_depth, n_shadow, 0u, 1u, tally);
         n_shadow = 0u;
       }
 #ifdef GLZ_PATH_TIMES

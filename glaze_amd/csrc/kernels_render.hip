@@ -221,12 +221,13 @@ __global__ void __launch_bounds__(kShadeBlock, GLZ_SHADE_WAVES) k_shade(const La
 template <bool COUNT>
 __global__ void __launch_bounds__(kBlock, GLZ_TRACE_WAVES) k_trace(const LaunchArgs A) {
   __shared__ int s_stack[kLdsStack * kBlock];
-  __shared__ alignas(16) int s_aux[(kBlock / 64) * kAuxPerWave];
+  __shared__ alignas(1024) int s_aux[kAuxPerBlock];
   __shared__ uint4 s_top[kLdsTop ? kBvhTopNodes * 4 : 1];
   static_assert(kBvhTopNodes * 4 <= kBlock, "stage_top copies one 16-byte piece per thread");
   GLZ_WAVE_STAMP(0);
   stage_top(A.scene, s_top);
-  int* aux = &s_aux[(threadIdx.x >> 6) * kAuxPerWave];
+  int* aux = wave_aux(s_aux, threadIdx.x >> 6);
+  int* links = wave_links(s_aux, threadIdx.x >> 6);
   if (blockIdx.x == 0 && threadIdx.x < kQueueShards) A.st.queue_count[A.shade_set * kQueueSetWords + threadIdx.x * kCounterStride] = 0;
   // counting build: the alpha tests' texture fetches are tallied through a copy of the scene that points at this thread's registers
   unsigned long long tex_tally[4] = {0ull, 0ull, 0ull, 0ull};
@@ -240,7 +241,7 @@ __global__ void __launch_bounds__(kBlock, GLZ_TRACE_WAVES) k_trace(const LaunchA
     TraceTally tally;
     ClosestSource src{A, A.frame, tally, 0u};
     ClosestSink sink{A};
-    trace_wave<false, COUNT>(TS, src, sink, &s_stack[threadIdx.x], aux, (LdsNodePtr)s_top, A.st.overflow, A.st.overflow_depth, A.map.n_local_pixels, wave_index(),
+    trace_wave<false, COUNT>(TS, src, sink, &s_stack[threadIdx.x], aux, links, (LdsNodePtr)s_top, A.st.overflow, A.st.overflow_depth, A.map.n_local_pixels, wave_index(),
                              wave_count(), tally);
     if (COUNT) flush_counters(A.counters, false, tally);
   }
@@ -261,7 +262,7 @@ __global__ void __launch_bounds__(kBlock, GLZ_TRACE_WAVES) k_trace(const LaunchA
     const uint32_t n_waves = wave_count();
     const uint32_t closest_groups = A.do_closest ? (A.map.n_local_pixels + 63u) / 64u : 0u;
     const uint32_t wave = (wave_index() + n_waves - closest_groups % n_waves) % n_waves;
-    trace_wave<true, COUNT>(TS, src, sink, &s_stack[threadIdx.x], aux, (LdsNodePtr)s_top, A.st.overflow, A.st.overflow_depth, start[kQueueShards], wave, n_waves, tally);
+    trace_wave<true, COUNT>(TS, src, sink, &s_stack[threadIdx.x], aux, links, (LdsNodePtr)s_top, A.st.overflow, A.st.overflow_depth, start[kQueueShards], wave, n_waves, tally);
     if (COUNT) flush_counters(A.counters, true, tally);
   }
   if (COUNT) flush_tex_tallies(A.counters->trace_tex, tex_tally);
@@ -280,17 +281,18 @@ struct ClosestSinkTl {
 template <bool COUNT>
 __global__ void __launch_bounds__(kBlock, GLZ_TRACE_TL_WAVES) k_trace_tl(const LaunchArgs A) {
   __shared__ int s_stack[kLdsStack * kBlock];
-  __shared__ alignas(16) int s_aux[(kBlock / 64) * kAuxPerWave];
+  __shared__ alignas(1024) int s_aux[kAuxPerBlock];
   __shared__ float s_top_ray[9 * kBlock];   // per lane: the top level's grid-space ray (trace_wave_tl)
   __shared__ uint4 s_top[kTlLdsTop ? kBvhTopNodes * 4 : 1];
   if (kTlLdsTop) stage_top(A.scene, s_top);
-  int* aux = &s_aux[(threadIdx.x >> 6) * kAuxPerWave];
+  int* aux = wave_aux(s_aux, threadIdx.x >> 6);
+  int* links = wave_links(s_aux, threadIdx.x >> 6);
   if (blockIdx.x == 0 && threadIdx.x < kQueueShards) A.st.queue_count[A.shade_set * kQueueSetWords + threadIdx.x * kCounterStride] = 0;
   if (A.do_closest) {
     TraceTally tally;
     ClosestSource src{A, A.frame, tally, 0u};
     ClosestSinkTl sink{A};
-    trace_wave_tl<false, COUNT>(A.scene, src, sink, &s_stack[threadIdx.x], aux, &s_top_ray[threadIdx.x], (LdsNodePtr)s_top, A.st.overflow, A.st.overflow_depth, A.map.n_local_pixels, wave_index(), wave_count(), tally);
+    trace_wave_tl<false, COUNT>(A.scene, src, sink, &s_stack[threadIdx.x], aux, links, &s_top_ray[threadIdx.x], (LdsNodePtr)s_top, A.st.overflow, A.st.overflow_depth, A.map.n_local_pixels, wave_index(), wave_count(), tally);
     if (COUNT) flush_counters(A.counters, false, tally);
   }
   if (A.do_shadow) {
@@ -305,7 +307,7 @@ __global__ void __launch_bounds__(kBlock, GLZ_TRACE_TL_WAVES) k_trace_tl(const L
     const uint32_t closest_groups = A.do_closest ? (A.map.n_local_pixels + 63u) / 64u : 0u;
     const uint32_t wave = (wave_index() + n_waves - closest_groups % n_waves) % n_waves;
     TraceTally tally;
-    trace_wave_tl<true, COUNT>(A.scene, src, sink, &s_stack[threadIdx.x], aux, &s_top_ray[threadIdx.x], (LdsNodePtr)s_top, A.st.overflow, A.st.overflow_depth, start[kQueueShards], wave, n_waves, tally);
+    trace_wave_tl<true, COUNT>(A.scene, src, sink, &s_stack[threadIdx.x], aux, links, &s_top_ray[threadIdx.x], (LdsNodePtr)s_top, A.st.overflow, A.st.overflow_depth, start[kQueueShards], wave, n_waves, tally);
     if (COUNT) flush_counters(A.counters, true, tally);
   }
 }
@@ -391,29 +393,29 @@ __global__ void __launch_bounds__(kBlock) k_debug_closest(const DeviceScene S, c
                                                           float tmin, float* t, uint32_t* tri, uint32_t* inst, float* u, float* v,
                                                           uint32_t* overflow, uint32_t overflow_depth) {
   __shared__ int s_stack[kLdsStack * kBlock];
-  __shared__ alignas(16) int s_aux[(kBlock / 64) * kAuxPerWave];
+  __shared__ alignas(1024) int s_aux[kAuxPerBlock];
   __shared__ uint4 s_top[kLdsTop ? kBvhTopNodes * 4 : 1];
   __shared__ float s_top_ray[9 * kBlock];
   stage_top(S, s_top);
   TraceTally tally;
   DebugSource src{o, d, nullptr, tmin};
   DebugClosestSink sink{S, t, tri, inst, u, v};
-  if (S.two_level) trace_wave_tl<false, false>(S, src, sink, &s_stack[threadIdx.x], &s_aux[(threadIdx.x >> 6) * kAuxPerWave], &s_top_ray[threadIdx.x], (LdsNodePtr)s_top, overflow, overflow_depth, n, wave_index(), wave_count(), tally);
-  else trace_wave<false, false>(S, src, sink, &s_stack[threadIdx.x], &s_aux[(threadIdx.x >> 6) * kAuxPerWave], (LdsNodePtr)s_top, overflow, overflow_depth, n, wave_index(), wave_count(), tally);
+  if (S.two_level) trace_wave_tl<false, false>(S, src, sink, &s_stack[threadIdx.x], wave_aux(s_aux, threadIdx.x >> 6), wave_links(s_aux, threadIdx.x >> 6), &s_top_ray[threadIdx.x], (LdsNodePtr)s_top, overflow, overflow_depth, n, wave_index(), wave_count(), tally);
+  else trace_wave<false, false>(S, src, sink, &s_stack[threadIdx.x], wave_aux(s_aux, threadIdx.x >> 6), wave_links(s_aux, threadIdx.x >> 6), (LdsNodePtr)s_top, overflow, overflow_depth, n, wave_index(), wave_count(), tally);
 }
 __global__ void __launch_bounds__(kBlock) k_debug_any(const DeviceScene S, const float* __restrict__ o, const float* __restrict__ d,
                                                       const float* __restrict__ tmax, uint32_t n, float tmin, uint8_t* out, uint32_t* overflow,
                                                       uint32_t overflow_depth) {
   __shared__ int s_stack[kLdsStack * kBlock];
-  __shared__ alignas(16) int s_aux[(kBlock / 64) * kAuxPerWave];
+  __shared__ alignas(1024) int s_aux[kAuxPerBlock];
   __shared__ uint4 s_top[kLdsTop ? kBvhTopNodes * 4 : 1];
   __shared__ float s_top_ray[9 * kBlock];
   stage_top(S, s_top);
   TraceTally tally;
   DebugSource src{o, d, tmax, tmin};
   DebugAnySink sink{out};
-  if (S.two_level) trace_wave_tl<true, false>(S, src, sink, &s_stack[threadIdx.x], &s_aux[(threadIdx.x >> 6) * kAuxPerWave], &s_top_ray[threadIdx.x], (LdsNodePtr)s_top, overflow, overflow_depth, n, wave_index(), wave_count(), tally);
-  else trace_wave<true, false>(S, src, sink, &s_stack[threadIdx.x], &s_aux[(threadIdx.x >> 6) * kAuxPerWave], (LdsNodePtr)s_top, overflow, overflow_depth, n, wave_index(), wave_count(), tally);
+  if (S.two_level) trace_wave_tl<true, false>(S, src, sink, &s_stack[threadIdx.x], wave_aux(s_aux, threadIdx.x >> 6), wave_links(s_aux, threadIdx.x >> 6), &s_top_ray[threadIdx.x], (LdsNodePtr)s_top, overflow, overflow_depth, n, wave_index(), wave_count(), tally);
+  else trace_wave<true, false>(S, src, sink, &s_stack[threadIdx.x], wave_aux(s_aux, threadIdx.x >> 6), wave_links(s_aux, threadIdx.x >> 6), (LdsNodePtr)s_top, overflow, overflow_depth, n, wave_index(), wave_count(), tally);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -1049,13 +1049,13 @@ void ext_trace(const Scene& sc, V3 o, V3 d, float tmin, float tmax, bool any, Co
         // one word per axis: lo | hi << 16
         const float e = box_entry_q((float)(w[3 * k] & 0xFFFFu), (float)(w[3 * k + 1] & 0xFFFFu), (float)(w[3 * k + 2] & 0xFFFFu), (float)(w[3 * k] >> 16),
                                     (float)(w[3 * k + 1] >> 16), (float)(w[3 * k + 2] >> 16), ig, cg, tmin, best);
-        key[k] = (e < INF && w[12 + k] != 0x7FFFFFFFu) ? ((fbits(e) & 0xFFFFFFFCu) | k) : 0xFFFFFFFFu;   // child_key, kernels_render.hip
+        key[k] = (e < INF && w[12 + k] != 0x7FFFFFFFu) ? ((fbits(e) & 0xFFFFFC00u) | (k << 8)) : 0xFFFFFFFFu;   // box_key, device/wavefront.h: distance bits, child index in bits 8..9
       }
       std::sort(key, key + 4);
       if (key[0] != 0xFFFFFFFFu) {
         for (int k = 3; k >= 1; --k)
-          if (key[k] != 0xFFFFFFFFu) stack[sp++] = (int)w[12 + (key[k] & 3u)];
-        cur = (int)w[12 + (key[0] & 3u)];
+          if (key[k] != 0xFFFFFFFFu) stack[sp++] = (int)w[12 + ((key[k] >> 8) & 3u)];
+        cur = (int)w[12 + ((key[0] >> 8) & 3u)];
         continue;
       }
     } else {
