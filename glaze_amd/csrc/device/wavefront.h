@@ -1260,8 +1260,7 @@ struct StagedState {
 #ifdef GLZ_SECTION_TIMES
   unsigned long long sec[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sec_last = 0;
   __device__ __forceinline__ void stamp(int k) {
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // what a section asked for is charged to it
-    const unsigned long long now = __builtin_amdgcn_s_memtime();
+    const unsigned long long now = __builtin_amdgcn_s_memtime();   // (no wait: a section is charged what the wave waited for in it, not what it asked for)
     sec[k] += now - sec_last;
     sec_last = now;
   }

@@ -27,7 +27,7 @@ constexpr uint32_t kSkyLdsFloats = 4096;   // the sky's marginal cdf (H + 1 floa
 // LOD: the build with the texture level of detail (shade_pixel<LOD>).
 constexpr uint32_t kShadeBlock = 256, kShadeWavesPerBlock = kShadeBlock / 64;   // the regrouping domain: pixels sorted by code path per block (512 -> 0.354 against 0.352 ms, 1 024 -> 0.368: purer waves do not pay, the kernel waits for memory)
 #ifdef GLZ_SECTION_TIMES
-static __device__ unsigned long long g_shade_sections[16];   // clocks summed over waves: {prologue, key, sort, [shade_pixel's six], epilogue}, [15] = waves
+static __device__ unsigned long long g_shade_sections[16 * 4096];   // per wave (the first 4 096 of the grid): clocks {prologue, key, sort, [shade_pixel's six], epilogue}, [15] = launches
 #endif
 template <bool COUNT, bool LOD>
 __global__ void __launch_bounds__(kShadeBlock, GLZ_SHADE_WAVES) k_shade(const LaunchArgs A) {
@@ -87,6 +87,8 @@ __global__ void __launch_bounds__(kShadeBlock, GLZ_SHADE_WAVES) k_shade(const La
   // a wave mostly runs one material and one light routine instead of all of them one after the other (lane utilisation
   // was 32 %, SQ_THREAD_CYCLES_VALU / 64 / SQ_ACTIVE_INST_VALU, profiles/r01_pmc.json).  Pixels are independent and
   // all state is addressed by pixel, so the permutation changes no result; only the order of the shadow queue differs.
+  // (The hit record requested before the tables are staged and the material id before the barrier they need -- three round trips in the
+  // time of one and a half on paper: k_shade 0.326 against 0.325 ms, ten more registers spilt.  Not kept.)
   uint32_t key = 63u;   // pixels outside the image sort last
   {
     const uint32_t lid0 = blockIdx.x * kShadeBlock + threadIdx.x;
@@ -200,9 +202,9 @@ __global__ void __launch_bounds__(kShadeBlock, GLZ_SHADE_WAVES) k_shade(const La
   if (COUNT) flush_tex_tallies(A.counters->shade_tex, tex_tally);   // every lane of the wave is here (the counting build returns nowhere above)
 #ifdef GLZ_SECTION_TIMES
   if (!COUNT) {
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     GLZ_KS(3);   // the state leaves through LDS
     unsigned long long v[10] = {ks[0], ks[1], ks[2], staged.sec[0], staged.sec[1], staged.sec[2], staged.sec[3], staged.sec[4], staged.sec[5], ks[3]};
+    const uint32_t w = blockIdx.x * kShadeWavesPerBlock + (threadIdx.x >> 6);
 #pragma unroll
     for (int k = 0; k < 10; ++k) {   // the wave's value of a section: the largest any of its lanes saw
       unsigned int lo = (unsigned int)v[k], hi = (unsigned int)(v[k] >> 32);
@@ -211,9 +213,9 @@ __global__ void __launch_bounds__(kShadeBlock, GLZ_SHADE_WAVES) k_shade(const La
         const unsigned long long a = ((unsigned long long)hi << 32) | lo, b = ((unsigned long long)hi2 << 32) | lo2;
         if (b > a) { lo = lo2; hi = hi2; }
       }
-      if ((threadIdx.x & 63u) == 0u) atomicAdd(&g_shade_sections[k], ((unsigned long long)hi << 32) | lo);
+      if ((threadIdx.x & 63u) == 0u && w < 4096u) g_shade_sections[16u * w + k] += ((unsigned long long)hi << 32) | lo;   // (a wave's own words: no atomics)
     }
-    if ((threadIdx.x & 63u) == 0u) atomicAdd(&g_shade_sections[15], 1ull);
+    if ((threadIdx.x & 63u) == 0u && w < 4096u) g_shade_sections[16u * w + 15u] += 1ull;
   }
 #endif
 }
@@ -505,10 +507,10 @@ hipError_t launch_debug_any(hipStream_t st, const DeviceScene& scene, const floa
 
 #ifdef GLZ_SECTION_TIMES
 extern "C" int glz_debug_shade_sections(unsigned long long* out, int reset) {
-  int e = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(glz::g_shade_sections), sizeof(unsigned long long) * 16);
+  int e = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(glz::g_shade_sections), sizeof(unsigned long long) * 16 * 4096);
   if (reset) {
     void* p = nullptr;
-    if (hipGetSymbolAddress(&p, HIP_SYMBOL(glz::g_shade_sections)) == hipSuccess) e = (int)hipMemset(p, 0, sizeof(unsigned long long) * 16);
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(glz::g_shade_sections)) == hipSuccess) e = (int)hipMemset(p, 0, sizeof(unsigned long long) * 16 * 4096);
   }
   return e;
 }

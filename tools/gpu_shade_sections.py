@@ -16,11 +16,13 @@ NAMES = ["stage tables", "key (hit -> material)", "regroup", "record + material"
 for world in (1, 8):
     r.set_partition(0, world); r.set_launch_mode("two_kernels")
     r.restart(); r.step(32); r.wait_idle()
-    buf = np.zeros(16, np.uint64)
+    buf = np.zeros((4096, 16), np.uint64)
     assert abi.lib().glz_debug_shade_sections(buf.ctypes.data_as(C.c_void_p), 1) == 0
     r.step(16); r.wait_idle()
     assert abi.lib().glz_debug_shade_sections(buf.ctypes.data_as(C.c_void_p), 1) == 0
     b = buf.astype(np.float64)
-    waves = b[15]
-    per = b[:10] / waves
-    print("world %d: %.0f waves, %.0f clocks per wave: " % (world, waves / 16, per.sum()) + ", ".join("%s %.0f (%.0f %%)" % (NAMES[k], per[k], 100 * per[k] / per.sum()) for k in range(10)), flush=True)
+    b = b[b[:, 15] > 0]
+    per = (b[:, :10] / b[:, 15:16]).mean(axis=0)                 # clocks per wave and launch
+    tot = (b[:, :10] / b[:, 15:16]).sum(axis=1)
+    print("world %d: %d waves sampled, %.0f clocks per wave and launch (p90 %.0f, max %.0f): " % (world, len(b), per.sum(), np.percentile(tot, 90), tot.max())
+          + ", ".join("%s %.0f (%.0f %%)" % (NAMES[k], per[k], 100 * per[k] / per.sum()) for k in range(10)), flush=True)
