@@ -136,6 +136,7 @@ hipError_t launch_shade(hipStream_t st, const LaunchArgs& a);
 // the per-wave launch loop of a small tile share: `batch.n` launches for every pixel in ONE kernel (a.frame holds what the launches
 // share; flattened scenes, no work counters); blocks from path_grid_blocks (device must be current)
 uint32_t path_grid_blocks(uint32_t n_local_pixels, const DeviceScene& scene);
+uint32_t path_resident_blocks(const DeviceScene& scene);   // blocks of k_path the chip holds at once
 hipError_t launch_path(hipStream_t st, const LaunchArgs& a, const PathBatch& batch, uint32_t blocks);
 // scatter the tile-major cumulative / result images into full-frame row-major RGBA32F buffers
 hipError_t launch_export(hipStream_t st, const TileMap& map, const float4* tiled, float4* frame, bool zero_first);

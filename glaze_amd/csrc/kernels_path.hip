@@ -268,7 +268,7 @@ static uint32_t path_table_bytes(const DeviceScene& sc) {
   const uint32_t bytes = sc.n_materials * (uint32_t)sizeof(RTMaterial) + sc.n_rt_lights * (uint32_t)sizeof(RTLight) + sc.n_textures * (uint32_t)sizeof(TexDesc);
   return bytes <= kShadeTableBytes ? bytes : 0u;
 }
-uint32_t path_grid_blocks(uint32_t n_local_pixels, const DeviceScene& sc) {
+uint32_t path_resident_blocks(const DeviceScene& sc) {
   int dev = 0, cus = 256, per_cu = 4;
   if (hipGetDevice(&dev) == hipSuccess) {
     hipDeviceProp_t prop;
@@ -276,8 +276,11 @@ uint32_t path_grid_blocks(uint32_t n_local_pixels, const DeviceScene& sc) {
   }
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_path<false>, kBlock, path_table_bytes(sc)) != hipSuccess || per_cu < 1) per_cu = 2;
   per_cu = std::min(per_cu, 8);
+  return (uint32_t)cus * (uint32_t)per_cu;
+}
+uint32_t path_grid_blocks(uint32_t n_local_pixels, const DeviceScene& sc) {
   const uint32_t groups = (n_local_pixels + 63u) / 64u, blocks = (groups + kBlock / 64 - 1) / (kBlock / 64);
-  return std::max<uint32_t>(1u, std::min<uint32_t>(blocks, (uint32_t)cus * (uint32_t)per_cu));
+  return std::max<uint32_t>(1u, std::min<uint32_t>(blocks, path_resident_blocks(sc)));
 }
 hipError_t launch_path(hipStream_t st, const LaunchArgs& a, const PathBatch& batch, uint32_t blocks) {
   static_assert(sizeof(LaunchArgs) + sizeof(PathBatch) <= 4096, "kernel arguments of k_path");

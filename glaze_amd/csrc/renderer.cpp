@@ -144,18 +144,23 @@ bool Renderer::forward(F f, Error& err) {
 
 namespace {
 constexpr uint32_t kTile = 64;
-// Kernel boundaries are timed with HIP events on one launch of every kEventStride, at a pseudo-random place inside each
-// group of kEventStride consecutive launches, and counted kEventStride times (three event records per launch cost 1-3 % of
-// a 1080p launch and 10 % of a small one).  A fixed place would beat against the path depth: launch i traces bounce
-// i mod depth of most pixels and the bounces differ in cost.
-constexpr uint64_t kEventStride = 4;
-inline bool timed_launch(uint64_t i /* 1-based */) {
-  const uint64_t group = (i - 1) / kEventStride;
+// Kernel boundaries are timed with HIP events on one launch of every `stride` (Renderer::event_stride), at a pseudo-random place
+// inside each group of `stride` consecutive launches, and counted `stride` times.  A fixed place would beat against the path depth:
+// launch i traces bounce i mod depth of most pixels and the bounces differ in cost.
+inline bool timed_launch(uint64_t i /* 1-based */, uint64_t stride) {
+  const uint64_t group = (i - 1) / stride;
   uint32_t x = (uint32_t)group * 747796405u + 2891336453u;   // PCG-RXS-M-XS-32
   x = ((x >> ((x >> 28) + 4u)) ^ x) * 277803737u;
   x ^= x >> 22;
-  return (i - 1) % kEventStride == x % kEventStride;
+  return (i - 1) % stride == x % stride;
 }
+}
+// Three event records around a timed launch cost 5 - 7 us in every chain: 1 % of a full 1080p launch, 5 % of a 1/8 share's (0.130 against
+// 0.123 ms per launch with one launch in four timed, tools/timeline_small_share.sh) -- a small share is timed one launch in sixteen.
+uint64_t Renderer::event_stride() const {
+  uint64_t pixels = 0;
+  for (const auto& c : chains_) pixels += c->map.n_local_pixels;
+  return pixels >= (1u << 20) ? 4u : 16u;
 }
 
 Renderer* Renderer::create(Instance* inst, std::shared_ptr<Scene> scene, uint32_t w, uint32_t h, Error& err) {
@@ -233,10 +238,9 @@ uint32_t Renderer::chains_for(uint32_t w, uint32_t h, uint32_t rank, uint32_t wo
 }
 uint32_t Renderer::pick_chains() const { return path_mode_ ? 1u : chains_for(w_, h_, rank_, world_, chains_wanted_); }
 
-// Automatic launch mode: a device runs its launches as k_path batches when every 64-pixel group it owns gets a resident wave of its
-// own (4 096 on an MI355X at k_path's four waves per SIMD: up to 262 144 pixels, e.g. 1/8 of a 1080p frame or a 512 x 512 one) -- with
-// more groups than waves some waves carry two groups one after the other and the launch loop loses to the two-kernel mode (a 1/6
-// share: 0.248 against 0.190 ms per launch; a 1/8 share: 0.153 against 0.153; tools/gpu_partition_timing.py).
+// Automatic launch mode: a device runs its launches as k_path batches only when every 64-pixel group it owns gets a resident wave of its
+// own (4 096 on an MI355X at k_path's four waves per SIMD: up to 262 144 pixels) -- with more groups than waves some waves carry two
+// groups one after the other and the launch loop loses to the two-kernel mode (a 1/6 share: 0.217 against 0.156 ms per launch) ...
 bool Renderer::allocate(Error& err) {
   release_chains();
   {
@@ -245,7 +249,12 @@ bool Renderer::allocate(Error& err) {
     bool fits = false;
     if (launch_mode_ == 0 && pixels > 0 && pixels <= (1u << 22) && scene_->dev.two_level == 0) {
       const uint32_t blocks = (uint32_t)((pixels / 64 + kTraceBlock / 64 - 1) / (kTraceBlock / 64));
-      fits = path_grid_blocks((uint32_t)pixels, scene_->dev) >= blocks;
+      const uint32_t resident = path_resident_blocks(scene_->dev);
+      // ... and the launch loop is what pays: where launches are short (a scene of a few thousand triangles: the 512 x 512 cube runs
+      // 34 % faster in it, its kernel boundaries were most of a launch) or the chip is less than four fifths full (a 1/16 share of the
+      // 1080p atrium: 0.096 against 0.098 ms per launch).  A share that fills every wave slot with a scene of its size is faster as two
+      // kernels since round 4 (1080p / 8: 0.129 against 0.134 ms; tools/gpu_partition_timing.py, tools/gpu_batch_length.py).
+      fits = resident >= blocks && (scene_->info.n_world_triangles < 4096 || (uint64_t)blocks * 5u <= (uint64_t)resident * 4u);
     }
     path_mode_ = scene_->dev.two_level == 0 && (launch_mode_ == 2 || fits);
   }
@@ -362,7 +371,7 @@ void Renderer::resolve_events(Chain& c) {
       c.path_ms += a;
     } else {
       (void)hipEventElapsedTime(&b, s.e[1], s.e[2]);
-      const double weight = (double)kEventStride;
+      const double weight = (double)s.weight;
       c.trace_ms += a * weight;
       c.shade_ms += b * weight;
     }
@@ -454,11 +463,13 @@ bool Renderer::one_launch(Error& err) {
     a.frame = fd;
     a.do_closest = 1;
     a.do_shadow = c.shadow_pending ? 1u : 0u;   // the previous launch's shadow rays ride in this launch's traversal kernel
-    const bool timed = profile_kernels_ && timed_launch(launches_);
+    const uint64_t stride = event_stride();
+    const bool timed = profile_kernels_ && timed_launch(launches_, stride);
     EventSet ev{};
     if (timed) {
       if (!acquire_events(c, ev, err)) return false;
       ev.kind = 0;
+      ev.weight = (uint32_t)stride;
       (void)hipEventRecord(ev.e[0], st);
     }
     if (!hip_ok(launch_trace(st, a, counting_ ? c.grid_counting : c.grid), "k_trace", err)) return false;

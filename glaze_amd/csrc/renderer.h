@@ -102,7 +102,9 @@ class Renderer {
   struct EventSet {
     hipEvent_t e[4];
     int kind;   // 0: e[0]..e[2] around k_trace, k_shade; 1: e[0]..e[1] around a stand-alone shadow pass; 2: e[0]..e[1] around k_path
+    uint32_t weight;   // kind 0: the launches this timed one stands for (event_stride())
   };
+  uint64_t event_stride() const;
   struct Chain {
     TileMap map{};
     hipStream_t stream = nullptr;

@@ -775,6 +775,8 @@ def test_full_size_atrium_1080p_tiles_vs_oracle(instance, atrium_file):
     # one GPU's share of the 8-way partition of this frame -- what bench.py --gpus 8 gives every device: 259 k pixels, rendered by the
     # per-wave launch loop (k_path), all 17 launches in one kernel
     r.set_partition(3, 8)
+    assert r.launch_mode() == "two_kernels"      # a share that fills every wave slot with a scene of this size: two kernels since round 4
+    r.set_launch_mode("path")
     assert r.launch_mode() == "path"
     r.step(launches)
     mine = [t for t in tiles if t % 8 == 3]
@@ -890,6 +892,11 @@ def test_auto_launch_mode_goes_by_the_pixels_a_device_owns(instance):
     r.set_partition(0, 1)
     r.change_resolution(320, 200)
     assert r.launch_mode() == "path"
+    # a scene of some size: the launch loop only where the chip is less than four fifths full
+    big = glaze_amd.RayTraceRenderer.new(instance, glaze_amd.RayTraceScene.from_desc(instance, atrium_scene()), 1920, 1080)
+    for world, mode in ((1, "two_kernels"), (8, "two_kernels"), (10, "path"), (16, "path")):
+        big.set_partition(0, world)
+        assert big.launch_mode() == mode, (world, big.launch_mode())
 
 
 def test_shading_side_work_counters(instance, mattest_desc):
