@@ -390,7 +390,9 @@ bool Renderer::acquire_events(Chain& c, EventSet& ev, Error& err) {
     if (c.free_events.empty()) {
       EventSet fresh{};
       for (auto& e : fresh.e)
-        if (!hip_ok(hipEventCreate(&e), "hipEventCreate", err)) return false;
+        // timing only: without the system-scope fence an event's completion otherwise carries -- the cache write-back and invalidate
+        // it costs the kernels that follow (the BVH leaves the L2s at every timed kernel boundary of every chain)
+        if (!hip_ok(hipEventCreateWithFlags(&e, hipEventDisableSystemFence), "hipEventCreate", err)) return false;
       c.free_events.push_back(fresh);
     }
   }
