@@ -585,6 +585,19 @@ int64_t glz_debug_read_bvh(glz_scene* h, void* nodes_out, int64_t cap_nodes, voi
         if (link < 0 && (size_t)~link < quads.size()) nd[i].w[12 + k] = (uint32_t)~(int)quads[(size_t)~link].slot;
       }
   }
+  if (nodes_out && cap_nodes > 0 && nn > 0 && s->dev.bvh_quads && s->dev.two_level) {
+    // the same for the meshes of a two-level scene: leaf number within the mesh -> ~(first slot within the mesh's triangles)
+    std::vector<BvhQuad> quads(s->d_quads_count());
+    if (!quads.empty() && !hip_ok(hipMemcpy(quads.data(), s->dev.bvh_quads, quads.size() * sizeof(BvhQuad), hipMemcpyDeviceToHost), "read leaf records", e)) return fail(e);
+    BvhNode4* nd = static_cast<BvhNode4*>(nodes_out);
+    for (const Scene::MeshRange& m : s->h_mesh_ranges)
+      for (int64_t i = m.node_base; i < std::min<int64_t>(std::min(cap_nodes, nn), (int64_t)m.node_base + m.n_nodes); ++i)
+        for (int k = 0; k < 4; ++k) {
+          const int link = (int)nd[i].w[12 + k];
+          const size_t q = (size_t)m.quad_base + (size_t)~link;
+          if (link < 0 && link != kBvhEmptyChild && q < quads.size()) nd[i].w[12 + k] = (uint32_t)~(int)quads[q].slot;
+        }
+  }
   if (tris_out && cap_tris > 0 && nt > 0 &&
       !hip_ok(hipMemcpy(tris_out, s->dev.bvh_tris, (size_t)std::min(cap_tris, nt) * sizeof(BvhTri), hipMemcpyDeviceToHost), "read tris", e))
     return fail(e);

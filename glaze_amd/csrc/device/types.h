@@ -160,8 +160,10 @@ struct alignas(16) TlasInstance {
   uint32_t world_base;    // world triangle id of the instance's primitive 0 (tie-break key, as in the flattened build)
   uint32_t instance;      // RTInstance index
   uint32_t non_opaque;    // the instance's material has an opacity map (acceleration.rs:136-141)
+  uint32_t quad_base;     // first leaf record of the mesh in bvh_quads (the meshes' leaf links are ~leaf number, relative to this)
+  uint32_t _pad[3];
 };
-static_assert(sizeof(TlasInstance) == 176, "TlasInstance is 11 x 16 bytes");
+static_assert(sizeof(TlasInstance) == 192, "TlasInstance is 12 x 16 bytes");
 
 // World-space triangle in BVH leaf order, 48 bytes (36 algorithmic + ids).  The three VERTICES, not a vertex and two edges:
 // the watertight test (ray_triangle) needs the floats two triangles share to be the same floats in both records.
@@ -220,7 +222,7 @@ struct DeviceScene {
   const BvhNode48* bvh_top48;
   BvhGrid bvh_grid;
   const BvhTri* bvh_tris;
-  const BvhQuad* bvh_quads;        // flattened build: one record per leaf, what trace_wave reads (null for two-level scenes)
+  const BvhQuad* bvh_quads;        // one 64-byte record per leaf, what the tracers read: world space (flattened build) or the meshes' object space, concatenated (two levels)
   // per-leaf shading record, 8 x float4 = 128 bytes, in leaf order: VertexPacked x 3 (object space), then
   // (geometric normal.xyz, material id), (dpdu.xyz, transform id | identity flag in bit 31)
   const float4* shade_tris;

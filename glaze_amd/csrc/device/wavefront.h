@@ -880,7 +880,6 @@ __device__ __forceinline__ void trace_wave_tl(const DeviceScene& S, Source& src,
                                               uint32_t* __restrict__ spill, uint32_t spill_depth, uint32_t total, uint32_t wave, uint32_t n_waves, TraceTally& tally) {
   constexpr uint32_t kNone = 0xFFFFFFFFu;
   const BvhNode4* __restrict__ nodes = S.bvh_nodes;        // top-level nodes first, the meshes' after them (TlasInstance::node_base)
-  const BvhTri* __restrict__ tris = S.bvh_tris;
   const TlasInstance* __restrict__ instances = S.tlas_instances;
   const int lane = threadIdx.x & 63;
   const unsigned long long lanes_below = (1ull << lane) - 1ull;
@@ -1036,33 +1035,33 @@ __device__ __forceinline__ void trace_wave_tl(const DeviceScene& S, Source& src,
         cur = 0;   // the mesh's root
       } else {
         const TlasInstance* ti = instances + cur_inst;
-        const uint32_t tri_base = ti->tri_base, first = (uint32_t)~cur;
-        bool finished = false;
+        // The mesh's leaf record (types.h BvhQuad; its hierarchy was built over the mesh under the identity transform, so the
+        // vertices are the object-space ones): one 64-byte line for one triangle or two.  The world triangles are exactly what
+        // k_world_tris builds -- points through o2w -- four of them for a pair instead of six.
+        const float4* qp = reinterpret_cast<const float4*>(S.bvh_quads + ti->quad_base + (uint32_t)~cur);
+        const float4 r0 = qp[0], r1 = qp[1], r2 = qp[2], r3 = qp[3];
+        const uint32_t id0 = __float_as_uint(r0.w), qflags = __float_as_uint(r2.w), slot0 = ti->tri_base + __float_as_uint(r3.w);
+        const bool pair = (qflags & kTriHasPartner) != 0u;
+        if (COUNT) tally.tris += pair ? 2 : 1;
+        const vec3 w0 = xform_point(ti->o2w, mk3(r0.x, r0.y, r0.z)), w1 = xform_point(ti->o2w, mk3(r1.x, r1.y, r1.z));
+        const vec3 w2 = xform_point(ti->o2w, mk3(r2.x, r2.y, r2.z)), w3 = xform_point(ti->o2w, mk3(r3.x, r3.y, r3.z));
         const RayShear rs = ray_shear(d);
-        for (uint32_t local = first;; ++local) {
-          const uint32_t slot = tri_base + local;
-          // the mesh's own triangle record: its hierarchy was built over the mesh under the identity transform, so the record's
-          // vertices are the object-space ones (one 48-byte line instead of three pieces of the 128-byte shading record)
-          const float4* tp = reinterpret_cast<const float4*>(tris + slot);
-          const float4 pa = tp[0], pb = tp[1], pc = tp[2];
-          const uint32_t prim_flags = __float_as_uint(pc.w);
-          if (COUNT) tally.tris += 1;
-          // world triangle exactly as k_world_tris builds it: three points through o2w
-          const vec3 v0 = xform_point(ti->o2w, mk3(pa.x, pa.y, pa.z)), v1 = xform_point(ti->o2w, mk3(pb.x, pb.y, pb.z)), v2 = xform_point(ti->o2w, mk3(pc.x, pc.y, pc.z));
-          BvhTri tr;
-          tr.v0[0] = v0.x; tr.v0[1] = v0.y; tr.v0[2] = v0.z;
-          tr.v1[0] = v1.x; tr.v1[1] = v1.y; tr.v1[2] = v1.z;
-          tr.v2[0] = v2.x; tr.v2[1] = v2.y; tr.v2[2] = v2.z;
-          float t, u, v;
-          if (ray_triangle(rs, tr, o, tmin, t, u, v) && t < tmax) {
-            const uint32_t world_id = ti->world_base + (prim_flags & kTriPrimMask);
+        const QuadHit qh = ray_quad(rs, make_float4(w0.x, w0.y, w0.z, 0.0f), make_float4(w1.x, w1.y, w1.z, 0.0f), make_float4(w2.x, w2.y, w2.z, 0.0f),
+                                    make_float4(w3.x, w3.y, w3.z, 0.0f), pair, o, tmin);
+        const uint32_t swapped = (qflags & kQuadSwapped) ? 1u : 0u;
+        bool finished = false;
+#pragma nounroll
+        for (uint32_t which = 0; which < 2u; ++which) {   // the leaf's first triangle, then its partner (the order the 48-byte records were walked in)
+          const bool is_b = (which ^ swapped) != 0u;
+          const float t = is_b ? qh.t[1] : qh.t[0], u = is_b ? qh.u[1] : qh.u[0], v = is_b ? qh.v[1] : qh.v[0];
+          if ((is_b ? qh.ok[1] : qh.ok[0]) && t < tmax) {
+            const uint32_t world_id = ti->world_base + id0 + which, slot = slot0 + which;
             const bool better = best.leaf == kNone ? true : (t < best.t || (t == best.t && world_id < best.world_id));
             if (better && (ti->non_opaque == 0u || alpha_test_instance(S, slot, ti->instance, u, v))) {
               best = HitRecord{t, u, v, slot, ti->instance, world_id};
               finished = ANY;
             }
           }
-          if (local != first || !(prim_flags & kTriHasPartner)) break;
         }
         cur = finished ? kRayDone : pop_next();
       }

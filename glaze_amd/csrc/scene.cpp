@@ -549,12 +549,15 @@ bool Scene::build_two_level(Error& err) {
   hipEvent_t e0, e1;
   if (!hip_ok(hipEventCreate(&e0), "event", err) || !hip_ok(hipEventCreate(&e1), "event", err)) return false;
   (void)hipEventRecord(e0, st);
+  h_mesh_ranges.clear();
   // ---- unique meshes (index ranges) ----
   struct MeshAs {
     uint32_t index_offset, index_count, tri_base, node_base, n_nodes, depth;
     BvhGrid grid;
     float lo[3], hi[3];
     BvhNode4* nodes;
+    BvhQuad* quads = nullptr;   // the mesh's leaf records (object space), as build_lbvh handed them out
+    uint32_t n_leaves = 0, quad_base = 0;
   };
   std::vector<MeshAs> meshes;
   std::vector<uint32_t> mesh_of(h_instances.size());
@@ -576,8 +579,12 @@ bool Scene::build_two_level(Error& err) {
     return false;
   }
   auto free_nodes = [&]() {
-    for (MeshAs& m : meshes)
+    for (MeshAs& m : meshes) {
       if (m.nodes) (void)hipFree(m.nodes);
+      if (m.quads) (void)hipFree(m.quads);
+      m.nodes = nullptr;
+      m.quads = nullptr;
+    }
   };
   const uint32_t nt = (uint32_t)total_tris;
   d_nodes_.release();
@@ -609,11 +616,15 @@ bool Scene::build_two_level(Error& err) {
       return false;
     }
     LbvhInputs in{d_vertices_.ptr, d_indices_.ptr, d_pseudo.ptr, d_zero.ptr, 1u, d_ident.ptr, d_opaque.ptr, n, instance->bvh_builder, instance->bvh_pair_area_ratio};
+    in.emit_quads = true;   // 64-byte leaf records (object space here), leaf links ~leaf number relative to the mesh
     LbvhOutputs out{};
     DeviceBuffer<BvhTri> tris;
     if (!hip_ok(tris.alloc((size_t)n + 1), "alloc mesh triangles", err)) { free_nodes(); return false; }
     out.tris = tris.ptr;
-    if (!hip_ok(build_lbvh(st, in, out), "mesh hierarchy", err)) { free_nodes(); return false; }
+    const hipError_t be = build_lbvh(st, in, out);
+    m.quads = out.quads;
+    m.n_leaves = out.quads ? out.n_leaves : 0u;
+    if (!hip_ok(be, "mesh hierarchy", err)) { if (out.nodes) (void)hipFree(out.nodes); free_nodes(); return false; }
     m.nodes = out.nodes;
     m.n_nodes = out.n_nodes;
     m.depth = out.depth;
@@ -629,6 +640,21 @@ bool Scene::build_two_level(Error& err) {
       free_nodes();
       return false;
     }
+  }
+  // ---- the meshes' leaf records, one array (TlasInstance::quad_base) ----
+  {
+    uint32_t total_leaves = 0;
+    for (MeshAs& m : meshes) {
+      m.quad_base = total_leaves;
+      total_leaves += m.n_leaves;
+    }
+    d_quads_.release();
+    bool ok = hip_ok(d_quads_.alloc((size_t)total_leaves + 1), "alloc leaf records", err);
+    if (ok) ok = hip_ok(hipMemsetAsync(d_quads_.ptr + total_leaves, 0, sizeof(BvhQuad), st), "clear leaf record padding", err);
+    for (MeshAs& m : meshes)
+      if (ok && m.n_leaves)
+        ok = hip_ok(hipMemcpyAsync(d_quads_.ptr + m.quad_base, m.quads, sizeof(BvhQuad) * m.n_leaves, hipMemcpyDeviceToDevice, st), "copy leaf records", err);
+    if (!ok) { (void)hipStreamSynchronize(st); free_nodes(); return false; }
   }
   // ---- instance boxes: world AABB of the mesh's VERTICES under the instance's transform, padded.  (The eight corners of the
   // mesh's object box, which is what a top level normally takes, give a box up to sqrt(2) too wide per axis for a rotated instance
@@ -728,6 +754,7 @@ bool Scene::build_two_level(Error& err) {
       }
       ok = hip_ok(hipMemcpyAsync(d_nodes_.ptr + at, &childless, sizeof(BvhNode4), hipMemcpyHostToDevice, st), "copy nodes", err);
     }
+    h_mesh_ranges.push_back(MeshRange{m.node_base, m.n_nodes, m.quad_base, m.tri_base});
     at += m.n_nodes ? m.n_nodes : 1u;
   }
   // instance records in the top level's leaf order
@@ -772,6 +799,7 @@ bool Scene::build_two_level(Error& err) {
     r.w2o_norm = (float)wnorm;   // the tracer adds 32 eps wnorm |o|_1 per ray: origins far outside the scene's bounds
     r.node_base = m.node_base;
     r.tri_base = m.tri_base;
+    r.quad_base = m.quad_base;
     r.world_base = inst_base_[i];
     r.instance = i;
     r.non_opaque = h_materials[in.material_id].opacity != 0 ? 1u : 0u;
@@ -809,8 +837,7 @@ bool Scene::build_two_level(Error& err) {
   dev.bvh_top = d_top_.ptr;
   dev.bvh_grid = top.grid;
   dev.bvh_tris = d_tris_.ptr;
-  dev.bvh_quads = nullptr;   // (the two-level tracer reads the meshes' 48-byte object-space records)
-  d_quads_.release();
+  dev.bvh_quads = d_quads_.ptr;   // the meshes' leaf records, concatenated
   dev.shade_tris = d_shade_tris_.ptr;
   dev.tlas_nodes = d_nodes_.ptr;
   dev.tlas_instances = d_tlas_instances_.ptr;

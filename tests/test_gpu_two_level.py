@@ -1,7 +1,7 @@
 """Two-level acceleration structure for instanced scenes (acceleration.rs:319-345: one BLAS per mesh, a TLAS over the instances).
 
 The flattened build keeps a world-space copy of every instanced triangle (192 bytes each); the two-level build keeps the meshes
-once and 176 bytes per instance.  Inside an instance only the box tests see the object-space ray -- the triangle test stays in
+once and 192 bytes per instance.  Inside an instance only the box tests see the object-space ray -- the triangle test stays in
 world space on the triangle transformed exactly as the flattened build transforms it -- so closest hits (t, world triangle,
 instance, u, v), occlusion and whole renders must be BIT-identical between the two shapes, and through the flattened twin to
 the oracle.
