@@ -10,7 +10,9 @@ inst = glaze_amd.RayTraceInstance.new()
 r = glaze_amd.RayTraceRenderer.new(inst, glaze_amd.RayTraceScene.from_desc(inst, atrium_scene()), 1920, 1080)
 r.set_depth(8)
 out = []
-for mode, world in (("two_kernels", 1), ("two_kernels", 8), ("path", 4), ("path", 8), ("path", 16)):
+import os
+cases = [(c.split("/")[0], int(c.split("/")[1])) for c in os.environ.get("GLZ_VARIANT_CASES", "two_kernels/1,two_kernels/8,path/4,path/8,path/16").split(",")]
+for mode, world in cases:
     r.set_partition(0, world); r.set_launch_mode(mode)
     r.restart(); r.step(16); r.wait_idle()
     n = 128
