@@ -899,10 +899,13 @@ __device__ __forceinline__ void trace_wave_tl(const DeviceScene& S, Source& src,
   // plus `cells` cells on every side
   auto set_grid_ray = [&](const float* glo, const float* gcell, const float* ginv, vec3 oo, vec3 dd, float slack, float cells) {
     const vec3 og = mk3((oo.x - glo[0]) * ginv[0], (oo.y - glo[1]) * ginv[1], (oo.z - glo[2]) * ginv[2]);
-    ig = mk3(grid_inv_dir(dd.x) * gcell[0], grid_inv_dir(dd.y) * gcell[1], grid_inv_dir(dd.z) * gcell[2]);
+    const vec3 id = mk3(grid_inv_dir(dd.x), grid_inv_dir(dd.y), grid_inv_dir(dd.z));
+    ig = mk3(id.x * gcell[0], id.y * gcell[1], id.z * gcell[2]);
     const vec3 cg = mk3(grid_addend(og.x, ig.x), grid_addend(og.y, ig.y), grid_addend(og.z, ig.z));
-    const vec3 pad = mk3(fminf(slack * ginv[0] + cells, 65536.0f), fminf(slack * ginv[1] + cells, 65536.0f), fminf(slack * ginv[2] + cells, 65536.0f));
-    const vec3 w = mk3(pad.x * fabsf(ig.x), pad.y * fabsf(ig.y), pad.z * fabsf(ig.z));
+    // The pad as a LENGTH of that space (slack + `cells` cells) over the direction, not as a number of cells: across the thin side of a
+    // flat mesh a cell is 1e-13 of a unit, and a pad counted in cells (it was, capped at twice the grid's span) is then far less than the
+    // rounding of the transformed ray it stands for -- coplanar meshes lost near ties, thin ones hits (tools/gpu_fuzz_parity.py).
+    const vec3 w = mk3((slack + cells * gcell[0]) * fabsf(id.x), (slack + cells * gcell[1]) * fabsf(id.y), (slack + cells * gcell[2]) * fabsf(id.z));
     cgn = cg - w;
     cgf = cg + w;
     sel = SlabSel{slab_sel(ig.x), slab_sel(ig.y), slab_sel(ig.z)};

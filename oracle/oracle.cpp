@@ -940,12 +940,18 @@ struct Hit {
 
 struct Counters { uint64_t nodes = 0, tris = 0; };
 
+// Conservative slab test of the oracle's own hierarchy (an accelerator only: orc_trace_closest_brute is the definition).  The plane
+// distances are widened by the rounding they can carry -- a difference of operands of size |plane| + |origin| times 1 / d, three
+// roundings -- so that a box is never left out because its entry rounds past the distance of a hit already found.  (Without it a
+// triangle lying in a plane near coordinate 0, seen from an origin a unit away, lost exact ties against a coincident triangle of
+// another instance: the 1e-5 relative pad of a near-zero coordinate vanishes in the subtraction.  tools/gpu_fuzz_parity.py.)
 inline bool ray_box(const float* lo, const float* hi, V3 o, V3 inv, float tmin, float tmax) {
   float t0 = tmin, t1 = tmax;
   const float* O = &o.x; const float* I = &inv.x;
   for (int k = 0; k < 3; ++k) {
     float a = (lo[k] - O[k]) * I[k], b = (hi[k] - O[k]) * I[k];
-    float n = fminf(a, b), f = fmaxf(a, b);   // fminf/fmaxf drop NaNs (0*inf on slab-parallel rays)
+    float e = ((fmaxf(fabsf(lo[k]), fabsf(hi[k])) + fabsf(O[k])) * fabsf(I[k])) * 3.6e-7f;
+    float n = fminf(a, b) - e, f = fmaxf(a, b) + e;   // fminf/fmaxf below drop NaNs (0*inf, inf-inf on slab-parallel rays)
     t0 = fmaxf(t0, n);
     t1 = fminf(t1, f * 1.0000005f);
   }

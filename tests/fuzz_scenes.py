@@ -1,0 +1,166 @@
+"""Random scenes nobody designed, for the parity fuzz runs (tests/test_oracle_fuzz.py, tests/test_gpu_fuzz.py, tools/gpu_fuzz_parity.py):
+random meshes (grids, boxes, triangle soups with degenerate and duplicate triangles), instances under random transforms (rotation,
+non-uniform and mirroring scales; the same mesh under the same transform twice happens -- coincident triangles, exact ties), every
+material family with random parameters and texture bindings (odd-sized sRGB / grey / normal textures, opacity maps), every light
+type, perspective and orthographic cameras, and a random way to render each (size, samples, depth, seed, integrator, launch mode,
+acceleration-structure levels, chains).  random_scene(seed) is deterministic.
+"""
+import numpy as np
+
+import glaze_amd
+from glaze_amd import abi
+from glaze_amd.scene_desc import INSTANCE_DTYPE, MESH_DTYPE, VERTEX_DTYPE, SceneDesc, make_camera, make_light, make_material, make_meta
+
+
+def col_major(m):
+    return np.asarray(m, np.float32).T.reshape(16)
+
+
+def rot(axis, deg):
+    a = np.radians(deg)
+    c, s = np.cos(a), np.sin(a)
+    m = np.eye(4)
+    i, j = [(1, 2), (2, 0), (0, 1)][axis]
+    m[i, i], m[i, j], m[j, i], m[j, j] = c, -s, s, c
+    return m
+
+
+def random_transform(rng, spread):
+    t = np.eye(4)
+    t[:3, 3] = rng.uniform(-spread, spread, 3)
+    s = np.diag(list(rng.uniform(0.2, 1.2, 3) * rng.choice([1.0, 1.0, 1.0, -1.0], 3)) + [1.0])
+    return t @ rot(int(rng.integers(3)), rng.uniform(0, 360)) @ rot(int(rng.integers(3)), rng.uniform(0, 360)) @ s
+
+
+def unit(v):
+    n = np.linalg.norm(v, axis=-1, keepdims=True)
+    return v / np.where(n > 0, n, 1.0)
+
+
+def mesh_grid(rng):
+    nu, nv = int(rng.integers(1, 7)), int(rng.integers(1, 7))
+    s, t = np.meshgrid(np.linspace(-0.5, 0.5, nu + 1), np.linspace(-0.5, 0.5, nv + 1), indexing="ij")
+    pos = np.stack([s, 0.15 * rng.standard_normal(s.shape) * rng.choice([0.0, 1.0]), t], -1).reshape(-1, 3)
+    nrm = unit(np.array([0.0, 1.0, 0.0]) + 0.3 * rng.standard_normal(pos.shape))
+    uv = np.stack([s, t], -1).reshape(-1, 2) * rng.uniform(0.5, 3.0) + rng.uniform(-1, 1, 2)
+    idx = np.arange((nu + 1) * (nv + 1)).reshape(nu + 1, nv + 1)
+    a, b, c, d = idx[:-1, :-1], idx[1:, :-1], idx[1:, 1:], idx[:-1, 1:]
+    tri = np.stack([a, b, c, a, c, d], -1).reshape(-1)
+    return pos, nrm, uv, tri
+
+
+def mesh_box(rng, inward=False, size=0.5):
+    c = np.array([[x, y, z] for x in (-1, 1) for y in (-1, 1) for z in (-1, 1)], np.float64) * size
+    faces = [(0, 1, 3, 2), (4, 6, 7, 5), (0, 4, 5, 1), (2, 3, 7, 6), (0, 2, 6, 4), (1, 5, 7, 3)]
+    pos, nrm, uv, tri = [], [], [], []
+    for f in faces:
+        p = c[list(f)]
+        n = unit(np.cross(p[1] - p[0], p[2] - p[0]))
+        if inward:
+            n = -n
+        base = len(pos)
+        pos += list(p)
+        nrm += [n] * 4
+        uv += [(0, 0), (1, 0), (1, 1), (0, 1)]
+        tri += [base, base + 1, base + 2, base, base + 2, base + 3]
+    return np.array(pos), np.array(nrm), np.array(uv, np.float64), np.array(tri)
+
+
+def mesh_soup(rng):
+    k = int(rng.integers(1, 24))
+    pos = rng.uniform(-0.5, 0.5, (3 * k, 3))
+    pos[1::3] = pos[0::3] + rng.uniform(-0.3, 0.3, (k, 3))
+    pos[2::3] = pos[0::3] + rng.uniform(-0.3, 0.3, (k, 3))
+    tri = np.arange(3 * k)
+    if k > 2 and rng.random() < 0.5:
+        tri[3:6] = tri[0:3]                      # a duplicate triangle
+    if k > 3 and rng.random() < 0.5:
+        pos[10] = pos[9]                         # a degenerate one
+    nrm = unit(rng.standard_normal(pos.shape))
+    return pos, nrm, rng.uniform(-2, 2, (3 * k, 2)), tri
+
+
+def random_texture(rng, fmt):
+    h, w = (int(rng.integers(1, 70)), int(rng.integers(1, 70))) if rng.random() < 0.7 else (int(2 ** rng.integers(0, 7)), int(2 ** rng.integers(0, 7)))
+    if fmt == abi.TEX_GRAY:
+        if rng.random() < 0.5:
+            y, x = np.mgrid[0:h, 0:w]
+            return np.where(((x // 3 + y // 2) % 2) == 0, 255, 0).astype(np.uint8)
+        return rng.integers(0, 256, (h, w), dtype=np.uint8)
+    px = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+    if fmt == abi.TEX_RGBA_NORM:
+        px[..., :2] = rng.integers(90, 166, (h, w, 2), dtype=np.uint8)
+        px[..., 2] = 255
+    px[..., 3] = 255
+    return px
+
+
+def random_scene(seed):
+    rng = np.random.default_rng(seed)
+    # textures: 0 = the white default
+    textures = [(abi.TEX_RGBA_SRGB, np.full((1, 1, 4), 255, np.uint8), "default")]
+    by_fmt = {abi.TEX_RGBA_SRGB: [0], abi.TEX_GRAY: [], abi.TEX_RGBA_NORM: []}
+    for _ in range(int(rng.integers(0, 6))):
+        fmt = int(rng.choice([abi.TEX_RGBA_SRGB, abi.TEX_RGBA_SRGB, abi.TEX_GRAY, abi.TEX_RGBA_NORM]))
+        by_fmt[fmt].append(len(textures))
+        textures.append((fmt, random_texture(rng, fmt), "t%d" % len(textures)))
+
+    def pick(fmt, p):
+        return int(rng.choice(by_fmt[fmt])) if by_fmt[fmt] and rng.random() < p else 0
+
+    materials = [make_material("default")]
+    for k in range(int(rng.integers(1, 6))):
+        emissive = tuple(int(v) for v in rng.integers(0, 256, 3)) if rng.random() < 0.2 else None
+        materials.append(make_material(
+            "m%d" % k, mtype=int(rng.integers(0, 7)), metal=int(rng.integers(0, 29)), diffuse_mul=tuple(int(v) for v in rng.integers(0, 256, 3)),
+            emissive=emissive, ior=float(rng.uniform(1.05, 2.2)), roughness_mul=float(rng.uniform(0, 1)), metalness_mul=float(rng.uniform(0, 1)),
+            anisotropy=float(rng.uniform(-0.9, 0.9)) if rng.random() < 0.5 else 0.0, diffuse=pick(abi.TEX_RGBA_SRGB, 0.6),
+            roughness=pick(abi.TEX_GRAY, 0.4), metalness=pick(abi.TEX_GRAY, 0.4), normal=pick(abi.TEX_RGBA_NORM, 0.5), opacity=pick(abi.TEX_GRAY, 0.3)))
+    # meshes: optionally a room around everything (inward box), then random objects
+    parts, meshes = [], []
+    nv = ni = 0
+
+    def add(pos, nrm, uv, tri, material):
+        nonlocal nv, ni
+        block = np.zeros(len(pos), VERTEX_DTYPE)
+        block["vv"], block["vn"], block["vt"] = pos, nrm, uv
+        parts.append((block, np.asarray(tri, np.uint32) + nv))
+        meshes.append((len(meshes), material, ni, len(tri)))
+        nv += len(pos)
+        ni += len(tri)
+
+    room = rng.random() < 0.7
+    if room:
+        add(*mesh_box(rng, inward=True, size=3.0), int(rng.integers(0, len(materials))))
+    for _ in range(int(rng.integers(1, 5))):
+        kind = int(rng.integers(3))
+        add(*(mesh_grid(rng) if kind == 0 else mesh_box(rng) if kind == 1 else mesh_soup(rng)), int(rng.integers(0, len(materials))))
+    transforms = [np.eye(4)] + [random_transform(rng, 1.5) for _ in range(int(rng.integers(1, 6)))]
+    instances = [(0, 0)] if room else []
+    for m in range(1 if room else 0, len(meshes)):
+        for _ in range(int(rng.integers(1, 4))):
+            instances.append((m, int(rng.integers(0, len(transforms)))))
+    lights = []
+    for _ in range(int(rng.integers(1, 4)) if rng.random() < 0.93 else 0):
+        lt = int(rng.integers(4))
+        if lt == abi.LIGHT_OMNI:
+            lights.append(make_light(abi.LIGHT_OMNI, "omni", position=tuple(rng.uniform(-2, 2, 3)), intensity=float(rng.uniform(0.2, 3))))
+        elif lt == abi.LIGHT_SUN:
+            lights.append(make_light(abi.LIGHT_SUN, "sun", direction=tuple(unit(rng.standard_normal(3))), intensity=float(rng.uniform(0.2, 2))))
+        elif lt == abi.LIGHT_AREA:
+            lights.append(make_light(abi.LIGHT_AREA, "area", resource_id=int(rng.integers(0, len(materials))), intensity=float(rng.uniform(0.2, 2))))
+        elif not any(l.ltype == abi.LIGHT_SKY for l in lights):
+            lights.append(make_light(abi.LIGHT_SKY, "sky", resource_id=int(rng.choice(by_fmt[abi.TEX_RGBA_SRGB])), intensity=float(rng.uniform(0.2, 2)),
+                                     yaw=float(rng.uniform(0, 360)), pitch=float(rng.uniform(-90, 90)), roll=float(rng.uniform(0, 360))))
+    eye = rng.uniform(-1.8, 1.8, 3)
+    ortho = rng.random() < 0.25
+    camera = make_camera(position=tuple(eye), target=tuple(rng.uniform(-0.5, 0.5, 3)), up=(0, 1, 0), fovx=np.float32(np.radians(rng.uniform(30, 110))),
+                         near=1e-3, far=100.0, orthographic=ortho, scale=float(rng.uniform(1, 4)))
+    vertices = np.concatenate([p[0] for p in parts])
+    indices = np.concatenate([p[1] for p in parts])
+    desc = SceneDesc(vertices, indices, np.array(meshes, MESH_DTYPE), np.stack([col_major(t) for t in transforms]), np.array(instances, INSTANCE_DTYPE),
+                     materials, lights, textures, camera, make_meta(centre=(0, 0, 0), radius=6.0, exposure=float(rng.uniform(0.5, 2))))
+    run = dict(w=int(rng.integers(9, 90)), h=int(rng.integers(9, 90)), spp=int(rng.integers(2, 6)), depth=int(rng.integers(1, 9)), seed=int(rng.integers(0, 1000)),
+               integrator=glaze_amd.Integrator.PATH_TRACE if rng.random() < 0.8 else glaze_amd.Integrator.DIRECT, mode=str(rng.choice(["two_kernels", "path", "auto"])),
+               levels=str(rng.choice(["auto", "flat", "two_level"])), chains=int(rng.integers(0, 4)))
+    return desc, run
