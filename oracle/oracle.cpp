@@ -22,6 +22,7 @@
 // Build: g++ -O2 -ffp-contract=off -fno-fast-math -shared -fPIC  (oracle/Makefile)
 #include <math.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -959,6 +960,12 @@ inline bool ray_box(const float* lo, const float* hi, V3 o, V3 inv, float tmin, 
 }
 
 // closest hit: smallest t; ties broken by smallest world triangle id (traversal-order independent)
+// ORC_NO_HIERARCHY=1 in the environment: every trace walks ALL triangles (the definition itself, for looking at a difference between
+// the HIP path and the oracle without the oracle's hierarchy in the picture; tools/gpu_fuzz_diag.py)
+static bool no_hierarchy() {
+  static const bool off = [] { const char* e = getenv("ORC_NO_HIERARCHY"); return e && *e && *e != '0'; }();
+  return off;
+}
 Hit trace_closest(const Scene& sc, V3 o, V3 d, float tmin, float tmax) {
   Hit best{tmax, 0, 0, 0, false};
   if (sc.nodes.empty()) return best;
@@ -966,9 +973,14 @@ Hit trace_closest(const Scene& sc, V3 o, V3 d, float tmin, float tmax) {
   int stack[128];
   int sp = 0;
   stack[sp++] = 0;
+  const bool all = no_hierarchy();
+  BNode everything{};
+  everything.first = 0;
+  everything.count = (int)sc.tris.size();
   while (sp) {
-    const BNode& nd = sc.nodes[stack[--sp]];
-    if (!ray_box(nd.lo, nd.hi, o, inv, tmin, best.t)) continue;
+    const BNode& nd = all ? everything : sc.nodes[stack[--sp]];
+    if (all) sp = 0;
+    if (!all && !ray_box(nd.lo, nd.hi, o, inv, tmin, best.t)) continue;
     if (nd.count > 0) {
       for (int i = nd.first; i < nd.first + nd.count; ++i) {
         float t, u, v;
@@ -994,9 +1006,14 @@ bool trace_any(const Scene& sc, V3 o, V3 d, float tmin, float tmax) {
   int stack[128];
   int sp = 0;
   stack[sp++] = 0;
+  const bool all = no_hierarchy();
+  BNode everything{};
+  everything.first = 0;
+  everything.count = (int)sc.tris.size();
   while (sp) {
-    const BNode& nd = sc.nodes[stack[--sp]];
-    if (!ray_box(nd.lo, nd.hi, o, inv, tmin, tmax)) continue;
+    const BNode& nd = all ? everything : sc.nodes[stack[--sp]];
+    if (all) sp = 0;
+    if (!all && !ray_box(nd.lo, nd.hi, o, inv, tmin, tmax)) continue;
     if (nd.count > 0) {
       for (int i = nd.first; i < nd.first + nd.count; ++i) {
         float t, u, v;
@@ -1774,6 +1791,16 @@ void closest_hit_shader(const Scene& sc, const Tri& tr, float t, float u, float 
   hit.shading_normal = mat_tdir(Wi, hit.shading_normal);
 }
 
+// ORC_DEBUG_PIXEL="x,y" in the environment: the rays that pixel traces and what comes back, one line each on stderr, floats as
+// hexadecimal literals (tools/gpu_fuzz_diag.py feeds the same rays to the HIP tracer's debug hooks)
+static bool debug_pixel(uint32_t px, uint32_t py) {
+  static int want[2] = {-2, -2};
+  if (want[0] == -2) {
+    want[0] = want[1] = -1;
+    if (const char* e = getenv("ORC_DEBUG_PIXEL")) sscanf(e, "%d,%d", &want[0], &want[1]);
+  }
+  return (int)px == want[0] && (int)py == want[1];
+}
 void trace_ray_closest(Renderer& R, V3 o, V3 d, Hit& h) {
   const Scene& sc = *R.scene;
   h = trace_closest(sc, o, d, 0.0001f, INF);
@@ -1858,6 +1885,10 @@ void raygen(Renderer& R, const FrameConsts& fc, uint32_t px, uint32_t py) {
   }
   Hit h;
   trace_ray_closest(R, origin, direction, h);                            // :169
+  const bool dbg = debug_pixel(px, py);
+  if (dbg)
+    fprintf(stderr, "orc closest o %a %a %a d %a %a %a bounce %g -> valid %d t %a u %a v %a world_id %u instance %u\n", origin.x, origin.y, origin.z, direction.x, direction.y,
+            direction.z, last.hit[3], (int)h.valid, h.t, h.u, h.v, h.valid ? sc.tris[h.tri].world_id : 0u, h.valid ? sc.tris[h.tri].instance : 0u);
   if (!h.valid) {                                                        // :170-179
     if ((last.hit[3] == 0.0f || last.wi[3] == 1.0f) && sc.sky_tex_id > 0) {
       V3 wv = normalize(mat_dir(sc.sky_world2obj, direction));           // sky_radiance :75-82
@@ -1900,8 +1931,12 @@ void raygen(Renderer& R, const FrameConsts& fc, uint32_t px, uint32_t py) {
       float rs = rnd(rng);
       Sp value = sp_uniform(0.0f);
       float bpdf = bsdf_value(sc, bin, rs, value);
+      if (dbg) fprintf(stderr, "orc light %u pdf %a distance %a bsdf pdf %a material %u\n", light_index, sam.pdf, sam.distance, bpdf, hit.material_id);
       if (bpdf > 0.0f) {
         bool shadow_ray_hit = trace_ray_shadow(R, hit.point, sam.wiW, sam.distance - 1e-3f);
+        if (dbg)
+          fprintf(stderr, "orc shadow o %a %a %a d %a %a %a tmax %a -> occluded %d\n", hit.point.x, hit.point.y, hit.point.z, sam.wiW.x, sam.wiW.y, sam.wiW.z,
+                  sam.distance - 1e-3f, (int)shadow_ray_hit);
         weight_light *= shadow_ray_hit ? 0.0f : 1.0f;
         weight_light *= fabsf(dot(sam.wiW, hit.shading_normal)) / sam.pdf;
         radiance_light = sp_mul(value, sam.emission);
