@@ -37,8 +37,8 @@ def unit(v):
     return v / np.where(n > 0, n, 1.0)
 
 
-def mesh_grid(rng):
-    nu, nv = int(rng.integers(1, 7)), int(rng.integers(1, 7))
+def mesh_grid(rng, large=False):
+    nu, nv = int(rng.integers(1, 49 if large else 7)), int(rng.integers(1, 49 if large else 7))
     s, t = np.meshgrid(np.linspace(-0.5, 0.5, nu + 1), np.linspace(-0.5, 0.5, nv + 1), indexing="ij")
     pos = np.stack([s, 0.15 * rng.standard_normal(s.shape) * rng.choice([0.0, 1.0]), t], -1).reshape(-1, 3)
     nrm = unit(np.array([0.0, 1.0, 0.0]) + 0.3 * rng.standard_normal(pos.shape))
@@ -66,8 +66,8 @@ def mesh_box(rng, inward=False, size=0.5):
     return np.array(pos), np.array(nrm), np.array(uv, np.float64), np.array(tri)
 
 
-def mesh_soup(rng):
-    k = int(rng.integers(1, 24))
+def mesh_soup(rng, large=False):
+    k = int(rng.integers(1, 400 if large else 24))
     pos = rng.uniform(-0.5, 0.5, (3 * k, 3))
     pos[1::3] = pos[0::3] + rng.uniform(-0.3, 0.3, (k, 3))
     pos[2::3] = pos[0::3] + rng.uniform(-0.3, 0.3, (k, 3))
@@ -95,8 +95,12 @@ def random_texture(rng, fmt):
     return px
 
 
+LARGE = 1000000     # seeds from here on: more and bigger meshes (thousands of triangles), bigger images
+
+
 def random_scene(seed):
     rng = np.random.default_rng(seed)
+    large = seed >= LARGE
     # textures: 0 = the white default
     textures = [(abi.TEX_RGBA_SRGB, np.full((1, 1, 4), 255, np.uint8), "default")]
     by_fmt = {abi.TEX_RGBA_SRGB: [0], abi.TEX_GRAY: [], abi.TEX_RGBA_NORM: []}
@@ -132,9 +136,9 @@ def random_scene(seed):
     room = rng.random() < 0.7
     if room:
         add(*mesh_box(rng, inward=True, size=3.0), int(rng.integers(0, len(materials))))
-    for _ in range(int(rng.integers(1, 5))):
+    for _ in range(int(rng.integers(1, 13 if large else 5))):
         kind = int(rng.integers(3))
-        add(*(mesh_grid(rng) if kind == 0 else mesh_box(rng) if kind == 1 else mesh_soup(rng)), int(rng.integers(0, len(materials))))
+        add(*(mesh_grid(rng, large) if kind == 0 else mesh_box(rng) if kind == 1 else mesh_soup(rng, large)), int(rng.integers(0, len(materials))))
     transforms = [np.eye(4)] + [random_transform(rng, 1.5) for _ in range(int(rng.integers(1, 6)))]
     instances = [(0, 0)] if room else []
     for m in range(1 if room else 0, len(meshes)):
@@ -160,7 +164,40 @@ def random_scene(seed):
     indices = np.concatenate([p[1] for p in parts])
     desc = SceneDesc(vertices, indices, np.array(meshes, MESH_DTYPE), np.stack([col_major(t) for t in transforms]), np.array(instances, INSTANCE_DTYPE),
                      materials, lights, textures, camera, make_meta(centre=(0, 0, 0), radius=6.0, exposure=float(rng.uniform(0.5, 2))))
-    run = dict(w=int(rng.integers(9, 90)), h=int(rng.integers(9, 90)), spp=int(rng.integers(2, 6)), depth=int(rng.integers(1, 9)), seed=int(rng.integers(0, 1000)),
+    run = dict(w=int(rng.integers(9, 200 if large else 90)), h=int(rng.integers(9, 160 if large else 90)), spp=int(rng.integers(2, 6)), depth=int(rng.integers(1, 9)), seed=int(rng.integers(0, 1000)),
                integrator=glaze_amd.Integrator.PATH_TRACE if rng.random() < 0.8 else glaze_amd.Integrator.DIRECT, mode=str(rng.choice(["two_kernels", "path", "auto"])),
                levels=str(rng.choice(["auto", "flat", "two_level"])), chains=int(rng.integers(0, 4)))
+    # more ways to render it, from a stream of their own (the scenes of the seeds that found something stay what they were)
+    more = np.random.default_rng(7000000 + seed)
+    run["builder"] = str(more.choice(["auto", "auto", "lbvh", "ploc", "sah_host"]))
+    run["lod"] = int(more.choice([0, 0, 0, 1, 2]))
+    run["exposure_after"] = int(more.integers(1, 6)) if more.random() < 0.3 else 0      # launches after which the exposure changes (0: never)
+    run["exposure"] = float(more.uniform(0.3, 3.0))
     return desc, run
+
+
+def render_both(desc, run, levels=None, mode=None):
+    """the scene through the HIP path and through the oracle, the way `run` says (levels / mode override it): (renderer, oracle renderer)"""
+    from oracle.pyoracle import OracleRenderer, OracleScene
+    inst = glaze_amd.RayTraceInstance.new()
+    inst.set_as_levels(levels or run["levels"])
+    inst.set_bvh_builder(run.get("builder", "auto"))
+    r = glaze_amd.RayTraceRenderer.new(inst, glaze_amd.RayTraceScene.from_desc(inst, desc), run["w"], run["h"])
+    o = OracleRenderer(OracleScene(desc), run["w"], run["h"])
+    r.set_launch_mode(mode or run["mode"])
+    r.set_chains(run["chains"])
+    for x in (r, o):
+        x.set_integrator(run["integrator"] if x is r else run["integrator"].value)
+        x.set_depth(run["depth"])
+        x.set_seed(run["seed"])
+        if run.get("lod", 0):
+            x.set_texture_lod(run["lod"])
+        x.restart()
+    launches = run["spp"] * r.steps_per_sample()
+    first = min(run.get("exposure_after", 0), launches)
+    for x in (r, o):
+        if first:
+            x.step(first)
+            x.set_exposure(run["exposure"])
+        x.step(launches - first)
+    return r, o

@@ -12,8 +12,8 @@ import numpy as np
 import pytest
 
 import glaze_amd
-from fuzz_scenes import col_major, random_scene, rot
-from oracle.pyoracle import OracleRenderer, OracleScene
+from fuzz_scenes import LARGE, col_major, random_scene, render_both, rot
+from oracle.pyoracle import OracleScene
 
 pytestmark = pytest.mark.gpu
 
@@ -24,27 +24,12 @@ def bits(a):
     return np.nan_to_num(a, nan=-1.0).view(np.uint32)
 
 
-def render_pair(desc, run, levels=None, mode=None):
-    inst = glaze_amd.RayTraceInstance.new()
-    inst.set_as_levels(levels or run["levels"])
-    r = glaze_amd.RayTraceRenderer.new(inst, glaze_amd.RayTraceScene.from_desc(inst, desc), run["w"], run["h"])
-    r.set_integrator(run["integrator"])
-    r.set_depth(run["depth"])
-    r.set_seed(run["seed"])
-    r.set_launch_mode(mode or run["mode"])
-    r.set_chains(run["chains"])
-    r.draw(run["spp"])
-    o = OracleRenderer(OracleScene(desc), run["w"], run["h"])
-    o.set_integrator(run["integrator"].value)
-    o.set_depth(run["depth"])
-    o.set_seed(run["seed"])
-    o.draw(run["spp"])
-    return r, o
+render_pair = render_both
 
 
 def test_random_scenes_bit_identical_to_the_oracle():
     lit = 0
-    for seed in list(range(150)) + FOUND_SOMETHING:
+    for seed in list(range(150)) + FOUND_SOMETHING + list(range(LARGE, LARGE + 12)):
         desc, run = random_scene(seed)
         r, o = render_pair(desc, run)
         g, c = r.read_hdr(), o.read_hdr()

@@ -12,11 +12,9 @@ import numpy as np
 
 sys.path.insert(0, ".")
 sys.path.insert(0, "tests")
-import glaze_amd
-from oracle.pyoracle import OracleRenderer, OracleScene
 
 
-from fuzz_scenes import random_scene
+from fuzz_scenes import random_scene, render_both
 
 
 def bits(a):
@@ -28,26 +26,12 @@ def matrix(seeds):
     """every launch mode x acceleration-structure level x chain count for the given seeds, against the oracle: where does a difference live?"""
     for seed in seeds:
         desc, run = random_scene(seed)
-        o = OracleRenderer(OracleScene(desc), run["w"], run["h"])
-        o.set_integrator(run["integrator"].value)
-        o.set_depth(run["depth"])
-        o.set_seed(run["seed"])
-        o.draw(run["spp"])
-        c, cr = o.read_hdr(), o.read_result()
-        print("seed %d (%dx%d spp %d depth %d %s; drawn with %s / %s / chains %d)" % (seed, run["w"], run["h"], run["spp"], run["depth"], run["integrator"].name, run["mode"], run["levels"], run["chains"]))
+        print("seed %d (%s)" % (seed, run))
         for levels in ("flat", "two_level"):
             for mode in ("two_kernels", "path"):
                 for chains in (1, 2, 3):
-                    inst = glaze_amd.RayTraceInstance.new()
-                    inst.set_as_levels(levels)
-                    r = glaze_amd.RayTraceRenderer.new(inst, glaze_amd.RayTraceScene.from_desc(inst, desc), run["w"], run["h"])
-                    r.set_integrator(run["integrator"])
-                    r.set_depth(run["depth"])
-                    r.set_seed(run["seed"])
-                    r.set_launch_mode(mode)
-                    r.set_chains(chains)
-                    r.draw(run["spp"])
-                    g, gr = r.read_hdr(), r.read_result()
+                    r, o = render_both(desc, dict(run, chains=chains), levels, mode)
+                    g, gr, c, cr = r.read_hdr(), r.read_result(), o.read_hdr(), o.read_result()
                     print("   %-9s %-11s chains %d: hdr differs in %4d pixels, result in %4d (of them only alpha: %d)" % (
                         levels, mode, chains, int((bits(g) != bits(c)).any(-1).sum()), int((bits(gr) != bits(cr)).any(-1).sum()),
                         int(((bits(gr) != bits(cr)).any(-1) & ~(bits(gr)[..., :3] != bits(cr)[..., :3]).any(-1)).sum())), flush=True)
@@ -66,23 +50,10 @@ def main():
     t0 = time.time()
     for seed in seeds:
         desc, run = random_scene(seed)
-        inst = glaze_amd.RayTraceInstance.new()
-        inst.set_as_levels(run["levels"])
         try:
-            scene = glaze_amd.RayTraceScene.from_desc(inst, desc)
-            r = glaze_amd.RayTraceRenderer.new(inst, scene, run["w"], run["h"])
-            r.set_integrator(run["integrator"])
-            r.set_depth(run["depth"])
-            r.set_seed(run["seed"])
-            r.set_launch_mode(run["mode"])
-            r.set_chains(run["chains"])
-            r.draw(run["spp"])
+            r, o = render_both(desc, run)
+            scene = None
             g, gr = r.read_hdr(), r.read_result()
-            o = OracleRenderer(OracleScene(desc), run["w"], run["h"])
-            o.set_integrator(run["integrator"].value)
-            o.set_depth(run["depth"])
-            o.set_seed(run["seed"])
-            o.draw(run["spp"])
             c, cr = o.read_hdr(), o.read_result()
             same = np.array_equal(bits(g), bits(c)) and np.array_equal(bits(gr), bits(cr))
             verdict = "identical"
@@ -94,9 +65,8 @@ def main():
                     verdict += "\n      (x %d, y %d): hip %s -> %s | oracle %s -> %s" % (x, y, g[y, x].tolist(), gr[y, x, :3].tolist(), c[y, x].tolist(), cr[y, x, :3].tolist())
         except Exception as e:   # an error on one side only is a finding as well
             same, verdict = False, "ERROR %s: %s" % (type(e).__name__, str(e)[:200])
-        info = scene.info() if "scene" in dir() else None
-        print("seed %4d  %3dx%-3d spp %d depth %d %-11s %-11s levels %-9s chains %d  tris %5d inst %2d lights %d mats %d tex %d  nan %5.1f %%  %s" % (
-            seed, run["w"], run["h"], run["spp"], run["depth"], run["integrator"].name, run["mode"], run["levels"], run["chains"], desc.n_triangles,
+        print("seed %4d  %3dx%-3d spp %d depth %d %-11s %-11s levels %-9s chains %d %-8s lod %d exp %d  tris %5d inst %2d lights %d mats %d tex %d  nan %5.1f %%  %s" % (
+            seed, run["w"], run["h"], run["spp"], run["depth"], run["integrator"].name, run["mode"], run["levels"], run["chains"], run["builder"], run["lod"], run["exposure_after"], desc.n_triangles,
             len(desc.instances), len(desc.lights), len(desc.materials), len(desc.textures), 100 * float(np.isnan(g).any(-1).mean()) if same or "g" in dir() else -1, verdict), flush=True)
         if not same:
             bad.append(seed)
