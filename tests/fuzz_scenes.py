@@ -173,6 +173,12 @@ def random_scene(seed):
     run["lod"] = int(more.choice([0, 0, 0, 1, 2]))
     run["exposure_after"] = int(more.integers(1, 6)) if more.random() < 0.3 else 0      # launches after which the exposure changes (0: never)
     run["exposure"] = float(more.uniform(0.3, 3.0))
+    run["camera_after"] = int(more.integers(1, 6)) if more.random() < 0.2 else 0        # launches after which update_camera replaces the camera (0: never)
+    run["camera"] = make_camera(position=tuple(more.uniform(-1.8, 1.8, 3)), target=tuple(more.uniform(-0.5, 0.5, 3)), up=(0, 1, 0),
+                                fovx=np.float32(np.radians(more.uniform(30, 110))), near=1e-3, far=100.0, orthographic=bool(more.random() < 0.3),
+                                scale=float(more.uniform(1, 4)))
+    world = int(more.integers(2, 6))
+    run["partition"] = (int(more.integers(0, world)), world) if more.random() < 0.25 else None   # render rank r's tiles of a world of n only
     return desc, run
 
 
@@ -193,11 +199,27 @@ def render_both(desc, run, levels=None, mode=None):
         if run.get("lod", 0):
             x.set_texture_lod(run["lod"])
         x.restart()
+    if run.get("partition"):
+        rank, world = run["partition"]
+        n_tiles = ((run["w"] + 63) // 64) * ((run["h"] + 63) // 64)
+        own = [t for t in range(n_tiles) if t % world == rank]
+        if own:                                  # (a rank without a tile has nothing to compare: the whole frame then)
+            r.set_partition(rank, world)
+            o.set_tiles(own)
+            r.restart()
+            o.restart()
     launches = run["spp"] * r.steps_per_sample()
-    first = min(run.get("exposure_after", 0), launches)
+    events = sorted([(min(run.get("exposure_after", 0), launches), "exposure"), (min(run.get("camera_after", 0), launches), "camera")])
     for x in (r, o):
-        if first:
-            x.step(first)
-            x.set_exposure(run["exposure"])
-        x.step(launches - first)
+        done = 0
+        for at, what in events:
+            if at == 0:
+                continue
+            x.step(at - done)
+            done = at
+            if what == "exposure":
+                x.set_exposure(run["exposure"])
+            else:
+                x.update_camera(run["camera"])
+        x.step(launches - done)
     return r, o
