@@ -179,6 +179,7 @@ def random_scene(seed):
                                 scale=float(more.uniform(1, 4)))
     world = int(more.integers(2, 6))
     run["partition"] = (int(more.integers(0, world)), world) if more.random() < 0.25 else None   # render rank r's tiles of a world of n only
+    run["devices"] = int(more.integers(2, 4)) if (run["partition"] is None and more.random() < 0.12) else 1   # the one GPU named n times (loop-back set_devices)
     return desc, run
 
 
@@ -190,6 +191,10 @@ def render_both(desc, run, levels=None, mode=None):
     inst.set_bvh_builder(run.get("builder", "auto"))
     r = glaze_amd.RayTraceRenderer.new(inst, glaze_amd.RayTraceScene.from_desc(inst, desc), run["w"], run["h"])
     o = OracleRenderer(OracleScene(desc), run["w"], run["h"])
+    if run.get("devices", 1) > 1:
+        import os
+        os.environ["GLAZE_MULTI_LOOPBACK"] = "1"
+        r.set_devices([inst.device] * run["devices"])
     r.set_launch_mode(mode or run["mode"])
     r.set_chains(run["chains"])
     for x in (r, o):
