@@ -1036,14 +1036,20 @@ __global__ void __launch_bounds__(256) k_dfs_ids(int n, const int2* __restrict__
 
 // Quantisation grid from the root box: kBvhGridMax (32 767) cells per axis, stretched by 2^-16 so the top plane stays below it.  15 bits:
 // the tracer turns a coordinate into the float 32768 + q with one byte permute (device/wavefront.h box_key).
+constexpr float kGridReach = 1.9073486e-6f;   // 2^-19
 __global__ void k_grid_params(const float4* __restrict__ node_lo, const float4* __restrict__ node_hi, BvhGrid* __restrict__ grid) {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
   const float lo[3] = {node_lo[0].x, node_lo[0].y, node_lo[0].z}, hi[3] = {node_hi[0].x, node_hi[0].y, node_hi[0].z};
+  // the grid reaches kGridReach of the largest coordinate past the bounds on every side, so that the margin the boxes get at
+  // quantisation (grid_margin below) has cells to be counted in: across the thin side of a flat scene the grid is then all margin
+  float largest = 0.0f;
+  for (int k = 0; k < 3; ++k) largest = fmaxf(largest, fmaxf(fabsf(lo[k]), fabsf(hi[k])));
+  const float reach = kGridReach * largest;
   for (int k = 0; k < 3; ++k) {
-    float ext = hi[k] - lo[k];
+    float ext = (hi[k] - lo[k]) + 2.0f * reach;
     if (!(ext > 0.0f)) ext = 1.0f;
     const float cell = ext * 1.00002f / (float)kBvhGridMax;
-    grid->lo[k] = lo[k] - 0.5f * cell;
+    grid->lo[k] = (lo[k] - reach) - 0.5f * cell;
     grid->cell[k] = cell;
     grid->inv_cell[k] = 1.0f / cell;
   }
@@ -1051,14 +1057,27 @@ __global__ void k_grid_params(const float4* __restrict__ node_lo, const float4* 
 
 // grid coordinate of a world coordinate; the SAME expression maps the ray origin in the tracer
 __device__ __forceinline__ float to_grid(float x, float lo, float inv_cell) { return (x - lo) * inv_cell; }
-__device__ __forceinline__ uint32_t quant_lo(float x, float lo, float inv_cell) {
+// `margin`: cells every box grows by on that axis beyond the 1/16 (grid_margin below)
+__device__ __forceinline__ uint32_t quant_lo(float x, float lo, float inv_cell, float margin) {
   // 1/16 cell of slack covers the rounding of to_grid() at grid coordinates up to 32767 (ulp 2^-9)
-  const float g = floorf(to_grid(x, lo, inv_cell) - 0.0625f);
+  const float g = floorf(to_grid(x, lo, inv_cell) - 0.0625f - margin);
   return (uint32_t)fminf(fmaxf(g, 0.0f), (float)kBvhGridMax);
 }
-__device__ __forceinline__ uint32_t quant_hi(float x, float lo, float inv_cell) {
-  const float g = ceilf(to_grid(x, lo, inv_cell) + 0.0625f);
+__device__ __forceinline__ uint32_t quant_hi(float x, float lo, float inv_cell, float margin) {
+  const float g = ceilf(to_grid(x, lo, inv_cell) + 0.0625f + margin);
   return (uint32_t)fminf(fmaxf(g, 0.0f), (float)kBvhGridMax);
+}
+// The tracer leaves a box out when its entry distance lies behind the hit it already has, so a box's entry must not round past the
+// distance of a triangle inside it: the plane distance (an fma in grid space) and the triangle's t (sheared coordinates) each carry a
+// few ulps of the coordinates involved.  Where a cell is a fair fraction of the scene the 1/16 above is that margin; across the thin
+// side of a FLAT scene (a floor plan: every box of no thickness, cells of 1e-13 units, the builders' relative pad nothing near
+// coordinate 0) it is not, and exact ties between coincident triangles went to whichever was met first (tools/gpu_fuzz_parity.py,
+// seed 61907).  So every box also grows by 2^-19 of the largest coordinate of the grid's bounds, whatever that is in cells
+// (k_grid_params lets the grid reach that far past the bounds).
+__device__ __forceinline__ void grid_margin(const BvhGrid& g, float* margin) {
+  float largest = 0.0f;
+  for (int k = 0; k < 3; ++k) largest = fmaxf(largest, fmaxf(fabsf(g.lo[k]), fabsf(g.lo[k] + (float)kBvhGridMax * g.cell[k])));
+  for (int k = 0; k < 3; ++k) margin[k] = fminf((kGridReach * largest) * g.inv_cell[k], 65536.0f);
 }
 
 // ---- 4-wide collapse.  A BVH4 node starts from the two children of a binary node and keeps opening the inner child
@@ -1141,6 +1160,8 @@ __global__ void __launch_bounds__(256) k_emit_nodes4(int n, const int2* __restri
   const int nk = kk.n;
   const int* kids = kk.link;
   const BvhGrid g = *grid;
+  float gm[3];
+  grid_margin(g, gm);
   BvhNode4 nd;
   for (int k = 0; k < 4; ++k) {
     const int ch = kids[k];
@@ -1151,8 +1172,8 @@ __global__ void __launch_bounds__(256) k_emit_nodes4(int n, const int2* __restri
     }
     const int box = ch >= 0 ? ch : (n - 1) + ~ch;
     const float4 l = node_lo[box], h = node_hi[box];
-    const uint32_t q[6] = {quant_lo(l.x, g.lo[0], g.inv_cell[0]), quant_lo(l.y, g.lo[1], g.inv_cell[1]), quant_lo(l.z, g.lo[2], g.inv_cell[2]),
-                           quant_hi(h.x, g.lo[0], g.inv_cell[0]), quant_hi(h.y, g.lo[1], g.inv_cell[1]), quant_hi(h.z, g.lo[2], g.inv_cell[2])};
+    const uint32_t q[6] = {quant_lo(l.x, g.lo[0], g.inv_cell[0], gm[0]), quant_lo(l.y, g.lo[1], g.inv_cell[1], gm[1]), quant_lo(l.z, g.lo[2], g.inv_cell[2], gm[2]),
+                           quant_hi(h.x, g.lo[0], g.inv_cell[0], gm[0]), quant_hi(h.y, g.lo[1], g.inv_cell[1], gm[1]), quant_hi(h.z, g.lo[2], g.inv_cell[2], gm[2])};
     nd.w[3 * k] = q[0] | (q[3] << 16);       // one word per axis: lo | hi << 16
     nd.w[3 * k + 1] = q[1] | (q[4] << 16);
     nd.w[3 * k + 2] = q[2] | (q[5] << 16);

@@ -1797,8 +1797,12 @@ static bool debug_pixel(uint32_t px, uint32_t py) {
   static int want[2] = {-2, -2};
   if (want[0] == -2) {
     want[0] = want[1] = -1;
-    if (const char* e = getenv("ORC_DEBUG_PIXEL")) sscanf(e, "%d,%d", &want[0], &want[1]);
+    if (const char* e = getenv("ORC_DEBUG_PIXEL")) {
+      if (!strcmp(e, "all")) want[0] = want[1] = -3;   // every pixel (single-threaded renders only: the lines of different pixels would mix)
+      else sscanf(e, "%d,%d", &want[0], &want[1]);
+    }
   }
+  if (want[0] == -3) return true;
   return (int)px == want[0] && (int)py == want[1];
 }
 void trace_ray_closest(Renderer& R, V3 o, V3 d, Hit& h) {
@@ -1887,8 +1891,8 @@ void raygen(Renderer& R, const FrameConsts& fc, uint32_t px, uint32_t py) {
   trace_ray_closest(R, origin, direction, h);                            // :169
   const bool dbg = debug_pixel(px, py);
   if (dbg)
-    fprintf(stderr, "orc closest o %a %a %a d %a %a %a bounce %g -> valid %d t %a u %a v %a world_id %u instance %u\n", origin.x, origin.y, origin.z, direction.x, direction.y,
-            direction.z, last.hit[3], (int)h.valid, h.t, h.u, h.v, h.valid ? sc.tris[h.tri].world_id : 0u, h.valid ? sc.tris[h.tri].instance : 0u);
+    fprintf(stderr, "orc closest o %a %a %a d %a %a %a bounce %g -> valid %d t %a u %a v %a world_id %u instance %u pixel %u %u\n", origin.x, origin.y, origin.z, direction.x, direction.y,
+            direction.z, last.hit[3], (int)h.valid, h.t, h.u, h.v, h.valid ? sc.tris[h.tri].world_id : 0u, h.valid ? sc.tris[h.tri].instance : 0u, px, py);
   if (!h.valid) {                                                        // :170-179
     if ((last.hit[3] == 0.0f || last.wi[3] == 1.0f) && sc.sky_tex_id > 0) {
       V3 wv = normalize(mat_dir(sc.sky_world2obj, direction));           // sky_radiance :75-82

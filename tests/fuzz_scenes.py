@@ -193,8 +193,15 @@ def render_both(desc, run, levels=None, mode=None):
     o = OracleRenderer(OracleScene(desc), run["w"], run["h"])
     if run.get("devices", 1) > 1:
         import os
+        before = os.environ.get("GLAZE_MULTI_LOOPBACK")
         os.environ["GLAZE_MULTI_LOOPBACK"] = "1"
-        r.set_devices([inst.device] * run["devices"])
+        try:
+            r.set_devices([inst.device] * run["devices"])
+        finally:
+            if before is None:
+                del os.environ["GLAZE_MULTI_LOOPBACK"]
+            else:
+                os.environ["GLAZE_MULTI_LOOPBACK"] = before
     r.set_launch_mode(mode or run["mode"])
     r.set_chains(run["chains"])
     for x in (r, o):

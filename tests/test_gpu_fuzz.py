@@ -6,7 +6,12 @@ The seeds listed by name are the ones that found something:
   * 297, 515, 520, 564: the ORACLE's hierarchy lost exact ties between coincident instances (tests/test_oracle_fuzz.py);
   * 118, 476, 653, 884, 986, 1340, 1401: the TWO-LEVEL tracer padded the object-space boxes by a number of cells that was capped at
     twice the grid's span -- across the thin side of a flat mesh (cells of 1e-13 units) far less than the rounding of the
-    transformed ray: coplanar meshes under one transform lost near ties, thin meshes hits (trace_wave_tl, set_grid_ray).
+    transformed ray: coplanar meshes under one transform lost near ties, thin meshes hits (trace_wave_tl, set_grid_ray);
+  * 61907: a FLAT SCENE (every instance a grid in the plane y = 0): the flattened structure's grid had cells of 1e-13 units across
+    the thin side, a box's entry distance -- the plane's, by an fma in grid space -- could round one ulp past the distance the
+    triangle test gives, and with a hit in hand the boxes of the coincident triangles of other instances were left out: the tie
+    went to whichever was met first.  The grid now reaches 2^-19 of the largest coordinate past the bounds and every box grows by
+    as much (kernels_build.hip k_grid_params, grid_margin).
 """
 import numpy as np
 import pytest
@@ -17,7 +22,7 @@ from oracle.pyoracle import OracleScene
 
 pytestmark = pytest.mark.gpu
 
-FOUND_SOMETHING = [118, 297, 476, 515, 520, 564, 653, 884, 986, 1340, 1401]
+FOUND_SOMETHING = [118, 297, 476, 515, 520, 564, 653, 884, 986, 1340, 1401, 61907]
 
 
 def bits(a):

@@ -37,4 +37,18 @@ for line in open(sys.argv[2]):
             if got != want:
                 t, tri, inst, u, v = sc.debug_trace_closest(o, d, tmin=1e-3)
                 print("SHADOW  %-9s differs: oracle occluded %d | hip %d (hip closest along it: t %r id %d; tmax %r)   ray o %s d %s tmax %s" % (levels, want, got, float(t[0]), tri[0], float(tmax[0]), w[3:6], w[7:10], w[11]))
+# all closest-hit rays of the file again, in ONE call per structure: the lanes of a wave then work on neighbouring rays, as in a render
+lines = [l.split() for l in open(sys.argv[2]) if l.startswith("orc closest")]
+if len(lines) > 1:
+    o = np.array([[fl(x) for x in w[3:6]] for w in lines], np.float32)
+    d = np.array([[fl(x) for x in w[7:10]] for w in lines], np.float32)
+    valid = np.array([int(w[14]) for w in lines])
+    wt = np.array([fl(w[16]) for w in lines], np.float32)
+    wid = np.array([int(w[22]) for w in lines])
+    for levels, sc in scenes.items():
+        t, tri, inst, u, v = sc.debug_trace_closest(o, d, tmin=1e-4)
+        bad = (np.isfinite(t) != (valid == 1)) | ((valid == 1) & ((t.view(np.uint32) != wt.view(np.uint32)) | (tri != wid)))
+        print("batch of %d closest rays, %-9s: %d differ" % (len(lines), levels, int(bad.sum())))
+        for i in np.nonzero(bad)[0][:8]:
+            print("   ray %d %s: oracle valid %d t %r id %d | hip t %r id %d" % (i, " ".join(lines[i][-3:]), valid[i], float(wt[i]), wid[i], float(t[i]), tri[i]))
 print("replayed", sys.argv[2])
