@@ -959,6 +959,15 @@ inline bool ray_box(const float* lo, const float* hi, V3 o, V3 inv, float tmin, 
   return t0 <= t1;
 }
 
+// The far end of the interval a box is tested against: the distance of the hit in hand (or the ray's tmax), widened by what the
+// TRIANGLE test's distance can be off -- a depth in sheared coordinates, a few ulps of the largest coordinates of origin and hit point,
+// whichever axis the box is thin in.  (ray_box's own widening covers the slab's rounding, in the units of the slab's axis: for a ray
+// that starts 0.0075 above a flat mesh at x = 0.32 that was 6e-9, the triangle's t 1.5e-8 below the plane's, and the coincident
+// triangle of another instance lost its tie; tools/gpu_fuzz_parity.py, seed 60378 with its second camera.)
+inline float far_bound(V3 o, float t) {
+  const float omax = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z));
+  return t + 4.8e-7f * (2.0f * omax + t);   // inf stays inf
+}
 // closest hit: smallest t; ties broken by smallest world triangle id (traversal-order independent)
 // ORC_NO_HIERARCHY=1 in the environment: every trace walks ALL triangles (the definition itself, for looking at a difference between
 // the HIP path and the oracle without the oracle's hierarchy in the picture; tools/gpu_fuzz_diag.py)
@@ -980,7 +989,7 @@ Hit trace_closest(const Scene& sc, V3 o, V3 d, float tmin, float tmax) {
   while (sp) {
     const BNode& nd = all ? everything : sc.nodes[stack[--sp]];
     if (all) sp = 0;
-    if (!all && !ray_box(nd.lo, nd.hi, o, inv, tmin, best.t)) continue;
+    if (!all && !ray_box(nd.lo, nd.hi, o, inv, tmin, far_bound(o, best.t))) continue;
     if (nd.count > 0) {
       for (int i = nd.first; i < nd.first + nd.count; ++i) {
         float t, u, v;
@@ -1013,7 +1022,7 @@ bool trace_any(const Scene& sc, V3 o, V3 d, float tmin, float tmax) {
   while (sp) {
     const BNode& nd = all ? everything : sc.nodes[stack[--sp]];
     if (all) sp = 0;
-    if (!all && !ray_box(nd.lo, nd.hi, o, inv, tmin, tmax)) continue;
+    if (!all && !ray_box(nd.lo, nd.hi, o, inv, tmin, far_bound(o, tmax))) continue;
     if (nd.count > 0) {
       for (int i = nd.first; i < nd.first + nd.count; ++i) {
         float t, u, v;
