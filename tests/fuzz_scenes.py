@@ -180,6 +180,7 @@ def random_scene(seed):
     world = int(more.integers(2, 6))
     run["partition"] = (int(more.integers(0, world)), world) if more.random() < 0.25 else None   # render rank r's tiles of a world of n only
     run["devices"] = int(more.integers(2, 4)) if (run["partition"] is None and more.random() < 0.12) else 1   # the one GPU named n times (loop-back set_devices)
+    run["via_file"] = bool(more.random() < 0.1)          # the HIP side reads the scene from a `.glaze` file (Serializer -> parse -> RayTraceScene.new)
     return desc, run
 
 
@@ -189,7 +190,17 @@ def render_both(desc, run, levels=None, mode=None):
     inst = glaze_amd.RayTraceInstance.new()
     inst.set_as_levels(levels or run["levels"])
     inst.set_bvh_builder(run.get("builder", "auto"))
-    r = glaze_amd.RayTraceRenderer.new(inst, glaze_amd.RayTraceScene.from_desc(inst, desc), run["w"], run["h"])
+    if run.get("via_file"):
+        import os
+        import tempfile
+        from glaze_amd.scene_desc import save_scene
+        with tempfile.TemporaryDirectory() as tmp:
+            path = os.path.join(tmp, "fuzz.glaze")
+            save_scene(desc, path)
+            scene = glaze_amd.RayTraceScene.new(inst, glaze_amd.parse(path))
+    else:
+        scene = glaze_amd.RayTraceScene.from_desc(inst, desc)
+    r = glaze_amd.RayTraceRenderer.new(inst, scene, run["w"], run["h"])
     o = OracleRenderer(OracleScene(desc), run["w"], run["h"])
     if run.get("devices", 1) > 1:
         import os

@@ -40,6 +40,7 @@ def test_random_scenes_bit_identical_to_the_oracle():
         g, c = r.read_hdr(), o.read_hdr()
         assert np.array_equal(bits(g), bits(c)), "seed %d (%s): accumulators differ in %d pixels" % (seed, run, int((bits(g) != bits(c)).any(-1).sum()))
         assert np.array_equal(bits(r.read_result()), bits(o.read_result())), "seed %d (%s): result images differ" % (seed, run)
+        assert np.array_equal(r.read_rgba8(), o.read_rgba8()), "seed %d (%s): 8-bit images differ" % (seed, run)
         lit += bool(np.nan_to_num(c[..., :3]).any())
     assert lit > 80          # most of the scenes show something
 

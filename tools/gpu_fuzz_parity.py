@@ -55,7 +55,7 @@ def main():
             scene = None
             g, gr = r.read_hdr(), r.read_result()
             c, cr = o.read_hdr(), o.read_result()
-            same = np.array_equal(bits(g), bits(c)) and np.array_equal(bits(gr), bits(cr))
+            same = np.array_equal(bits(g), bits(c)) and np.array_equal(bits(gr), bits(cr)) and np.array_equal(r.read_rgba8(), o.read_rgba8())
             verdict = "identical"
             if not same:
                 d = (bits(g) != bits(c)).any(-1) | (bits(gr) != bits(cr)).any(-1)
