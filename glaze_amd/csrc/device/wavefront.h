@@ -156,6 +156,7 @@ __device__ __forceinline__ vec3 shear_vertex(const RayShear& r, const float* p, 
   const float az = r.z_is_x ? a.x : (r.z_is_y ? a.y : a.z), ax = r.z_is_x ? a.y : (r.z_is_y ? a.z : a.x), ay = r.z_is_x ? a.z : (r.z_is_y ? a.x : a.y);
   return mk3(fmaf(-r.sx, az, ax), fmaf(-r.sy, az, ay), r.sz * az);
 }
+constexpr float kDetNoise = 1.9073486e-6f;   // 2^-19 of three of the six products (about 2^-20 of their sum): see triangle_finish
 __device__ __forceinline__ bool ray_triangle(const RayShear& rs, const BvhTri& tr, vec3 o, float tmin, float& t, float& u, float& v) {
   const vec3 A = shear_vertex(rs, tr.v0, o), B = shear_vertex(rs, tr.v1, o), C = shear_vertex(rs, tr.v2, o);
   const float pu = C.x * B.y, qu = C.y * B.x, pv = A.x * C.y, qv = A.y * C.x, pw = B.x * A.y, qw = B.y * A.x;
@@ -171,7 +172,8 @@ __device__ __forceinline__ bool ray_triangle(const RayShear& rs, const BvhTri& t
   u = V * inv;
   v = W * inv;
   t = fmaf(W, C.z, fmaf(V, B.z, U * A.z)) * inv;
-  return !((lo < 0.0f) & (hi > 0.0f)) & (det != 0.0f) & (t > tmin);
+  const float noise = ((fabsf(pu) + fabsf(pv)) + fabsf(pw)) * kDetNoise;   // (triangle_finish)
+  return !((lo < 0.0f) & (hi > 0.0f)) & (fabsf(det) > noise) & (t > tmin);
 }
 
 // The same test on a leaf record of the flattened build (types.h BvhQuad): triangle A = (q0, q1, q2) and, for a leaf of two,
@@ -188,15 +190,18 @@ __device__ __forceinline__ vec3 shear_point(const RayShear& r, float px, float p
   const float az = r.z_is_x ? a.x : (r.z_is_y ? a.y : a.z), ax = r.z_is_x ? a.y : (r.z_is_y ? a.z : a.x), ay = r.z_is_x ? a.z : (r.z_is_y ? a.x : a.y);
   return mk3(fmaf(-r.sx, az, ax), fmaf(-r.sy, az, ay), r.sz * az);
 }
-// the part of ray_triangle behind the edge functions
-__device__ __forceinline__ bool triangle_finish(float U, float V, float W, float Az, float Bz, float Cz, float tmin, float& t, float& u, float& v) {
+// the part of ray_triangle behind the edge functions.  `products` = |first product of U| + |of V| + |of W|: a det smaller than kDetNoise
+// of it is the products' rounding, not a number -- the ray lies in the triangle's plane as far as single precision can tell (a shadow
+// ray towards a light in the plane of the surface it leaves), and the distance that would come out of it is anything.  The oracle's
+// ray_tri has the same line; oracle.cpp says what it was found by.
+__device__ __forceinline__ bool triangle_finish(float U, float V, float W, float Az, float Bz, float Cz, float products, float tmin, float& t, float& u, float& v) {
   const float lo = fminf(fminf(U, V), W), hi = fmaxf(fmaxf(U, V), W);
   const float det = (U + V) + W;
   const float inv = 1.0f / det;
   u = V * inv;
   v = W * inv;
   t = fmaf(W, Cz, fmaf(V, Bz, U * Az)) * inv;
-  return !((lo < 0.0f) & (hi > 0.0f)) & (det != 0.0f) & (t > tmin);
+  return !((lo < 0.0f) & (hi > 0.0f)) & (fabsf(det) > products * kDetNoise) & (t > tmin);
 }
 __device__ __forceinline__ QuadHit ray_quad(const RayShear& rs, float4 r0, float4 r1, float4 r2, float4 r3, bool pair, vec3 o, float tmin) {
   QuadHit h;
@@ -212,7 +217,7 @@ __device__ __forceinline__ QuadHit ray_quad(const RayShear& rs, float4 r0, float
       if (V == 0.0f) V = fmaf(S0.x, S2.y, -pv) - fmaf(S0.y, S2.x, -qv);
       if (W == 0.0f) W = fmaf(S1.x, S0.y, -pw) - fmaf(S1.y, S0.x, -qw);
     }
-    h.ok[0] = triangle_finish(U, V, W, S0.z, S1.z, S2.z, tmin, h.t[0], h.u[0], h.v[0]);
+    h.ok[0] = triangle_finish(U, V, W, S0.z, S1.z, S2.z, (fabsf(pu) + fabsf(pv)) + fabsf(pw), tmin, h.t[0], h.u[0], h.v[0]);
   }
   __builtin_amdgcn_sched_barrier(0);   // A is finished before B begins: interleaved for ILP the two keep twice the values alive (20 registers spilt)
   {
@@ -225,7 +230,7 @@ __device__ __forceinline__ QuadHit ray_quad(const RayShear& rs, float4 r0, float
       if (V == 0.0f) V = fmaf(S0.x, S3.y, -pv2) - fmaf(S0.y, S3.x, -qv2);
       if (W == 0.0f) W = fmaf(S2.x, S0.y, -qv) - fmaf(S2.y, S0.x, -pv);
     }
-    h.ok[1] = triangle_finish(U, V, W, S0.z, S2.z, S3.z, tmin, h.t[1], h.u[1], h.v[1]) & pair;
+    h.ok[1] = triangle_finish(U, V, W, S0.z, S2.z, S3.z, (fabsf(pu) + fabsf(pv2)) + fabsf(qv), tmin, h.t[1], h.u[1], h.v[1]) & pair;
   }
   return h;
 }

@@ -184,6 +184,40 @@ def random_scene(seed):
     return desc, run
 
 
+def render_oracle(desc, run):
+    """the oracle's half of render_both alone (for a child process that runs with ORC_DEBUG_PIXEL set)"""
+    from oracle.pyoracle import OracleRenderer, OracleScene
+    o = OracleRenderer(OracleScene(desc), run["w"], run["h"])
+    o.set_threads(1)
+    o.set_integrator(run["integrator"].value)
+    o.set_depth(run["depth"])
+    o.set_seed(run["seed"])
+    if run.get("lod", 0):
+        o.set_texture_lod(run["lod"])
+    o.restart()
+    if run.get("partition"):
+        rank, world = run["partition"]
+        n_tiles = ((run["w"] + 63) // 64) * ((run["h"] + 63) // 64)
+        own = [t for t in range(n_tiles) if t % world == rank]
+        if own:
+            o.set_tiles(own)
+            o.restart()
+    launches = run["spp"] * o.steps_per_sample()
+    events = sorted([(min(run.get("exposure_after", 0), launches), "exposure"), (min(run.get("camera_after", 0), launches), "camera")])
+    done = 0
+    for at, what in events:
+        if at == 0:
+            continue
+        o.step(at - done)
+        done = at
+        if what == "exposure":
+            o.set_exposure(run["exposure"])
+        else:
+            o.update_camera(run["camera"])
+    o.step(launches - done)
+    return o
+
+
 def render_both(desc, run, levels=None, mode=None):
     """the scene through the HIP path and through the oracle, the way `run` says (levels / mode override it): (renderer, oracle renderer)"""
     from oracle.pyoracle import OracleRenderer, OracleScene

@@ -11,7 +11,11 @@ The seeds listed by name are the ones that found something:
     the thin side, a box's entry distance -- the plane's, by an fma in grid space -- could round one ulp past the distance the
     triangle test gives, and with a hit in hand the boxes of the coincident triangles of other instances were left out: the tie
     went to whichever was met first.  The grid now reaches 2^-19 of the largest coordinate past the bounds and every box grows by
-    as much (kernels_build.hip k_grid_params, grid_margin).
+    as much (kernels_build.hip k_grid_params, grid_margin);
+  * 3257, 11494, 50759, 68482, 73991, 100817, 102401, 102759, 103497, 107249, 223644, 230234, 234947, 235554, 236777, 244722: a shadow ray
+    IN THE PLANE of a triangle (towards a light coplanar with the surface it leaves): det is rounding noise, the distance anything, and
+    whether the candidate was even offered depended on the structure that walked the scene -- the oracle's own hierarchy included.
+    Both sides now leave out a candidate whose |det| is not above 2^-19 of its products (oracle.cpp ray_tri, triangle_finish).
 """
 import numpy as np
 import pytest
@@ -23,6 +27,7 @@ from oracle.pyoracle import OracleScene
 pytestmark = pytest.mark.gpu
 
 FOUND_SOMETHING = [118, 297, 476, 515, 520, 564, 653, 884, 986, 1340, 1401, 61907]
+RAYS_IN_A_PLANE = [3257, 11494, 50759, 68482, 73991, 100817, 102401, 102759, 103497, 107249, 223644, 230234, 234947, 235554, 236777, 244722]
 
 
 def bits(a):
@@ -34,7 +39,7 @@ render_pair = render_both
 
 def test_random_scenes_bit_identical_to_the_oracle():
     lit = 0
-    for seed in list(range(150)) + FOUND_SOMETHING + list(range(LARGE, LARGE + 12)):
+    for seed in list(range(150)) + FOUND_SOMETHING + RAYS_IN_A_PLANE + list(range(LARGE, LARGE + 12)):
         desc, run = random_scene(seed)
         r, o = render_pair(desc, run)
         g, c = r.read_hdr(), o.read_hdr()
