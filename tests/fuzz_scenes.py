@@ -181,6 +181,7 @@ def random_scene(seed):
     run["partition"] = (int(more.integers(0, world)), world) if more.random() < 0.25 else None   # render rank r's tiles of a world of n only
     run["devices"] = int(more.integers(2, 4)) if (run["partition"] is None and more.random() < 0.12) else 1   # the one GPU named n times (loop-back set_devices)
     run["via_file"] = bool(more.random() < 0.1)          # the HIP side reads the scene from a `.glaze` file (Serializer -> parse -> RayTraceScene.new)
+    run["stored_mips"] = int(more.integers(2, 12)) if more.random() < 0.5 else 0   # ... whose textures carry that many mip levels (0: level 0 only)
     return desc, run
 
 
@@ -230,7 +231,17 @@ def render_both(desc, run, levels=None, mode=None):
         from glaze_amd.scene_desc import save_scene
         with tempfile.TemporaryDirectory() as tmp:
             path = os.path.join(tmp, "fuzz.glaze")
-            save_scene(desc, path)
+            stored = desc
+            if run.get("stored_mips"):
+                # never the COMPLETE chain: a texture that brings all its levels is rendered from them (the converter's Catmull-Rom levels,
+                # materials/texture.rs:196-221; tests/test_gpu_texture_lod.py), which the oracle, given the description, cannot know;
+                # an incomplete chain is dropped and regenerated, and that path is what this exercises
+                def some(t):
+                    full = 1 + int(np.floor(np.log2(max(t[1].shape[0], t[1].shape[1]))))
+                    return max(1, min(run["stored_mips"], full - 1))
+                stored = desc.copy()
+                stored.textures = [(t[0], t[1], t[2], some(t)) for t in desc.textures]
+            save_scene(stored, path)
             scene = glaze_amd.RayTraceScene.new(inst, glaze_amd.parse(path))
     else:
         scene = glaze_amd.RayTraceScene.from_desc(inst, desc)
