@@ -61,7 +61,6 @@ for seed in [int(v) for v in sys.argv[1].split(",")]:
     code = "import sys; sys.path.insert(0, '.'); sys.path.insert(0, 'tests'); from fuzz_scenes import random_scene, render_oracle; d, r = random_scene(%d); render_oracle(d, r)" % seed
     child = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ORC_DEBUG_PIXEL="%d,%d" % (x, y)), capture_output=True, text=True)
     lines = [l.split() for l in child.stderr.splitlines() if l.startswith("orc closest") or l.startswith("orc shadow")]
-    levels = r_levels = "two_level" if getattr(r, "_scene_two_level", None) else None
     inst = glaze_amd.RayTraceInstance.new()
     inst.set_as_levels(run["levels"])
     inst.set_bvh_builder(run["builder"])
