@@ -34,8 +34,8 @@ def test_oracle_renders_the_same_with_and_without_its_hierarchy():
     """Whole renders, so that the rays are the ones a path makes -- bounce and shadow rays that start on a surface, almost in the plane of its
     neighbours -- with the camera replaced half way: ORC_NO_HIERARCHY=1 (every trace walks all triangles) against the default, in two child
     processes (the switch is read once).  Seed 60378 is the scene whose second camera found the tie the widened slab test still lost.
-    (Not in the list: the scenes with a phantom hit of an edge-on triangle, DESIGN.md section 3 -- there any hierarchy, this one included, may cull
-    what the walk over all triangles keeps.)"""
+    The last five: scenes with a shadow ray in the plane of a triangle -- before ray_tri left candidates with a noise-sized det out, the
+    hierarchy (any hierarchy) culled what the walk over all triangles kept."""
     import hashlib
     import os
     import subprocess
@@ -46,7 +46,7 @@ sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import numpy as np
 from fuzz_scenes import random_scene
 from oracle.pyoracle import OracleRenderer, OracleScene
-for seed in list(range(60)) + [60378, 61907]:
+for seed in list(range(60)) + [60378, 61907, 3257, 11494, 50759, 103497, 230234]:
     desc, run = random_scene(seed)
     o = OracleRenderer(OracleScene(desc), run["w"], run["h"])
     o.set_integrator(run["integrator"].value); o.set_depth(run["depth"]); o.set_seed(run["seed"]); o.restart()
@@ -59,5 +59,5 @@ for seed in list(range(60)) + [60378, 61907]:
     for extra in ({}, {"ORC_NO_HIERARCHY": "1"}):
         env = dict(os.environ, **extra)
         outs.append(subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, check=True).stdout.splitlines())
-    assert len(outs[0]) == 62
+    assert len(outs[0]) == 67
     assert outs[0] == outs[1], [a for a, b in zip(*outs) if a != b]
