@@ -393,6 +393,13 @@ class RayTraceScene:
         abi.check(abi.lib().glz_debug_read_bvh(self._h, _ptr(nodes), i.bvh_nodes, _ptr(tris), i.n_as_triangles))
         return nodes[:i.bvh_nodes], tris[:i.n_as_triangles]
 
+    def debug_bvh8(self):
+        """The 8-wide nodes of the same hierarchy ((n, 32) uint32; empty for two-level scenes and scenes of one leaf)."""
+        n = self.info().bvh_nodes8
+        nodes = np.zeros((max(1, n), 32), np.uint32)
+        abi.check(abi.lib().glz_debug_read_bvh8(self._h, _ptr(nodes), n))
+        return nodes[:n]
+
     def __del__(self):
         if getattr(self, "_h", None):
             abi.lib().glz_scene_destroy(self._h)
@@ -471,6 +478,14 @@ class RayTraceRenderer:
 
     def launch_mode(self):
         return {1: "two_kernels", 2: "path"}[int(abi.lib().glz_renderer_launch_mode(self._h))]
+
+    def set_node_width(self, width):
+        """0 (by the pixels this device owns), 4 (k_trace over the 4-wide nodes) or 8 (k_trace8 over the 8-wide nodes: small tile shares);
+        the image does not depend on it"""
+        abi.check(abi.lib().glz_renderer_set_node_width(self._h, int(width)))
+
+    def node_width(self):
+        return int(abi.lib().glz_renderer_node_width(self._h))
 
     def device_count(self):
         return int(abi.lib().glz_renderer_device_count(self._h))

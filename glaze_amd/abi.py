@@ -89,7 +89,8 @@ class SceneInfo(C.Structure):
                 ("n_textures", C.c_uint32), ("bvh_nodes", C.c_uint32), ("bvh_depth", C.c_uint32),
                 ("bvh_sah_cost", C.c_float), ("build_ms", C.c_float), ("bounds_min", C.c_float * 3), ("bounds_max", C.c_float * 3),
                 ("bvh_grid_lo", C.c_float * 3), ("bvh_grid_cell", C.c_float * 3),
-                ("as_levels", C.c_uint32), ("n_as_triangles", C.c_uint32), ("as_bytes", C.c_uint64)]
+                ("as_levels", C.c_uint32), ("n_as_triangles", C.c_uint32), ("as_bytes", C.c_uint64),
+                ("bvh_nodes8", C.c_uint32), ("_reserved", C.c_uint32)]
 
 
 class RenderStats(C.Structure):
@@ -174,6 +175,7 @@ PROTOTYPES = {
     "glz_debug_read_rt_lights": (C.c_int64, [_P, _P, C.c_int64]),
     "glz_debug_read_sky": (C.c_int64, [_P, _P, C.c_int64]),
     "glz_debug_read_bvh": (C.c_int64, [_P, _P, C.c_int64, _P, C.c_int64]),
+    "glz_debug_read_bvh8": (C.c_int64, [_P, _P, C.c_int64]),
     "glz_host_launch_constants": (C.c_int, [C.c_uint64, C.c_uint32, _P, _P]),
     "glz_host_push_constants": (C.c_int, [_P, C.c_uint32, C.c_uint32, _P]),
     "glz_host_chain_owner": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _P]),
@@ -187,6 +189,8 @@ PROTOTYPES = {
     "glz_instance_set_as_levels": (C.c_int, [_P, C.c_int]),
     "glz_renderer_set_devices": (C.c_int, [_P, _P, C.c_int]),
     "glz_renderer_set_launch_mode": (C.c_int, [_P, C.c_int]),
+    "glz_renderer_set_node_width": (C.c_int, [_P, C.c_int]),
+    "glz_renderer_node_width": (C.c_int, [_P]),
     "glz_renderer_launch_mode": (C.c_int, [_P]),
     "glz_renderer_device_count": (C.c_int, [_P]),
     "glz_renderer_device_scene_info": (C.c_int, [_P, C.c_int, _P]),

@@ -417,6 +417,8 @@ int glz_renderer_set_devices(glz_renderer* h, const int* devices, int n) {
 }
 int glz_renderer_set_launch_mode(glz_renderer* h, int mode) { GLZ_GUARD_BEGIN GLZ_R(h); GLZ_RET(h->r->set_launch_mode(mode, e)); GLZ_GUARD_END(GLZ_E_IO) }
 int glz_renderer_launch_mode(glz_renderer* h) { return h ? (h->r->path_mode() ? GLZ_LAUNCH_PATH : GLZ_LAUNCH_TWO_KERNELS) : 0; }
+int glz_renderer_set_node_width(glz_renderer* h, int width) { GLZ_GUARD_BEGIN GLZ_R(h); GLZ_RET(h->r->set_node_width(width, e)); GLZ_GUARD_END(GLZ_E_IO) }
+int glz_renderer_node_width(glz_renderer* h) { return h ? (h->r->wide8() ? 8 : 4) : 0; }
 int glz_renderer_set_chains(glz_renderer* h, uint32_t n) { GLZ_GUARD_BEGIN GLZ_R(h); GLZ_RET(h->r->set_chains(n, e)); GLZ_GUARD_END(GLZ_E_IO) }
 int glz_renderer_export_device(glz_renderer* h, int which, void* dev) {
   GLZ_GUARD_BEGIN GLZ_R(h);
@@ -601,6 +603,28 @@ int64_t glz_debug_read_bvh(glz_scene* h, void* nodes_out, int64_t cap_nodes, voi
   if (tris_out && cap_tris > 0 && nt > 0 &&
       !hip_ok(hipMemcpy(tris_out, s->dev.bvh_tris, (size_t)std::min(cap_tris, nt) * sizeof(BvhTri), hipMemcpyDeviceToHost), "read tris", e))
     return fail(e);
+  return nn;
+  GLZ_GUARD_END(GLZ_E_IO)
+}
+
+int64_t glz_debug_read_bvh8(glz_scene* h, void* nodes_out, int64_t cap_nodes) {
+  GLZ_GUARD_BEGIN
+  if (!h || !h->s) return fail(GLZ_E_ARG, "scene is null");
+  Scene* s = h->s.get();
+  Error e;
+  if (!hip_ok(hipSetDevice(s->instance->device), "hipSetDevice", e)) return fail(e);
+  const int64_t nn = s->dev.bvh_nodes8 ? (int64_t)s->info.bvh_nodes8 : 0;
+  if (nodes_out && cap_nodes > 0 && nn > 0) {
+    if (!hip_ok(hipMemcpy(nodes_out, s->dev.bvh_nodes8, (size_t)std::min(cap_nodes, nn) * sizeof(BvhNode8), hipMemcpyDeviceToHost), "read 8-wide nodes", e)) return fail(e);
+    std::vector<BvhQuad> quads(s->d_quads_count());   // leaf number -> ~(first slot), as glz_debug_read_bvh hands its links out
+    if (!quads.empty() && !hip_ok(hipMemcpy(quads.data(), s->dev.bvh_quads, quads.size() * sizeof(BvhQuad), hipMemcpyDeviceToHost), "read leaf records", e)) return fail(e);
+    BvhNode8* nd = static_cast<BvhNode8*>(nodes_out);
+    for (int64_t i = 0; i < std::min(cap_nodes, nn); ++i)
+      for (int k = 0; k < 8; ++k) {
+        const int link = (int)nd[i].w[24 + k];
+        if (link < 0 && (size_t)~link < quads.size()) nd[i].w[24 + k] = (uint32_t)~(int)quads[(size_t)~link].slot;
+      }
+  }
   return nn;
   GLZ_GUARD_END(GLZ_E_IO)
 }

@@ -9,6 +9,9 @@
 //   GLZ_TRACE_TL_WAVES        4     ... the two-level tracer (128 VGPRs)
 //   GLZ_SHADE_WAVES           4     ... k_shade (128 VGPRs)
 //   GLZ_PATH_WAVES            4     ... k_path (128 VGPRs)
+//   GLZ_TRACE8_WAVES          4     ... k_trace8, the 8-wide walk of a small tile share (128 VGPRs)
+//   GLZ_TRACE8_PREFETCH       1     k_trace8: the next node's loads issued as soon as the node is known
+//   GLZ_TRACE8_STACK         28     k_trace8: stack levels kept in LDS (1 KB a level and block)
 //   GLZ_REFILL               16     idle lanes at which a wave takes new rays
 //   GLZ_LEAF_QUORUM          24     lanes waiting on a leaf at which the inner-node phase ends
 //   GLZ_TL_LEAF_QUORUM       32     the same for the two-level tracer (a leaf visit there is an instance entry: dearer)
@@ -29,6 +32,15 @@
 #endif
 #ifndef GLZ_PATH_WAVES
 #define GLZ_PATH_WAVES 4
+#endif
+#ifndef GLZ_TRACE8_WAVES
+#define GLZ_TRACE8_WAVES 4
+#endif
+#ifndef GLZ_TRACE8_STACK
+#define GLZ_TRACE8_STACK 28
+#endif
+#ifndef GLZ_TRACE8_PREFETCH
+#define GLZ_TRACE8_PREFETCH 1
 #endif
 #ifndef GLZ_REFILL
 #define GLZ_REFILL 16

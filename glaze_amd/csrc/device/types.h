@@ -127,6 +127,13 @@ struct alignas(16) BvhNode4 {
 struct alignas(16) BvhNode48 {
   uint32_t w[12];
 };
+// The same hierarchy collapsed EIGHT wide, 128 bytes = two lines = eight dwordx4 fetches per visit: what the tracer of a small tile share
+// reads (k_trace8: a GPU that holds one 64-ray group per wave is bound by the latency of a ray's chain of dependent node fetches, and
+// this chain is a third shorter -- DESIGN.md section 6).  Same grid, same padding:
+//   child k (k = 0..7):  w[3k], w[3k+1], w[3k+2] as above      w[24 + k] = link of child k (leaf links are ~leaf number)
+struct alignas(128) BvhNode8 {
+  uint32_t w[32];
+};
 constexpr int kBvhEmptyChild = 0x7FFFFFFF;
 // Top of the tree, staged in LDS by the tracers ("node packets"): the root, its inner children and their inner children in
 // breadth-first order, at most kBvhTopNodes nodes (1 + 4 + 16).  Inside this table -- and in `cur` of a lane that sits on
@@ -218,6 +225,7 @@ struct DeviceScene {
   const float* srgb_lut;           // 256 entries
   const BvhNode4* bvh_nodes;
   const BvhNode4* bvh_top;         // kBvhTopNodes nodes: the top levels with links into the table flagged (kBvhTopFlag)
+  const BvhNode8* bvh_nodes8;      // the 8-wide collapse of the same hierarchy (flattened builds of more than one leaf; null otherwise)
   const BvhNode48* bvh_nodes48;    // -DGLZ_NODE48 builds only (null otherwise): the same nodes / staged top in the 48-byte format
   const BvhNode48* bvh_top48;
   BvhGrid bvh_grid;

@@ -89,6 +89,19 @@ __device__ __forceinline__ uint32_t box_key(uint32_t wx, uint32_t wy, uint32_t w
   const float t1 = fminf(fminf(tx.y, ty.y), fminf(tz.y, tmax));
   return (t0 <= t1 && (!CHECK_LINK || link != (uint32_t)kBvhEmptyChild)) ? ((__float_as_uint(t0) & kKeyDistanceMask) | k) : 0xFFFFFFFFu;
 }
+// The same test for a child of an 8-wide node (types.h BvhNode8): the child index takes three bits of the key (8..10)
+constexpr uint32_t kKey8DistanceMask = 0xFFFFF800u, kKey8ChildMask = 0x700u;
+__device__ __forceinline__ uint32_t box_key8(uint32_t wx, uint32_t wy, uint32_t wz, uint32_t k, SlabSel sel, vec3 ig, vec3 cg, float tmin, float tmax) {
+  const float nx = __uint_as_float(__builtin_amdgcn_perm(wx, kSlabMagic, sel.x)), fx = __uint_as_float(__builtin_amdgcn_perm(wx, kSlabMagic, sel.x ^ kSlabSelFlip));
+  const float ny = __uint_as_float(__builtin_amdgcn_perm(wy, kSlabMagic, sel.y)), fy = __uint_as_float(__builtin_amdgcn_perm(wy, kSlabMagic, sel.y ^ kSlabSelFlip));
+  const float nz = __uint_as_float(__builtin_amdgcn_perm(wz, kSlabMagic, sel.z)), fz = __uint_as_float(__builtin_amdgcn_perm(wz, kSlabMagic, sel.z ^ kSlabSelFlip));
+  const f32x2 tx = __builtin_elementwise_fma(f32x2{nx, fx}, f32x2{ig.x, ig.x}, f32x2{cg.x, cg.x});
+  const f32x2 ty = __builtin_elementwise_fma(f32x2{ny, fy}, f32x2{ig.y, ig.y}, f32x2{cg.y, cg.y});
+  const f32x2 tz = __builtin_elementwise_fma(f32x2{nz, fz}, f32x2{ig.z, ig.z}, f32x2{cg.z, cg.z});
+  const float t0 = fmaxf(fmaxf(tx.x, ty.x), fmaxf(tz.x, tmin));
+  const float t1 = fminf(fminf(tx.y, ty.y), fminf(tz.y, tmax));
+  return t0 <= t1 ? ((__float_as_uint(t0) & kKey8DistanceMask) | k) : 0xFFFFFFFFu;   // (an unused slot's box is inverted: no ray enters it)
+}
 #ifdef GLZ_NODE48
 // EXPERIMENT: the slab test on a 48-byte node's child (types.h BvhNode48).  `word` holds the planes of one axis for two children as bytes
 // lo | hi << 8 | lo' << 16 | hi' << 24; the selector puts one of them into bits 8..15 of 0x47000000 -- the float 32768 + q -- and the
@@ -279,19 +292,20 @@ constexpr int kStolen = 0x7FFFFFFE;
 // (tools/gpu_sections.py, round 4: ~1 000 of ~2 400 clocks on an otherwise idle chip).  The staged top of the tree had the same
 // problem in round 2 (LdsNodePtr).
 typedef __attribute__((address_space(3))) int* LdsIntPtr;
-struct Stack {
+template <int kLevels>
+struct StackT {
   LdsIntPtr lds;        // &s_stack[threadIdx.x]
   uint32_t* spill;      // overflow words of this lane
   int sp;
-  __device__ __forceinline__ Stack(int* lds_column, uint32_t* spill_words, int sp0) : lds((LdsIntPtr)lds_column), spill(spill_words), sp(sp0) {}
+  __device__ __forceinline__ StackT(int* lds_column, uint32_t* spill_words, int sp0) : lds((LdsIntPtr)lds_column), spill(spill_words), sp(sp0) {}
   __device__ __forceinline__ void push(int v) {
-    if (sp < kLdsStack) lds[sp * kBlock] = v; else spill[sp - kLdsStack] = (uint32_t)v;
+    if (sp < kLevels) lds[sp * kBlock] = v; else spill[sp - kLevels] = (uint32_t)v;
     ++sp;
   }
   __device__ __forceinline__ int pop() {
     --sp;
     int v;
-    if (__builtin_expect(sp < kLdsStack, 1)) v = lds[sp * kBlock]; else v = (int)spill[sp - kLdsStack];   // two loads of two address spaces: not to be merged
+    if (__builtin_expect(sp < kLevels, 1)) v = lds[sp * kBlock]; else v = (int)spill[sp - kLevels];   // two loads of two address spaces: not to be merged
     return v;
   }
   // Hand-overs take the OLDEST live entry of a stack (the lowest level, aux_sb) and move that mark up by one, so the stolen entries are
@@ -307,6 +321,8 @@ struct Stack {
     return kRayDone;
   }
 };
+using Stack = StackT<kLdsStack>;
+constexpr int kLdsStack8 = GLZ_TRACE8_STACK;   // LDS levels of the 8-wide tracer's stacks (a visit pushes up to seven; its blocks run four to a CU: 28 KB + 8 KB of scratch each)
 
 struct TraceTally {
   unsigned long long rays = 0, nodes = 0, tris = 0, hits = 0, fresh = 0;
@@ -418,10 +434,22 @@ __device__ unsigned long long g_tl_stats[8];      // two-level tracer, summed ov
 // that they are in flight during the pushes, the loop's ballots and the hand-overs to idle lanes in between.  A small share of the frame is
 // bound by the LATENCY of this dependent chain (tools/gpu_sections.py: a node visit of a 1/32 share, on an otherwise idle chip, still takes
 // 1 800 clocks, most of them waiting for the node), not by issue; the full-frame k_trace is issue bound and has no 16 registers to spare.
-template <bool ANY, bool COUNT, bool MIXED = false, bool PREFETCH = false, class Source, class Sink>
+// WIDE8 (k_trace8, the tracer of a small tile share): the hierarchy's 8-wide nodes (types.h BvhNode8, two lines a visit).  A GPU that holds
+// one 64-ray group per resident wave is bound by the LATENCY of a ray's chain of dependent node fetches (1 800 - 2 100 clocks per node
+// iteration whatever the load), and eight-wide that chain is 31 % shorter (17.3 against 24.9 visits per sample on the bench scene,
+// tools/bvh_lab); the full frame is bound by VALU issue and by the address units, where twice the boxes per visit cost more than the
+// visits saved (it keeps the 4-wide nodes).  The nearest child is entered, the others are pushed in slot order -- no sort: ordering the
+// rest by distance as well saves 0.7 % of the visits (tools/bvh_lab order=nearest) for 38 instructions a visit; the child links are
+// picked in registers (a select tree on the key's child bits) rather than through LDS, one round trip less on the chain.  Hits do not
+// depend on the visit order, so the images are those of the 4-wide walk bit for bit.  No staged top (the root is node 0), a deeper LDS
+// stack (kLdsStack8).
+template <bool ANY, bool COUNT, bool MIXED = false, bool PREFETCH = false, bool WIDE8 = false, class Source, class Sink>
 __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Sink& sink, int* __restrict__ lds_col, int* aux, int* link_scratch, LdsNodePtr top_lds,
                                            uint32_t* __restrict__ spill, uint32_t spill_depth, uint32_t total, uint32_t wave, uint32_t n_waves, TraceTally& tally) {
   constexpr bool SHARE = !COUNT;
+  constexpr bool TOP = kLdsTop && !WIDE8;
+  constexpr int kLevels = WIDE8 ? kLdsStack8 : kLdsStack;
+  const BvhNode8* __restrict__ nodes8 = S.bvh_nodes8;
   constexpr uint32_t kNone = 0xFFFFFFFFu;
   const BvhNode4* __restrict__ nodes = S.bvh_nodes;
   const BvhGrid grid = S.bvh_grid;
@@ -463,12 +491,17 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
   HitRecord best{0.0f, 0.0f, 0.0f, kNone};
   uint32_t best_id = kNone;
   // the spill area is indexed by the physical lane slot of the grid (a lane traverses one ray or subtree at a time)
-  Stack st{lds_col, spill + ((size_t)(blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 64u + (uint32_t)lane) * spill_depth, 0};
+  StackT<kLevels> st{lds_col, spill + ((size_t)(blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 64u + (uint32_t)lane) * spill_depth, 0};
   // PREFETCH: the node `pf_cur` as loaded (or on its way)
-  u32x4 pf0 = {0u, 0u, 0u, 0u}, pf1 = pf0, pf2 = pf0, pf3 = pf0;
+  u32x4 pf0 = {0u, 0u, 0u, 0u}, pf1 = pf0, pf2 = pf0, pf3 = pf0, pf4 = pf0, pf5 = pf0, pf6 = pf0, pf7 = pf0;
   int pf_cur = -1;
   auto prefetch_node = [&]() {
-    if (PREFETCH && cur >= 0 && !(cur & kBvhTopFlag)) {   // a node of the table in memory (staged nodes, kRayDone and kStolen carry bit 30)
+    if (PREFETCH && WIDE8 && cur >= 0 && cur < kStolen) {
+      const u32x4* np = reinterpret_cast<const u32x4*>(nodes8 + cur);
+      pf0 = np[0]; pf1 = np[1]; pf2 = np[2]; pf3 = np[3]; pf4 = np[4]; pf5 = np[5]; pf6 = np[6]; pf7 = np[7];
+      pf_cur = cur;
+    } else
+    if (PREFETCH && !WIDE8 && cur >= 0 && !(cur & kBvhTopFlag)) {   // a node of the table in memory (staged nodes, kRayDone and kStolen carry bit 30)
 #ifdef GLZ_NODE48
       const u32x4* np = reinterpret_cast<const u32x4*>(S.bvh_nodes48 + cur);
       pf0 = np[0]; pf1 = np[1]; pf2 = np[2];
@@ -509,7 +542,7 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
       if (busy && cur != kRayDone) {
         sb = aux_sb[lane];
         if (sb > st.sp) sb = st.sp;
-        lim = st.sp < kLdsStack ? st.sp : kLdsStack;
+        lim = st.sp < kLevels ? st.sp : kLevels;
         while (sb < lim && st.lds[sb * kBlock] == kStolen) ++sb;
         aux_sb[lane] = sb;
       }
@@ -597,7 +630,7 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
             sel = SlabSel{slab_sel(ig.x), slab_sel(ig.y), slab_sel(ig.z)};
             st.sp = 0;
             if (SHARE) aux_sb[lane] = 0;
-            cur = kLdsTop ? kBvhTopFlag : 0;   // the root (slot 0 of the staged table)
+            cur = TOP ? kBvhTopFlag : 0;   // the root (slot 0 of the staged table)
             open = true;
           }
         }
@@ -636,6 +669,51 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
       sec_iters += 1;
 #endif
       GLZ_SEC_STAMP(sec_ctl);
+      if (WIDE8) {
+       if (at_node) {
+        // 128-byte node = 8 x dwordx4: eight child boxes and eight links.  The nearest child is entered, the others pushed in slot order.
+        u32x4 w0, w1, w2, w3, w4, w5, w6, w7;
+        if (PREFETCH) {
+          if (pf_cur != cur) prefetch_node();
+          w0 = pf0; w1 = pf1; w2 = pf2; w3 = pf3; w4 = pf4; w5 = pf5; w6 = pf6; w7 = pf7;
+        } else {
+          const u32x4* np = reinterpret_cast<const u32x4*>(nodes8 + cur);
+          w0 = np[0]; w1 = np[1]; w2 = np[2]; w3 = np[3]; w4 = np[4]; w5 = np[5]; w6 = np[6]; w7 = np[7];
+        }
+        if (COUNT) tally.nodes += 1;
+        float bound = best.t;
+        if (SHARE && !ANY && exhausted) bound = fminf(bound, __uint_as_float(aux_t[helper ? (int)ray : lane]));
+        uint32_t key[8];
+        key[0] = box_key8(w0.x, w0.y, w0.z, 0u << 8, sel, ig, cg, tmin, bound); key[1] = box_key8(w0.w, w1.x, w1.y, 1u << 8, sel, ig, cg, tmin, bound);
+        key[2] = box_key8(w1.z, w1.w, w2.x, 2u << 8, sel, ig, cg, tmin, bound); key[3] = box_key8(w2.y, w2.z, w2.w, 3u << 8, sel, ig, cg, tmin, bound);
+        key[4] = box_key8(w3.x, w3.y, w3.z, 4u << 8, sel, ig, cg, tmin, bound); key[5] = box_key8(w3.w, w4.x, w4.y, 5u << 8, sel, ig, cg, tmin, bound);
+        key[6] = box_key8(w4.z, w4.w, w5.x, 6u << 8, sel, ig, cg, tmin, bound); key[7] = box_key8(w5.y, w5.z, w5.w, 7u << 8, sel, ig, cg, tmin, bound);
+        const uint32_t ka = key[0] < key[1] ? key[0] : key[1], kb = key[2] < key[3] ? key[2] : key[3], kc = key[4] < key[5] ? key[4] : key[5], kd = key[6] < key[7] ? key[6] : key[7];
+        const uint32_t kab = ka < kb ? ka : kb, kcd = kc < kd ? kc : kd;
+        const uint32_t kmin = kab < kcd ? kab : kcd;
+        if (kmin == 0xFFFFFFFFu) {
+          cur = SHARE ? st.pop_live() : (st.sp ? st.pop() : kRayDone);
+          prefetch_node();
+        } else {
+          const int link[8] = {(int)w6.x, (int)w6.y, (int)w6.z, (int)w6.w, (int)w7.x, (int)w7.y, (int)w7.z, (int)w7.w};
+          const bool b0 = (kmin & 0x100u) != 0u, b1 = (kmin & 0x200u) != 0u, b2 = (kmin & 0x400u) != 0u;
+          const int s01 = b0 ? link[1] : link[0], s23 = b0 ? link[3] : link[2], s45 = b0 ? link[5] : link[4], s67 = b0 ? link[7] : link[6];
+          const int t03 = b1 ? s23 : s01, t47 = b1 ? s67 : s45;
+          const int nearest = b2 ? t47 : t03;
+          if (__ballot(st.sp + 7 > kLevels) == 0ull) {   // wave-uniform: every lane stays inside the LDS part of its stack
+#pragma unroll
+            for (int k = 7; k >= 0; --k)
+              if (key[k] != 0xFFFFFFFFu && key[k] != kmin) { st.lds[st.sp * kBlock] = link[k]; ++st.sp; }
+          } else {
+#pragma unroll
+            for (int k = 7; k >= 0; --k)
+              if (key[k] != 0xFFFFFFFFu && key[k] != kmin) st.push(link[k]);
+          }
+          cur = nearest;
+          prefetch_node();
+        }
+       }
+      } else
       if (at_node) {
         // 64-byte node = 4 x dwordx4: four child boxes in 16-bit grid coordinates (the ray was mapped into grid units at
         // refill) and four links.  Children are entered nearest first; the others are pushed farthest first.
@@ -666,7 +744,7 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
         uint32_t k2 = box_key48(w0.w, w1.y, w1.w, 2u * kKeyChild, 0u, s48, na, nc, tmin, bound), k3 = box_key48(w0.w, w1.y, w1.w, 3u * kKeyChild, 0x0200u, s48, na, nc, tmin, bound);
 #else
         u32x4 w0, w1, w2, w3;
-        if (kLdsTop && (cur & kBvhTopFlag)) {
+        if (TOP && (cur & kBvhTopFlag)) {
           LdsNodePtr np = top_lds + 4 * (cur & 0xFFFF);
           w0 = np[0]; w1 = np[1]; w2 = np[2]; w3 = np[3];
         } else if (PREFETCH) {
@@ -1261,6 +1339,7 @@ struct DirectState {
   __device__ __forceinline__ void ray_o(uint32_t lid, float4 v) { A.st.ray_o[lid] = v; }
   __device__ __forceinline__ void ray_d(uint32_t lid, float4 v) { A.st.ray_d[lid] = v; }
   __device__ __forceinline__ void imp(int q, uint32_t lid, float4 v) { A.st.imp[q][lid] = v; }
+  __device__ __forceinline__ float4 read_imp(int q, uint32_t lid) const { return A.st.imp[q][lid]; }
   __device__ __forceinline__ void accumulate(uint32_t lid, vec3 c, bool add, bool update, float exposure) { accumulate_pixel(A, lid, c, add, update, exposure); }
 };
 struct StagedState {
@@ -1280,6 +1359,15 @@ struct StagedState {
   __device__ __forceinline__ void ray_d(uint32_t, float4 v) { rd = v; mask |= 2u; }
   __device__ __forceinline__ void imp(int q, uint32_t, float4 v) { im[q] = v; mask |= 4u; }
   const LaunchArgs* A = nullptr;   // the accumulator is updated where the pixel is shaded
+  // The importance the pixel arrived with: k_shade's prologue reads the block's 4 x 4 KB in whole lines, in pixel order, into LDS, and the
+  // (up to three) reads of shade_pixel come from there -- read where they are used, by threads in regrouped order, they were twelve
+  // scattered 16-byte accesses per pixel on the vector-memory path, which is what bounds the kernel.
+  LdsNodePtr lds_imp = nullptr;   // &s_imp[pixel's index in the block] (a pointer that keeps its address space: ds_read_b128); component q at [q * kShadeBlockPixels]
+  static constexpr uint32_t kShadeBlockPixels = 256;
+  __device__ __forceinline__ float4 read_imp(int q, uint32_t) const {
+    const u32x4 v = lds_imp[q * kShadeBlockPixels];
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+  }
   __device__ __forceinline__ void accumulate(uint32_t lid, vec3 cc, bool add, bool update, float exposure) { accumulate_pixel(*A, lid, cc, add, update, exposure); }
 };
 template <bool LOD, class Queue, class State>
@@ -1299,7 +1387,7 @@ __device__ __forceinline__ void shade_pixel(const LaunchArgs& A, const DeviceSce
     } else {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const float4 v = A.st.imp[q][lid];
+        const float4 v = out.read_imp(q, lid);
         imp.w[4 * q] = v.x; imp.w[4 * q + 1] = v.y; imp.w[4 * q + 2] = v.z; imp.w[4 * q + 3] = v.w;
       }
     }
@@ -1523,7 +1611,10 @@ __device__ __forceinline__ void shade_pixel(const LaunchArgs& A, const DeviceSce
   out.ray_d(lid, make_float4(wiW.x, wiW.y, wiW.z, spec_flag));
 }
 
-constexpr uint32_t kShadeTableBytes = 16384;   // LDS copy of the material / light / texture-descriptor tables (78 materials alone would fill it)
+#ifndef GLZ_SHADE_TABLE_BYTES
+#define GLZ_SHADE_TABLE_BYTES 16384
+#endif
+constexpr uint32_t kShadeTableBytes = GLZ_SHADE_TABLE_BYTES;   // LDS copy of the material / light / texture-descriptor tables (78 materials alone would fill it)
 
 // ---------------------------------------------------------------------------------------------
 // Shadow rays: the shadow traceRayEXT (path_trace.rgen:106-110) for the compacted queue written by k_shade,

@@ -28,6 +28,8 @@ struct LbvhInputs {
   // The flattened world build: also emit the 64-byte per-leaf records (BvhQuad) and make leaf links ~leaf number instead of
   // ~first triangle slot (the record names the slot).  Pairs are only formed in the two vertex orders a quad record can hold.
   bool emit_quads = false;
+  // ... and the same hierarchy collapsed eight wide (types.h BvhNode8; needs emit_quads): LbvhOutputs::nodes8
+  bool emit_wide8 = false;
 };
 constexpr int kBvhBuilderLbvh = 0, kBvhBuilderPloc = 1, kBvhBuilderSah = 2, kBvhBuilderAuto = 3, kBvhBuilderSahHost = 4;   // = GLZ_BVH_LBVH / _PLOC / _SAH / _AUTO / _SAH_HOST
 // host side of the SAH builder (bvh_sah.cpp): binary hierarchy over n leaf boxes -> children / parent arrays
@@ -35,6 +37,8 @@ void build_sah_host(uint32_t n, const float4* lo, const float4* hi, int2* childr
 struct LbvhOutputs {
   BvhNode4* nodes;  // n_nodes entries, hipMalloc'ed by build_lbvh: the caller owns them afterwards
   uint32_t n_nodes;
+  BvhNode8* nodes8; // emit_wide8: n_nodes8 entries, hipMalloc'ed by build_lbvh (the caller owns them), else null; a scene of one leaf has none
+  uint32_t n_nodes8, depth8;
   BvhGrid grid;     // quantisation grid of the node boxes
   BvhTri* tris;     // n_world + 1 entries (the tracer reads one past a leaf's first triangle), preallocated; leaf order, a leaf's triangles adjacent
   BvhQuad* quads;   // emit_quads: n_leaves records, hipMalloc'ed by build_lbvh (the caller owns them), else null
@@ -130,8 +134,9 @@ struct PathBatch {
 constexpr uint32_t kTraceBlock = 256;          // threads per block of the render kernels (4 waves)
 constexpr uint32_t kQueueSetWords = 8 * 32;   // 8 shard counters, 128 bytes apart
 
-uint32_t trace_grid_blocks(uint32_t n_local_pixels, bool counting, bool two_level);   // persistent grid of k_trace / k_trace_tl (device must be current)
-hipError_t launch_trace(hipStream_t st, const LaunchArgs& a, uint32_t blocks);
+// persistent grid of k_trace / k_trace_tl / (wide8) k_trace8 (device must be current); wide8: the walk over the 8-wide nodes, flattened scenes without work counters
+uint32_t trace_grid_blocks(uint32_t n_local_pixels, bool counting, bool two_level, bool wide8 = false);
+hipError_t launch_trace(hipStream_t st, const LaunchArgs& a, uint32_t blocks, bool wide8 = false);
 hipError_t launch_shade(hipStream_t st, const LaunchArgs& a);
 // the per-wave launch loop of a small tile share: `batch.n` launches for every pixel in ONE kernel (a.frame holds what the launches
 // share; flattened scenes, no work counters); blocks from path_grid_blocks (device must be current)

@@ -1087,30 +1087,39 @@ __device__ __forceinline__ void grid_margin(const BvhGrid& g, float* margin) {
 // down, one launch per level of the binary hierarchy (a node marks its final children, which lie 1-3 levels below).
 // flags[dfs id] = 1 for those heads, so an exclusive scan over the depth-first order numbers the BVH4 nodes depth-first.
 // (Folding every odd level instead -- children = grandchildren -- left 3.0 children per node; this leaves 3.4+.)
-struct Kids4 {
-  int link[4];
+template <int W>
+struct Kids {
+  int link[W];
   int n;
 };
+using Kids4 = Kids<4>;
 __device__ __forceinline__ float box_area(const float4* __restrict__ node_lo, const float4* __restrict__ node_hi, int slot) {
   const float4 l = node_lo[slot], h = node_hi[slot];
   const float dx = h.x - l.x, dy = h.y - l.y, dz = h.z - l.z;
   return 2.0f * (dx * dy + dy * dz + dz * dx);
 }
-__device__ __forceinline__ Kids4 collapse4(int node, const int2* __restrict__ children, const float4* __restrict__ node_lo,
-                                           const float4* __restrict__ node_hi) {
-  Kids4 k;
+// W = 4: the nodes every tracer reads; W = 8: the 128-byte nodes of the tracer for small tile shares (types.h BvhNode8) -- the same
+// rule carried on until eight children are open
+template <int W>
+__device__ __forceinline__ Kids<W> collapse_wide(int node, const int2* __restrict__ children, const float4* __restrict__ node_lo,
+                                                 const float4* __restrict__ node_hi) {
+  Kids<W> k;
   const int2 c = children[node];
-  k.link[0] = c.x; k.link[1] = c.y; k.link[2] = k.link[3] = kBvhEmptyChild;
+  float area[W];
+#pragma unroll
+  for (int i = 0; i < W; ++i) { k.link[i] = kBvhEmptyChild; area[i] = -1.0f; }
+  k.link[0] = c.x; k.link[1] = c.y;
   k.n = 2;
-  float area[4] = {c.x >= 0 ? box_area(node_lo, node_hi, c.x) : -1.0f, c.y >= 0 ? box_area(node_lo, node_hi, c.y) : -1.0f, -1.0f, -1.0f};
-  while (k.n < 4) {
+  area[0] = c.x >= 0 ? box_area(node_lo, node_hi, c.x) : -1.0f;
+  area[1] = c.y >= 0 ? box_area(node_lo, node_hi, c.y) : -1.0f;
+  while (k.n < W) {
     int j = -1;
     float best = -1.0f;
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < W; ++i)
       if (i < k.n && k.link[i] >= 0 && area[i] > best) { best = area[i]; j = i; }   // ties: the leftmost
     if (j < 0) break;   // only leaves left
     const int2 g = children[k.link[j]];
-    for (int i = 3; i > 0; --i)
+    for (int i = W - 1; i > 0; --i)
       if (i > j + 1) { k.link[i] = k.link[i - 1]; area[i] = area[i - 1]; }
     k.link[j] = g.x; area[j] = g.x >= 0 ? box_area(node_lo, node_hi, g.x) : -1.0f;
     k.link[j + 1] = g.y; area[j + 1] = g.y >= 0 ? box_area(node_lo, node_hi, g.y) : -1.0f;
@@ -1118,7 +1127,11 @@ __device__ __forceinline__ Kids4 collapse4(int node, const int2* __restrict__ ch
   }
   return k;
 }
+__device__ __forceinline__ Kids4 collapse4(int node, const int2* __restrict__ children, const float4* __restrict__ node_lo, const float4* __restrict__ node_hi) {
+  return collapse_wide<4>(node, children, node_lo, node_hi);
+}
 // head[t] = level of the BVH4 node headed by binary node t (root = 1), 0 = folded into an ancestor
+template <int W>
 __global__ void __launch_bounds__(256) k_mark_heads(int n, int level, const int* __restrict__ node_depth, const int2* __restrict__ children,
                                                     const float4* __restrict__ node_lo, const float4* __restrict__ node_hi,
                                                     int* head, int* __restrict__ max_level) {
@@ -1127,8 +1140,8 @@ __global__ void __launch_bounds__(256) k_mark_heads(int n, int level, const int*
   const int mine = t == 0 ? 1 : head[t];
   if (t == 0) head[0] = 1;
   if (mine == 0) return;
-  const Kids4 k = collapse4(t, children, node_lo, node_hi);
-  for (int i = 0; i < 4; ++i)
+  const Kids<W> k = collapse_wide<W>(t, children, node_lo, node_hi);
+  for (int i = 0; i < W; ++i)
     if (i < k.n && k.link[i] >= 0) head[k.link[i]] = mine + 1;
   atomicMax(max_level, mine);
 }
@@ -1180,6 +1193,36 @@ __global__ void __launch_bounds__(256) k_emit_nodes4(int n, const int2* __restri
     // inner: its number among the BVH4 nodes; leaf: ~(first slot of the leaf in bvh_tris), or ~(leaf number) when the tracer reads
     // per-leaf records that name the slot (LbvhInputs::emit_quads)
     nd.w[12 + k] = (uint32_t)(ch >= 0 ? (int)pos[new_id[ch]] : (leaf_links_by_number ? ch : ~(int)slot[~ch]));
+  }
+  nodes[pos[new_id[i]]] = nd;
+}
+
+// The same hierarchy collapsed eight wide (types.h BvhNode8): heads found by k_mark_heads<8>, numbered depth-first like the 4-wide
+// nodes; same grid, same padding, leaf links by leaf number (only the flattened build with per-leaf records carries these nodes).
+__global__ void __launch_bounds__(256) k_emit_nodes8(int n, const int2* __restrict__ children, const float4* __restrict__ node_lo,
+                                                     const float4* __restrict__ node_hi, const BvhGrid* __restrict__ grid,
+                                                     const int* __restrict__ new_id, const unsigned long long* __restrict__ flags,
+                                                     const unsigned long long* __restrict__ pos, BvhNode8* __restrict__ nodes) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n - 1 || !flags[new_id[i]]) return;
+  const Kids<8> kk = collapse_wide<8>(i, children, node_lo, node_hi);
+  const BvhGrid g = *grid;
+  float gm[3];
+  grid_margin(g, gm);
+  BvhNode8 nd;
+  for (int k = 0; k < 8; ++k) {
+    const int ch = kk.link[k];
+    if (k >= kk.n) {
+      nd.w[3 * k] = nd.w[3 * k + 1] = nd.w[3 * k + 2] = kBvhGridMax;   // an inverted box: no ray enters it
+      nd.w[24 + k] = (uint32_t)kBvhEmptyChild;
+      continue;
+    }
+    const int box = ch >= 0 ? ch : (n - 1) + ~ch;
+    const float4 l = node_lo[box], h = node_hi[box];
+    nd.w[3 * k] = quant_lo(l.x, g.lo[0], g.inv_cell[0], gm[0]) | (quant_hi(h.x, g.lo[0], g.inv_cell[0], gm[0]) << 16);
+    nd.w[3 * k + 1] = quant_lo(l.y, g.lo[1], g.inv_cell[1], gm[1]) | (quant_hi(h.y, g.lo[1], g.inv_cell[1], gm[1]) << 16);
+    nd.w[3 * k + 2] = quant_lo(l.z, g.lo[2], g.inv_cell[2], gm[2]) | (quant_hi(h.z, g.lo[2], g.inv_cell[2], gm[2]) << 16);
+    nd.w[24 + k] = (uint32_t)(ch >= 0 ? (int)pos[new_id[ch]] : ch);
   }
   nodes[pos[new_id[i]]] = nd;
 }
@@ -1349,6 +1392,9 @@ hipError_t build_lbvh(hipStream_t st, const LbvhInputs& in, LbvhOutputs& out) {
   out.sah = 0.0f;
   out.rounds = 0;
   out.nodes = nullptr;
+  out.nodes8 = nullptr;
+  out.n_nodes8 = 0;
+  out.depth8 = 0;
   out.quads = nullptr;
   out.n_nodes = 0;
   out.n_leaves = 0;
@@ -1591,7 +1637,7 @@ hipError_t build_lbvh(hipStream_t st, const LbvhInputs& in, LbvhOutputs& out) {
     GLZ_TRY(hipMemsetAsync(head, 0, sizeof(int) * n, st));
     GLZ_TRY(hipMemsetAsync(scalars + 7, 0, sizeof(int), st));
     for (int level = 0; level <= inner_depth; ++level) {
-      hipLaunchKernelGGL(k_mark_heads, grd, blk, 0, st, (int)n, level, node_depth, children, node_lo, node_hi, head, scalars + 7);
+      hipLaunchKernelGGL(k_mark_heads<4>, grd, blk, 0, st, (int)n, level, node_depth, children, node_lo, node_hi, head, scalars + 7);
       GLZ_TRY(hipGetLastError());
     }
     hipLaunchKernelGGL(k_head_flags, grd, blk, 0, st, (int)n, head, new_id, flags);
@@ -1600,12 +1646,39 @@ hipError_t build_lbvh(hipStream_t st, const LbvhInputs& in, LbvhOutputs& out) {
     hipLaunchKernelGGL(k_scan_total, dim3(1), dim3(64), 0, st, (int)n - 1, flags, pos, scan_total);
     GLZ_TRY(hipGetLastError());
     unsigned long long n4 = 0;
+    int depth4_keep = 0;
     GLZ_TRY(hipMemcpyAsync(&n4, scan_total, sizeof(n4), hipMemcpyDeviceToHost, st));
+    GLZ_TRY(hipMemcpyAsync(&depth4_keep, scalars + 7, sizeof(int), hipMemcpyDeviceToHost, st));
     GLZ_TRY(hipStreamSynchronize(st));
     out.n_nodes = (uint32_t)n4;
     GLZ_TRY(hipMalloc(&out.nodes, sizeof(BvhNode4) * (size_t)n4));
     hipLaunchKernelGGL(k_emit_nodes4, grd, blk, 0, st, (int)n, children, node_lo, node_hi, grid, new_id, flags, pos, slot, in.emit_quads ? 1u : 0u, out.nodes, sah);
     GLZ_TRY(hipGetLastError());
+    if (in.emit_wide8 && in.emit_quads) {
+      // the 8-wide collapse of the same binary hierarchy: heads, depth-first numbers, nodes (head / flags / pos are free again)
+      GLZ_TRY(hipMemsetAsync(head, 0, sizeof(int) * n, st));
+      GLZ_TRY(hipMemsetAsync(scalars + 7, 0, sizeof(int), st));
+      for (int level = 0; level <= inner_depth; ++level) {
+        hipLaunchKernelGGL(k_mark_heads<8>, grd, blk, 0, st, (int)n, level, node_depth, children, node_lo, node_hi, head, scalars + 7);
+        GLZ_TRY(hipGetLastError());
+      }
+      hipLaunchKernelGGL(k_head_flags, grd, blk, 0, st, (int)n, head, new_id, flags);
+      GLZ_TRY(hipGetLastError());
+      GLZ_TRY(scan_exclusive(st, (int)n - 1, flags, pos, scan_tmp));
+      hipLaunchKernelGGL(k_scan_total, dim3(1), dim3(64), 0, st, (int)n - 1, flags, pos, scan_total);
+      GLZ_TRY(hipGetLastError());
+      unsigned long long n8 = 0;
+      int depth8 = 0;
+      GLZ_TRY(hipMemcpyAsync(&n8, scan_total, sizeof(n8), hipMemcpyDeviceToHost, st));
+      GLZ_TRY(hipMemcpyAsync(&depth8, scalars + 7, sizeof(int), hipMemcpyDeviceToHost, st));
+      GLZ_TRY(hipStreamSynchronize(st));
+      out.n_nodes8 = (uint32_t)n8;
+      out.depth8 = (uint32_t)depth8;
+      GLZ_TRY(hipMalloc(&out.nodes8, sizeof(BvhNode8) * (size_t)n8));
+      hipLaunchKernelGGL(k_emit_nodes8, grd, blk, 0, st, (int)n, children, node_lo, node_hi, grid, new_id, flags, pos, out.nodes8);
+      GLZ_TRY(hipGetLastError());
+      GLZ_TRY(hipMemcpyAsync(scalars + 7, &depth4_keep, sizeof(int), hipMemcpyHostToDevice, st));   // host_scalars[7] below is the 4-wide depth
+    }
   }
   int host_scalars[8];
   float host_sah = 0.0f;

@@ -17,7 +17,11 @@ using namespace dev;
 // ---------------------------------------------------------------------------------------------
 // k_shade: path_trace.rgen:170-237 minus the two traceRayEXT calls, raytrace_hit.rchit:30-71
 // ---------------------------------------------------------------------------------------------
-constexpr uint32_t kSkyLdsFloats = 4096;   // the sky's marginal cdf (H + 1 floats) is staged in LDS when it fits (the values and row integrals next to it are read once per sample, from memory: staging all 3 H + 1 floats was 12 of the 19 KB a block copies before it starts)
+#ifndef GLZ_SKY_LDS_FLOATS
+#define GLZ_SKY_LDS_FLOATS 1088
+#endif
+constexpr uint32_t kSkyLdsFloats = GLZ_SKY_LDS_FLOATS;   // (skies of up to 1 087 rows; a taller one is searched in memory)
+constexpr uint32_t kShadeLdsTableBytes = 8192;   // k_shade's LDS copy of the material / light / texture-descriptor tables (38 materials; larger tables are read from memory)   // the sky's marginal cdf (H + 1 floats) is staged in LDS when it fits (the values and row integrals next to it are read once per sample, from memory: staging all 3 H + 1 floats was 12 of the 19 KB a block copies before it starts)
 
 // (GLZ_SHADE_WAVES = 4, device/tuning.h: 128 VGPRs, 4 of them spilled, since the light's spectrum is made after the BSDF evaluation and the
 // importance is read where it is used (natural demand 152 -> 132): 0.357 -> 0.348 ms; at three waves the same code takes 0.363 ms.)
@@ -41,12 +45,16 @@ __global__ void __launch_bounds__(kShadeBlock, GLZ_SHADE_WAVES) k_shade(const La
   // VALU instructions nothing; 1 / 2 / 3 / 4 waves per SIMD take 0.76 / 0.45 / 0.36 / 0.35 ms), so the two small tables every texture fetch /
   // sky sample walks are staged in LDS once per block: the sRGB decode LUT (12 lookups per bilinear fetch) and the sky marginal CDF (an 11-step dependent search).
   __shared__ float s_lut[256];
-  // one pool: the sky marginal table and the scene tables while the block shades; after its last barrier the staging area of the
-  // state the pixels leave (StagedState): 6 x 16 bytes per pixel, written where the pixel lives instead of where its thread sat
-  __shared__ uint4 s_pool[kSkyLdsFloats / 4 + kShadeTableBytes / 16];
-  float* s_sky = reinterpret_cast<float*>(s_pool);
-  uint4* s_tables = s_pool + kSkyLdsFloats / 4;
-  static_assert(6u * kShadeBlock <= kSkyLdsFloats / 4 + kShadeTableBytes / 16, "the staging area of the path state fits the pool");
+  // One pool: [the importance the block's 256 pixels arrived with, 4 x 4 KB, read in whole lines by the prologue | the sky's marginal cdf |
+  // the scene tables] while the block shades; after its last barrier the first 24 KB are the staging area of the state the pixels leave
+  // (StagedState): 6 x 16 bytes per pixel, written where the pixel lives instead of where its thread sat.
+  __shared__ uint4 s_pool[kShadeBlock * 4 + kSkyLdsFloats / 4 + kShadeLdsTableBytes / 16];
+  uint4* s_imp = s_pool;
+  float* s_sky = reinterpret_cast<float*>(s_pool + kShadeBlock * 4);
+  uint4* s_tables = s_pool + kShadeBlock * 4 + kSkyLdsFloats / 4;
+#ifndef GLZ_SHADE_SLOT_TIMING
+  static_assert(6u * kShadeBlock <= kShadeBlock * 4 + kSkyLdsFloats / 4 + kShadeLdsTableBytes / 16, "the staging area of the path state fits the pool");
+#endif
   // The small scene tables every hit walks through one after the other -- shading record -> RTMaterial -> texture descriptor
   // -> texels, light pick -> RTLight -- are staged in LDS when they fit: each lookup that stays on chip takes a dependent
   // memory round trip (1-2 us under load, the kernel's bound) off the hit's critical path.
@@ -62,7 +70,7 @@ __global__ void __launch_bounds__(kShadeBlock, GLZ_SHADE_WAVES) k_shade(const La
   // [RTMaterial x n_materials | RTLight x n_rt_lights | TexDesc x n_textures] in 16-byte pieces
   const uint32_t qm = A.scene.n_materials * (uint32_t)(sizeof(RTMaterial) / 16), ql = A.scene.n_rt_lights * (uint32_t)(sizeof(RTLight) / 16),
                  qt = A.scene.n_textures * (uint32_t)(sizeof(TexDesc) / 16);
-  const bool tables_in_lds = (qm + ql + qt) * 16u <= kShadeTableBytes;   // uniform over the grid
+  const bool tables_in_lds = (qm + ql + qt) * 16u <= kShadeLdsTableBytes;   // uniform over the grid
   if (tables_in_lds) {
     const uint4* gm = reinterpret_cast<const uint4*>(A.scene.materials);
     const uint4* gl = reinterpret_cast<const uint4*>(A.scene.lights);
@@ -95,6 +103,8 @@ __global__ void __launch_bounds__(kShadeBlock, GLZ_SHADE_WAVES) k_shade(const La
     const PixelId px0 = pixel_of(A.map, lid0);
     if (px0.active) {
       const float4 h0 = A.st.hit[lid0];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) s_imp[q * kShadeBlock + threadIdx.x] = *reinterpret_cast<const uint4*>(&A.st.imp[q][lid0]);   // whole lines, pixel order (a fresh path's is never read)
       s_hit[threadIdx.x] = h0;   // the thread at this pixel's sorted slot reads it back after the barriers below: one dependent global load less
       const uint32_t leaf0 = __float_as_uint(h0.w);
       key = 0u;
@@ -152,7 +162,16 @@ __global__ void __launch_bounds__(kShadeBlock, GLZ_SHADE_WAVES) k_shade(const La
     }
   }
   __syncthreads();
-  s_perm[s_bin[(threadIdx.x >> 6) * 64u + key] + rank] = (uint16_t)threadIdx.x;
+  {
+    uint32_t pos = s_bin[(threadIdx.x >> 6) * 64u + key] + rank;   // the pixel's place in the block's order by code path
+#ifdef GLZ_SHADE_DEAL   // EXPERIMENT: the sorted sequence dealt to the four waves in chunks of GLZ_SHADE_DEAL pixels instead of 64 (balance against purity)
+    constexpr uint32_t kChunk = GLZ_SHADE_DEAL, kPerWave = 64u / kChunk;
+    const uint32_t chunk = pos / kChunk;
+    pos = (chunk % kShadeWavesPerBlock) * 64u + (chunk / kShadeWavesPerBlock) * kChunk + pos % kChunk;
+    static_assert(kPerWave * kChunk == 64u, "chunk divides a wave");
+#endif
+    s_perm[pos] = (uint16_t)threadIdx.x;
+  }
   __syncthreads();
   GLZ_KS(2);   // regrouped
   const uint32_t lid = blockIdx.x * kShadeBlock + s_perm[threadIdx.x];
@@ -167,6 +186,7 @@ __global__ void __launch_bounds__(kShadeBlock, GLZ_SHADE_WAVES) k_shade(const La
     const LaunchArgs& A2 = *(const LaunchArgs*)reread_kernarg();
     SharedQueue queue{A2};
     staged.A = &A2;
+    staged.lds_imp = (LdsNodePtr)(reinterpret_cast<u32x4*>(s_imp) + s_perm[threadIdx.x]);
 #ifdef GLZ_SECTION_TIMES
     staged.sec_last = __builtin_amdgcn_s_memtime();
 #endif
@@ -175,6 +195,18 @@ __global__ void __launch_bounds__(kShadeBlock, GLZ_SHADE_WAVES) k_shade(const La
 #ifdef GLZ_SECTION_TIMES
   ks_last = __builtin_amdgcn_s_memtime();
 #endif
+#ifdef GLZ_SHADE_SLOT_TIMING   // TIMING ONLY (images are wrong): every thread stores the state it made at ITS OWN index -- whole lines without the meeting at the barrier, what a slot-indexed path state would do; the pixels of a block exchange paths, the workload stays what it is
+  {
+    const LaunchArgs& A3 = A;
+    const uint32_t at = blockIdx.x * kShadeBlock + threadIdx.x;
+    if (staged.mask & 1u) A3.st.ray_o[at] = staged.ro;
+    if (staged.mask & 2u) A3.st.ray_d[at] = staged.rd;
+    if (staged.mask & 4u) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) A3.st.imp[q][at] = staged.im[q];
+    }
+  }
+#else
   {
     // The regrouped threads would store 16-byte pieces scattered over the block's 4 KB of each state array (six arrays); the L2 has
     // to assemble the lines.  Thread i stores pixel i's state instead: the values travel through LDS, which nobody needs any more
@@ -199,6 +231,7 @@ __global__ void __launch_bounds__(kShadeBlock, GLZ_SHADE_WAVES) k_shade(const La
       for (int q = 0; q < 4; ++q) A3.st.imp[q][at] = stage[(2u + q) * kShadeBlock + threadIdx.x];
     }
   }
+#endif
   if (COUNT) flush_tex_tallies(A.counters->shade_tex, tex_tally);   // every lane of the wave is here (the counting build returns nowhere above)
 #ifdef GLZ_SECTION_TIMES
   if (!COUNT) {
@@ -269,6 +302,39 @@ __global__ void __launch_bounds__(kBlock, GLZ_TRACE_WAVES) k_trace(const LaunchA
   }
   if (COUNT) flush_tex_tallies(A.counters->trace_tex, tex_tally);
   GLZ_WAVE_STAMP(2);
+}
+
+// k_trace for a small tile share: the same two phases over the hierarchy's 8-wide nodes (trace_wave<WIDE8>).  Compiled
+// for GLZ_TRACE8_WAVES waves per SIMD: a share of <= 262 144 pixels has a resident wave for every 64-ray group at four, and the node's 32
+// words, the eight keys and (PREFETCH) the next node's 32 words want the registers.  No staged top, a deeper LDS stack.
+__global__ void __launch_bounds__(kBlock, GLZ_TRACE8_WAVES) k_trace8(const LaunchArgs A) {
+  __shared__ int s_stack[kLdsStack8 * kBlock];
+  __shared__ alignas(1024) int s_aux[kAuxPerBlock];
+  int* aux = wave_aux(s_aux, threadIdx.x >> 6);
+  int* links = wave_links(s_aux, threadIdx.x >> 6);
+  if (blockIdx.x == 0 && threadIdx.x < kQueueShards) A.st.queue_count[A.shade_set * kQueueSetWords + threadIdx.x * kCounterStride] = 0;
+  if (A.do_closest) {
+    TraceTally tally;
+    ClosestSource src{A, A.frame, tally, 0u};
+    ClosestSink sink{A};
+    trace_wave<false, false, false, GLZ_TRACE8_PREFETCH != 0, true>(A.scene, src, sink, &s_stack[threadIdx.x], aux, links, (LdsNodePtr) nullptr, A.st.overflow, A.st.overflow_depth,
+                                                                    A.map.n_local_pixels, wave_index(), wave_count(), tally);
+  }
+  if (A.do_shadow) {
+    const uint32_t* counts = A.st.queue_count + (A.shade_set ^ 1u) * kQueueSetWords;
+    uint32_t start[kQueueShards + 1];
+    start[0] = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kQueueShards; ++k) start[k + 1] = start[k] + counts[k * kCounterStride];
+    TraceTally tally;
+    ShadowSource src{A, start, queue_capacity(A.map.n_local_pixels), 0u, make_float4(0.0f, 0.0f, 0.0f, 0.0f)};
+    ShadowSink sink{A, src};
+    const uint32_t n_waves = wave_count();
+    const uint32_t closest_groups = A.do_closest ? (A.map.n_local_pixels + 63u) / 64u : 0u;
+    const uint32_t wave = (wave_index() + n_waves - closest_groups % n_waves) % n_waves;
+    trace_wave<true, false, false, GLZ_TRACE8_PREFETCH != 0, true>(A.scene, src, sink, &s_stack[threadIdx.x], aux, links, (LdsNodePtr) nullptr, A.st.overflow, A.st.overflow_depth,
+                                                                   start[kQueueShards], wave, n_waves, tally);
+  }
 }
 
 // the same kernel for two-level scenes (trace_wave_tl): closest hits additionally record the instance
@@ -446,18 +512,21 @@ static dim3 persistent_grid(Kernel kernel, uint32_t n_rays) {
 // answer to every launch_trace; needs the device current).  Up to one closest-hit and one shadow ray per pixel: a small
 // tile share still gets a wave per 64-ray group of either kind (fewer, longer-lived waves -- 2 to 4 groups per wave --
 // measured 25-50 % slower for small shares: spread as wide as possible).
-uint32_t trace_grid_blocks(uint32_t n_local_pixels, bool counting, bool two_level) {
+uint32_t trace_grid_blocks(uint32_t n_local_pixels, bool counting, bool two_level, bool wide8) {
   uint32_t rays = 2u * n_local_pixels;
+  if (wide8 && !counting && !two_level) return persistent_grid(k_trace8, rays).x;
   if (two_level) return counting ? persistent_grid(k_trace_tl<true>, rays).x : persistent_grid(k_trace_tl<false>, rays).x;   // compiled for fewer waves per SIMD: its own residency
   return counting ? persistent_grid(k_trace<true>, rays).x : persistent_grid(k_trace<false>, rays).x;
 }
 
-hipError_t launch_trace(hipStream_t st, const LaunchArgs& a, uint32_t blocks) {
+hipError_t launch_trace(hipStream_t st, const LaunchArgs& a, uint32_t blocks, bool wide8) {
   if (a.map.n_local_pixels == 0) return hipSuccess;
+  if (wide8 && (a.scene.two_level || a.counters || !a.scene.bvh_nodes8)) return hipErrorInvalidValue;   // the 8-wide walk: flattened scenes, no work counters
   if (blocks == 0 || (uint64_t)blocks * kBlock > 2ull * a.map.n_local_pixels + kBlock) return hipErrorInvalidValue;   // the spill area holds one slot per lane of this bound
   if (a.scene.two_level && a.counters) hipLaunchKernelGGL(k_trace_tl<true>, dim3(blocks), dim3(kBlock), 0, st, a);   // node visits of both levels, triangle tests inside the instances
   else if (a.scene.two_level) hipLaunchKernelGGL(k_trace_tl<false>, dim3(blocks), dim3(kBlock), 0, st, a);
   else if (a.counters) hipLaunchKernelGGL(k_trace<true>, dim3(blocks), dim3(kBlock), 0, st, a);
+  else if (wide8) hipLaunchKernelGGL(k_trace8, dim3(blocks), dim3(kBlock), 0, st, a);
   else hipLaunchKernelGGL(k_trace<false>, dim3(blocks), dim3(kBlock), 0, st, a);
   return hipGetLastError();
 }

@@ -257,6 +257,12 @@ bool Renderer::allocate(Error& err) {
       fits = resident >= blocks && (scene_->info.n_world_triangles < 4096 || (uint64_t)blocks * 5u <= (uint64_t)resident * 4u);
     }
     path_mode_ = scene_->dev.two_level == 0 && (launch_mode_ == 2 || fits);
+    // The two-kernel mode's traversal walks the hierarchy's 8-wide nodes only on request (set_node_width(8), GLAZE_NODE_WIDTH=8): built to
+    // shorten a small tile share's chain of dependent node fetches (17.3 against 24.9 visits per sample), measured slower at every share --
+    // a 1080p / 8 share 0.140 - 0.145 against 0.1285 ms per launch, / 16 0.098 against 0.097, the full frame 0.93 against 0.79
+    // (profiles/r05_wide_nodes.txt): twice the boxes and up to seven conditional pushes make a visit 1.9 x the instructions, and one wave
+    // issues them one after the other, so the shorter chain takes as long.
+    wide8_ = scene_->dev.two_level == 0 && scene_->dev.bvh_nodes8 != nullptr && node_width_ == 8;
   }
   const uint32_t S = pick_chains();
   const uint32_t od = scene_->stack_overflow_depth;
@@ -289,9 +295,10 @@ bool Renderer::allocate(Error& err) {
     if (!hip_ok(c->hit_inst.alloc(n), "alloc path state", err)) return false;
     c->grid = trace_grid_blocks(m.n_local_pixels, false, scene_->dev.two_level != 0);
     c->grid_counting = trace_grid_blocks(m.n_local_pixels, true, scene_->dev.two_level != 0);
+    c->grid8 = wide8_ ? trace_grid_blocks(m.n_local_pixels, false, false, true) : 0u;
     c->grid_path = path_mode_ ? path_grid_blocks(m.n_local_pixels, scene_->dev) : 0u;
     // traversal spill: one slot of `od` entries per lane of the largest of the persistent grids
-    if (!hip_ok(c->overflow.alloc((size_t)std::max(std::max(c->grid, c->grid_counting), c->grid_path) * kTraceBlock * od), "alloc traversal spill", err)) return false;
+    if (!hip_ok(c->overflow.alloc((size_t)std::max(std::max(std::max(c->grid, c->grid_counting), c->grid_path), c->grid8) * kTraceBlock * od), "alloc traversal spill", err)) return false;
     if (!hip_ok(c->queue_count.alloc(2 * kQueueSetWords), "alloc queue counters", err)) return false;
     if (!hip_ok(c->path_cost.alloc(8 + n / 64 + 1), "alloc path costs", err)) return false;
     if (!hip_ok(hipMemsetAsync(c->path_cost.ptr, 0, sizeof(uint32_t) * (8 + n / 64 + 1), c->stream), "clear path costs", err)) return false;
@@ -414,7 +421,7 @@ bool Renderer::flush_shadows(Chain& c, Error& err) {
     ev.kind = 1;
     (void)hipEventRecord(ev.e[0], c.stream);
   }
-  if (!hip_ok(launch_trace(c.stream, a, counting_ ? c.grid_counting : c.grid), "k_trace (shadow pass)", err)) return false;
+  if (!hip_ok(launch_trace(c.stream, a, counting_ ? c.grid_counting : (wide8() ? c.grid8 : c.grid), wide8()), "k_trace (shadow pass)", err)) return false;
   if (profile_kernels_) {
     (void)hipEventRecord(ev.e[1], c.stream);
     c.pending_events.push_back(ev);
@@ -474,7 +481,7 @@ bool Renderer::one_launch(Error& err) {
       ev.weight = (uint32_t)stride;
       (void)hipEventRecord(ev.e[0], st);
     }
-    if (!hip_ok(launch_trace(st, a, counting_ ? c.grid_counting : c.grid), "k_trace", err)) return false;
+    if (!hip_ok(launch_trace(st, a, counting_ ? c.grid_counting : (wide8() ? c.grid8 : c.grid), wide8()), "k_trace", err)) return false;
     if (timed) (void)hipEventRecord(ev.e[1], st);
     if (!hip_ok(launch_shade(st, a), "k_shade", err)) return false;
     if (timed) {
@@ -550,6 +557,20 @@ bool Renderer::set_launch_mode(int mode, Error& err) {
   launch_mode_ = mode;
   if (!allocate(err)) return false;
   const bool ok = forward([=](Peer& p, Error& e) { return p.r->set_launch_mode(mode, e); }, err);
+  (void)hipSetDevice(inst_->device);
+  return ok;
+}
+
+bool Renderer::set_node_width(int width, Error& err) {
+  if (width != 0 && width != 4 && width != 8) {
+    err.code = GLZ_E_ARG;
+    err.msg = "node width must be 0 (automatic), 4 or 8";
+    return false;
+  }
+  if (!wait_idle(err)) return false;
+  node_width_ = width;
+  if (!allocate(err)) return false;
+  const bool ok = forward([=](Peer& p, Error& e) { return p.r->set_node_width(width, e); }, err);
   (void)hipSetDevice(inst_->device);
   return ok;
 }
@@ -1056,6 +1077,7 @@ bool Renderer::configure_peer(Renderer& p, Error& err) const {
   p.cam_ = cam_;
   p.chains_wanted_ = chains_wanted_;
   p.launch_mode_ = launch_mode_;
+  p.node_width_ = node_width_;
   p.counting_ = counting_;
   p.profile_kernels_ = profile_kernels_;
   p.request_new_frame_ = true;

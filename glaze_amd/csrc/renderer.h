@@ -48,6 +48,9 @@ class Renderer {
   // owns.  Images do not depend on it.
   bool set_launch_mode(int mode, Error& err);
   bool path_mode() const { return path_mode_; }
+  // Which nodes the two-kernel mode's traversal walks: 4 (k_trace), 8 (k_trace8: flattened scenes, counters off), 0 = by the pixels this device owns.
+  bool set_node_width(int width, Error& err);
+  bool wide8() const { return wide8_ && !counting_; }
   uint32_t chains() const { return (uint32_t)chains_.size(); }
   static uint32_t chains_for(uint32_t w, uint32_t h, uint32_t rank, uint32_t world, uint32_t wanted);
   bool export_device(int which, void* dev_rgba32f, Error& err);
@@ -93,6 +96,8 @@ class Renderer {
   uint32_t chains_wanted_ = 0;      // 0 = automatic (pick_chains)
   int launch_mode_ = getenv("GLAZE_LAUNCH_MODE") ? atoi(getenv("GLAZE_LAUNCH_MODE")) : 0;   // set_launch_mode
   bool path_mode_ = false;          // decided in allocate(): this device's launches run as k_path batches
+  int node_width_ = getenv("GLAZE_NODE_WIDTH") ? atoi(getenv("GLAZE_NODE_WIDTH")) : 0;   // set_node_width
+  bool wide8_ = false;              // decided in allocate(): k_trace8 (the 8-wide nodes) traces this device's rays while the counters are off
 
   // One chain = one independent sequence of launches over a subset of this rank's tiles, on its own HIP stream.
   // Pixels never interact, so the tiles of a rank can advance as several concurrent chains: chain s of S renders the
@@ -115,6 +120,7 @@ class Renderer {
     DeviceBuffer<uint32_t> overflow, queue_count, path_cost;
     uint32_t path_batches = 0;
     uint32_t grid = 0, grid_counting = 0;   // blocks of k_trace's persistent grid (plain / instrumented kernel)
+    uint32_t grid8 = 0;                     // ... of k_trace8's (0 unless the renderer walks the 8-wide nodes)
     uint32_t grid_path = 0;                 // blocks of k_path's grid (0: this chain never runs it)
     // shadow rays queued by the last launch's k_shade and not traced yet (they ride in the next launch's k_trace, or in
     // a stand-alone pass as soon as anything looks at the images: flush_shadows)

@@ -843,10 +843,14 @@ bool Scene::build_two_level(Error& err) {
   dev.tlas_instances = d_tlas_instances_.ptr;
   dev.xf_identity = d_xf_identity_.ptr;
   dev.two_level = 1u;
+  d_nodes8_.release();   // (the two-level tracer walks 4-wide nodes only)
+  dev.bvh_nodes8 = nullptr;
+  info.bvh_nodes8 = 0;
   dev.n_world_tris = (uint32_t)info.n_world_triangles;
   info.as_levels = 2;
   info.n_as_triangles = nt;
-  info.as_bytes = (uint64_t)n_nodes * sizeof(BvhNode4) + (uint64_t)(nt + 1) * sizeof(BvhTri) + (uint64_t)nt * 128u + (uint64_t)ni * sizeof(TlasInstance);
+  info.as_bytes = (uint64_t)n_nodes * sizeof(BvhNode4) + (uint64_t)(nt + 1) * sizeof(BvhTri) + (uint64_t)nt * 128u + (uint64_t)ni * sizeof(TlasInstance) +
+                  (uint64_t)d_quads_.count * sizeof(BvhQuad);
   return true;
 }
 
@@ -876,9 +880,11 @@ bool Scene::build_bvh(Error& err) {
   LbvhInputs in{d_vertices_.ptr, d_indices_.ptr, d_instances_.ptr, d_inst_base_.ptr, (uint32_t)h_instances.size(), d_transforms_.ptr,
                 d_materials_.ptr, n, instance->bvh_builder, instance->bvh_pair_area_ratio};
   in.emit_quads = true;   // the flattened tracer reads one 64-byte record per leaf (types.h BvhQuad); leaf links are ~leaf number
+  in.emit_wide8 = true;   // ... and a small tile share the same hierarchy eight wide (types.h BvhNode8, k_trace8)
   LbvhOutputs out{};
   out.tris = d_tris_.ptr;
   d_quads_.release();
+  d_nodes8_.release();
   hipEvent_t e0, e1;
   if (!hip_ok(hipEventCreate(&e0), "event", err) || !hip_ok(hipEventCreate(&e1), "event", err)) return false;
   (void)hipEventRecord(e0, st);
@@ -891,6 +897,8 @@ bool Scene::build_bvh(Error& err) {
   (void)hipEventDestroy(e1);
   d_quads_.ptr = out.quads;       // ours whatever the build returned
   d_quads_.count = out.quads ? out.n_leaves : 0;
+  d_nodes8_.ptr = out.nodes8;
+  d_nodes8_.count = out.nodes8 ? out.n_nodes8 : 0;
   if (!hip_ok(be, "LBVH build", err)) return false;
   d_nodes_.ptr = out.nodes;       // allocated by the build once the number of 4-wide nodes is known
   d_nodes_.count = out.n_nodes;
@@ -904,7 +912,7 @@ bool Scene::build_bvh(Error& err) {
   }
   // traversal stack: kTraversalLdsStack levels live in LDS, the rest spills to a per-lane HBM area
   // (a 4-wide visit pushes up to three siblings, so the bound is 3 entries per level)
-  const uint32_t stack_bound = 3u * out.depth + 1u;
+  const uint32_t stack_bound = std::max(3u * out.depth, 7u * out.depth8) + 1u;   // (an 8-wide visit pushes up to seven)
   stack_overflow_depth = stack_bound > (uint32_t)kTraversalLdsStack ? stack_bound - kTraversalLdsStack + 1 : 1;
   dev.bvh_nodes = d_nodes_.ptr;
   if (out.n_nodes >= (uint32_t)kBvhTopFlag) {
@@ -916,6 +924,8 @@ bool Scene::build_bvh(Error& err) {
   if (!d_top_.ptr && !hip_ok(d_top_.alloc(kBvhTopNodes), "alloc BVH top table", err)) return false;
   if (!hip_ok(launch_top_table(st, d_nodes_.ptr, out.n_nodes, d_top_.ptr), "k_top_table", err)) return false;
   dev.bvh_top = d_top_.ptr;
+  dev.bvh_nodes8 = d_nodes8_.ptr;
+  info.bvh_nodes8 = d_nodes8_.ptr ? out.n_nodes8 : 0;
   dev.bvh_nodes48 = nullptr;
   dev.bvh_top48 = nullptr;
 #ifdef GLZ_NODE48
@@ -950,7 +960,8 @@ bool Scene::build_bvh(Error& err) {
   dev.n_world_tris = n;
   info.as_levels = 1;
   info.n_as_triangles = n;
-  info.as_bytes = (uint64_t)out.n_nodes * sizeof(BvhNode4) + (uint64_t)(n + 1) * sizeof(BvhTri) + (uint64_t)n * 128u + (uint64_t)out.n_leaves * sizeof(BvhQuad);
+  info.as_bytes = (uint64_t)out.n_nodes * sizeof(BvhNode4) + (uint64_t)(n + 1) * sizeof(BvhTri) + (uint64_t)n * 128u + (uint64_t)out.n_leaves * sizeof(BvhQuad) +
+                  (uint64_t)info.bvh_nodes8 * sizeof(BvhNode8);
   return true;
 }
 

@@ -284,7 +284,8 @@ typedef struct glz_scene_info {
   float bvh_grid_lo[3], bvh_grid_cell[3];    /* quantisation grid of the BVH node boxes: world = lo + q * cell */
   uint32_t as_levels;                        /* 1 = one hierarchy over all instanced triangles, 2 = TLAS over per-mesh BLAS */
   uint32_t n_as_triangles;                   /* triangle records the structure holds (= n_world_triangles when flattened) */
-  uint64_t as_bytes;                         /* device bytes of nodes + triangle records + shading records + instance records */
+  uint64_t as_bytes;                         /* device bytes of nodes + triangle / leaf records + shading records + instance records */
+  uint32_t bvh_nodes8, _reserved;            /* 8-wide nodes of the same hierarchy (the tracer of small tile shares; flattened builds), 0 = none */
 } glz_scene_info;
 int glz_scene_get_info(const glz_scene*, glz_scene_info* out);
 int glz_scene_camera(const glz_scene*, glz_camera* out);
@@ -389,6 +390,13 @@ int glz_renderer_set_chains(glz_renderer*, uint32_t n);
 #define GLZ_LAUNCH_PATH 2
 int glz_renderer_set_launch_mode(glz_renderer*, int mode);
 int glz_renderer_launch_mode(glz_renderer*);
+/* Which nodes the two-kernel mode's traversal walks (build-defined; the reference's structure is the driver's, acceleration.rs:319-345):
+ * 4 = the 64-byte 4-wide nodes (k_trace), 8 = the 128-byte 8-wide nodes of the same hierarchy (k_trace8; flattened scenes, and only
+ * while the work counters are off -- the counted walk is the 4-wide one), 0 (default) = automatic, which is 4: the 8-wide walk visits
+ * 31 % fewer nodes and measured slower at every tile share, it is kept as a tested option.  The image does not
+ * depend on it.  glz_renderer_node_width returns the width in force. */
+int glz_renderer_set_node_width(glz_renderer*, int width);
+int glz_renderer_node_width(glz_renderer*);
 /* Multi-GPU inside ONE process (what a Rust glaze-cli bound to this library uses for `--devices`; the reference drives exactly one
  * VkPhysicalDevice, lib/src/vulkan/device.rs:252-321): hip_devices[0] must be the renderer's own device (glz_instance_device);
  * every further device gets a stream, a replica of the scene (upload + BVH build on that device), a renderer for the 64x64 tiles
@@ -448,6 +456,9 @@ int64_t glz_debug_read_sky(glz_scene*, float* out, int64_t cap_floats);        /
  * triangles in leaf order (n_world_triangles of them; a leaf is one triangle or two adjacent ones, bit 30 of the
  * first one's last word says which, and leaf links name the first); see DESIGN.md for the layouts. */
 int64_t glz_debug_read_bvh(glz_scene*, void* nodes_out, int64_t cap_nodes, void* tris_out, int64_t cap_tris);
+/* The same hierarchy as 128-byte 8-wide nodes (what the tracer of a small tile share walks; glz_scene_info::bvh_nodes8 of them, flattened
+ * builds only): child k's box words at [3k .. 3k+2], its link at [24 + k], leaf links name the first triangle slot as above. */
+int64_t glz_debug_read_bvh8(glz_scene*, void* nodes_out, int64_t cap_nodes);
 
 /* one level of a scene texture's mip chain as the device holds it (level 0 = the texture; builds the chain if needed): returns the
  * byte count (0 past the last level), writes up to cap bytes and the level's dimensions */

@@ -3,6 +3,7 @@ launch modes (two kernels per launch / the per-wave launch loop k_path).  Predic
 the 8-GPU run: speed-up(N) ~ t(1) / t(N), against the best mode at world 1.
 
     python tools/gpu_partition_timing.py [two_kernels|path|auto ...]        env: CHAINS=<n> NOPROFILE=1 STEPS=<n>
+                                                                            WIDTH HEIGHT DEPTH WORLDS=1,2,4,8 (BASELINE configs[4]: 3840 2160 12) NODE_WIDTH=0|4|8
 """
 import os
 import sys
@@ -15,16 +16,20 @@ scene = glaze_amd.RayTraceScene.from_desc(inst, atrium_scene())
 chains = int(os.environ.get('CHAINS', '0'))
 n = int(os.environ.get('STEPS', '128'))
 modes = sys.argv[1:] or ["two_kernels", "path", "auto"]
-r = glaze_amd.RayTraceRenderer.new(inst, scene, 1920, 1080)
-r.set_depth(8)
+W, H, D = int(os.environ.get('WIDTH', '1920')), int(os.environ.get('HEIGHT', '1080')), int(os.environ.get('DEPTH', '8'))
+worlds = [int(w) for w in os.environ.get('WORLDS', '1,2,3,4,6,8,16').split(',')]
+print("frame %d x %d, depth %d, %d launches per call" % (W, H, D, n), flush=True)
+r = glaze_amd.RayTraceRenderer.new(inst, scene, W, H)
+r.set_depth(D)
 base = None
 for mode in modes:
-    for world in (1, 2, 3, 4, 6, 8, 16):
+    for world in worlds:
         if mode == "path" and world == 1 and os.environ.get("SKIP_PATH_1", "1") == "1":
             continue            # the full frame through k_path: 8 groups per wave one after the other, of no interest
         r.set_partition(0, world)
         r.set_launch_mode(mode)
         r.set_chains(chains)
+        r.set_node_width(int(os.environ.get('NODE_WIDTH', '0')))
         if os.environ.get('NOPROFILE'):
             r.enable_counters(False, False)
         r.restart(); r.step(16); r.wait_idle(); r.stats()
@@ -33,5 +38,5 @@ for mode in modes:
         s = r.stats()
         k = [(s.trace_closest_ms - s0.trace_closest_ms) / n, (s.shade_ms - s0.shade_ms) / n, (s.trace_shadow_ms - s0.trace_shadow_ms) / n, (s.other_ms - s0.other_ms) / n]
         base = base or dt
-        print("%-11s world %2d (%s): %.4f ms/launch wall (k_trace %.3f + k_shade %.3f + shadow pass %.3f + k_path %.3f = %.3f) -> speed-up %.2fx, efficiency %.0f%%" % (
-            mode, world, r.launch_mode(), dt, k[0], k[1], k[2], k[3], sum(k), base / dt, 100 * base / dt / world), flush=True)
+        print("%-11s world %2d (%s, %d-wide nodes): %.4f ms/launch wall (k_trace %.3f + k_shade %.3f + shadow pass %.3f + k_path %.3f = %.3f) -> speed-up %.2fx, efficiency %.0f%%" % (
+            mode, world, r.launch_mode(), r.node_width(), dt, k[0], k[1], k[2], k[3], sum(k), base / dt, 100 * base / dt / world), flush=True)
