@@ -7,7 +7,7 @@
 
 Workload (BASELINE.json configs[3]): the Sponza-class frame, 1920x1080, path tracer, depth 8.  Sponza
 itself is not in the reference repository, so the scene is the deterministic synthetic
-atrium of glaze_amd/scenes.py (262 140 triangles, 25 materials, sun + sky), written as a `.glaze` V1 file
+atrium of glaze_amd/scenes.py (262 267 triangles, 25 Lambert / Uber materials each with its own 1024^2 sRGB texture, sun + 2048x1024 sky), written as a `.glaze` V1 file
 (glz_serialize) and loaded the way glaze-cli loads a scene: parse -> RayTraceScene::new.  Inputs (scene, BVH,
 path state) are resident in HBM before the timed region starts.
 
@@ -27,6 +27,14 @@ against the frame it renders alone (--no-verify skips it).  Two ways to get ther
 GLAZE_MULTI_EXCHANGE=reduce switches both to one ncclReduce(sum) of the zero-padded W*H*4 frame; =peer (in-process form only) sends
 the packed tiles by hipMemcpyPeerAsync instead of RCCL -- also what the in-process form falls back to, saying so, when RCCL cannot be
 loaded or its communicators / first exchange fail on this machine.
+
+After the timed regions (and outside them) the same invocation also times, for at most half a second each, the other BASELINE
+configurations on one GPU (`extra.configs`: 2 = cube 512^2 depth 2, 3 = mattest.glaze 1024^2 depth 8, 5 = the atrium at 3840x2160 depth 12)
+and the atrium with the content classes real Sponza has and the stand-in lacks (`extra.atrium_sponza_like`: opacity-mapped cloth, foliage
+cards and vines, normal maps on stone, roughness maps on the Uber materials); `--no-extras` skips them.  N > 1: every step that can block
+on another GPU -- spanning the devices, every exchange, the process group's barrier -- runs under a watchdog: after its time-out
+(GLAZE_BENCH_WATCHDOG_S, default 180 s to span the devices, 90 s per exchange) it prints `multi_gpu.diagnostics` (which call, how long, RCCL
+version, the peer-access matrix, bytes per peer, the RCCL / HSA environment) to stderr and ends the process with status 3 through os._exit.
 
 The timed region is EXACTLY K steps between barrier + synchronize pairs, MAX over ranks.  A region shorter than 0.5 s is
 repeated (five regions in all, the accumulation simply continues) and `value` comes from the MEDIAN region; every
@@ -69,6 +77,8 @@ def parse_args():
                     help="also time BASELINE configs[4] (3840x2160, depth 12, same scene) as a second, separately named measurement "
                          "(default: when N > 1)")
     ap.add_argument("--no-config5", dest="config5", action="store_false")
+    ap.add_argument("--no-extras", action="store_true", help="N = 1: do not time the other BASELINE configurations and the Sponza-like atrium after the timed regions")
+    ap.add_argument("--no-configs", action="store_true", help="N = 1: do not time BASELINE configs 2, 3 and 5 (extra.configs)")
     return ap.parse_args()
 
 
@@ -94,7 +104,59 @@ def run_bounded(cmd, timeout, **kw):
     return p.returncode, out, err
 
 
-def measure_pmc(args):
+class Watchdog:
+    """Ends the process when a step that can block on another GPU does not come back: `with dog.phase(name, seconds, **facts)` arms it, leaving
+    the block disarms it.  A hang inside ncclGroupEnd (or a barrier) on the first contact between ranks would otherwise burn the caller's
+    whole time-out and leave nothing to look at; this prints what is known -- as one JSON object, `multi_gpu.diagnostics` -- and exits
+    with status 3 through os._exit (no re-exec, no retry in the same process: the GPU state of a wedged collective is not worth keeping)."""
+
+    def __init__(self, facts):
+        import threading
+        self.facts = facts              # callable -> dict of what the diagnostics always carry
+        self.lock = threading.Lock()
+        self.current = None             # (name, deadline, started, extra)
+        self.history = []
+        t = threading.Thread(target=self._run, name="bench-watchdog", daemon=True)
+        t.start()
+
+    def phase(self, name, seconds, **extra):
+        dog = self
+
+        class _Phase:
+            def __enter__(self_inner):
+                with dog.lock:
+                    dog.current = (name, time.monotonic() + seconds, time.monotonic(), extra, seconds)
+                return self_inner
+
+            def __exit__(self_inner, *exc):
+                with dog.lock:
+                    nm, _, started, _, _ = dog.current
+                    dog.history.append((nm, round((time.monotonic() - started) * 1e3, 3)))
+                    dog.current = None
+                return False
+        return _Phase()
+
+    def _run(self):
+        while True:
+            time.sleep(0.25)
+            with self.lock:
+                cur = self.current
+            if cur is None or time.monotonic() < cur[1]:
+                continue
+            name, _, started, extra, seconds = cur
+            diag = {"stuck_in": name, "timeout_s": seconds, "elapsed_s": round(time.monotonic() - started, 1), "completed_before": self.history[-8:]}
+            diag.update(extra)
+            try:
+                diag.update(self.facts())
+            except Exception as e:      # noqa: BLE001 -- the diagnostics must come out whatever else is broken
+                diag["facts_error"] = repr(e)
+            sys.stderr.write("bench.py: watchdog: `%s` did not return within %g s -- giving up\n" % (name, seconds))
+            sys.stderr.write(json.dumps({"multi_gpu": {"diagnostics": diag}}) + "\n")
+            sys.stderr.flush()
+            os._exit(3)
+
+
+def measure_pmc(args, scene_file=None):
     """roofline.traffic and the dominant kernel's real bound, measured by THIS invocation: three short runs of this very workload under
     `rocprofv3 --pmc` (FETCH_SIZE, WRITE_SIZE and the SQ issue counters in separate passes with --kernel-trace only, as
     MI355X_MICROARCH.md prescribes), per-kernel averages over the steady-state launches: the first PMC_CHILD_WARMUP launches of every
@@ -120,7 +182,7 @@ def measure_pmc(args):
             out = os.path.join(tmp, counters[0])
             cmd = [exe, "--pmc", *counters, "--kernel-trace", "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__),
                    "--pmc-child", "--no-pmc", "--steps", str(PMC_CHILD_STEPS), "--warmup", str(PMC_CHILD_WARMUP), "--width", str(args.width), "--height", str(args.height),
-                   "--depth", str(args.depth), "--seed", str(args.seed)] + (["--scene", os.path.abspath(args.scene)] if args.scene else [])
+                   "--depth", str(args.depth), "--seed", str(args.seed)] + (["--scene", os.path.abspath(args.scene or scene_file)] if (args.scene or scene_file) else [])
             rc, so, se = run_bounded(cmd, 150, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
             why = None
             if rc is None:
@@ -146,7 +208,10 @@ def measure_pmc(args):
                             rows.setdefault((k, row["Counter_Name"]), []).append((int(row.get("Dispatch_Id", 0) or 0), float(row["Counter_Value"])))
             for (k, c), v in rows.items():
                 v.sort()
-                steady = [x for _, x in v[PMC_CHILD_WARMUP:]] or [x for _, x in v]
+                # by LAUNCH, not by row: a kernel may be dispatched more than once per launch (several chains) or once more at the end (the
+                # stand-alone shadow pass), and the warm-up's launches must go whole
+                per_launch = max(1, round(len(v) / float(PMC_CHILD_WARMUP + PMC_CHILD_STEPS)))
+                steady = [x for _, x in v[PMC_CHILD_WARMUP * per_launch:]] or [x for _, x in v]
                 acc.setdefault(k, {})[c] = (sum(steady) / len(steady), len(steady))
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
@@ -244,11 +309,37 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+    def diagnostics_facts():
+        """what the watchdog's report always carries (nothing here may block on another GPU)"""
+        n_seen = torch.cuda.device_count()
+        facts = {"rank": rank, "world_size": world, "devices_in_process": n_dev, "gpus_visible": n_seen, "exchange": exchange, "loopback": bool(loopback), "rehearsal": rehearsal,
+                 "env": {k: v for k, v in os.environ.items() if k.startswith(("NCCL_", "RCCL_", "HSA_", "HIP_", "GLAZE_", "GPU_MAX", "ROCR_")) or k in ("MASTER_ADDR", "MASTER_PORT", "LOCAL_RANK")}}
+        try:
+            facts["rccl_version"] = int(glaze_amd.abi.lib().glz_rccl_version()) if world == 1 else list(torch.cuda.nccl.version())
+        except Exception as e:      # noqa: BLE001
+            facts["rccl_version"] = "unavailable: %r" % (e,)
+        try:
+            facts["peer_access"] = [[bool(i == j or torch.cuda.can_device_access_peer(i, j)) for j in range(n_seen)] for i in range(n_seen)]
+        except Exception as e:      # noqa: BLE001
+            facts["peer_access"] = "unavailable: %r" % (e,)
+        return facts
+
+    dog = Watchdog(diagnostics_facts) if n_gpus > 1 else None
+    span_timeout = float(os.environ.get("GLAZE_BENCH_WATCHDOG_S", "180"))
+    exchange_timeout = float(os.environ.get("GLAZE_BENCH_WATCHDOG_S", "90"))
+
+    def guarded(name, seconds, fn, **extra):
+        if dog is None:
+            return fn()
+        with dog.phase(name, seconds, **extra):
+            return fn()
+
     if world > 1:
         if rehearsal:
-            dist.init_process_group(backend="gloo")
+            guarded("dist.init_process_group(gloo)", span_timeout, lambda: dist.init_process_group(backend="gloo"))
         else:
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            guarded("dist.init_process_group(nccl = RCCL)", span_timeout, lambda: dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank)))
 
     inst = glaze_amd.RayTraceInstance.new(local_rank)
     if inst is None:
@@ -258,7 +349,12 @@ def main():
     from glaze_amd.scene_desc import save_scene
     serialize_s = 0.0
     desc = None                 # what the CPU baseline renders: the generator's description, or the oracle's own reading of the file
-    with tempfile.TemporaryDirectory(prefix="glaze_bench_") as tmp:
+    import atexit
+    import shutil
+    tmp = tempfile.mkdtemp(prefix="glaze_bench_")        # kept until the process ends: the PMC passes' children read the scene file again
+    atexit.register(shutil.rmtree, tmp, ignore_errors=True)
+    scene_file = None
+    if True:
         if args.scene:
             # a supplied scene (BASELINE configs[3] reads "Sponza .glaze"; the reference's README links one): the file as it is, or an
             # .obj through the converter (glz_convert_obj = glaze-converter, converter/src/main.rs)
@@ -279,6 +375,7 @@ def main():
             t0 = time.time()
             save_scene(desc, path)
             serialize_s = time.time() - t0
+            scene_file = path
             scene_name = "Sponza-class synthetic atrium"
             data_tag = "synthetic"
         glaze_bytes = os.path.getsize(path)
@@ -312,7 +409,7 @@ def main():
         nonlocal exchange, rccl_fallback
         ids = [0] * n_dev if loopback else list(range(n_dev))
         try:
-            renderer.set_devices(ids)
+            guarded("glz_renderer_set_devices (scene replicas, BVH builds, ncclCommInitAll)", span_timeout, lambda: renderer.set_devices(ids), devices=ids)
         except glaze_amd.abi.GlazeError as e:
             if exchange == "peer" or (loopback and os.environ.get("GLAZE_MULTI_LOOPBACK") != "rccl"):
                 raise
@@ -336,11 +433,21 @@ def main():
         renderer.wait_idle()
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier()
+            guarded("dist.barrier", exchange_timeout, dist.barrier)
             torch.cuda.synchronize()
 
+    n_exchanges = [0]
+
     def exchange_to_gpu0():
-        """every GPU's tiles onto GPU 0 (RCCL over xGMI; gloo on host tensors in a rehearsal)"""
+        """every GPU's tiles onto GPU 0 (RCCL over xGMI; gloo on host tensors in a rehearsal), under the watchdog"""
+        n_exchanges[0] += 1
+        per_peer = int(renderer_size[0] * renderer_size[1] * 16 / n_gpus) if exchange != "reduce" else renderer_size[0] * renderer_size[1] * 16
+        guarded("exchange #%d onto GPU 0 (%s)" % (n_exchanges[0], exchange), exchange_timeout, exchange_unguarded, bytes_per_peer=per_peer, peers=n_gpus - 1,
+                frame="%dx%d" % (renderer_size[0], renderer_size[1]))
+
+    renderer_size = [W, H]
+
+    def exchange_unguarded():
         if n_dev > 1:
             renderer.export_device(0, frame.data_ptr())     # set_devices: the library's own exchange, synchronised on return
         elif rehearsal:
@@ -363,9 +470,12 @@ def main():
     # ---- warmup (untimed): same accumulation continues afterwards, like the interactive draw_frame loop
     renderer.restart()
     renderer.step(args.warmup)
+    first_exchange_ms = None
     if n_gpus > 1:
         try:
+            t_first = time.perf_counter()
             exchange_to_gpu0()      # first use of the communicators / the process group belongs to the warm-up
+            first_exchange_ms = (time.perf_counter() - t_first) * 1e3
         except glaze_amd.abi.GlazeError as e:
             if n_dev == 1 or exchange == "peer" or (loopback and os.environ.get("GLAZE_MULTI_LOOPBACK") != "rccl"):
                 raise
@@ -424,6 +534,7 @@ def main():
     if args.config5 if args.config5 is not None else n_gpus > 1:
         W5, H5, D5 = 3840, 2160, 12
         renderer.change_resolution(W5, H5)
+        renderer_size[:] = [W5, H5]
         renderer.set_depth(D5)
         frame_1080 = frame
         frame = torch.zeros((H5, W5, 4), dtype=torch.float32, device="cuda")
@@ -437,6 +548,7 @@ def main():
                    "value": round(W5 * H5 * args.steps / e5 / 1e6, 2), "unit": "Msamples/s", "regions_ms": [round(t * 1e3, 3) for t in r5], "launch_mode": renderer.launch_mode()}
         frame = frame_1080
         renderer.change_resolution(W, H)
+        renderer_size[:] = [W, H]
         renderer.set_depth(args.depth)
         renderer.restart()
         sync_all()
@@ -489,7 +601,7 @@ def main():
         # processes, N = 1 only); if that is not possible, the per-launch average of the committed passes (profiles/pmc_summary.json)
         traffic, traffic_source, traffic_all = None, None, None
         if n_gpus == 1 and not args.no_pmc:
-            measured, note = measure_pmc(args)
+            measured, note = measure_pmc(args, scene_file)
             if measured is not None and dominant in measured:
                 traffic, traffic_source, traffic_all = measured[dominant]["hbm_bytes_per_launch"], note, measured
             else:
@@ -576,6 +688,82 @@ def main():
             dt1 = time.perf_counter() - tc
             cpu["single_thread"] = {"value": round(W * H / dt1 / 1e6, 3), "unit": "Msamples/s", "cores": 1,
                                     "sample": "1 launch (%.1f s)" % dt1}
+        extra = None
+        if n_gpus == 1 and not args.no_extras and not args.scene:
+            extra = {}
+
+            def quick_time(r, w, h, budget_s=0.4, warm=16):
+                """<= ~0.5 s of launches of a renderer after a warm-up: ms per launch, Msamples/s"""
+                r.restart()
+                r.step(warm)
+                r.wait_idle()
+                tq = time.perf_counter()
+                r.step(16)
+                r.wait_idle()
+                est = (time.perf_counter() - tq) / 16
+                n = int(max(16, min(2048, budget_s / max(est, 1e-6))))
+                tq = time.perf_counter()
+                r.step(n)
+                r.wait_idle()
+                dtq = time.perf_counter() - tq
+                return {"ms_per_step": round(dtq / n * 1e3, 4), "value": round(w * h * n / dtq / 1e6, 2), "unit": "Msamples/s", "steps": n, "launch_mode": r.launch_mode()}
+
+            if not args.no_configs:
+                # the other BASELINE configurations on this GPU (parity-test cases, not bench lines: timed here so that every one of them has a
+                # number the driver's own run produced)
+                from glaze_amd.scenes import cube_scene
+                cfgs = {}
+                r2 = glaze_amd.RayTraceRenderer.new(inst, glaze_amd.RayTraceScene.from_desc(inst, cube_scene()), 512, 512)
+                r2.set_depth(2)
+                r2.set_seed(args.seed)
+                cfgs["2"] = dict(quick_time(r2, 512, 512), workload="cube (12 tris, Lambert + omni light), 512x512, depth 2")
+                del r2
+                mt = os.path.join(ROOT, "tests", "golden", "mattest.glaze")
+                if os.path.exists(mt):
+                    r3 = glaze_amd.RayTraceRenderer.new(inst, glaze_amd.RayTraceScene.new(inst, glaze_amd.parse(mt)), 1024, 1024)
+                    r3.set_depth(8)
+                    r3.set_seed(args.seed)
+                    cfgs["3"] = dict(quick_time(r3, 1024, 1024), workload="mattest.glaze as it is (138 480 tris), 1024x1024, depth 8")
+                    del r3
+                else:
+                    cfgs["3"] = {"skipped": "tests/golden/mattest.glaze is not here"}
+                renderer.change_resolution(3840, 2160)
+                renderer.set_depth(12)
+                cfgs["5"] = dict(quick_time(renderer, 3840, 2160), workload="%s, 3840x2160, depth 12, the whole frame on ONE GPU" % scene_name)
+                renderer.change_resolution(W, H)
+                renderer.set_depth(args.depth)
+                extra["configs"] = cfgs
+            # the atrium with what real Sponza has and the stand-in lacks: alpha-tested cloth / foliage / vines (the any-hit texture fetch
+            # inside the traversal), normal maps on stone, roughness maps on the Uber materials -- through the file format like the headline
+            tq = time.time()
+            sp_path = os.path.join(tmp, "atrium_sponza_like.glaze")
+            save_scene(atrium_scene(sponza_like=True), sp_path)
+            sp_scene = glaze_amd.RayTraceScene.new(inst, glaze_amd.parse(sp_path))
+            sp_info = sp_scene.info()
+            rs = glaze_amd.RayTraceRenderer.new(inst, sp_scene, W, H)
+            rs.set_depth(args.depth)
+            rs.set_seed(args.seed)
+            sp = quick_time(rs, W, H)
+            rs.enable_counters(True, True)
+            rs.restart()
+            rs.step(args.warmup)
+            rs.wait_idle()
+            qa = rs.stats()
+            rs.step(64)
+            rs.wait_idle()
+            qc = rs.stats()
+            qr = max(1, qc.closest_rays - qa.closest_rays)
+            sp.update({"workload": "atrium + lace cloth, foliage cards, vines (opacity maps), normal maps on stone / brick, roughness maps on Uber (%d tris), %dx%d, depth %d"
+                                   % (int(sp_info.n_world_triangles), W, H, args.depth),
+                       "tex_bytes_trace": round((qc.alpha_tex_bytes - qa.alpha_tex_bytes) / qr, 3),
+                       "counted_per_sample": {"nodes_closest": round((qc.closest_nodes - qa.closest_nodes) / qr, 3), "tris_closest": round((qc.closest_tris - qa.closest_tris) / qr, 3),
+                                              "nodes_shadow": round((qc.shadow_nodes - qa.shadow_nodes) / qr, 3), "tris_shadow": round((qc.shadow_tris - qa.shadow_tris) / qr, 3),
+                                              "f_hit": round((qc.hits - qa.hits) / qr, 3), "f_shadow": round((qc.shadow_rays - qa.shadow_rays) / qr, 3),
+                                              "tex_fetches": round((qc.tex_fetches - qa.tex_fetches) / qr, 3),
+                                              "tex_bytes_shade": round(((qc.tex_bytes - qa.tex_bytes) - (qc.alpha_tex_bytes - qa.alpha_tex_bytes)) / qr, 3)},
+                       "setup_s": round(time.time() - tq, 2)})
+            extra["atrium_sponza_like"] = sp
+            del rs
         multi = None
         how = ""
         if n_gpus > 1:
@@ -598,6 +786,9 @@ def main():
                 seen = dist.get_world_size()
             multi = {"mode": mode, "exchange": how, "exchange_ms": round(exchange_ms, 4), "exchange_bytes_to_gpu0": int(W * H * 16 * (n_gpus - 1) / n_gpus) if exchange != "reduce" or loopback else W * H * 16,
                      "rccl_version": rccl, "gpus_seen": seen, "measurement": not (loopback or rehearsal), "set_devices_s": None if devices_s is None else round(devices_s, 3), "rccl_fallback": rccl_fallback,
+                     "first_exchange_ms": None if first_exchange_ms is None else round(first_exchange_ms, 3),
+                     "exchange_bytes_per_peer": int(W * H * 16 / n_gpus) if exchange != "reduce" else W * H * 16,
+                     "watchdog": {"span_timeout_s": span_timeout, "exchange_timeout_s": exchange_timeout, "phases_ms": dog.history[:6] + dog.history[-4:] if dog else None},
                      "config5": config5}
         out = {
             "metric": "Msamples/s + achieved HBM GB/s, Sponza 1080p, 1/2/4/8xMI355X",
@@ -605,15 +796,16 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
             "regions_ms": [round(t * 1e3, 3) for t in regions],
             "vs_baseline": None, "dtype": "f32", "data": data_tag,
-            "config": {"workload": "%s (%d tris) as a .glaze V1 file (%d bytes) through parse, %dx%d, path tracer depth %d, %d steps = %.1f spp"
-                                   % (scene_name, int(info.n_world_triangles), glaze_bytes, W, H, args.depth, args.steps, args.steps / args.depth),
+            "config": {"workload": "%s (%d tris, %d materials, %d textures) as a .glaze V1 file (%d bytes) through parse, %dx%d, path tracer depth %d, %d steps = %.1f spp"
+                                   % (scene_name, int(info.n_world_triangles), int(info.n_materials), int(info.n_textures), glaze_bytes, W, H, args.depth, args.steps, args.steps / args.depth),
+                       "materials": int(info.n_materials), "textures": int(info.n_textures),
                        "scene": scene_name,
                        "width": W, "height": H, "depth": args.depth, "triangles": int(info.n_world_triangles),
                        "sharding": "64x64 tiles round-robin over %d GPU(s)%s" % (n_gpus, "" if n_gpus == 1 else ", RGBA32F accumulator onto GPU 0: " + how),
                        "bvh": {"builder": "binned SAH on the GPU, leaves of 1-2 triangles, 4-wide quantised nodes", "nodes": int(info.bvh_nodes),
                                "depth": int(info.bvh_depth), "sah_cost": round(float(info.bvh_sah_cost), 2), "build_ms": round(float(info.build_ms), 3)},
                        "setup_s": round(setup_s, 3), "serialize_s": round(serialize_s, 3)},
-            "roofline": roofline, "cpu_baseline": cpu, "multi_gpu": multi, "config5": config5 if multi is None else None,
+            "roofline": roofline, "cpu_baseline": cpu, "multi_gpu": multi, "config5": config5 if multi is None else None, "extra": extra,
             "mpaths_per_s": round(value / args.depth, 2),
             "grays_per_s": round(value * (1 + counted["f_shadow"]) / 1e3, 3),
         }

@@ -182,33 +182,123 @@ def _sky_texture(width=2048, height=1024):
     return out
 
 
-def atrium_scene(seed=1, detail=0.564, texture_size=512, sky_size=(2048, 1024)):
+def _height_normal_map(rng, size, cells, strength):
+    """RGBA8 UNORM tangent-space normal map of a smooth value-noise height field (`cells` x `cells` control points, tiling)."""
+    n = rng.random((cells, cells)).astype(np.float32)
+    n = np.concatenate([n, n[:1]], 0)
+    n = np.concatenate([n, n[:, :1]], 1)
+    t = (np.arange(size, dtype=np.float32) + 0.5) / size * cells
+    i = np.floor(t).astype(int)
+    f = t - i
+    f = f * f * (3.0 - 2.0 * f)
+    rows = n[i][:, :] * (1.0 - f)[:, None] + n[i + 1][:, :] * f[:, None]                 # (size, cells + 1)
+    h = rows[:, i] * (1.0 - f)[None, :] + rows[:, i + 1] * f[None, :]                     # (size, size)
+    dx = (np.roll(h, -1, 1) - np.roll(h, 1, 1)) * (0.5 * size / cells) * strength
+    dy = (np.roll(h, -1, 0) - np.roll(h, 1, 0)) * (0.5 * size / cells) * strength
+    nrm = np.stack([-dx, -dy, np.ones_like(h)], -1)
+    nrm /= np.linalg.norm(nrm, axis=-1, keepdims=True)
+    rgb = np.clip((nrm * 0.5 + 0.5) * 255.0 + 0.5, 0, 255).astype(np.uint8)
+    return np.concatenate([rgb, np.full((size, size, 1), 255, np.uint8)], axis=-1)
+
+
+def _opacity_map(rng, size, kind):
+    """Gray opacity map (the any-hit shader keeps a candidate when the red channel is >= 0.5, raytrace_hit.rahit:24-39): `lace` -- a
+    woven cloth with a regular grid of holes; `leaves` -- a card of overlapping leaf blobs on a transparent ground."""
+    y, x = np.mgrid[0:size, 0:size].astype(np.float32) / size
+    if kind == "lace":
+        u, v = (x * 24.0) % 1.0, (y * 24.0) % 1.0
+        hole = ((u - 0.5) ** 2 + (v - 0.5) ** 2) < 0.11
+        a = np.where(hole, 0.0, 1.0)
+    else:
+        a = np.zeros((size, size), np.float32)
+        for _ in range(70):
+            cx, cy = rng.random(), 0.08 + 0.9 * rng.random()
+            ang, lx, ly = rng.random() * np.pi, 0.03 + 0.05 * rng.random(), 0.012 + 0.02 * rng.random()
+            dxw = (x - cx + 0.5) % 1.0 - 0.5            # wraps in u, so the card tiles around a plant
+            dx = dxw * np.cos(ang) + (y - cy) * np.sin(ang)
+            dy = -dxw * np.sin(ang) + (y - cy) * np.cos(ang)
+            a = np.maximum(a, ((dx / lx) ** 2 + (dy / ly) ** 2 < 1.0).astype(np.float32))
+        a = np.maximum(a, ((np.abs(x - 0.5) < 0.012) & (y > 0.3)).astype(np.float32))      # a stem
+    return np.clip(a * 255.0 + 0.5, 0, 255).astype(np.uint8)
+
+
+def _roughness_map(rng, size):
+    """Gray roughness map: worn patches (value noise in 32-texel blocks) over a fine grain."""
+    n = rng.random((size // 32 + 1, size // 32 + 1)).astype(np.float32)
+    n = np.kron(n, np.ones((32, 32), np.float32))[:size, :size]
+    g = rng.random((size, size)).astype(np.float32)
+    return np.clip((0.35 + 0.5 * n + 0.15 * g) * 255.0 + 0.5, 0, 255).astype(np.uint8)
+
+
+N_ATRIUM_MATERIALS = 25     # scene materials of the atrium (SURVEY 8(d) row 4), each with its own texture; material 0 is the format's default
+
+
+def atrium_scene(seed=1, detail=0.564, texture_size=1024, sky_size=(2048, 1024), sponza_like=False):
     """Sponza-like atrium: floor, four walls with window openings, two storeys of colonnades
     (fluted columns + vaulted arches), draped cloth between columns, roof beams; open to the sky.
-    The default detail gives 262 140 triangles (Sponza has 262 267)."""
+    The default detail gives 262 267 triangles -- Sponza's count -- in 25 Lambert / Uber materials, each with its
+    own `texture_size`^2 procedural sRGB texture (1024^2: 100 MB of texels), a sun and a 2048 x 1024 sky.
+
+    sponza_like=True adds the content classes real Sponza exercises and this stand-in otherwise lacks (reference README.md:59-61):
+    opacity-mapped geometry -- the draped cloths become lace, foliage cards stand between the ground-floor columns and vines hang from
+    the gallery (candidates on them go through the any-hit alpha test, raytrace_hit.rahit:24-39, acceleration.rs:136-141) -- normal
+    maps on the stone materials (raytrace_hit.rchit:53-60) and roughness maps on the Uber materials."""
+    # (tools may pass a subset of {"opacity", "normal", "roughness"} to see what each class costs)
+    classes = {"opacity", "normal", "roughness"} if sponza_like is True else set(sponza_like or ())
+    sponza_like = bool(classes)
     rng = np.random.default_rng(seed)
     B = _Builder()
     L, Wd, H = 36.0, 16.0, 14.0            # length (x), width (z), height (y)
     d = float(detail)
     k = lambda n: max(2, int(round(n * np.sqrt(d))))
-    # materials: 0 default, then 24 scene materials (25 total with textures 1..8)
-    kinds = [("stone", (200, 190, 170)), ("brick", (170, 90, 70)), ("tiles", (210, 200, 180)), ("stone", (150, 150, 155)),
-             ("cloth", (190, 40, 40)), ("cloth", (40, 80, 170)), ("cloth", (60, 150, 70)), ("stone", (120, 100, 80))]
+    # materials: 0 default, then 25 scene materials, every one with a texture of its own (texture id = material id)
+    # by role: 0 short walls, 1 long walls, 2 floor, 3 gallery floor, 4-6 drapes, 7 gallery underside, 8-11 ground-floor columns, 12 their
+    # capitals, 13 / 14 arches of the two storeys, 15-18 upper columns, 19 their capitals, 20 roof beams, 21-24 braziers
+    stone, brick, tiles, cloth = "stone", "brick", "tiles", "cloth"
+    kinds = [(stone, (200, 190, 170)), (brick, (170, 90, 70)), (tiles, (210, 200, 180)), (stone, (150, 150, 155)),
+             (cloth, (190, 40, 40)), (cloth, (40, 80, 170)), (cloth, (60, 150, 70)), (stone, (120, 100, 80)),
+             (stone, (205, 195, 180)), (stone, (190, 185, 170)), (stone, (210, 200, 175)), (stone, (185, 175, 165)), (stone, (225, 215, 200)),
+             (brick, (180, 120, 90)), (brick, (160, 110, 95)),
+             (stone, (195, 190, 185)), (stone, (180, 180, 175)), (stone, (200, 195, 190)), (stone, (175, 170, 170)), (stone, (215, 210, 200)),
+             (stone, (110, 80, 55)), (tiles, (150, 140, 120)), (brick, (140, 70, 60)), (tiles, (120, 130, 140)), (stone, (90, 90, 95))]
+    assert len(kinds) == N_ATRIUM_MATERIALS
     textures = [(abi.TEX_RGBA_SRGB, np.full((1, 1, 4), 255, np.uint8), "default")]
-    for i, (kind, base) in enumerate(kinds):
-        textures.append((abi.TEX_RGBA_SRGB, _procedural_texture(rng, texture_size, kind, base), "%s%d" % (kind, i)))
+    material_kind = []
+    for i in range(N_ATRIUM_MATERIALS):
+        kind, tint = kinds[i]
+        textures.append((abi.TEX_RGBA_SRGB, _procedural_texture(rng, texture_size, kind, tint), "%s%d" % (kind, i)))
+        material_kind.append(kind)
     sky_tex_id = len(textures)
     textures.append((abi.TEX_RGBA_SRGB, _sky_texture(*sky_size), "sky"))
+    extra = {}
+    if sponza_like:
+        def add_texture(fmt, pixels, name):
+            textures.append((fmt, pixels, name))
+            return len(textures) - 1
+        extra["lace"] = add_texture(abi.TEX_GRAY, _opacity_map(rng, texture_size, "lace"), "lace")
+        extra["leaves"] = add_texture(abi.TEX_GRAY, _opacity_map(rng, texture_size, "leaves"), "leaves")
+        extra["normal"] = [add_texture(abi.TEX_RGBA_NORM, _height_normal_map(rng, texture_size, 48 + 16 * j, 0.6 + 0.2 * j), "stone_normal%d" % j) for j in range(3)]
+        extra["rough"] = [add_texture(abi.TEX_GRAY, _roughness_map(rng, texture_size), "rough%d" % j) for j in range(2)]
     materials = [make_material("default")]
-    for i in range(24):
-        tex = 1 + (i % len(kinds))
+    for i in range(N_ATRIUM_MATERIALS):
+        tex = 1 + i
+        maps = {}
+        if "normal" in classes and material_kind[i] in ("stone", "brick"):
+            maps["normal"] = extra["normal"][i % 3]
+        if "opacity" in classes and material_kind[i] == "cloth":
+            maps["opacity"] = extra["lace"]
         if i % 5 == 3:
+            if "roughness" in classes:
+                maps["roughness"] = extra["rough"][(i // 5) % 2]
             materials.append(make_material("uber%d" % i, mtype=abi.MAT_UBER, diffuse=tex, roughness_mul=0.35 + 0.02 * i,
-                                           metalness_mul=0.0, diffuse_mul=(230, 230, 230)))
+                                           metalness_mul=0.0, diffuse_mul=(230, 230, 230), **maps))
         else:
             materials.append(make_material("lambert%d" % i, mtype=abi.MAT_LAMBERT, diffuse=tex,
-                                           diffuse_mul=(255 - 3 * i, 250 - 2 * i, 245 - 2 * i)))
-    M = lambda i: 1 + (i % 24)
+                                           diffuse_mul=(255 - 3 * i, 250 - 2 * i, 245 - 2 * i), **maps))
+    if sponza_like:
+        materials.append(make_material("foliage", mtype=abi.MAT_LAMBERT, diffuse=1 + 6, diffuse_mul=(150, 235, 140), opacity=extra["leaves"] if "opacity" in classes else 0))   # (the green cloth's texture)
+    M = lambda i: 1 + (i % N_ATRIUM_MATERIALS)
+    FOLIAGE = N_ATRIUM_MATERIALS + 1
 
     def bumpy(amp, freq):
         def f(pos, nrm, s, t):
@@ -235,10 +325,10 @@ def atrium_scene(seed=1, detail=0.564, texture_size=512, sky_size=(2048, 1024)):
     for zi, z in enumerate((-Wd / 2 + 3.0, Wd / 2 - 3.0)):
         for storey, (y0, hc, rad) in enumerate(((0.0, 5.0, 0.38), (6.0, 4.2, 0.30))):
             for ci, x in enumerate(xs):
-                B.column((x, y0, z), rad, hc, k(40), k(36), M(8 + (ci + zi + storey) % 4))
+                B.column((x, y0, z), rad, hc, k(40), k(36), M((8 if storey == 0 else 15) + (ci + zi) % 4))
                 # capital + base as short wide rings
-                B.column((x, y0 + hc, z), rad * 1.5, 0.35, k(24), 2, M(12))
-                B.column((x, y0 - 0.0, z), rad * 1.4, 0.25, k(24), 2, M(12))
+                B.column((x, y0 + hc, z), rad * 1.5, 0.35, k(24), 2, M(12 if storey == 0 else 19))
+                B.column((x, y0 - 0.0, z), rad * 1.4, 0.25, k(24), 2, M(12 if storey == 0 else 19))
             for ci in range(ncol - 1):
                 B.arch((xs[ci], 0, z), (xs[ci + 1], 0, z), y0 + hc + 0.35, 0.9 if storey == 0 else 0.7, 0.8, k(28), k(6),
                        M(13 + storey))
@@ -258,12 +348,50 @@ def atrium_scene(seed=1, detail=0.564, texture_size=512, sky_size=(2048, 1024)):
             n /= np.maximum(np.linalg.norm(n, axis=-1, keepdims=True), 1e-8)
             return pos, n.astype(np.float32)
 
-        B.grid((x0, 5.4, z), (x1 - x0, 0, 0), (0, -3.2, 0), k(56), k(56), M(16 + ci % 3), uv_scale=2.0, displace=drape)
+        B.grid((x0, 5.4, z), (x1 - x0, 0, 0), (0, -3.2, 0), k(56), k(56), M(4 + ci % 3), uv_scale=2.0, displace=drape)
     # roof beams across the opening
     for x in np.linspace(-L / 2 + 3, L / 2 - 3, 9):
         B.grid((x - 0.2, H - 0.6, -Wd / 2), (0.4, 0, 0), (0, 0, Wd), 2, k(60), M(20))
         B.grid((x - 0.2, H - 0.6, -Wd / 2), (0, 0, Wd), (0, 0.6, 0), k(60), 2, M(20))
         B.grid((x + 0.2, H - 0.6, Wd / 2), (0, 0, -Wd), (0, 0.6, 0), k(60), 2, M(20))
+    # a brazier in the middle of the floor: an open cone of single triangles -- they bring the count to Sponza's 262 267 and give the
+    # hierarchy leaves of one triangle next to the paired ones (materials 21 ... 24 are its rings' and the braziers' along the walls)
+    def cone(base, radius, height, segs, material):
+        th = np.linspace(0, 2 * np.pi, segs + 1, dtype=np.float32)
+        ring = np.stack([base[0] + radius * np.cos(th), np.full_like(th, base[1]), base[2] + radius * np.sin(th)], -1)
+        pos = np.concatenate([ring, np.array([[base[0], base[1] + height, base[2]]], np.float32)])
+        out = np.stack([np.cos(th), np.full_like(th, radius / height), np.sin(th)], -1)
+        nrm = np.concatenate([out / np.linalg.norm(out, axis=-1, keepdims=True), np.array([[0, 1, 0]], np.float32)])
+        uv = np.concatenate([np.stack([th / (2 * np.pi) * 3.0, np.zeros_like(th)], -1), np.array([[1.5, 1.0]], np.float32)])
+        apex = segs + 1
+        tri = np.stack([np.arange(segs, dtype=np.uint32), np.full(segs, apex, np.uint32), np.arange(1, segs + 1, dtype=np.uint32)], -1)
+        B.add(pos, nrm, uv, tri, material)
+
+    if detail == 0.564:
+        need = 262267 - B.ni // 3
+        segs = [need // 4 + (1 if j < need % 4 else 0) for j in range(4)]
+        for j, (cx, cz) in enumerate(((0.0, 0.0), (-9.0, 2.5), (9.0, -2.5), (4.0, 3.0))):
+            cone((cx, 0.0, cz), 0.45, 1.1, segs[j], M(21 + j))
+    else:
+        for j, (cx, cz) in enumerate(((0.0, 0.0), (-9.0, 2.5), (9.0, -2.5), (4.0, 3.0))):
+            cone((cx, 0.0, cz), 0.45, 1.1, k(32), M(21 + j))
+    if sponza_like:
+        # foliage: three crossed cards per planter between the ground-floor columns of both rows, vines hanging from the gallery's edge
+        def card(centre, half_w, height, yaw, material):
+            c, s_ = np.cos(yaw), np.sin(yaw)
+            ax = np.array([c, 0, s_], np.float32) * half_w
+            p0 = np.asarray(centre, np.float32)
+            pos = np.stack([p0 - ax, p0 + ax, p0 + ax + (0, height, 0), p0 - ax + (0, height, 0)]).astype(np.float32)
+            n = np.array([-s_, 0, c], np.float32)
+            uv = np.array([[0, 1], [1, 1], [1, 0], [0, 0]], np.float32)
+            B.add(pos, np.broadcast_to(n, pos.shape).copy(), uv, np.array([0, 1, 2, 0, 2, 3], np.uint32), material)
+        for zi, z in enumerate((-Wd / 2 + 3.0, Wd / 2 - 3.0)):
+            for ci in range(ncol - 1):
+                cx = 0.5 * (xs[ci] + xs[ci + 1])
+                for j in range(3):
+                    card((cx, 0.0, z + (0.9 if zi == 0 else -0.9)), 0.8, 1.9, j * np.pi / 3 + 0.2 * ci, FOLIAGE)
+                for j in range(2):   # vines: narrow tall cards in front of the arches
+                    card((cx + (j - 0.5) * 1.1, 2.2, z + (0.45 if zi == 0 else -0.45)), 0.35, 3.4, 0.15 * (ci + j), FOLIAGE)
     vertices, indices, meshes = B.finish()
     instances = np.array([(m, 0) for m in range(meshes.shape[0])], INSTANCE_DTYPE)
     lights = [make_light(abi.LIGHT_SUN, "sun", direction=(-0.35, -0.85, 0.25), intensity=2.5),

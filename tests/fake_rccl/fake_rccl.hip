@@ -9,9 +9,10 @@
 //   * the work is stream-ordered and asynchronous: data is read on the sender's stream position and written on the receiver's,
 //     nothing is synchronised with the host -- whoever reads the result must wait for the ROOT's stream, and a sender may only
 //     touch its buffer again after waiting for its own stream.
-// Every entry point appends one JSON line to the file named by GLAZE_FAKE_RCCL_LOG; GLAZE_FAKE_RCCL_FAIL=<function>:<k> makes
+// Every entry point appends one JSON line to the file named by GLAZE_FAKE_RCCL_LOG; GLAZE_FAKE_RCCL_HANG=<function>:<k> makes the k-th call of an entry point hang for ever; GLAZE_FAKE_RCCL_FAIL=<function>:<k> makes
 // the k-th call (1-based) of that function fail with ncclInternalError.
 #include <hip/hip_runtime.h>
+#include <unistd.h>
 #include <rccl/rccl.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -57,6 +58,13 @@ void logf(const char* fn, const Comm* c, const void* send, const void* recv, siz
 }
 bool should_fail(const char* fn) {
   const int k = ++g_calls[fn];
+  // GLAZE_FAKE_RCCL_HANG=<function>:<k>: the k-th call of that entry point never returns -- a collective whose peer never arrives, what a
+  // first contact between ranks that goes wrong looks like from the caller's side (bench.py's watchdog is tested against it)
+  if (const char* hang = getenv("GLAZE_FAKE_RCCL_HANG")) {
+    const char* colon = strchr(hang, ':');
+    if (colon && strlen(fn) == (size_t)(colon - hang) && !strncmp(hang, fn, colon - hang) && atoi(colon + 1) == k)
+      for (;;) sleep(1);
+  }
   const char* spec = getenv("GLAZE_FAKE_RCCL_FAIL");
   if (!spec) return false;
   const char* colon = strchr(spec, ':');

@@ -518,3 +518,27 @@ def test_bench_falls_back_to_peer_copies_when_rccl_will_not_start(tmp_path):
         assert out["n_gpus"] == 4 and out["multi_gpu"]["gpus_seen"] == 4
         assert "hipMemcpyPeerAsync" in out["multi_gpu"]["exchange"] and fail in out["multi_gpu"]["rccl_fallback"] and out["multi_gpu"]["rccl_version"] is None
         assert out["verify"]["bit_identical_to_one_gpu"] is True
+
+
+def test_bench_watchdog_ends_a_hung_first_exchange_with_diagnostics(tmp_path):
+    """The first contact between ranks goes wrong in the worst way -- ncclGroupEnd never returns (injected into the stand-in library):
+    bench.py's watchdog prints multi_gpu.diagnostics (which call, RCCL version, peer-access matrix, bytes per peer) to stderr and ends
+    the process with status 3 within its time-out, instead of burning the caller's."""
+    import time
+    lib = os.path.join(ROOT, "tests", "fake_rccl", "libfake_rccl.so")
+    if not os.path.exists(lib):
+        pytest.skip("tests/fake_rccl/libfake_rccl.so is not built (__graft_entry__.build())")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "3", "--warmup", "2", "--width", "640", "--height", "360", "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "GLAZE_MULTI_EXCHANGE")}
+    t0 = time.time()
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600,
+                       env=dict(env, GLAZE_MULTI_LOOPBACK="rccl", GLAZE_RCCL_LIBRARY=lib, GLAZE_FAKE_RCCL_HANG="ncclGroupEnd:1", GLAZE_BENCH_WATCHDOG_S="6",
+                                GLAZE_FAKE_RCCL_LOG=str(tmp_path / "hang.log")))
+    assert p.returncode == 3, (p.returncode, p.stderr[-2000:])
+    assert time.time() - t0 < 240
+    tail = p.stderr.strip().splitlines()[-1]
+    diag = json.loads(tail)["multi_gpu"]["diagnostics"]
+    assert diag["stuck_in"].startswith("exchange #1") and diag["timeout_s"] == 6.0 and diag["elapsed_s"] >= 6.0
+    assert diag["peers"] == 3 and diag["bytes_per_peer"] == 640 * 360 * 16 // 4 and diag["devices_in_process"] == 4
+    assert isinstance(diag["peer_access"], list) and "rccl_version" in diag and "GLAZE_RCCL_LIBRARY" in diag["env"]
+    assert not p.stdout.strip(), "no result line from a run that did not finish"

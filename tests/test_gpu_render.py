@@ -786,6 +786,55 @@ def test_full_size_atrium_1080p_tiles_vs_oracle(instance, atrium_file):
     assert (part[~_tile_mask(w, h, list(range(3, 30 * 17, 8)))] == 0).all()                   # nothing outside its own tiles
 
 
+def test_full_size_sponza_like_atrium_1080p_tiles_vs_oracle(instance, tmp_path):
+    """The atrium with the content classes real Sponza has (bench.py's extra.atrium_sponza_like): opacity-mapped lace cloth, foliage cards
+    and vines -- candidates on them go through the any-hit alpha test INSIDE the traversal (raytrace_hit.rahit:24-39) -- normal maps on
+    stone and brick (raytrace_hit.rchit:53-60), roughness maps on the Uber materials; 1920 x 1080, depth 8, through the file format, the
+    sampled tiles (the planters' and the cloths' rows among them) bit for bit against the oracle's own reading of the same file."""
+    from glaze_amd.scene_desc import save_scene
+    w, h, launches = 1920, 1080, 17
+    path = str(tmp_path / "atrium_sponza_like.glaze")
+    save_scene(atrium_scene(sponza_like=True), path)
+    desc = desc_from_oracle_parse(path)
+    assert sum(1 for m in desc.materials if m.opacity) >= 4 and sum(1 for m in desc.materials if m.normal) >= 10 and sum(1 for m in desc.materials if m.roughness) >= 4
+    scene = glaze_amd.RayTraceScene.new(instance, glaze_amd.parse(path))
+    assert scene.info().n_world_triangles == 262487
+    r = glaze_amd.RayTraceRenderer.new(instance, scene, w, h)
+    r.set_depth(8)
+    r.step(launches)
+    tiles = sorted(set(_sample_tiles(w, h, 8, 5)) | {row * 30 + col for row in (7, 9, 11, 13) for col in (3, 12, 20, 27)})
+    o = OracleRenderer(OracleScene(desc), w, h)
+    o.set_depth(8)
+    o.set_tiles(tiles)
+    o.step(launches)
+    _assert_tiles_bit_equal(r, o, w, h, tiles, "Sponza-like atrium 1080p")
+    # the alpha test's texture fetches happened, inside k_trace (the counting build books them apart from k_shade's)
+    r.enable_counters(True, False)
+    r.restart()
+    r.step(9)
+    st = r.stats()
+    assert st.alpha_tex_bytes > 0 and st.tex_bytes > st.alpha_tex_bytes
+    # and the other launch mode / the 8-wide walk see the same image on a tile share
+    r.enable_counters(False, False)
+    r.set_partition(3, 8)
+    r.restart()
+    r.step(launches)
+    a = r.read_hdr()
+    r.set_node_width(8)
+    r.step(launches)
+    b = r.read_hdr()
+    r.set_node_width(0)
+    r.set_launch_mode("path")
+    r.step(launches)
+    c = r.read_hdr()
+    bits = lambda x: np.nan_to_num(x, nan=-1.0).view(np.uint32)
+    assert np.array_equal(bits(a), bits(b)) and np.array_equal(bits(a), bits(c))
+    mine = [t for t in tiles if t % 8 == 3]
+    m = _tile_mask(w, h, mine)
+    ref = o.read_hdr()
+    assert m.any() and ((a[m].view(np.uint32) == ref[m].view(np.uint32)) | (np.isnan(a[m]) & np.isnan(ref[m]))).all()
+
+
 def test_full_size_atrium_4k_depth12_tiles_vs_oracle(instance, atrium_file):
     """Config 5: the same file, 3840 x 2160 (60 x 34 tiles, ragged bottom row), depth 12, rendered as rank 3's share of the 8-way
     partition plus the whole frame: the sampled tiles that rank 3 owns must match the oracle in both, the others in the whole frame."""

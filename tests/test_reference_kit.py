@@ -72,7 +72,7 @@ def test_kit_scenes_are_valid_glaze_files_and_reproducible(tmp_path):
     cube = glaze_v1.parse(os.path.join(ROOT, "kit", "scenes", "cube.glaze"))
     assert cube.vertices().shape[0] == 24 and len(cube.meshes()) == 1 and len(cube.materials()) == 3 and len(cube.lights()) == 1 and len(cube.cameras()) == 1
     atrium = glaze_v1.parse(os.path.join(ROOT, "kit", "scenes", "atrium.glaze"))
-    assert sum(m["indices"].size for m in atrium.meshes()) // 3 == 262140 and len(atrium.lights()) == 2 and atrium.meta() is not None
+    assert sum(m["indices"].size for m in atrium.meshes()) // 3 == 262267 and len(atrium.materials()) == 26 and len(atrium.lights()) == 2 and atrium.meta() is not None
     import hashlib
     from glaze_amd.scene_desc import save_scene
     from glaze_amd.scenes import cube_scene

@@ -11,6 +11,7 @@ from glaze_amd.scenes import atrium_scene, cube_scene
 out = os.path.join(ROOT, "kit", "scenes")
 os.makedirs(out, exist_ok=True)
 save_scene(cube_scene(), os.path.join(out, "cube.glaze"))
-save_scene(atrium_scene(), os.path.join(out, "atrium.glaze"))
+# (the bench renders this scene with 1024^2 textures -- an 11 MB file; the kit carries the same geometry, materials and lights with 256^2 ones)
+save_scene(atrium_scene(texture_size=256), os.path.join(out, "atrium.glaze"))
 for f in sorted(os.listdir(out)):
     print(f, os.path.getsize(os.path.join(out, f)))
