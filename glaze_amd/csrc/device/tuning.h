@@ -15,6 +15,7 @@
 //   GLZ_REFILL               16     idle lanes at which a wave takes new rays
 //   GLZ_LEAF_QUORUM          24     lanes waiting on a leaf at which the inner-node phase ends
 //   GLZ_TL_LEAF_QUORUM       32     the same for the two-level tracer (a leaf visit there is an instance entry: dearer)
+//   GLZ_ALPHA_QUORUM         12     lanes waiting with a candidate on non-opaque geometry at which the alpha phase runs
 //   GLZ_PATH_PREFETCH         1     k_path: the next node's loads issued as soon as the node is known (trace_wave<PREFETCH>)
 //   GLZ_NODE48               off    EXPERIMENT: 48-byte nodes (types.h BvhNode48; tools/build_variant_full.sh: scene.cpp needs it too)
 //   GLZ_WAVE_TIMES           off    instrumentation: per-wave time stamps of k_trace            (tools/gpu_wave_times.py)
@@ -47,6 +48,9 @@
 #endif
 #ifndef GLZ_LEAF_QUORUM
 #define GLZ_LEAF_QUORUM 24
+#endif
+#ifndef GLZ_ALPHA_QUORUM
+#define GLZ_ALPHA_QUORUM 12
 #endif
 #ifndef GLZ_TL_LEAF_QUORUM
 #define GLZ_TL_LEAF_QUORUM 32

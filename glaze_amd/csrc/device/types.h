@@ -240,6 +240,7 @@ struct DeviceScene {
   const TlasInstance* tlas_instances;
   const uint32_t* xf_identity;     // per transform: 1 = exactly the identity
   uint32_t two_level;
+  uint32_t has_non_opaque;         // some material carries an opacity map: candidates on its triangles go through the alpha test (kTriNonOpaque in the leaf records)
   uint32_t n_world_tris;
   uint32_t n_textures;
   uint32_t n_materials;            // RTMaterial records

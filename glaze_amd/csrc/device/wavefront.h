@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "device/math.h"
 #include "device/shading.h"
@@ -250,6 +251,9 @@ __device__ __forceinline__ QuadHit ray_quad(const RayShear& rs, float4 r0, float
 
 // raytrace_hit.rahit:24-39 -- candidates on non-opaque geometry are dropped when opacity.r < 0.5
 __device__ __forceinline__ bool alpha_test(const DeviceScene& S, uint32_t leaf, float u, float v) {
+#ifdef GLZ_ALPHA_TIMING_NOFETCH   // TIMING ONLY: the verdict from the barycentrics alone (about half pass), no fetch
+  return u + v < 0.5f;
+#endif
   // uv of the three vertices and the material id come from the leaf's 128-byte shading record (the same values the
   // reference's any-hit shader reads through instance -> indices -> vertices)
   const float4* rec = S.shade_tris + 8u * (size_t)leaf;
@@ -362,6 +366,7 @@ struct TraceTally {
 constexpr bool kLdsTop = true;   // the top kBvhTopNodes nodes of the tree come from a per-block LDS copy ("LDS-staged node packets")
 constexpr int kRefill = GLZ_REFILL;
 constexpr int kLeafQuorum = GLZ_LEAF_QUORUM;
+constexpr int kAlphaQuorum = GLZ_ALPHA_QUORUM;   // lanes waiting for the alpha test at which the alpha phase runs (trace_wave)
 constexpr int kAuxPerWave = 3 * 64 + 4 * 64;   // work sharing (3 x 64) + the four child links of the node a lane is visiting
 // The block's scratch, as the kernels declare it (__shared__ alignas(1024) int s_aux[kAuxPerBlock]): the waves' link areas first -- 256 ints
 // each, so that every one of them starts on a 1 KB boundary (sorted_link) -- then their work-sharing words.
@@ -443,7 +448,11 @@ __device__ unsigned long long g_tl_stats[8];      // two-level tracer, summed ov
 // picked in registers (a select tree on the key's child bits) rather than through LDS, one round trip less on the chain.  Hits do not
 // depend on the visit order, so the images are those of the 4-wide walk bit for bit.  No staged top (the root is node 0), a deeper LDS
 // stack (kLdsStack8).
-template <bool ANY, bool COUNT, bool MIXED = false, bool PREFETCH = false, bool WIDE8 = false, class Source, class Sink>
+// ALPHA: what becomes of a candidate on non-opaque geometry -- kAlphaNone: the scene has none (DeviceScene::has_non_opaque == 0; the
+// kernel carries no alpha code), kAlphaInline: tested where it is met (the counting kernels, whose fetch counts are defined by the
+// serial walk; k_path; k_trace8), kAlphaPhase: it waits for an alpha phase of its own (k_trace for scenes with opacity maps).
+constexpr int kAlphaNone = 0, kAlphaInline = 1, kAlphaPhase = 2;
+template <bool ANY, bool COUNT, bool MIXED = false, bool PREFETCH = false, bool WIDE8 = false, int ALPHA = kAlphaInline, class Source, class Sink>
 __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Sink& sink, int* __restrict__ lds_col, int* aux, int* link_scratch, LdsNodePtr top_lds,
                                            uint32_t* __restrict__ spill, uint32_t spill_depth, uint32_t total, uint32_t wave, uint32_t n_waves, TraceTally& tally) {
   constexpr bool SHARE = !COUNT;
@@ -482,6 +491,7 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
   bool helper = false;                                      // this lane traverses a subtree of lane `ray`'s ray (work sharing)
   bool found_own = false;                                   // ... and has accepted a hit of its own since it took the subtree over (merge)
   bool any_lane = ANY;                                      // the ray in this lane ends with its first accepted hit (MIXED: per ray)
+  bool alpha_wait = false;                                  // the lane sits on a leaf (cur < 0) with a candidate that needs the alpha test: it waits for the alpha phase
   int cur = kRayDone;
   uint32_t ray = 0;                                         // ray index (open) or owner lane (helper)
   vec3 o = mk3(0.0f, 0.0f, 0.0f), d = mk3(0.0f, 0.0f, 1.0f);
@@ -585,6 +595,7 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
           aux_sb[lane] = 0;
           helper = true;
           found_own = false;
+          alpha_wait = false;
           atomicAdd(&aux_out[t_owner], 1);
           prefetch_node();
         }
@@ -617,6 +628,7 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
       if (!open && next_ray < total) {
         if (src.load(next_ray, o, d, tmin, tmax)) {
           ray = next_ray;
+          alpha_wait = false;
           best = HitRecord{tmax, 0.0f, 0.0f, kNone};
           best_id = kNone;
           if constexpr (MIXED) any_lane = src.any;
@@ -809,7 +821,7 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
       if (!PREFETCH) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the visit's loads and LDS traffic are charged to the visit
 #endif
       GLZ_SEC_STAMP(sec_node);
-      if (__popcll(__ballot(cur < 0)) >= kLeafQuorum) break;
+      if (__popcll(__ballot(cur < 0 && !(ALPHA == kAlphaPhase && alpha_wait))) >= kLeafQuorum) break;
       // (Postponed leaves -- a lane parks the first leaf it arrives at and goes on with its stack, blocks at the second, the parked
       // leaves are tested first in the next leaf phase; Aila & Laine's speculative traversal -- k_trace 0.512 -> 0.540 ms with the
       // leaf phase at 24 waiting lanes, 0.542 / 0.555 at 16 / 32: the visits made without the parked leaf's bound and the second
@@ -830,7 +842,23 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
 #ifdef GLZ_WAVE_TIMES
     { const unsigned long long ml = __ballot(cur < 0); if (ml) { wt_leaf_iters += 1; wt_leaf_lanes += (unsigned)__popcll(ml); } }
 #endif
-    if (cur < 0) {
+    // Candidates on NON-OPAQUE geometry go through the alpha test (raytrace_hit.rahit:24-39) -- the triangle's texture coordinates, the
+    // material's opacity map, its descriptor, four texels: a chain of dependent fetches that the whole wave used to sit through whenever ONE
+    // of its lanes met such a candidate (with a twentieth of the rays meeting one, most leaf phases: the Sponza-like atrium's k_trace took
+    // 0.72 ms against 0.48 without the opacity maps, tools/gpu_sponza_like.py).  So the test has a phase of its own, with a quorum like the
+    // leaf phase's: a lane whose leaf holds such a candidate stays on the leaf (alpha_wait) while the others go on, and the waiting lanes
+    // take the test together.  The leaf is then tested again from the start -- same operations, same bits -- so nothing is kept per lane
+    // but the flag; the candidates of one ray may be decided in another order than the serial walk's, which changes no result (the closest
+    // hit is a minimum over the candidates that pass, ties by world id; an occluded ray is occluded).  The counting kernels keep the serial
+    // walk: their texture-fetch counts are defined by it.  Measured on one box (tools/gpu_sponza_variants.py, profiles/r05_alpha_phase.txt):
+    // the atrium with opacity maps 0.716 -> 0.670 ms per k_trace (quorum 1 / 4 / 8 / 12 / 16 / 24 / 48: 0.807 / 0.745 / 0.686 / 0.673 / 0.670 /
+    // 0.701 / 1.018; with the verdict for free 0.601: what is left are the rays that go on through the holes), and the atrium WITHOUT
+    // non-opaque geometry 0.489 -> 0.502 for the two ballots a round and the second copy of the leaf code -- so a scene without opacity
+    // maps runs the kernel that has no alpha code at all (kAlphaNone).
+    constexpr bool DEFER = ALPHA == kAlphaPhase;
+    static_assert(!(COUNT && DEFER), "the counting kernels keep the serial walk");
+    auto leaf_visit = [&](auto with_alpha_tag) {
+      constexpr bool WITH_ALPHA = decltype(with_alpha_tag)::value;
       // A leaf is one 64-byte record (types.h BvhQuad): one triangle or two that share an edge, tested together (ray_quad).  The
       // candidates are then taken in slot order, the order the 48-byte records were walked in (the alpha test's fetches are counted).
       const uint32_t leaf = (uint32_t)~cur;
@@ -842,7 +870,8 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
       const RayShear rs = ray_shear(d);   // (kept in registers with the ray instead: fits without spills, 0.555 against 0.552 ms -- no gain)
       const QuadHit qh = ray_quad(rs, r0, r1, r2, r3, pair, o, tmin);
       const uint32_t swapped = (qflags & kQuadSwapped) ? 1u : 0u;
-      bool finished = false;
+      const bool non_opaque = ALPHA != kAlphaNone && (qflags & kTriNonOpaque) != 0u;
+      bool finished = false, wait = false;
 #pragma nounroll
       for (uint32_t which = 0; which < 2u; ++which) {   // the leaf's first triangle, then its partner
         const bool is_b = (which ^ swapped) != 0u;
@@ -850,7 +879,9 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
         if ((is_b ? qh.ok[1] : qh.ok[0]) && t < tmax) {
           const uint32_t wid = id0 + which, slot = slot0 + which;
           const bool better = best.leaf == kNone ? true : (t < best.t || (t == best.t && wid < best_id));
-          if (better && (!(qflags & kTriNonOpaque) || alpha_test(S, slot, u, v))) {
+          if (better && non_opaque && !WITH_ALPHA) {
+            wait = true;   // decided in the alpha phase
+          } else if (better && (!non_opaque || alpha_test(S, slot, u, v))) {
             best = HitRecord{t, u, v, slot};
             best_id = wid;
             found_own = true;
@@ -859,8 +890,23 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
           }
         }
       }
-      cur = finished ? kRayDone : (SHARE ? st.pop_live() : (st.sp ? st.pop() : kRayDone));
-      prefetch_node();
+      if (!WITH_ALPHA && wait) {
+        alpha_wait = true;   // stays on the leaf
+      } else {
+        alpha_wait = false;
+        cur = finished ? kRayDone : (SHARE ? st.pop_live() : (st.sp ? st.pop() : kRayDone));
+        prefetch_node();
+      }
+    };
+    if (cur < 0 && !(DEFER && alpha_wait)) {
+      if constexpr (DEFER) leaf_visit(std::false_type{}); else leaf_visit(std::true_type{});
+    }
+    if constexpr (DEFER) {
+      // ---- alpha phase: when enough lanes wait for it, or when nobody has anything else to do
+      const unsigned long long m_wait = __ballot(alpha_wait && cur < 0);
+      if (m_wait != 0ull && (__popcll(m_wait) >= kAlphaQuorum || __ballot((open || helper) && cur != kRayDone && !(alpha_wait && cur < 0)) == 0ull)) {
+        if (alpha_wait && cur < 0) leaf_visit(std::true_type{});
+      }
     }
 #ifdef GLZ_SECTION_TIMES
     if (!PREFETCH) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");

@@ -253,7 +253,7 @@ __global__ void __launch_bounds__(kShadeBlock, GLZ_SHADE_WAVES) k_shade(const La
 #endif
 }
 
-template <bool COUNT>
+template <bool COUNT, int ALPHA>
 __global__ void __launch_bounds__(kBlock, GLZ_TRACE_WAVES) k_trace(const LaunchArgs A) {
   __shared__ int s_stack[kLdsStack * kBlock];
   __shared__ alignas(1024) int s_aux[kAuxPerBlock];
@@ -276,8 +276,8 @@ __global__ void __launch_bounds__(kBlock, GLZ_TRACE_WAVES) k_trace(const LaunchA
     TraceTally tally;
     ClosestSource src{A, A.frame, tally, 0u};
     ClosestSink sink{A};
-    trace_wave<false, COUNT>(TS, src, sink, &s_stack[threadIdx.x], aux, links, (LdsNodePtr)s_top, A.st.overflow, A.st.overflow_depth, A.map.n_local_pixels, wave_index(),
-                             wave_count(), tally);
+    trace_wave<false, COUNT, false, false, false, ALPHA>(TS, src, sink, &s_stack[threadIdx.x], aux, links, (LdsNodePtr)s_top, A.st.overflow, A.st.overflow_depth, A.map.n_local_pixels, wave_index(),
+                                                         wave_count(), tally);
     if (COUNT) flush_counters(A.counters, false, tally);
   }
   GLZ_WAVE_STAMP(1);
@@ -297,7 +297,7 @@ __global__ void __launch_bounds__(kBlock, GLZ_TRACE_WAVES) k_trace(const LaunchA
     const uint32_t n_waves = wave_count();
     const uint32_t closest_groups = A.do_closest ? (A.map.n_local_pixels + 63u) / 64u : 0u;
     const uint32_t wave = (wave_index() + n_waves - closest_groups % n_waves) % n_waves;
-    trace_wave<true, COUNT>(TS, src, sink, &s_stack[threadIdx.x], aux, links, (LdsNodePtr)s_top, A.st.overflow, A.st.overflow_depth, start[kQueueShards], wave, n_waves, tally);
+    trace_wave<true, COUNT, false, false, false, ALPHA>(TS, src, sink, &s_stack[threadIdx.x], aux, links, (LdsNodePtr)s_top, A.st.overflow, A.st.overflow_depth, start[kQueueShards], wave, n_waves, tally);
     if (COUNT) flush_counters(A.counters, true, tally);
   }
   if (COUNT) flush_tex_tallies(A.counters->trace_tex, tex_tally);
@@ -516,7 +516,7 @@ uint32_t trace_grid_blocks(uint32_t n_local_pixels, bool counting, bool two_leve
   uint32_t rays = 2u * n_local_pixels;
   if (wide8 && !counting && !two_level) return persistent_grid(k_trace8, rays).x;
   if (two_level) return counting ? persistent_grid(k_trace_tl<true>, rays).x : persistent_grid(k_trace_tl<false>, rays).x;   // compiled for fewer waves per SIMD: its own residency
-  return counting ? persistent_grid(k_trace<true>, rays).x : persistent_grid(k_trace<false>, rays).x;
+  return counting ? persistent_grid(k_trace<true, kAlphaInline>, rays).x : std::min(persistent_grid(k_trace<false, kAlphaNone>, rays).x, persistent_grid(k_trace<false, kAlphaPhase>, rays).x);
 }
 
 hipError_t launch_trace(hipStream_t st, const LaunchArgs& a, uint32_t blocks, bool wide8) {
@@ -525,9 +525,13 @@ hipError_t launch_trace(hipStream_t st, const LaunchArgs& a, uint32_t blocks, bo
   if (blocks == 0 || (uint64_t)blocks * kBlock > 2ull * a.map.n_local_pixels + kBlock) return hipErrorInvalidValue;   // the spill area holds one slot per lane of this bound
   if (a.scene.two_level && a.counters) hipLaunchKernelGGL(k_trace_tl<true>, dim3(blocks), dim3(kBlock), 0, st, a);   // node visits of both levels, triangle tests inside the instances
   else if (a.scene.two_level) hipLaunchKernelGGL(k_trace_tl<false>, dim3(blocks), dim3(kBlock), 0, st, a);
-  else if (a.counters) hipLaunchKernelGGL(k_trace<true>, dim3(blocks), dim3(kBlock), 0, st, a);
+  else if (a.counters) hipLaunchKernelGGL((k_trace<true, kAlphaInline>), dim3(blocks), dim3(kBlock), 0, st, a);
   else if (wide8) hipLaunchKernelGGL(k_trace8, dim3(blocks), dim3(kBlock), 0, st, a);
-  else hipLaunchKernelGGL(k_trace<false>, dim3(blocks), dim3(kBlock), 0, st, a);
+#ifdef GLZ_TRACE_ALPHA_INLINE   // A/B builds (tools/build_variant.sh): the alpha test where the candidate is met, whatever the scene -- rounds 1-4's kernel
+  else if (true) hipLaunchKernelGGL((k_trace<false, kAlphaInline>), dim3(blocks), dim3(kBlock), 0, st, a);
+#endif
+  else if (a.scene.has_non_opaque) hipLaunchKernelGGL((k_trace<false, kAlphaPhase>), dim3(blocks), dim3(kBlock), 0, st, a);   // candidates on non-opaque geometry wait for an alpha phase
+  else hipLaunchKernelGGL((k_trace<false, kAlphaNone>), dim3(blocks), dim3(kBlock), 0, st, a);   // no opacity map in the scene: no alpha code in the kernel
   return hipGetLastError();
 }
 hipError_t launch_shade(hipStream_t st, const LaunchArgs& a) {

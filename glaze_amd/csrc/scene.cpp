@@ -411,6 +411,8 @@ bool Scene::build_materials(Error& err) {
   if (!hip_ok(hipStreamSynchronize(instance->stream), "materials upload", err)) return false;
   dev.materials = d_materials_.ptr;
   dev.n_materials = (uint32_t)h_materials.size();
+  dev.has_non_opaque = 0u;   // which k_trace runs (launch_trace): the one without alpha code, or the one with the alpha phase
+  for (const RTMaterial& m : h_materials) dev.has_non_opaque |= m.opacity != 0u ? 1u : 0u;
   return true;
 }
 
