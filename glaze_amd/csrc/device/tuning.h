@@ -6,6 +6,7 @@
 //   switch                 default  what
 //   ---------------------  -------  ----------------------------------------------------------------------------------------------
 //   GLZ_TRACE_WAVES           6     waves per SIMD k_trace is compiled for (80 VGPRs)
+//   GLZ_TRACE_PREFETCH        0     k_trace: the next node's loads issued as soon as the node is known (as k_path does; wants 16 more registers)
 //   GLZ_TRACE_TL_WAVES        4     ... the two-level tracer (128 VGPRs)
 //   GLZ_SHADE_WAVES           4     ... k_shade (128 VGPRs)
 //   GLZ_PATH_WAVES            4     ... k_path (128 VGPRs)
@@ -24,6 +25,9 @@
 #pragma once
 #ifndef GLZ_TRACE_WAVES
 #define GLZ_TRACE_WAVES 6
+#endif
+#ifndef GLZ_TRACE_PREFETCH
+#define GLZ_TRACE_PREFETCH 0
 #endif
 #ifndef GLZ_TRACE_TL_WAVES
 #define GLZ_TRACE_TL_WAVES 4

@@ -276,7 +276,7 @@ __global__ void __launch_bounds__(kBlock, GLZ_TRACE_WAVES) k_trace(const LaunchA
     TraceTally tally;
     ClosestSource src{A, A.frame, tally, 0u};
     ClosestSink sink{A};
-    trace_wave<false, COUNT, false, false, false, ALPHA>(TS, src, sink, &s_stack[threadIdx.x], aux, links, (LdsNodePtr)s_top, A.st.overflow, A.st.overflow_depth, A.map.n_local_pixels, wave_index(),
+    trace_wave<false, COUNT, false, GLZ_TRACE_PREFETCH != 0, false, ALPHA>(TS, src, sink, &s_stack[threadIdx.x], aux, links, (LdsNodePtr)s_top, A.st.overflow, A.st.overflow_depth, A.map.n_local_pixels, wave_index(),
                                                          wave_count(), tally);
     if (COUNT) flush_counters(A.counters, false, tally);
   }
@@ -297,7 +297,7 @@ __global__ void __launch_bounds__(kBlock, GLZ_TRACE_WAVES) k_trace(const LaunchA
     const uint32_t n_waves = wave_count();
     const uint32_t closest_groups = A.do_closest ? (A.map.n_local_pixels + 63u) / 64u : 0u;
     const uint32_t wave = (wave_index() + n_waves - closest_groups % n_waves) % n_waves;
-    trace_wave<true, COUNT, false, false, false, ALPHA>(TS, src, sink, &s_stack[threadIdx.x], aux, links, (LdsNodePtr)s_top, A.st.overflow, A.st.overflow_depth, start[kQueueShards], wave, n_waves, tally);
+    trace_wave<true, COUNT, false, GLZ_TRACE_PREFETCH != 0, false, ALPHA>(TS, src, sink, &s_stack[threadIdx.x], aux, links, (LdsNodePtr)s_top, A.st.overflow, A.st.overflow_depth, start[kQueueShards], wave, n_waves, tally);
     if (COUNT) flush_counters(A.counters, true, tally);
   }
   if (COUNT) flush_tex_tallies(A.counters->trace_tex, tex_tally);

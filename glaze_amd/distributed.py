@@ -55,25 +55,31 @@ def gather_frame(renderer, frame, which=0, dst=0, group=None):
     # torch.empty: a torch.zeros would enqueue its fill on torch's CURRENT stream, while export_packed writes the same buffer on the
     # renderer's own non-blocking stream -- nothing orders the two, and a late fill would wipe the tiles.  scatter_packed only reads
     # the packed_pixels(r) pixels rank r really owns, so the tail of a shorter rank's buffer is never looked at.
-    key = (str(frame.device), n_max, world, rank == dst)
+    key = (str(frame.device), n_max, world, rank == dst, id(group))
     cache = getattr(renderer, "_gather_buffers", None)
     if cache is None or cache[0] != key:
         packed = torch.empty((n_max, 4), dtype=torch.float32, device=frame.device)
         parts = [torch.empty_like(packed) for _ in range(world)] if rank == dst else None
         cache = (key, packed, parts)
-        renderer._gather_buffers = cache
+        renderer._gather_buffers = cache          # (about a frame's worth on `dst`; release_gather_buffers() drops them)
     _, packed, parts = cache
     if frame.is_cuda:
-        # whatever torch / RCCL still have in flight on `packed` (the allocator's work, the previous call's send on a rank that is
-        # not `dst`) is done before the renderer's stream writes it again
-        torch.cuda.synchronize(frame.device)
+        # whatever torch / RCCL still have in flight on `packed` on torch's CURRENT stream (the allocator's work, the previous call's send on
+        # a rank that is not `dst`) is done before the renderer's stream writes it again -- that stream only, not the whole device
+        torch.cuda.current_stream(frame.device).synchronize()
     renderer.export_packed(which, packed.data_ptr())      # synchronised on return (the renderer's stream has finished writing `packed`)
     dist.gather(packed, parts, dst=dst, group=group)
     if rank == dst:
         if frame.is_cuda:
-            torch.cuda.synchronize(frame.device)      # the scatter below runs on the renderer's own stream
+            torch.cuda.current_stream(frame.device).synchronize()      # the gather's receives are done: the scatter below runs on the renderer's own stream
         renderer.export_device(which, frame.data_ptr())
         for r in range(world):
             if r != dst:
                 renderer.scatter_packed(r, world, parts[r].data_ptr(), frame.data_ptr())
     return frame
+
+
+def release_gather_buffers(renderer):
+    """Drops the staging buffers gather_frame keeps on the renderer between calls."""
+    if getattr(renderer, "_gather_buffers", None) is not None:
+        renderer._gather_buffers = None

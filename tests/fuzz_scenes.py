@@ -182,6 +182,7 @@ def random_scene(seed):
     run["devices"] = int(more.integers(2, 4)) if (run["partition"] is None and more.random() < 0.12) else 1   # the one GPU named n times (loop-back set_devices)
     run["via_file"] = bool(more.random() < 0.1)          # the HIP side reads the scene from a `.glaze` file (Serializer -> parse -> RayTraceScene.new)
     run["stored_mips"] = int(more.integers(2, 12)) if more.random() < 0.5 else 0   # ... whose textures carry that many mip levels (0: level 0 only)
+    run["node_width"] = int(more.choice([0, 0, 8]))      # the two-kernel mode's traversal over the hierarchy's 8-wide nodes (k_trace8) a third of the time
     return desc, run
 
 
@@ -259,6 +260,7 @@ def render_both(desc, run, levels=None, mode=None):
             else:
                 os.environ["GLAZE_MULTI_LOOPBACK"] = before
     r.set_launch_mode(mode or run["mode"])
+    r.set_node_width(run.get("node_width", 0))
     r.set_chains(run["chains"])
     for x in (r, o):
         x.set_integrator(run["integrator"] if x is r else run["integrator"].value)

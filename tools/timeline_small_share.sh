@@ -4,9 +4,9 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 export TMPDIR=/tmp
 cd /tmp
 rm -rf $REPO/gpurun_out/prof_share
-cat > /tmp/share_run.py <<'PY'
+cat > /tmp/share_run.py <<PY
 import sys
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, "$REPO")
 import glaze_amd
 from glaze_amd.scenes import atrium_scene
 inst = glaze_amd.RayTraceInstance.new()
