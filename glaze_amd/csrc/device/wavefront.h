@@ -952,6 +952,8 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
     }
     GLZ_SEC_STAMP(sec_merge);
     // ---- retire ----
+    // (Storing finished rays only when they make up a refill together with the idle lanes -- a fifth as many executions of the sink's code,
+    // with a quarter of the wave in it instead of a lane or two: k_trace 0.483 against 0.483 ms, a 1/8 share 0.1312 against 0.1302.)
     if (open && cur == kRayDone && (!SHARE || aux_out[lane] == 0)) {
       if (COUNT) tally.hits += best.leaf != kNone;
       sink.store(ray, best);
