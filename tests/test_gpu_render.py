@@ -186,6 +186,37 @@ def test_alpha_and_normal_maps(instance):
     assert (r.read_hdr()[..., :3].sum(-1) == 0).any()      # some primary rays leave through the holes
 
 
+def test_opacity_map_switched_on_and_off_on_a_live_renderer(instance):
+    """The traversal kernel is chosen by what the scene holds: without an opacity map k_trace carries no alpha code, with one its candidates
+    on non-opaque geometry wait for the alpha phase (launch_trace, DeviceScene::has_non_opaque).  update_materials_and_lights switches a
+    live renderer from the one to the other and back (the leaf records are rebuilt: the flag lives in them), in both launch modes, and
+    every state must match the oracle -- alpha-tested candidates decided in a phase of their own change no pixel."""
+    y, x = np.mgrid[0:64, 0:64]
+    alpha = np.where(((x // 4 + y // 4) % 2) == 0, 255, 0).astype(np.uint8)
+    desc = cube_scene()
+    desc.textures.append((abi.TEX_GRAY, alpha, "alpha"))
+    desc.lights.append(make_light(abi.LIGHT_SUN, "sun", direction=(0.1, -0.8, 0.5), intensity=1.0))
+    for mode in ("two_kernels", "path"):
+        cur = desc.copy()
+        r = glaze_amd.RayTraceRenderer.new(instance, glaze_amd.RayTraceScene.from_desc(instance, cur), 200, 120)
+        r.set_launch_mode(mode)
+        r.set_depth(4)
+        r.set_seed(5)
+        holes = []
+        for opacity in (0, 2, 0, 2):
+            cur = cur.copy()
+            cur.materials[2].opacity = opacity
+            r.update_materials_and_lights(cur.materials, cur.lights)
+            r.step(9)
+            o = OracleRenderer(OracleScene(cur), 200, 120)
+            o.set_depth(4)
+            o.set_seed(5)
+            o.step(9)
+            assert_parity(r, o, "%s, opacity map %s" % (mode, "on" if opacity else "off"))
+            holes.append(int((r.read_hdr()[..., :3].sum(-1) == 0).sum()))
+        assert holes[0] == holes[2] and holes[1] == holes[3] and holes[1] > holes[0] + 500, holes   # primary rays leave through the holes exactly while the map is bound
+
+
 def test_no_lights_renders_black_and_counts_nothing(instance):
     """lights_no == 0: the raygen shader returns before touching anything (path_trace.rgen:137-141)."""
     r, o, img = render_both(instance, cube_scene(light=False), 32, 32, spp=2)
