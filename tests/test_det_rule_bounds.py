@@ -75,10 +75,12 @@ def _case(kind, seed):
         return np.einsum("ij,ij->i", np.cross(Q - P, R - P), nrm) / np.maximum(area2, 1e-300)
     w0, w1, w2 = bary(hp, B, C), bary(A, hp, C), bary(A, B, hp)
     inside = (np.minimum(np.minimum(w0, w1), w2) > 0.02) & (t > 1e-3)
-    true_sine = np.abs(denom) / np.linalg.norm(dd, axis=1)
+    with np.errstate(all="ignore"):      # (a sliver that rounds to a segment has no normal: its ray is excluded by `inside` below)
+        true_sine = np.abs(denom) / np.linalg.norm(dd, axis=1)
     # the projected triangle's aspect: longest side over the height the ray sees
     longest = np.maximum(np.maximum(np.linalg.norm(B - A, axis=1), np.linalg.norm(C - B, axis=1)), np.linalg.norm(A - C, axis=1))
-    aspect = longest * longest / np.maximum(area2 * true_sine, 1e-300)
+    with np.errstate(all="ignore"):
+        aspect = longest * longest / np.maximum(area2 * true_sine, 1e-300)
     tri = np.arange(3 * N, dtype=np.uint32)
     return _scene(pos.reshape(-1, 3), tri), o32, d32, np.arange(N), t, true_sine, aspect, inside, (A, B, C, nrm)
 
