@@ -571,6 +571,10 @@ class RayTraceRenderer:
         """rank 0: puts the packed tiles received from `rank` into their place of a full-frame device buffer"""
         abi.check(abi.lib().glz_renderer_scatter_packed(self._h, rank, world, C.c_void_p(packed_ptr), C.c_void_p(frame_ptr)))
 
+    def scatter_packed_all(self, world, packed_ptr, stride_pixels, frame_ptr):
+        """the receiving side of a gather in one call: the parts of ranks 0 .. world - 1 lie `stride_pixels` pixels apart in one device buffer"""
+        abi.check(abi.lib().glz_renderer_scatter_packed_all(self._h, world, C.c_void_p(packed_ptr), stride_pixels, C.c_void_p(frame_ptr)))
+
     def tonemap_device(self, device_ptr):
         out = np.zeros((self.height, self.width, 4), np.uint8)
         abi.check(abi.lib().glz_renderer_tonemap_device(self._h, C.c_void_p(device_ptr), _ptr(out)))

@@ -165,6 +165,7 @@ PROTOTYPES = {
     "glz_renderer_packed_pixels": (C.c_uint64, [_P, C.c_uint32, C.c_uint32]),
     "glz_renderer_export_packed": (C.c_int, [_P, C.c_int, _P]),
     "glz_renderer_scatter_packed": (C.c_int, [_P, C.c_uint32, C.c_uint32, _P, _P]),
+    "glz_renderer_scatter_packed_all": (C.c_int, [_P, C.c_uint32, _P, C.c_uint64, _P]),
     "glz_renderer_tonemap_device": (C.c_int, [_P, _P, _P]),
     "glz_renderer_enable_counters": (C.c_int, [_P, C.c_int]),
     "glz_renderer_get_stats": (C.c_int, [_P, _P]),

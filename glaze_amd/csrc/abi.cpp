@@ -442,6 +442,12 @@ int glz_renderer_scatter_packed(glz_renderer* h, uint32_t rank, uint32_t world, 
   GLZ_RET(h->r->scatter_packed(rank, world, packed, frame, e));
   GLZ_GUARD_END(GLZ_E_IO)
 }
+int glz_renderer_scatter_packed_all(glz_renderer* h, uint32_t world, const void* packed, uint64_t stride_pixels, void* frame) {
+  GLZ_GUARD_BEGIN GLZ_R(h);
+  if (!packed || !frame) return fail(GLZ_E_ARG, "device buffer is null");
+  GLZ_RET(h->r->scatter_packed_all(world, packed, stride_pixels, frame, e));
+  GLZ_GUARD_END(GLZ_E_IO)
+}
 int glz_renderer_tonemap_device(glz_renderer* h, const void* dev, uint8_t* out) {
   GLZ_GUARD_BEGIN GLZ_R(h);
   if (!dev || !out) return fail(GLZ_E_ARG, "null argument");

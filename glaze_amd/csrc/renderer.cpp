@@ -1272,6 +1272,30 @@ bool Renderer::scatter_packed(uint32_t rank, uint32_t world, const void* dev_pac
   return hip_ok(hipStreamSynchronize(st), "scatter_packed", err);
 }
 
+bool Renderer::scatter_packed_all(uint32_t world, const void* dev_packed, uint64_t stride_pixels, void* dev_frame, Error& err) {
+  if (world == 0 || stride_pixels < packed_count(w_, h_, 0, world)) {
+    err.code = GLZ_E_ARG;
+    err.msg = "scatter_packed_all: the parts must lie at least packed_pixels(0, world) pixels apart";
+    return false;
+  }
+  if (!hip_ok(hipSetDevice(inst_->device), "hipSetDevice", err)) return false;
+  hipStream_t st = chains_[0]->stream;
+  for (uint32_t rank = 0; rank < world; ++rank) {
+    TileMap m{};
+    m.width = w_;
+    m.height = h_;
+    m.tiles_x = (w_ + kTile - 1) / kTile;
+    m.tiles_y = (h_ + kTile - 1) / kTile;
+    m.rank = rank;
+    m.world = world;
+    m.n_local_pixels = (uint32_t)packed_count(w_, h_, rank, world);
+    m.n_local_tiles = m.n_local_pixels / (kTile * kTile);
+    if (m.n_local_pixels == 0) continue;
+    if (!hip_ok(launch_export(st, m, static_cast<const float4*>(dev_packed) + (size_t)rank * stride_pixels, static_cast<float4*>(dev_frame), false), "k_export (packed tiles)", err)) return false;
+  }
+  return hip_ok(hipStreamSynchronize(st), "scatter_packed_all", err);
+}
+
 bool Renderer::tonemap_device(const void* dev_result, uint8_t* out, Error& err) {
   if (!hip_ok(hipSetDevice(inst_->device), "hipSetDevice", err)) return false;
   hipStream_t st = chains_[0]->stream;

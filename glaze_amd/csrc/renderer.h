@@ -57,6 +57,7 @@ class Renderer {
   static size_t packed_count(uint32_t w, uint32_t h, uint32_t rank, uint32_t world);   // float4s of a rank's packed tiles
   bool export_packed(int which, void* dev_packed, Error& err);
   bool scatter_packed(uint32_t rank, uint32_t world, const void* dev_packed, void* dev_frame, Error& err);
+  bool scatter_packed_all(uint32_t world, const void* dev_packed, uint64_t stride_pixels, void* dev_frame, Error& err);   // every rank's part of one gathered buffer, one synchronisation
   bool tonemap_device(const void* dev_result, uint8_t* out, Error& err);
   bool launch_constants(uint32_t launch, uint32_t* seed, float off[2]);
   void push_constants(float out[32]) const;

@@ -59,10 +59,12 @@ def gather_frame(renderer, frame, which=0, dst=0, group=None):
     cache = getattr(renderer, "_gather_buffers", None)
     if cache is None or cache[0] != key:
         packed = torch.empty((n_max, 4), dtype=torch.float32, device=frame.device)
-        parts = [torch.empty_like(packed) for _ in range(world)] if rank == dst else None
-        cache = (key, packed, parts)
+        # one buffer for everybody's part: the receiving side then takes ONE call (scatter_packed_all), not a kernel + a synchronisation per rank
+        whole = torch.empty((world, n_max, 4), dtype=torch.float32, device=frame.device) if rank == dst else None
+        parts = [whole[r] for r in range(world)] if rank == dst else None
+        cache = (key, packed, parts, whole)
         renderer._gather_buffers = cache          # (about a frame's worth on `dst`; release_gather_buffers() drops them)
-    _, packed, parts = cache
+    _, packed, parts, whole = cache
     if frame.is_cuda:
         # whatever torch / RCCL still have in flight on `packed` on torch's CURRENT stream (the allocator's work, the previous call's send on
         # a rank that is not `dst`) is done before the renderer's stream writes it again -- that stream only, not the whole device
@@ -72,10 +74,8 @@ def gather_frame(renderer, frame, which=0, dst=0, group=None):
     if rank == dst:
         if frame.is_cuda:
             torch.cuda.current_stream(frame.device).synchronize()      # the gather's receives are done: the scatter below runs on the renderer's own stream
-        renderer.export_device(which, frame.data_ptr())
-        for r in range(world):
-            if r != dst:
-                renderer.scatter_packed(r, world, parts[r].data_ptr(), frame.data_ptr())
+        # every rank's tiles, dst's own among them (the gather put `packed` into parts[dst]), to their place: the tiles of all ranks cover the frame
+        renderer.scatter_packed_all(world, whole.data_ptr(), n_max, frame.data_ptr())
     return frame
 
 

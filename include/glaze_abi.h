@@ -375,6 +375,11 @@ int glz_renderer_export_device(glz_renderer*, int which, void* dev_rgba32f);
 uint64_t glz_renderer_packed_pixels(glz_renderer*, uint32_t rank, uint32_t world);
 int glz_renderer_export_packed(glz_renderer*, int which, void* dev_packed_rgba32f);
 int glz_renderer_scatter_packed(glz_renderer*, uint32_t rank, uint32_t world, const void* dev_packed_rgba32f, void* dev_frame_rgba32f);
+/* The receiving side of a gather in ONE call: `dev_packed_rgba32f` holds the packed tiles of ranks 0 .. world - 1 one after the other,
+ * `stride_pixels` pixels apart (what a gather into one buffer leaves; >= glz_renderer_packed_pixels(r, 0, world)); every rank's tiles go
+ * to their place in the frame -- world small kernels on the instance stream, ONE synchronisation (rank 0's own tiles included: the
+ * frame needs no glz_renderer_export_device first, the tiles of all ranks cover it). */
+int glz_renderer_scatter_packed_all(glz_renderer*, uint32_t world, const void* dev_packed_rgba32f, uint64_t stride_pixels, void* dev_frame_rgba32f);
 /* Concurrent chains: the tiles of this process advance as `n` independent launch sequences on `n` HIP streams (0 = automatic:
  * one chain while the rank owns a million pixels, two down to 400 k, three below).  Pixels never interact, so the image does not depend on n; with a small
  * tile share per GPU the chains fill the machine while the longest rays of a launch finish. */

@@ -293,6 +293,25 @@ def test_packed_tiles_export_and_scatter(instance):
         assert np.array_equal(bits(frame.numpy()), bits(want)), chains
     with pytest.raises(abi.GlazeError):
         one.scatter_packed(3, 3, frame.ptr, frame.ptr)
+    # the receiving side of a gather in one call (what glaze_amd.distributed.gather_frame does on rank 0): every rank's part in ONE buffer,
+    # n_max pixels apart, rank 0's own among them -- the frame needs nothing else (it starts as garbage here)
+    n_max = one.packed_pixels(0, world)
+    whole = np.full((world, n_max, 4), -7.0, np.float32)
+    for rank in range(world):
+        r = glaze_amd.RayTraceRenderer.new(instance, glaze_amd.RayTraceScene.from_desc(instance, desc), w, h)
+        r.set_depth(3)
+        r.set_partition(rank, world)
+        r.step(5)
+        packed = DeviceArray((n_max, 4), fill=-7.0)
+        r.export_packed(0, packed.ptr)
+        whole[rank] = packed.numpy()
+    gathered = DeviceArray((world, n_max, 4))
+    gathered.upload(whole)
+    frame = DeviceArray((h, w, 4), fill=123.0)
+    one.scatter_packed_all(world, gathered.ptr, n_max, frame.ptr)
+    assert np.array_equal(bits(frame.numpy()), bits(want))
+    with pytest.raises(abi.GlazeError):
+        one.scatter_packed_all(world, gathered.ptr, n_max - 1, frame.ptr)
 
 
 FAKE_RCCL = r'''
