@@ -15,7 +15,7 @@ from PIL import Image as PILImage
 import glaze_amd
 import glaze_amd.distributed
 from glaze_amd import abi
-from glaze_amd.scene_desc import make_camera, make_light, make_material
+from glaze_amd.scene_desc import INSTANCE_DTYPE, MESH_DTYPE, make_camera, make_light, make_material
 from glaze_amd.scenes import atrium_scene, cube_scene
 from oracle.pyoracle import OracleRenderer, OracleScene
 
@@ -215,6 +215,41 @@ def test_opacity_map_switched_on_and_off_on_a_live_renderer(instance):
             assert_parity(r, o, "%s, opacity map %s" % (mode, "on" if opacity else "off"))
             holes.append(int((r.read_hdr()[..., :3].sum(-1) == 0).sum()))
         assert holes[0] == holes[2] and holes[1] == holes[3] and holes[1] > holes[0] + 500, holes   # primary rays leave through the holes exactly while the map is bound
+
+
+def test_tables_too_large_for_lds_and_a_sky_taller_than_its_lds_copy(instance):
+    """k_shade stages the material / light / descriptor tables (8 KB) and the sky's marginal cdf (1 087 rows) in LDS when they fit; a
+    scene with 64 materials (13 KB of RTMaterial) and a 16 x 1500 sky reads both from memory instead -- same pixels as the oracle, in both
+    launch modes (k_path sizes its table copy by itself)."""
+    desc = cube_scene()
+    base = desc.materials[2]
+    rng = np.random.default_rng(4)
+    for i in range(61):
+        desc.materials.append(make_material("m%d" % i, mtype=abi.MAT_UBER if i % 3 == 0 else abi.MAT_LAMBERT, diffuse=1,
+                                            diffuse_mul=tuple(int(v) for v in rng.integers(60, 255, 3)), roughness_mul=0.3 + 0.01 * i))
+    assert len(desc.materials) == 64
+    # six instances of the cube's mesh... the cube is one mesh of 12 triangles: give every face pair its own mesh / material
+    idx = desc.indices.reshape(-1, 3)
+    desc.meshes = np.array([(k, 3 + 10 * k, 6 * k, 6) for k in range(6)], MESH_DTYPE)     # materials 3, 13, 23, 33, 43, 53
+    desc.instances = np.array([(k, 0) for k in range(6)], INSTANCE_DTYPE)
+    sky = np.zeros((1500, 16, 4), np.uint8)
+    sky[..., :3] = rng.integers(0, 256, (1500, 1, 3))
+    sky[::37, :, :3] = 255
+    sky[..., 3] = 255
+    desc.textures.append((abi.TEX_RGBA_SRGB, sky, "tall sky"))
+    desc.lights.append(make_light(abi.LIGHT_SKY, "sky", resource_id=2, intensity=0.4, yaw=10, pitch=80, roll=0))
+    assert idx.shape[0] == 12
+    for mode in ("two_kernels", "path"):
+        r = glaze_amd.RayTraceRenderer.new(instance, glaze_amd.RayTraceScene.from_desc(instance, desc), 96, 80)
+        r.set_launch_mode(mode)
+        r.set_depth(5)
+        r.set_seed(2)
+        r.step(12)
+        o = OracleRenderer(OracleScene(desc), 96, 80)
+        o.set_depth(5)
+        o.set_seed(2)
+        o.step(12)
+        assert assert_parity(r, o, "64 materials, tall sky, " + mode) == 1.0
 
 
 def test_no_lights_renders_black_and_counts_nothing(instance):
