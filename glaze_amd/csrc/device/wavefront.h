@@ -1144,13 +1144,11 @@ __device__ __forceinline__ void trace_wave_tl(const DeviceScene& S, Source& src,
           cur = l0;
         }
       }
+      // (Instance entries and triangle tests with a quorum each -- 8 / 16 / 24 lanes for entries, 24 / 32 for triangles -- so that neither kind of
+      // leaf work runs for a handful of lanes: forest x 200 0.803 -> 0.816 ... 0.838 ms per launch, x 2 000 1.082 -> 1.106 ... 1.129: slower.)
       if (__popcll(__ballot(cur < 0)) >= GLZ_TL_LEAF_QUORUM) break;
     }
     // ---- leaf phase: an instance to enter (top level) or triangles to test (inside an instance) ----
-#ifdef GLZ_WAVE_TIMES
-    if (lane == 0 && __ballot(cur < 0) != 0ull) tl_liter += 1;
-    if (cur < 0) { if (cur_inst == kNone) tl_enter += 1; else tl_tris += 1; }
-#endif
     if (cur < 0) {
       if (cur_inst == kNone) {
         cur_inst = (uint32_t)~cur;
