@@ -1,5 +1,6 @@
 """Determinism soak: the same render repeated (and with other chain counts) must give bit-identical float images; run after kernel changes.
-Usage: python tools/gpu_soak.py [launches] [repeats]"""
+Usage: python tools/gpu_soak.py [launches] [repeats]          env: SOAK_SCENE=sponza_like (the atrium with opacity / normal / roughness maps: the
+alpha phase decides candidates in whatever order its quorum fills, which must change no pixel) SOAK_PATH=<renders of the k_path part>"""
 import sys, time, hashlib
 sys.path.insert(0, ".")
 import numpy as np
@@ -8,7 +9,8 @@ from glaze_amd.scenes import atrium_scene
 launches = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 repeats = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 inst = glaze_amd.RayTraceInstance.new()
-scene = glaze_amd.RayTraceScene.from_desc(inst, atrium_scene())
+import os
+scene = glaze_amd.RayTraceScene.from_desc(inst, atrium_scene(sponza_like=os.environ.get("SOAK_SCENE") == "sponza_like"))
 r = glaze_amd.RayTraceRenderer.new(inst, scene, 1920, 1080)
 r.set_depth(8); r.set_seed(5)
 ref = None
