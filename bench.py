@@ -33,7 +33,7 @@ configurations on one GPU (`extra.configs`: 2 = cube 512^2 depth 2, 3 = mattest.
 and the atrium with the content classes real Sponza has and the stand-in lacks (`extra.atrium_sponza_like`: opacity-mapped cloth, foliage
 cards and vines, normal maps on stone, roughness maps on the Uber materials); `--no-extras` skips them.  N > 1: every step that can block
 on another GPU -- spanning the devices, every exchange, the process group's barrier -- runs under a watchdog: after its time-out
-(GLAZE_BENCH_WATCHDOG_S, default 180 s to span the devices, 90 s per exchange) it prints `multi_gpu.diagnostics` (which call, how long, RCCL
+(GLAZE_BENCH_WATCHDOG_SPAN_S, default 180 s, to span the devices; GLAZE_BENCH_WATCHDOG_S, default 90 s, per exchange or barrier) it prints `multi_gpu.diagnostics` (which call, how long, RCCL
 version, the peer-access matrix, bytes per peer, the RCCL / HSA environment) to stderr and ends the process with status 3 through os._exit.
 
 The timed region is EXACTLY K steps between barrier + synchronize pairs, MAX over ranks.  A region shorter than 0.5 s is
@@ -326,8 +326,8 @@ def main():
         return facts
 
     dog = Watchdog(diagnostics_facts) if n_gpus > 1 else None
-    span_timeout = float(os.environ.get("GLAZE_BENCH_WATCHDOG_S", "180"))
-    exchange_timeout = float(os.environ.get("GLAZE_BENCH_WATCHDOG_S", "90"))
+    span_timeout = float(os.environ.get("GLAZE_BENCH_WATCHDOG_SPAN_S", "180"))      # spanning the devices / the process group's init
+    exchange_timeout = float(os.environ.get("GLAZE_BENCH_WATCHDOG_S", "90"))        # every exchange, every barrier
 
     def guarded(name, seconds, fn, **extra):
         if dog is None:
