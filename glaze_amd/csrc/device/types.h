@@ -29,7 +29,11 @@ struct FrameData {
   uint32_t lod_mode;
   float cone_spread;
   float cone_width0;
-  uint32_t _pad[3];
+  // FrameData::pixel_offset of the launch AFTER this one (host: WorkScheduler::peek) and whether the shading of this launch may use it:
+  // a path that ends in this launch gets its next camera ray from the shading code (shade_pixel, `pregen`), in whole waves of pixels
+  // that ended together, instead of from the traversal kernel's refill, which runs with a quarter of its lanes (ClosestSource::load)
+  float next_pixel_offset[2];
+  uint32_t pregen;
 };
 
 // raytrace_structures.rs:36-42

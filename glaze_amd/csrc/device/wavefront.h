@@ -1264,6 +1264,30 @@ __device__ __forceinline__ uint32_t wave_count() { return gridDim.x * (kBlock / 
 // ---------------------------------------------------------------------------------------------
 // (k_path with a wave's 64 pixels dealt from 4 ... 64 different groups, to average the groups' persistent cost differences: it does at a
 // half-empty machine and not at a 1/8 share, where the coherence lost costs more: EXPERIMENTS.md.)
+// The camera ray of a new path through the jittered pixel (ray_origin / ray_dir, path_trace.rgen:47-73).  Two callers, the same
+// operations in the same order: the traversal kernel's refill for a pixel whose path is new and has no ray yet (the first launch after
+// a restart, the direct-light integrator), and the shading code for a path that has just ended, with the NEXT launch's pixel offset.
+__device__ __forceinline__ void camera_ray(const LaunchArgs& A, const FrameData& F, PixelId px, float off_x, float off_y, vec3& origin, vec3& direction) {
+  const float pxf = (float)px.x + off_x, pyf = (float)px.y + off_y;
+  const float ndcx = -1.0f + 2.0f * (pxf / F.scene_size[0]), ndcy = -1.0f + 2.0f * (pyf / F.scene_size[1]);
+  const float* c2w = A.cam.camera2world;
+  const float* s2c = A.cam.screen2camera;
+  const float ortho = gl_step(0.5f, F.camera_persp ? 0.0f : 1.0f), persp = gl_step(0.5f, F.camera_persp ? 1.0f : 0.0f);
+  const float ox = ndcx * ortho, oy = ndcy * ortho;
+  origin = mk3((c2w[0] * ox + c2w[4] * oy) + c2w[12], (c2w[1] * ox + c2w[5] * oy) + c2w[13], (c2w[2] * ox + c2w[6] * oy) + c2w[14]);
+  const float fx = ndcx * persp, fy = ndcy * persp;
+  const vec3 target = mk3(((s2c[0] * fx + s2c[4] * fy) + s2c[8]) + s2c[12], ((s2c[1] * fx + s2c[5] * fy) + s2c[9]) + s2c[13],
+                          ((s2c[2] * fx + s2c[6] * fy) + s2c[10]) + s2c[14]);
+  const vec3 nt = normalize3(target);
+  const float dx = (c2w[0] * nt.x + c2w[4] * nt.y) + c2w[8] * nt.z, dy = (c2w[1] * nt.x + c2w[5] * nt.y) + c2w[9] * nt.z;
+  const float dz = (c2w[2] * nt.x + c2w[6] * nt.y) + c2w[10] * nt.z, dw = (c2w[3] * nt.x + c2w[7] * nt.y) + c2w[11] * nt.z;
+  const float inv = 1.0f / sqrtf(((dx * dx + dy * dy) + dz * dz) + dw * dw);   // normalize() of the vec4
+  direction = mk3(dx * inv, dy * inv, dz * inv);
+}
+// ray_o.w of a pixel is the bounce its path is at; 0 = a new path.  +0.0: the camera ray is still to be made (by the refill below);
+// -0.0 (kPregenBounce): the shading code of the previous launch has made it already (shade_pixel) and ray_o / ray_d hold it.  Both
+// compare equal to 0.0f, which is all the shading code asks.
+constexpr uint32_t kPregenBounceBits = 0x80000000u;
 struct ClosestSource {
   const LaunchArgs& A;
   const FrameData& F;   // the launch's constants (k_trace: A.frame; k_path: one entry of its batch)
@@ -1278,24 +1302,13 @@ struct ClosestSource {
     const PixelId px = pixel_of(A.map, lid);
     if (!px.active) return false;
     const float4 ro = A.st.ray_o[lid], rd = A.st.ray_d[lid];
-    if (F.direct_only || ro.w == 0.0f) {
-      tally.fresh += 1;
-      // new path: camera ray through the jittered pixel (ray_origin / ray_dir, path_trace.rgen:47-73)
-      const float pxf = (float)px.x + F.pixel_offset[0], pyf = (float)px.y + F.pixel_offset[1];
-      const float ndcx = -1.0f + 2.0f * (pxf / F.scene_size[0]), ndcy = -1.0f + 2.0f * (pyf / F.scene_size[1]);
-      const float* c2w = A.cam.camera2world;
-      const float* s2c = A.cam.screen2camera;
-      const float ortho = gl_step(0.5f, F.camera_persp ? 0.0f : 1.0f), persp = gl_step(0.5f, F.camera_persp ? 1.0f : 0.0f);
-      const float ox = ndcx * ortho, oy = ndcy * ortho;
-      origin = mk3((c2w[0] * ox + c2w[4] * oy) + c2w[12], (c2w[1] * ox + c2w[5] * oy) + c2w[13], (c2w[2] * ox + c2w[6] * oy) + c2w[14]);
-      const float fx = ndcx * persp, fy = ndcy * persp;
-      const vec3 target = mk3(((s2c[0] * fx + s2c[4] * fy) + s2c[8]) + s2c[12], ((s2c[1] * fx + s2c[5] * fy) + s2c[9]) + s2c[13],
-                              ((s2c[2] * fx + s2c[6] * fy) + s2c[10]) + s2c[14]);
-      const vec3 nt = normalize3(target);
-      const float dx = (c2w[0] * nt.x + c2w[4] * nt.y) + c2w[8] * nt.z, dy = (c2w[1] * nt.x + c2w[5] * nt.y) + c2w[9] * nt.z;
-      const float dz = (c2w[2] * nt.x + c2w[6] * nt.y) + c2w[10] * nt.z, dw = (c2w[3] * nt.x + c2w[7] * nt.y) + c2w[11] * nt.z;
-      const float inv = 1.0f / sqrtf(((dx * dx + dy * dy) + dz * dz) + dw * dw);   // normalize() of the vec4
-      direction = mk3(dx * inv, dy * inv, dz * inv);
+    if (F.direct_only || ro.w == 0.0f) tally.fresh += 1;
+    // A refill runs with the 16 - 24 lanes that were idle, and a quarter of the pixels start a new path in every launch: making their
+    // camera rays here -- ~170 VALU instructions with four divisions and two square roots, at a quarter of the lanes, in nearly every
+    // refill of a kernel that is bound by VALU issue -- was 8 % of k_trace's instructions.  The shading code makes them now where the
+    // paths end (whole waves of misses after k_shade's regrouping), and the branch below is taken by the launch after a restart only.
+    if (F.direct_only || __float_as_uint(ro.w) == 0u) {
+      camera_ray(A, F, px, F.pixel_offset[0], F.pixel_offset[1], origin, direction);
       A.st.ray_o[lid] = make_float4(origin.x, origin.y, origin.z, ro.w);
       A.st.ray_d[lid] = make_float4(direction.x, direction.y, direction.z, rd.w);
     } else {
@@ -1416,9 +1429,12 @@ struct StagedState {
   }
   __device__ __forceinline__ void accumulate(uint32_t lid, vec3 cc, bool add, bool update, float exposure) { accumulate_pixel(*A, lid, cc, add, update, exposure); }
 };
+// Returns 0 when the pixel's next path state has been written (or, with the direct-light integrator, is not needed), 1 / 2 when the path
+// has ENDED and its reset is left to shade_pixel below: 1 = only ray_o is to be written (a miss: ray_d keeps its flag), 2 = ray_o and
+// ray_d, the latter with the flag `end_w`.
 template <bool LOD, class Queue, class State>
-__device__ __forceinline__ void shade_pixel(const LaunchArgs& A, const DeviceScene& S, const FrameData& F, uint32_t lid, PixelId px, float4 ro, float4 rd, float4 hr, Queue& queue,
-                                            State& out) {
+__device__ __forceinline__ int shade_pixel_body(const LaunchArgs& A, const DeviceScene& S, const FrameData& F, uint32_t lid, PixelId px, float4 ro, float4 rd, float4 hr, Queue& queue,
+                                                State& out, float& end_w) {
   const bool fresh = F.direct_only || ro.w == 0.0f;
   float bounce = F.direct_only ? 0.0f : ro.w;
   const vec3 direction = mk3(rd.x, rd.y, rd.z);
@@ -1452,8 +1468,8 @@ __device__ __forceinline__ void shade_pixel(const LaunchArgs& A, const DeviceSce
       flags = kFlagUpdate;
     }
     out.accumulate(lid, c, true, flags != 0, F.exposure);
-    if (!F.direct_only) out.ray_o(lid, make_float4(ro.x, ro.y, ro.z, 0.0f));   // RESET_PATH
-    return;
+    end_w = rd.w;
+    return F.direct_only ? 0 : 1;   // RESET_PATH
   }
   // ---- closest-hit shader (raytrace_hit.rchit:30-71), inputs from the 128-byte per-leaf shading record ----
   const float4* rec = S.shade_tris + 8u * (size_t)leaf;
@@ -1620,16 +1636,15 @@ __device__ __forceinline__ void shade_pixel(const LaunchArgs& A, const DeviceSce
     out.accumulate(lid, mk3(0.0f, 0.0f, 0.0f), false, false, F.exposure);
     spec_flag = 1.0f;
   }
-  if (F.direct_only) return;
+  if (F.direct_only) return 0;
   GLZ_SHADE_STAMP(4);   // queue entry / accumulator update
   // Russian roulette (:197-210)
   float rr_scale = 1.0f;   // importance * 1.0f is importance, bit for bit: the paths that skip the roulette multiply by it too
   if (bounce > (float)(F.pt_steps / 2u)) {
     const float kill = gl_max(0.05f, 1.0f - (have_lum ? imp_lum : spec_luminance(load_importance())));
     if (rand01(rng) < kill) {
-      out.ray_o(lid, make_float4(ro.x, ro.y, ro.z, 0.0f));
-      out.ray_d(lid, make_float4(rd.x, rd.y, rd.z, spec_flag));
-      return;
+      end_w = spec_flag;
+      return 2;
     }
     rr_scale = 1.0f / (1.0f - kill);
   }
@@ -1639,9 +1654,8 @@ __device__ __forceinline__ void shade_pixel(const LaunchArgs& A, const DeviceSce
   vec3 wiW = mk3(0.0f, 0.0f, 0.0f);
   const float pdf = bsdf_sample(S, P, xi, value, wiW);   // :212-218
   if (pdf == 0.0f) {
-    out.ray_o(lid, make_float4(ro.x, ro.y, ro.z, 0.0f));
-    out.ray_d(lid, make_float4(rd.x, rd.y, rd.z, spec_flag));
-    return;
+    end_w = spec_flag;
+    return 2;
   }
   float weight = fabsf(dot3(wiW, ns));
   weight /= pdf;
@@ -1653,8 +1667,35 @@ __device__ __forceinline__ void shade_pixel(const LaunchArgs& A, const DeviceSce
   bounce = bounce < (float)F.pt_steps ? bounce + 1.0f : 0.0f;   // :230-237
   GLZ_SHADE_STAMP(5);   // roulette, BSDF sample, new importance
   if constexpr (LOD) A.st.cone[lid] = cone_w;
+  if (F.pregen && bounce == 0.0f) {   // the path has reached its last step: the next launch starts a new one (only its flag survives)
+    end_w = spec_flag;
+    return 2;
+  }
   out.ray_o(lid, make_float4(point.x, point.y, point.z, bounce));
   out.ray_d(lid, make_float4(wiW.x, wiW.y, wiW.z, spec_flag));
+  return 0;
+}
+// shade_pixel_body, then the reset of a path that ended (RESET_PATH, path_trace.rgen:170-179 / :197-218): ray_o.w = 0 tells the next launch
+// to start a new path at this pixel.  With FrameData::pregen the new path's camera ray is made right here, from the next launch's
+// pixel offset (camera_ray: the operations ClosestSource::load would run in the next launch, bit for bit), and ray_o.w = -0.0 says so --
+// k_shade's regrouping puts the pixels that missed into waves of their own, so the code runs with full waves where the traversal
+// kernel's refill ran it with a quarter of the lanes.
+template <bool LOD, class Queue, class State>
+__device__ __forceinline__ void shade_pixel(const LaunchArgs& A, const DeviceScene& S, const FrameData& F, uint32_t lid, PixelId px, float4 ro, float4 rd, float4 hr, Queue& queue,
+                                            State& out) {
+  float end_w = 0.0f;
+  const int ended = shade_pixel_body<LOD>(A, S, F, lid, px, ro, rd, hr, queue, out, end_w);
+  if (ended != 0) {
+    if (F.pregen) {
+      vec3 co, cd;
+      camera_ray(A, F, px, F.next_pixel_offset[0], F.next_pixel_offset[1], co, cd);
+      out.ray_o(lid, make_float4(co.x, co.y, co.z, __uint_as_float(kPregenBounceBits)));
+      out.ray_d(lid, make_float4(cd.x, cd.y, cd.z, end_w));
+    } else {
+      out.ray_o(lid, make_float4(ro.x, ro.y, ro.z, 0.0f));
+      if (ended == 2) out.ray_d(lid, make_float4(rd.x, rd.y, rd.z, end_w));
+    }
+  }
 }
 
 #ifndef GLZ_SHADE_TABLE_BYTES

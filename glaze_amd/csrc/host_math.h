@@ -240,6 +240,13 @@ class WorkScheduler {
     out[0] = mx;
     out[1] = my;
   }
+  // what the next call of next() will return, without taking it (the launch after this one: FrameData::next_pixel_offset)
+  void peek(float out[2]) const {
+    const Area full{{0.0f, 0.0f}, {1.0f, 1.0f}};
+    const Area& a = !current_.empty() ? current_.back() : (!next_.empty() ? next_.back() : full);
+    out[0] = (a.lo[0] + a.hi[0]) / 2.0f;
+    out[1] = (a.lo[1] + a.hi[1]) / 2.0f;
+  }
 
  private:
   struct Area {

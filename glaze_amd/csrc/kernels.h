@@ -128,7 +128,7 @@ struct PathBatch {
   uint32_t tables_in_lds;                  // filled by launch_path
   uint32_t parity;                         // which of the two cost accumulators this batch adds to (it reads the other one)
   uint32_t seed[kPathMaxLaunches];         // FrameData::seed of each launch (the rest of FrameData is LaunchArgs::frame)
-  float offset[kPathMaxLaunches][2];       // FrameData::pixel_offset
+  float offset[kPathMaxLaunches + 1][2];   // FrameData::pixel_offset; entry n: of the launch after the batch (FrameData::next_pixel_offset)
   float exposure[kPathMaxLaunches];        // FrameData::exposure
 };
 constexpr uint32_t kTraceBlock = 256;          // threads per block of the render kernels (4 waves)

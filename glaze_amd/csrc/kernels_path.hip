@@ -121,6 +121,8 @@ __device__ __forceinline__ FrameData launch_frame(const LaunchArgs& A, const Pat
   F.seed = B.seed[L];
   F.pixel_offset[0] = B.offset[L][0];
   F.pixel_offset[1] = B.offset[L][1];
+  F.next_pixel_offset[0] = B.offset[L + 1][0];
+  F.next_pixel_offset[1] = B.offset[L + 1][1];
   F.exposure = B.exposure[L];
   return F;
 }

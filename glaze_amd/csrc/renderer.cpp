@@ -461,6 +461,10 @@ bool Renderer::one_launch(Error& err) {
   if (!launch_constants_common(fd, err)) return false;
   fd.seed = rng_.next();                  // rng.gen::<u32>(), raytracer.rs:487
   sched_.next(fd.pixel_offset);           // WorkScheduler::next(), :489
+  // the launch after this one, for the paths that end in this one (shade_pixel): anything that could make the next launch differ from
+  // what is assumed here -- a new camera, resolution, scene, integrator, a restart -- resets the path state before it runs (reset_buffers)
+  sched_.peek(fd.next_pixel_offset);
+  fd.pregen = fd.direct_only ? 0u : 1u;
   fd.exposure = exposure_;
   ++launches_;
   if (fd.lights_no == 0) return true;   // the raygen shader returns before touching anything (path_trace.rgen:137-141)
@@ -509,6 +513,8 @@ bool Renderer::path_batch(uint32_t n, Error& err) {
     sched_.next(b.offset[i]);          // WorkScheduler::next(), :489
     b.exposure[i] = exposure_;
   }
+  sched_.peek(b.offset[n]);            // the launch after the batch (FrameData::next_pixel_offset of its last launch)
+  fd.pregen = fd.direct_only ? 0u : 1u;
   launches_ += n;
   if (fd.lights_no == 0) return true;   // the raygen shader returns before touching anything (path_trace.rgen:137-141)
   Chain& c = *chains_[0];
