@@ -130,6 +130,15 @@ __device__ __forceinline__ float grid_inv_dir(float d) {
   const float i = 1.0f / d;
   return fabsf(i) <= 1e30f ? i : copysignf(1e30f, i);
 }
+// The same from the hardware's reciprocal (v_rcp_f32, one ulp) instead of the correctly rounded division (ten instructions): for the
+// flattened tracer's refill, which runs with a quarter of the wave's lanes.  The grid-space ray only PRUNES -- hits come from the exact
+// test on the world ray -- and an error of 2^-23 in ig moves a plane crossing by at most 32 768 cells x 2^-23 = 0.004 cell, inside the
+// 1/16 cell the boxes are padded by (the rounding of the plane distances themselves takes 0.01).  The counting kernels keep the
+// division: their node counts are compared with the oracle's walk.
+__device__ __forceinline__ float grid_inv_dir_fast(float d) {
+  const float i = __builtin_amdgcn_rcpf(d);
+  return fabsf(i) <= 1e30f ? i : copysignf(1e30f, i);
+}
 // rays with a NaN / infinite origin or direction cannot be accepted by ray_triangle (every comparison fails): they
 // are reported as misses without traversal
 __device__ __forceinline__ bool ray_is_finite(vec3 o, vec3 d) {
@@ -637,7 +646,8 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
             sink.store(ray, best);                          // nothing to intersect / nothing can be hit: a miss
           } else {
             const vec3 og = mk3((o.x - grid.lo[0]) * grid.inv_cell[0], (o.y - grid.lo[1]) * grid.inv_cell[1], (o.z - grid.lo[2]) * grid.inv_cell[2]);
-            ig = mk3(grid_inv_dir(d.x) * grid.cell[0], grid_inv_dir(d.y) * grid.cell[1], grid_inv_dir(d.z) * grid.cell[2]);
+            if (COUNT) ig = mk3(grid_inv_dir(d.x) * grid.cell[0], grid_inv_dir(d.y) * grid.cell[1], grid_inv_dir(d.z) * grid.cell[2]);
+            else ig = mk3(grid_inv_dir_fast(d.x) * grid.cell[0], grid_inv_dir_fast(d.y) * grid.cell[1], grid_inv_dir_fast(d.z) * grid.cell[2]);
             cg = mk3(grid_addend(og.x, ig.x), grid_addend(og.y, ig.y), grid_addend(og.z, ig.z));
             sel = SlabSel{slab_sel(ig.x), slab_sel(ig.y), slab_sel(ig.z)};
             st.sp = 0;
@@ -1299,19 +1309,23 @@ struct ClosestSource {
   // longest dependent chain among its 64 rays.  Median and end of the phase moved by +3 ... +8 % with the coherence lost.)
   __device__ __forceinline__ bool load(uint32_t i, vec3& origin, vec3& direction, float& tmin, float& tmax) {
     const uint32_t lid = base + i;
-    const PixelId px = pixel_of(A.map, lid);
-    if (!px.active) return false;
+    if (lid >= A.map.n_local_pixels) return false;
     const float4 ro = A.st.ray_o[lid], rd = A.st.ray_d[lid];
-    if (F.direct_only || ro.w == 0.0f) tally.fresh += 1;
     // A refill runs with the 16 - 24 lanes that were idle, and a quarter of the pixels start a new path in every launch: making their
     // camera rays here -- ~170 VALU instructions with four divisions and two square roots, at a quarter of the lanes, in nearly every
     // refill of a kernel that is bound by VALU issue -- was 8 % of k_trace's instructions.  The shading code makes them now where the
     // paths end (whole waves of misses after k_shade's regrouping), and the branch below is taken by the launch after a restart only.
+    // (Where the pixel is -- a division by the tiles per row -- only matters here: the pixels of an edge tile that lie outside the image
+    // are never written by anybody, stay at +0.0 and come this way in every launch.)
     if (F.direct_only || __float_as_uint(ro.w) == 0u) {
+      const PixelId px = pixel_of(A.map, lid);
+      if (!px.active) return false;
+      tally.fresh += 1;
       camera_ray(A, F, px, F.pixel_offset[0], F.pixel_offset[1], origin, direction);
       A.st.ray_o[lid] = make_float4(origin.x, origin.y, origin.z, ro.w);
       A.st.ray_d[lid] = make_float4(direction.x, direction.y, direction.z, rd.w);
     } else {
+      if (ro.w == 0.0f) tally.fresh += 1;
       origin = mk3(ro.x, ro.y, ro.z);
       direction = mk3(rd.x, rd.y, rd.z);
     }
