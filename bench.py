@@ -258,9 +258,11 @@ def algorithmic_bytes(c):
     bilinear fetch of an RGBA texture, 4 B per gray one: SURVEY 8(d)'s "16 B/texture tap"), 112 B of RTLight per light sample, and
     per sky-light sample the binary search of the marginal table (4 B a step), one marginal and two conditional values.
     """
-    closest = 32 + 16 + 32 * c["f_fresh"] + 64 * c["nodes_closest"] + 36 * c["tris_closest"]
+    # (the camera ray of a new path: written by k_trace's refill until round 5 -- 32 B x f_fresh there -- and since then by the shading
+    # code where the old path ends: the pixels that hit write their 96 B of state either way, the ones that missed 32 B they did not)
+    closest = 32 + 16 + 64 * c["nodes_closest"] + 36 * c["tris_closest"]
     shade = (16 + 32 + 64 * (1 - c["f_fresh"]) + 192 * c["f_hit"] + 48 * c["f_shadow"] + 48 * (1 - c["f_shadow"])
-             + 96 * c["f_hit"])
+             + 96 * c["f_hit"] + 32 * (1 - c["f_hit"]))
     shade += c.get("tex_bytes_shade", 0.0) + 112 * (c.get("light_samples", 0.0) + c.get("sky_samples", 0.0)) + c.get("sky_bytes_per_sample", 0.0) * c.get("sky_samples", 0.0)
     shadow = 48 * c["f_shadow"] + 48 * c["f_shadow"] + 64 * c["nodes_shadow"] + 36 * c["tris_shadow"]
     # k_trace traverses the closest-hit rays of a launch and the shadow rays of the launch before it in one kernel
