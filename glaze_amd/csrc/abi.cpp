@@ -740,7 +740,10 @@ int glz_host_launch_constants(uint64_t seed, uint32_t launch, uint32_t* seed_out
   float o[2] = {0, 0};
   for (uint32_t i = 0; i <= launch; ++i) {
     s = rng.next();
+    float ahead[2] = {-1.0f, -1.0f};
+    ws.peek(ahead);   // what the launch before this one was told about it (FrameData::next_pixel_offset): must be what next() now hands out
     ws.next(o);
+    if (memcmp(ahead, o, sizeof(o)) != 0) return fail(GLZ_E_IO, "WorkScheduler::peek disagrees with next()");
   }
   *seed_out = s;
   offset[0] = o[0];

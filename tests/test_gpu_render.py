@@ -410,6 +410,43 @@ def test_progressive_step_equals_draw(instance):
     assert np.array_equal(a.view(np.uint32), r.read_hdr().view(np.uint32))
 
 
+def test_camera_rays_made_by_the_shading_code_in_every_launch_shape(instance):
+    """A path that ends gets the NEXT launch's camera ray from the shading code (shade_pixel's reset site, FrameData::next_pixel_offset,
+    ray_o.w = -0.0) instead of from the traversal kernel's refill.  The marker has to mean the same to everybody who reads the state: the
+    two kernels and the per-wave launch loop, any number of launch chains, calls of any length (the last launch of a call peeks at the
+    pixel offset of a launch that a later call makes), an exposure changed in between (no restart), a restart in the middle (camera rays
+    that nobody has made yet), an image whose edge tiles reach past it (those pixels never get a ray) -- against the oracle's plain
+    sequence of launches, bit for bit after every call."""
+    desc = cube_scene(material_type=abi.MAT_UBER)
+    desc.lights.append(make_light(abi.LIGHT_SUN, "sun", direction=(0.2, -0.7, 0.4), intensity=1.5))
+    w, h = 150, 83                                # 3 x 2 tiles, the right and the bottom ones partly outside
+    r = glaze_amd.RayTraceRenderer.new(instance, glaze_amd.RayTraceScene.from_desc(instance, desc), w, h)
+    o = OracleRenderer(OracleScene(desc), w, h)
+    for x in (r, o):
+        x.set_depth(4)                            # short paths: every pixel starts several new ones
+        x.set_seed(11)
+    for mode, chains in (("two_kernels", 1), ("path", 0), ("two_kernels", 2), ("two_kernels", 3)):
+        r.set_launch_mode(mode)                   # (a change of the launch shape restarts the frame: the state arrays are laid out anew)
+        r.set_chains(chains)
+        o.restart()
+        total = 0
+        for n, exposure in ((1, 1.0), (3, 1.0), (2, 0.5), (7, 2.0), (1, 2.0), (4, 1.0)):
+            r.set_exposure(exposure)
+            o.set_exposure(exposure)
+            r.step(n)
+            o.step(n)
+            total += n
+            g, c = r.read_hdr(), o.read_hdr()
+            assert g[..., 3].max() == float(total)
+            assert np.array_equal(bits(g), bits(c)), "%s, %d chains, after %d launches: %d pixels differ" % (mode, chains, total, int((bits(g) != bits(c)).any(-1).sum()))
+        assert np.array_equal(bits(r.read_result()), bits(o.read_result()))
+        r.restart()
+        o.restart()
+        r.step(3)
+        o.step(3)
+        assert np.array_equal(bits(r.read_hdr()), bits(o.read_hdr())), "%s, %d chains: after a restart" % (mode, chains)
+
+
 def test_exposure_applies_without_restart_and_resolution_change(instance):
     desc = cube_scene()
     r = glaze_amd.RayTraceRenderer.new(instance, glaze_amd.RayTraceScene.from_desc(instance, desc), 32, 32)
