@@ -13,7 +13,8 @@
 //   GLZ_TRACE8_WAVES          4     ... k_trace8, the 8-wide walk of a small tile share (128 VGPRs)
 //   GLZ_TRACE8_PREFETCH       1     k_trace8: the next node's loads issued as soon as the node is known
 //   GLZ_TRACE8_STACK         28     k_trace8: stack levels kept in LDS (1 KB a level and block)
-//   GLZ_REFILL               16     idle lanes at which a wave takes new rays
+//   GLZ_REFILL               10     idle lanes at which a wave takes new rays (16 until the camera rays left the refill: round 5)
+//   GLZ_TL_REFILL            16     the same for the two-level tracer (8: 0.834 against 0.827 ms, round 3)
 //   GLZ_LEAF_QUORUM          24     lanes waiting on a leaf at which the inner-node phase ends
 //   GLZ_TL_LEAF_QUORUM       32     the same for the two-level tracer (a leaf visit there is an instance entry: dearer)
 //   GLZ_ALPHA_QUORUM         12     lanes waiting with a candidate on non-opaque geometry at which the alpha phase runs
@@ -48,7 +49,10 @@
 #define GLZ_TRACE8_PREFETCH 1
 #endif
 #ifndef GLZ_REFILL
-#define GLZ_REFILL 16
+#define GLZ_REFILL 10
+#endif
+#ifndef GLZ_TL_REFILL
+#define GLZ_TL_REFILL 16
 #endif
 #ifndef GLZ_LEAF_QUORUM
 #define GLZ_LEAF_QUORUM 24

@@ -374,6 +374,7 @@ struct TraceTally {
 // the tail of a small share and the shadow rays have the same optimum.)
 constexpr bool kLdsTop = true;   // the top kBvhTopNodes nodes of the tree come from a per-block LDS copy ("LDS-staged node packets")
 constexpr int kRefill = GLZ_REFILL;
+constexpr int kTlRefill = GLZ_TL_REFILL;
 constexpr int kLeafQuorum = GLZ_LEAF_QUORUM;
 constexpr int kAlphaQuorum = GLZ_ALPHA_QUORUM;   // lanes waiting for the alpha test at which the alpha phase runs (trace_wave)
 constexpr int kAuxPerWave = 3 * 64 + 4 * 64;   // work sharing (3 x 64) + the four child links of the node a lane is visiting
@@ -1086,7 +1087,7 @@ __device__ __forceinline__ void trace_wave_tl(const DeviceScene& S, Source& src,
     // ---- refill ----
     const unsigned long long idle = __ballot(!open);
     const int n_idle = __popcll(idle);
-    if (!exhausted && n_idle >= kRefill) {
+    if (!exhausted && n_idle >= kTlRefill) {
       const uint32_t next_ray = rays.ray_at(seq + (uint32_t)__popcll(idle & lanes_below));
       if (!open && next_ray < total) {
         if (src.load(next_ray, o, d, tmin, tmax)) {
