@@ -238,6 +238,11 @@ struct DeviceScene {
   // per-leaf shading record, 8 x float4 = 128 bytes, in leaf order: VertexPacked x 3 (object space), then
   // (geometric normal.xyz, material id), (dpdu.xyz, transform id | identity flag in bit 31)
   const float4* shade_tris;
+  // Flattened scenes with an opacity map (null otherwise): per triangle slot 3 x float4 = (uv0, uv1), (uv2, TexDesc::offset, ::width),
+  // (::height, ::format, 0, 0) of the material's opacity map -- what the alpha test of a candidate needs (raytrace_hit.rahit:24-39) in
+  // ONE line and one round trip instead of shading record -> RTMaterial -> descriptor, three dependent ones (Scene::build_alpha_records;
+  // rebuilt whenever materials or textures change)
+  const float4* alpha_recs;
   // two-level scenes (null / 0 otherwise): TLAS nodes, instance records in TLAS leaf order; bvh_nodes / bvh_tris / shade_tris
   // then hold the meshes' object-space hierarchies and per-OBJECT-triangle records
   const BvhNode4* tlas_nodes;

@@ -263,14 +263,16 @@ __device__ __forceinline__ bool alpha_test(const DeviceScene& S, uint32_t leaf, 
 #ifdef GLZ_ALPHA_TIMING_NOFETCH   // TIMING ONLY: the verdict from the barycentrics alone (about half pass), no fetch
   return u + v < 0.5f;
 #endif
-  // uv of the three vertices and the material id come from the leaf's 128-byte shading record (the same values the
-  // reference's any-hit shader reads through instance -> indices -> vertices)
-  const float4* rec = S.shade_tris + 8u * (size_t)leaf;
-  const float4 a = rec[1], b = rec[3], c = rec[5];
-  const uint32_t material_id = __float_as_uint(rec[6].w);
+  // One 48-byte record per triangle slot (types.h DeviceScene::alpha_recs; every flattened scene with an opacity map has them): the
+  // three texture coordinates -- the values the reference's any-hit shader reads through instance -> indices -> vertices -- and the
+  // descriptor of the material's opacity map: record -> texels, two round trips where shading record -> material -> descriptor ->
+  // texels were four (a wave sits through them with the dozen lanes of an alpha phase: 0.07 ms of the Sponza-like atrium's k_trace).
   const float w = 1.0f - u - v;
-  const float tu = (a.z * w + b.z * u) + c.z * v, tv = (a.w * w + b.w * u) + c.w * v;
-  return !(texture_r(S, S.materials[material_id].opacity, vec2{tu, tv}) < 0.5f);
+  const float4* rec = S.alpha_recs + 3u * (size_t)leaf;
+  const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+  const float tu = (r0.x * w + r0.z * u) + r1.x * v, tv = (r0.y * w + r0.w * u) + r1.y * v;
+  const TexDesc t{__float_as_uint(r1.z), __float_as_uint(r1.w), __float_as_uint(r2.x), __float_as_uint(r2.y)};
+  return !(bilinear_level(S, t, S.tex_pool, tu, tv).x < 0.5f);
 }
 
 // the same for a two-level scene: the shading record is per OBJECT triangle, the material is the instance's

@@ -1252,6 +1252,22 @@ __global__ void __launch_bounds__(256) k_shade_records(uint32_t n, const BvhTri*
   r[7] = make_float4(du.x, du.y, du.z, __uint_as_float(in.transform_id | (xf_identity[in.transform_id] ? 0x80000000u : 0u)));
 }
 
+// The alpha test's inputs per triangle slot (types.h DeviceScene::alpha_recs): the three texture coordinates out of the shading record
+// and the descriptor of the material's opacity map, side by side.  A slot whose material has no opacity map gets a record nobody reads.
+__global__ void __launch_bounds__(256) k_alpha_records(uint32_t n, const float4* __restrict__ shade_tris, const RTMaterial* __restrict__ materials,
+                                                       const TexDesc* __restrict__ tex_desc, float4* __restrict__ out) {
+  const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= n) return;
+  const float4* rec = shade_tris + 8u * (size_t)slot;
+  const float4 a = rec[1], b = rec[3], c = rec[5];
+  const uint32_t opacity = materials[__float_as_uint(rec[6].w)].opacity;
+  const TexDesc t = tex_desc[opacity];
+  float4* r = out + 3u * (size_t)slot;
+  r[0] = make_float4(a.z, a.w, b.z, b.w);
+  r[1] = make_float4(c.z, c.w, __uint_as_float(t.offset), __uint_as_float(t.width));
+  r[2] = make_float4(__uint_as_float(t.height), __uint_as_float(t.format), 0.0f, 0.0f);
+}
+
 // ---------------------------------------------------------------------------------------------
 // host-side launcher
 // ---------------------------------------------------------------------------------------------
@@ -1382,6 +1398,12 @@ hipError_t launch_shade_records(hipStream_t st, uint32_t n, const BvhTri* tris, 
                                 const float4* vertices, const float4* derivatives, const uint32_t* xf_identity, float4* out) {
   if (n == 0) return hipSuccess;
   hipLaunchKernelGGL(k_shade_records, dim3((n + 255) / 256), dim3(256), 0, st, n, tris, instances, indices, vertices, derivatives, xf_identity, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_alpha_records(hipStream_t st, uint32_t n, const float4* shade_tris, const RTMaterial* materials, const TexDesc* tex_desc, float4* out) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_alpha_records, dim3((n + 255) / 256), dim3(256), 0, st, n, shade_tris, materials, tex_desc, out);
   return hipGetLastError();
 }
 

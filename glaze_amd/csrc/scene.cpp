@@ -960,10 +960,26 @@ bool Scene::build_bvh(Error& err) {
   dev.shade_tris = d_shade_tris_.ptr;
   dev.xf_identity = d_xf_identity_.ptr;
   dev.n_world_tris = n;
+  n_shade_slots_ = n;
+  if (!build_alpha_records(err)) return false;
   info.as_levels = 1;
   info.n_as_triangles = n;
   info.as_bytes = (uint64_t)out.n_nodes * sizeof(BvhNode4) + (uint64_t)(n + 1) * sizeof(BvhTri) + (uint64_t)n * 128u + (uint64_t)out.n_leaves * sizeof(BvhQuad) +
                   (uint64_t)info.bvh_nodes8 * sizeof(BvhNode8);
+  return true;
+}
+
+// What the alpha test of a candidate reads (DeviceScene::alpha_recs): texture coordinates and the opacity map's descriptor per triangle
+// slot.  Flattened scenes only (the two-level tracer takes the material from the instance, alpha_test_instance); nothing without an
+// opacity map.  Called by the flattened build and again by everything that changes a material's opacity map or moves texels.
+bool Scene::build_alpha_records(Error& err) {
+  dev.alpha_recs = nullptr;
+  if (dev.two_level || !dev.has_non_opaque || n_shade_slots_ == 0 || !d_shade_tris_.ptr) return true;
+  hipStream_t st = instance->stream;
+  if (!hip_ok(d_alpha_recs_.alloc((size_t)n_shade_slots_ * 3), "alloc alpha records", err)) return false;
+  if (!hip_ok(launch_alpha_records(st, n_shade_slots_, d_shade_tris_.ptr, dev.materials, dev.tex_desc, d_alpha_recs_.ptr), "k_alpha_records", err)) return false;
+  if (!hip_ok(hipStreamSynchronize(st), "alpha records", err)) return false;
+  dev.alpha_recs = d_alpha_recs_.ptr;
   return true;
 }
 
@@ -1026,6 +1042,7 @@ bool Scene::update_materials_and_lights(const glz_material* mats, uint32_t n_mat
   if (!build_materials(err)) return false;
   if (!build_lights_and_sky(err)) return false;
   if (opacity_changed && !build_bvh(err)) return false;   // the non-opaque flag lives in the leaf records
+  if (!build_alpha_records(err)) return false;             // which opacity map a material names, where its texels lie
   info.n_lights = lights_no;
   info.n_rt_lights = (uint32_t)h_lights.size();
   return hip_ok(hipStreamSynchronize(instance->stream), "update_materials_and_lights", err);

@@ -217,6 +217,61 @@ def test_opacity_map_switched_on_and_off_on_a_live_renderer(instance):
         assert holes[0] == holes[2] and holes[1] == holes[3] and holes[1] > holes[0] + 500, holes   # primary rays leave through the holes exactly while the map is bound
 
 
+def test_alpha_records_follow_the_opacity_map_a_material_names_and_its_texels(instance):
+    """The alpha test reads one record per triangle slot (DeviceScene::alpha_recs: texture coordinates + the opacity map's descriptor,
+    Scene::build_alpha_records).  The records have to follow every change that does NOT rebuild the hierarchy: a material pointed at
+    ANOTHER opacity map (still non-opaque: the leaf flags stay), the texture array replaced by maps of another size and format (the
+    descriptors move), and refresh_binded_textures on a running accumulation -- in both launch modes, against the oracle."""
+    y, x = np.mgrid[0:64, 0:64]
+    checker = np.where(((x // 4 + y // 4) % 2) == 0, 255, 0).astype(np.uint8)
+    yy, xx = np.mgrid[0:40, 0:24]
+    discs = np.where(((xx % 12 - 6) ** 2 + (yy % 10 - 5) ** 2) < 14, 0, 255).astype(np.uint8)
+    bars = np.zeros((16, 48, 4), np.uint8)
+    bars[..., 0] = np.where((np.arange(48) // 3) % 2 == 0, 255, 30)[None, :]          # an RGBA map: the test reads its red channel
+    bars[..., 3] = 255
+    desc = cube_scene()
+    desc.lights.append(make_light(abi.LIGHT_SUN, "sun", direction=(0.1, -0.8, 0.5), intensity=1.0))
+    desc.textures.append((abi.TEX_GRAY, checker, "checker"))      # 2
+    desc.textures.append((abi.TEX_GRAY, discs, "discs"))          # 3
+    for mode in ("two_kernels", "path"):
+        cur = desc.copy()
+        cur.materials[2].opacity = 2
+        r = glaze_amd.RayTraceRenderer.new(instance, glaze_amd.RayTraceScene.from_desc(instance, cur), 160, 96)
+        r.set_launch_mode(mode)
+        r.set_depth(4)
+        r.set_seed(9)
+
+        def check(what, launches=7):
+            r.step(launches)
+            o = OracleRenderer(OracleScene(cur), 160, 96)
+            o.set_depth(4)
+            o.set_seed(9)
+            o.step(launches)
+            assert np.array_equal(bits(r.read_hdr()), bits(o.read_hdr())), "%s, %s" % (mode, what)
+            return int((r.read_hdr()[..., :3].sum(-1) == 0).sum())
+
+        holes = [check("the checker as opacity map")]
+        cur = cur.copy()
+        cur.materials[2].opacity = 3                                                     # another map, no flip: nothing rebuilds the hierarchy
+        r.update_materials_and_lights(cur.materials, cur.lights)
+        holes.append(check("the discs as opacity map"))
+        cur = cur.copy()
+        cur.textures = [cur.textures[0], cur.textures[1], (abi.TEX_RGBA_NORM, bars, "bars"), (abi.TEX_GRAY, checker[:32, :16].copy(), "small checker")]
+        r.update_materials_and_lights(cur.materials, cur.lights, cur.textures)           # other sizes, another format: every descriptor moves
+        holes.append(check("the small checker after the texture array was replaced"))
+        cur = cur.copy()
+        cur.materials[2].opacity = 2
+        r.update_materials_and_lights(cur.materials, cur.lights)
+        holes.append(check("the red channel of an RGBA map"))
+        assert len(set(holes)) == len(holes), holes                                      # four different sets of holes
+        # refresh_binded_textures keeps accumulating: compare a fresh frame on the refreshed textures
+        cur = cur.copy()
+        cur.textures = [cur.textures[0], cur.textures[1], (abi.TEX_GRAY, discs, "discs again"), cur.textures[3]]
+        r.refresh_binded_textures(cur.textures)
+        r.restart()
+        check("after refresh_binded_textures")
+
+
 def test_tables_too_large_for_lds_and_a_sky_taller_than_its_lds_copy(instance):
     """k_shade stages the material / light / descriptor tables (8 KB) and the sky's marginal cdf (1 087 rows) in LDS when they fit; a
     scene with 64 materials (13 KB of RTMaterial) and a 16 x 1500 sky reads both from memory instead -- same pixels as the oracle, in both
