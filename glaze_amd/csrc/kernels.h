@@ -56,10 +56,10 @@ hipError_t launch_top_table(hipStream_t st, const BvhNode4* nodes, uint32_t n_no
 hipError_t launch_compress_nodes(hipStream_t st, const BvhNode4* nodes, uint32_t n, BvhNode48* out);
 #endif
 // 128-byte per-leaf shading records (see k_shade_records); xf_identity[t] != 0 marks an exact identity transform
-// DeviceScene::alpha_recs for `n` triangle slots (flattened scenes with an opacity map)
-hipError_t launch_alpha_records(hipStream_t st, uint32_t n, const float4* shade_tris, const RTMaterial* materials, const TexDesc* tex_desc, float4* out);
 hipError_t launch_shade_records(hipStream_t st, uint32_t n, const BvhTri* tris, const RTInstance* instances, const uint32_t* indices,
                                 const float4* vertices, const float4* derivatives, const uint32_t* xf_identity, float4* out);
+// DeviceScene::alpha_recs for `n` triangle slots (flattened scenes with an opacity map)
+hipError_t launch_alpha_records(hipStream_t st, uint32_t n, const float4* shade_tris, const RTMaterial* materials, const TexDesc* tex_desc, float4* out);
 
 // Traversal stack entries each lane keeps in LDS (a near-first 4-wide traversal holds at most three entries per
 // level of the tree; what does not fit spills to a per-lane HBM area).
