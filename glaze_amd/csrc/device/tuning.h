@@ -20,6 +20,8 @@
 //   GLZ_ALPHA_QUORUM         12     lanes waiting with a candidate on non-opaque geometry at which the alpha phase runs
 //   GLZ_PATH_PREFETCH         1     k_path: the next node's loads issued as soon as the node is known (trace_wave<PREFETCH>)
 //   GLZ_NODE48               off    EXPERIMENT: 48-byte nodes (types.h BvhNode48; tools/build_variant_full.sh: scene.cpp needs it too)
+//   GLZ_NO_SHARE / _ANY / _CLOSEST, GLZ_NO_LDS_TOP, GLZ_DEBUG_REPRO_R5   off   debugging: the tail's work sharing off (both passes / the shadow pass / the closest-hit pass), every node from memory,
+//                                    the reproducer of EXPERIMENTS.md round 5 (kernels_render.hip k_trace)
 //   GLZ_WAVE_TIMES           off    instrumentation: per-wave time stamps of k_trace            (tools/gpu_wave_times.py)
 //   GLZ_PATH_TIMES           off    instrumentation: per-wave tracing / shading time of k_path  (tools/gpu_path_phases.py)
 //   GLZ_SECTION_TIMES        off    instrumentation: clocks per part of trace_wave's round; = 2: the node visit in pieces too (tools/gpu_sections.py)

@@ -374,7 +374,11 @@ struct TraceTally {
 // ---------------------------------------------------------------------------------------------
 // (thresholds: device/tuning.h.  Leaf quorum: 12 / 16 / 20 / 24 / 32 lanes -> 0.571 / 0.554 / 0.542 / 0.541 / 0.557 ms per k_trace;
 // the tail of a small share and the shadow rays have the same optimum.)
-constexpr bool kLdsTop = true;   // the top kBvhTopNodes nodes of the tree come from a per-block LDS copy ("LDS-staged node packets")
+#ifdef GLZ_NO_LDS_TOP   // debugging switch: every node from memory
+constexpr bool kLdsTop = false;
+#else
+constexpr bool kLdsTop = true;
+#endif   // the top kBvhTopNodes nodes of the tree come from a per-block LDS copy ("LDS-staged node packets")
 constexpr int kRefill = GLZ_REFILL;
 constexpr int kTlRefill = GLZ_TL_REFILL;
 constexpr int kLeafQuorum = GLZ_LEAF_QUORUM;
@@ -467,7 +471,15 @@ constexpr int kAlphaNone = 0, kAlphaInline = 1, kAlphaPhase = 2;
 template <bool ANY, bool COUNT, bool MIXED = false, bool PREFETCH = false, bool WIDE8 = false, int ALPHA = kAlphaInline, class Source, class Sink>
 __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Sink& sink, int* __restrict__ lds_col, int* aux, int* link_scratch, LdsNodePtr top_lds,
                                            uint32_t* __restrict__ spill, uint32_t spill_depth, uint32_t total, uint32_t wave, uint32_t n_waves, TraceTally& tally) {
+#if defined(GLZ_NO_SHARE_ANY)      // debugging switches (tools/build_variant.sh): the tail's work sharing off in one pass, or in both
+  constexpr bool SHARE = !COUNT && !ANY;
+#elif defined(GLZ_NO_SHARE_CLOSEST)
+  constexpr bool SHARE = !COUNT && ANY;
+#elif defined(GLZ_NO_SHARE)
+  constexpr bool SHARE = false;
+#else
   constexpr bool SHARE = !COUNT;
+#endif
   constexpr bool TOP = kLdsTop && !WIDE8;
   constexpr int kLevels = WIDE8 ? kLdsStack8 : kLdsStack;
   const BvhNode8* __restrict__ nodes8 = S.bvh_nodes8;
