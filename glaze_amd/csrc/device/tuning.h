@@ -6,6 +6,7 @@
 //   switch                 default  what
 //   ---------------------  -------  ----------------------------------------------------------------------------------------------
 //   GLZ_TRACE_WAVES           6     waves per SIMD k_trace is compiled for (80 VGPRs)
+//   GLZ_TRACE_SPLIT           1     k_trace: with more groups than waves, waves take groups of ONE kind (closest-hit or shadow); _NUM / _DEN (9 / 10): the shadow waves' share relative to the shadow groups' share
 //   GLZ_TRACE_PREFETCH        0     k_trace: the next node's loads issued as soon as the node is known (as k_path does; wants 16 more registers)
 //   GLZ_TRACE_TL_WAVES        4     ... the two-level tracer (128 VGPRs)
 //   GLZ_SHADE_WAVES           4     ... k_shade (128 VGPRs)
@@ -20,14 +21,22 @@
 //   GLZ_ALPHA_QUORUM         12     lanes waiting with a candidate on non-opaque geometry at which the alpha phase runs
 //   GLZ_PATH_PREFETCH         1     k_path: the next node's loads issued as soon as the node is known (trace_wave<PREFETCH>)
 //   GLZ_NODE48               off    EXPERIMENT: 48-byte nodes (types.h BvhNode48; tools/build_variant_full.sh: scene.cpp needs it too)
-//   GLZ_NO_SHARE / _ANY / _CLOSEST, GLZ_NO_LDS_TOP, GLZ_DEBUG_REPRO_R5   off   debugging: the tail's work sharing off (both passes / the shadow pass / the closest-hit pass), every node from memory,
-//                                    the reproducer of EXPERIMENTS.md round 5 (kernels_render.hip k_trace)
+//   GLZ_NO_SHARE / _ANY / _CLOSEST, GLZ_NO_LDS_TOP   off   debugging: the tail's work sharing off (both passes / the shadow pass / the closest-hit pass), every node from memory
 //   GLZ_WAVE_TIMES           off    instrumentation: per-wave time stamps of k_trace            (tools/gpu_wave_times.py)
 //   GLZ_PATH_TIMES           off    instrumentation: per-wave tracing / shading time of k_path  (tools/gpu_path_phases.py)
 //   GLZ_SECTION_TIMES        off    instrumentation: clocks per part of trace_wave's round; = 2: the node visit in pieces too (tools/gpu_sections.py)
 #pragma once
 #ifndef GLZ_TRACE_WAVES
 #define GLZ_TRACE_WAVES 6
+#endif
+#ifndef GLZ_TRACE_SPLIT
+#define GLZ_TRACE_SPLIT 1
+#endif
+#ifndef GLZ_TRACE_SPLIT_NUM
+#define GLZ_TRACE_SPLIT_NUM 9
+#endif
+#ifndef GLZ_TRACE_SPLIT_DEN
+#define GLZ_TRACE_SPLIT_DEN 10
 #endif
 #ifndef GLZ_TRACE_PREFETCH
 #define GLZ_TRACE_PREFETCH 0

@@ -484,6 +484,14 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
   constexpr int kLevels = WIDE8 ? kLdsStack8 : kLdsStack;
   const BvhNode8* __restrict__ nodes8 = S.bvh_nodes8;
   constexpr uint32_t kNone = 0xFFFFFFFFu;
+  // The wave's place in the deal is the same in all of its lanes, and the compiler has to KNOW that: everything that steers the rounds below
+  // (`seq`, `exhausted`, the loops' exits) derives from these three, and a build in which they arrived through variables the compiler
+  // could not prove uniform turned the loops into divergent ones -- lanes "leave" one by one, EXEC is empty behind the last exit -- and
+  // placed the reloads of spilt registers in front of the instruction that restores EXEC: what was kept across the pass came back as
+  // whatever the registers held (EXPERIMENTS.md, round 5: a few wrong pixels from run to run; clang 22).  v_readfirstlane says it.
+  wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave);
+  n_waves = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_waves);
+  total = (uint32_t)__builtin_amdgcn_readfirstlane((int)total);
   const BvhNode4* __restrict__ nodes = S.bvh_nodes;
   const BvhGrid grid = S.bvh_grid;
   const int lane = threadIdx.x & 63;
@@ -1035,6 +1043,9 @@ template <bool ANY, bool COUNT, class Source, class Sink>
 __device__ __forceinline__ void trace_wave_tl(const DeviceScene& S, Source& src, Sink& sink, int* __restrict__ lds_col, int* aux, int* link_scratch, float* __restrict__ top_ray, LdsNodePtr top_lds,
                                               uint32_t* __restrict__ spill, uint32_t spill_depth, uint32_t total, uint32_t wave, uint32_t n_waves, TraceTally& tally) {
   constexpr uint32_t kNone = 0xFFFFFFFFu;
+  wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave);   // (uniform, and said so: see trace_wave)
+  n_waves = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_waves);
+  total = (uint32_t)__builtin_amdgcn_readfirstlane((int)total);
   const BvhNode4* __restrict__ nodes = S.bvh_nodes;        // top-level nodes first, the meshes' after them (TlasInstance::node_base)
   const TlasInstance* __restrict__ instances = S.tlas_instances;
   const int lane = threadIdx.x & 63;

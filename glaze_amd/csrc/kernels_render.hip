@@ -272,11 +272,11 @@ __global__ void __launch_bounds__(kBlock, GLZ_TRACE_WAVES) k_trace(const LaunchA
     counted_scene.tex_counter = tex_tally;
   }
   const DeviceScene& TS = COUNT ? counted_scene : A.scene;
-#ifdef GLZ_DEBUG_REPRO_R5
-  // REPRODUCER, off by default (EXPERIMENTS.md, round 5, "Waves that specialise"; tools/dbg_split.py): the remains of an experiment whose
-  // condition can never hold at run time -- the two passes below run exactly as in the product -- and whose presence alone makes the
-  // compiled kernel differ from the oracle in a few pixels of a 150 x 83 frame, from run to run (with -DGLZ_NO_SHARE_ANY or with
-  // -mllvm -amdgpu-spill-sgpr-to-vgpr=0 on top: in two thirds of them).  The product build has never shown it; the cause is open.
+#if GLZ_TRACE_SPLIT
+  // Waves that specialise (device/tuning.h GLZ_TRACE_SPLIT): with more 64-ray groups than waves, a share of the waves -- GLZ_TRACE_SPLIT_NUM /
+  // _DEN of the shadow groups' share of all groups, spread evenly over the grid wave by wave -- takes only shadow groups and the others only
+  // closest-hit groups: a wave then drains ONCE, at the end of the kernel, instead of once per kind, and a CU holds waves of both kinds at
+  // all times.  With fewer groups than waves every group gets a wave of its own either way.  The counting kernels keep the two passes per wave.
   uint32_t split_closest = A.do_closest, split_shadow = A.do_shadow, split_wave_c = wave_index(), split_waves_c = wave_count(), split_wave_s = 0, split_waves_s = 0;
   bool split = false;
   if (!COUNT && A.do_closest && A.do_shadow) {
@@ -285,18 +285,18 @@ __global__ void __launch_bounds__(kBlock, GLZ_TRACE_WAVES) k_trace(const LaunchA
 #pragma unroll
     for (uint32_t k = 0; k < kQueueShards; ++k) n_sh += counts0[k * kCounterStride];
     const uint32_t gc = (A.map.n_local_pixels + 63u) / 64u, gs = (n_sh + 63u) / 64u, nw = wave_count();
-    if (gc + gs > nw + A.map.width * 100000u && gs > 0u) {   // never true at run time, not foldable
+    if (gc + gs > nw && gs > 0u) {
       split = true;
-      uint32_t ws = (uint32_t)(((unsigned long long)nw * gs * 9u) / ((unsigned long long)gc * 10u + (unsigned long long)gs * 9u));
+      uint32_t ws = (uint32_t)(((unsigned long long)nw * gs * GLZ_TRACE_SPLIT_NUM) / ((unsigned long long)gc * GLZ_TRACE_SPLIT_DEN + (unsigned long long)gs * GLZ_TRACE_SPLIT_NUM));
       ws = ws < 1u ? 1u : (ws > nw - 1u ? nw - 1u : ws);
       const uint32_t w = wave_index();
       const uint32_t s_before = (uint32_t)(((unsigned long long)w * ws) / nw), s_after = (uint32_t)(((unsigned long long)(w + 1u) * ws) / nw);
-      const bool is_shadow = s_after > s_before;
+      const bool is_shadow = s_after > s_before;   // the same in all lanes of a wave
       split_closest = is_shadow ? 0u : 1u;
       split_shadow = is_shadow ? 1u : 0u;
-      split_wave_c = w - s_before;
+      split_wave_c = w - s_before;    // this wave's number among the closest-hit waves ...
       split_waves_c = nw - ws;
-      split_wave_s = s_before;
+      split_wave_s = s_before;        // ... or among the shadow waves
       split_waves_s = ws;
     }
   }
@@ -320,7 +320,7 @@ __global__ void __launch_bounds__(kBlock, GLZ_TRACE_WAVES) k_trace(const LaunchA
     ShadowSink sink{A, src};
     uint32_t n_waves = wave_count();
     const uint32_t closest_groups = A.do_closest ? (A.map.n_local_pixels + 63u) / 64u : 0u;
-    uint32_t wave = (wave_index() + n_waves - closest_groups % n_waves) % n_waves;
+    uint32_t wave = (wave_index() + n_waves - closest_groups % n_waves) % n_waves;   // (not specialised: the shadow groups dealt behind the closest-hit ones)
     if (split) { wave = split_wave_s; n_waves = split_waves_s; }
     trace_wave<true, COUNT, false, GLZ_TRACE_PREFETCH != 0, false, ALPHA>(TS, src, sink, &s_stack[threadIdx.x], aux, links, (LdsNodePtr)s_top, A.st.overflow, A.st.overflow_depth, start[kQueueShards], wave, n_waves, tally);
     if (COUNT) flush_counters(A.counters, true, tally);
