@@ -17,6 +17,7 @@
 //   GLZ_REFILL               10     idle lanes at which a wave takes new rays (16 until the camera rays left the refill: round 5)
 //   GLZ_TL_REFILL            16     the same for the two-level tracer (8: 0.834 against 0.827 ms, round 3)
 //   GLZ_LEAF_QUORUM          24     lanes waiting on a leaf at which the inner-node phase ends
+//   GLZ_LEAF_QUORUM_ANY      30     ... in a pass of shadow rays only (18 / 24 / 30 / 36 / 42: 0.444 / 0.432 / 0.429 / 0.431 / 0.434 ms per k_trace); GLZ_REFILL_ANY: = GLZ_REFILL (6 / 16: no difference)
 //   GLZ_TL_LEAF_QUORUM       32     the same for the two-level tracer (a leaf visit there is an instance entry: dearer)
 //   GLZ_ALPHA_QUORUM         12     lanes waiting with a candidate on non-opaque geometry at which the alpha phase runs
 //   GLZ_PATH_PREFETCH         1     k_path: the next node's loads issued as soon as the node is known (trace_wave<PREFETCH>)
@@ -61,6 +62,12 @@
 #endif
 #ifndef GLZ_REFILL
 #define GLZ_REFILL 10
+#endif
+#ifndef GLZ_REFILL_ANY
+#define GLZ_REFILL_ANY GLZ_REFILL
+#endif
+#ifndef GLZ_LEAF_QUORUM_ANY
+#define GLZ_LEAF_QUORUM_ANY 30
 #endif
 #ifndef GLZ_TL_REFILL
 #define GLZ_TL_REFILL 16

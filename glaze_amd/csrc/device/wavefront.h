@@ -382,6 +382,7 @@ constexpr bool kLdsTop = true;
 constexpr int kRefill = GLZ_REFILL;
 constexpr int kTlRefill = GLZ_TL_REFILL;
 constexpr int kLeafQuorum = GLZ_LEAF_QUORUM;
+constexpr int kRefillAny = GLZ_REFILL_ANY, kLeafQuorumAny = GLZ_LEAF_QUORUM_ANY;   // the same for a pass of shadow rays only (k_trace's second pass, its shadow waves)
 constexpr int kAlphaQuorum = GLZ_ALPHA_QUORUM;   // lanes waiting for the alpha test at which the alpha phase runs (trace_wave)
 constexpr int kAuxPerWave = 3 * 64 + 4 * 64;   // work sharing (3 x 64) + the four child links of the node a lane is visiting
 // The block's scratch, as the kernels declare it (__shared__ alignas(1024) int s_aux[kAuxPerBlock]): the waves' link areas first -- 256 ints
@@ -654,7 +655,7 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
     // ---- refill ----
     const unsigned long long idle = __ballot(!(open || helper));
     const int n_idle = __popcll(idle);
-    if (!exhausted && n_idle >= kRefill) {
+    if (!exhausted && n_idle >= (ANY ? kRefillAny : kRefill)) {
       if (COUNT && lane == 0) { tally.refill_iters += 1; tally.refill_lanes += (unsigned)n_idle; }
       const uint32_t next_ray = rays.ray_at(seq + (uint32_t)__popcll(idle & lanes_below));
       if (!open && next_ray < total) {
@@ -854,7 +855,7 @@ __device__ __forceinline__ void trace_wave(const DeviceScene& S, Source& src, Si
       if (!PREFETCH) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the visit's loads and LDS traffic are charged to the visit
 #endif
       GLZ_SEC_STAMP(sec_node);
-      if (__popcll(__ballot(cur < 0 && !(ALPHA == kAlphaPhase && alpha_wait))) >= kLeafQuorum) break;
+      if (__popcll(__ballot(cur < 0 && !(ALPHA == kAlphaPhase && alpha_wait))) >= (ANY ? kLeafQuorumAny : kLeafQuorum)) break;
       // (Postponed leaves -- a lane parks the first leaf it arrives at and goes on with its stack, blocks at the second, the parked
       // leaves are tested first in the next leaf phase; Aila & Laine's speculative traversal -- k_trace 0.512 -> 0.540 ms with the
       // leaf phase at 24 waiting lanes, 0.542 / 0.555 at 16 / 32: the visits made without the parked leaf's bound and the second
